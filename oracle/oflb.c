@@ -1,0 +1,967 @@
+/*
+ * oracle/oflb.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (oracle) of the reference filter hot path, one function per reference
+ * function, each citing the reference lines it follows:
+ *
+ *   oflb_regex_create     src/flb_regex.c:60-152   (check_option + str_to_regex: /pat/imx)
+ *   oflb_parser_create    src/flb_parser.c:805-1049 (time format analysis, %L split, types)
+ *   oflb_parser_do        src/flb_parser_regex.c:44-227 (cb_results + flb_parser_regex_do)
+ *   time lookup           src/flb_parser.c:1876-2065, include/fluent-bit/flb_parser.h:80-94
+ *   typecast              src/flb_parser.c:2067-2164
+ *   oflb_grep_*           plugins/filter_grep/grep.c:56-392, src/flb_ra_key.c:108-434
+ *   oflb_fparser_*        plugins/filter_parser/filter_parser.c:174-442,
+ *                         src/flb_pack.c:1664-1738 (flb_msgpack_expand_map),
+ *                         src/flb_log_event_encoder.c:172-363
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <stdio.h>
+#include <time.h>
+#include <limits.h>
+#include "omp.h"
+#include "orx.h"
+#include "otime.h"
+
+#define FLB_FILTER_MODIFIED 1   /* include/fluent-bit/flb_filter.h:41-42 */
+#define FLB_FILTER_NOTOUCH  2
+
+/* ------------------------------------------------------------------ flb_regex */
+typedef struct oflb_regex { orx_t *rx; } oflb_regex;
+
+/* src/flb_regex.c:60-114 check_option(); returns option bits or -1 for ONIG_OPTION_DEFAULT */
+static int check_option(const char *start, const char *end, const char **new_end)
+{
+    const char *chr;
+    int option = 0;
+    *new_end = NULL;
+    if (start[0] != '/') return -1;
+    chr = strrchr(start, '/');
+    if (!chr) return -1;
+    if (chr == start || chr == end) return -1;
+    *new_end = chr;
+    chr++;
+    while (chr != end && *chr != '\0') {
+        switch (*chr) {
+        case 'm': option |= ORX_OPT_MULTILINE; break;
+        case 'i': option |= ORX_OPT_IGNORECASE; break;
+        case 'o': break;
+        case 'x': option |= ORX_OPT_EXTEND; break;
+        default:
+            *new_end = NULL;
+            return -1;
+        }
+        chr++;
+    }
+    if (option == 0) { *new_end = NULL; return -1; }
+    return option;
+}
+
+oflb_regex *oflb_regex_create(const char *pattern)
+{
+    size_t len = strlen(pattern);
+    const char *start = pattern, *end = pattern + len, *new_end = NULL;
+    int option = check_option(start, end, &new_end);
+    oflb_regex *r;
+    orx_t *rx;
+    if (len > 1 && pattern[0] == '/' && pattern[len - 1] == '/') { start++; end--; }
+    if (new_end != NULL) { start++; end = new_end; }
+    /* ONIG_OPTION_DEFAULT == ONIG_OPTION_NONE */
+    rx = orx_compile(start, (int) (end - start), option < 0 ? 0 : (unsigned) option, NULL, 0);
+    if (!rx) return NULL;
+    r = calloc(1, sizeof(*r));
+    r->rx = rx;
+    return r;
+}
+
+void oflb_regex_destroy(oflb_regex *r) { if (r) { orx_free(r->rx); free(r); } }
+
+/* src/flb_regex.c:270-291 */
+int oflb_regex_match(oflb_regex *r, const char *s, size_t len) { return orx_match(r->rx, s, (int) len); }
+
+/* ------------------------------------------------------------------ parser */
+enum { T_INT = 1, T_FLOAT, T_BOOL, T_STRING, T_HEX };
+struct ptype { char *key; int key_len; int type; };
+
+typedef struct oflb_parser {
+    oflb_regex *regex;
+    int skip_empty;
+    char *time_fmt;          /* cut at %L */
+    char *time_fmt_year;     /* "%Y " + fmt, cut at %L */
+    char *time_frac_secs;    /* format text after %L, or NULL */
+    char *time_key;
+    int time_offset;
+    int time_keep;
+    int time_strict;
+    int time_with_year;
+    int time_with_tz;
+    struct ptype *types;
+    int types_len;
+} oflb_parser;
+
+/* src/flb_parser.c:1806-1870 flb_parser_tzone_offset */
+static int tzone_offset(const char *str, int len, int *tmdiff)
+{
+    int neg;
+    long hour, min;
+    const char *end, *p = str;
+    if (*p == 'Z') { *tmdiff = 0; return 0; }
+    if (*p != '+' && *p != '-') { *tmdiff = 0; return -1; }
+    if (len < 4) { *tmdiff = 0; return -1; }
+    neg = (*p++ == '-');
+    end = str + len;
+    hour = ((p[0] - '0') * 10) + (p[1] - '0');
+    if (end - p == 5 && p[2] == ':') {
+        if (len < 5) { *tmdiff = 0; return -1; }
+        min = ((p[3] - '0') * 10) + (p[4] - '0');
+    }
+    else min = ((p[2] - '0') * 10) + (p[3] - '0');
+    if (hour < 0 || hour > 59 || min < 0 || min > 59) return -1;
+    *tmdiff = (int) ((hour * 3600) + (min * 60));
+    if (neg) *tmdiff = -*tmdiff;
+    return 0;
+}
+
+/* src/flb_parser.c:1130-1182 proc_types_str */
+static int proc_types(const char *types_str, struct ptype **out)
+{
+    /* flb_utils_split(str, ' ', 256): tokens separated by single spaces, leading ones skipped */
+    int n = 0, cap = 8;
+    struct ptype *t = calloc(cap, sizeof(*t));
+    const char *p = types_str;
+    while (*p) {
+        const char *q, *colon;
+        while (*p == ' ') p++;
+        if (!*p) break;
+        q = strchr(p, ' ');
+        if (!q) q = p + strlen(p);
+        if (n == cap) { cap *= 2; t = realloc(t, cap * sizeof(*t)); }
+        t[n].key = NULL; t[n].type = T_STRING; t[n].key_len = 0;
+        colon = memchr(p, ':', q - p);
+        if (colon) {
+            size_t tl = q - (colon + 1);
+            const char *ts = colon + 1;
+            t[n].key = strndup(p, colon - p);
+            t[n].key_len = (int) (colon - p);
+            if (tl == 7 && !strncasecmp(ts, "integer", 7)) t[n].type = T_INT;
+            else if (tl == 4 && !strncasecmp(ts, "bool", 4)) t[n].type = T_BOOL;
+            else if (tl == 5 && !strncasecmp(ts, "float", 5)) t[n].type = T_FLOAT;
+            else if (tl == 3 && !strncasecmp(ts, "hex", 3)) t[n].type = T_HEX;
+            else t[n].type = T_STRING;
+        }
+        n++;
+        p = *q ? q + 1 : q;
+    }
+    *out = t;
+    return n;
+}
+
+oflb_parser *oflb_parser_create(const char *regex, int skip_empty, const char *time_fmt,
+                                const char *time_key, const char *time_offset, int time_keep,
+                                int time_strict, const char *types_str)
+{
+    oflb_parser *p = calloc(1, sizeof(*p));
+    p->regex = oflb_regex_create(regex);
+    if (!p->regex) { free(p); return NULL; }
+    p->skip_empty = skip_empty;
+    if (time_fmt && time_fmt[0]) {
+        int is_epoch = 0;
+        char *timeptr, *tmp;
+        p->time_fmt = strdup(time_fmt);
+        if (strstr(p->time_fmt, "%Y") || strstr(p->time_fmt, "%y")) p->time_with_year = 1;
+        else if (strstr(p->time_fmt, "%s")) { is_epoch = 1; p->time_with_year = 1; }
+        else {
+            size_t size = strlen(p->time_fmt);
+            p->time_with_year = 0;
+            p->time_fmt_year = malloc(size + 4);
+            memcpy(p->time_fmt_year, "%Y ", 3);
+            memcpy(p->time_fmt_year + 3, p->time_fmt, size + 1);
+        }
+        if (strstr(p->time_fmt, "%z") || strstr(p->time_fmt, "%Z") || strstr(p->time_fmt, "%SZ")
+            || strstr(p->time_fmt, "%S.%LZ")) p->time_with_tz = 1;
+        timeptr = (is_epoch || p->time_with_year) ? p->time_fmt : p->time_fmt_year;
+        tmp = strstr(timeptr, "%L");
+        if (tmp) { tmp[0] = '\0'; tmp[1] = '\0'; p->time_frac_secs = tmp + 2; }
+        if (time_offset && time_offset[0]) {
+            int diff = 0;
+            if (tzone_offset(time_offset, (int) strlen(time_offset), &diff) == -1) {
+                oflb_regex_destroy(p->regex); free(p); return NULL;
+            }
+            p->time_offset = diff;
+        }
+    }
+    if (time_key && time_key[0]) p->time_key = strdup(time_key);
+    p->time_keep = time_keep;
+    p->time_strict = time_strict;
+    if (types_str && types_str[0]) p->types_len = proc_types(types_str, &p->types);
+    return p;
+}
+
+void oflb_parser_destroy(oflb_parser *p)
+{
+    int i;
+    if (!p) return;
+    oflb_regex_destroy(p->regex);
+    free(p->time_fmt); free(p->time_fmt_year); free(p->time_key);
+    for (i = 0; i < p->types_len; i++) free(p->types[i].key);
+    free(p->types);
+    free(p);
+}
+
+/* src/flb_parser.c:1876-1897 */
+static int parse_subseconds(const char *str, int len, double *subsec)
+{
+    char buf[16];
+    char *end;
+    int consumed, digits = 9;
+    if (len < digits) digits = len;
+    memcpy(buf, "0.", 2);
+    memcpy(buf + 2, str, digits);
+    buf[digits + 2] = '\0';
+    *subsec = strtod(buf, &end);
+    consumed = (int) (end - buf - 2);
+    if (consumed <= 0) return -1;
+    return consumed;
+}
+
+/* src/flb_parser.c:1899-2065 (time_zone / system timezone branches not restated) */
+static int time_lookup(const char *time_str, size_t tsize, time_t now, oflb_parser *parser,
+                       struct otm *tm, double *ns)
+{
+    int ret, time_len = (int) tsize;
+    const char *p, *time_ptr = time_str;
+    char tmp[64];
+    char *buf = tmp, *time_buf = NULL;
+    size_t buf_size = sizeof(tmp);
+    *ns = 0;
+    if (tsize > sizeof(tmp) - 1) {
+        buf_size = tsize + 8;
+        time_buf = malloc(buf_size);
+        buf = time_buf;
+    }
+    if (!parser->time_with_year) {
+        time_t time_now;
+        struct tm tmy;
+        char *fmt;
+        if (time_len + 6 >= (int) buf_size) { free(time_buf); return -1; }
+        time_now = now <= 0 ? time(NULL) : now;
+        gmtime_r(&time_now, &tmy);
+        tm->tm.tm_mon = tmy.tm_mon;
+        tm->tm.tm_mday = tmy.tm_mday;
+        fmt = buf;
+        sprintf(fmt, "%04d", tmy.tm_year + 1900);
+        fmt += 4;
+        *fmt++ = ' ';
+        memcpy(fmt, time_ptr, time_len);
+        fmt += time_len;
+        *fmt++ = '\0';
+        time_ptr = buf;
+        time_len = (int) strlen(buf);
+        p = o_strptime(time_ptr, parser->time_fmt_year, tm);
+    }
+    else {
+        if (time_len >= (int) buf_size) { free(time_buf); return -1; }
+        memcpy(buf, time_ptr, time_len);
+        buf[time_len] = '\0';
+        time_ptr = buf;
+        time_len = (int) strlen(buf);
+        p = o_strptime(time_ptr, parser->time_fmt, tm);
+    }
+    if (p == NULL) {
+        free(time_buf);
+        return parser->time_strict ? -1 : 0;
+    }
+    if (parser->time_frac_secs) {
+        ret = parse_subseconds(p, time_len - (int) (p - time_ptr), ns);
+        if (ret < 0) { free(time_buf); return parser->time_strict ? -1 : 0; }
+        p += ret;
+        p = o_strptime(p, parser->time_frac_secs, tm);
+        if (p == NULL) { free(time_buf); return parser->time_strict ? -1 : 0; }
+    }
+    if (!parser->time_with_tz) tm->gmtoff = parser->time_offset;
+    free(time_buf);
+    return 0;
+}
+
+/* include/fluent-bit/flb_parser.h:80-94 (use_system_timezone == FALSE) */
+static time_t tm2time(const struct otm *src)
+{
+    struct tm tmp = src->tm;
+    return timegm(&tmp) - src->gmtoff;
+}
+
+/* src/flb_parser.c:2067-2164 */
+static void typecast(oflb_parser *parser, const char *key, int key_len, const char *val, int val_len,
+                     omp_buf *pck)
+{
+    int i, casted = 0, error = 0;
+    char *tmp_str;
+    for (i = 0; i < parser->types_len; i++) {
+        struct ptype *t = &parser->types[i];
+        if (t->key != NULL && key_len == t->key_len && !strncmp(key, t->key, key_len)) {
+            casted = 1;
+            omp_pack_str_with_body(pck, key, key_len);
+            switch (t->type) {
+            case T_INT:
+                tmp_str = strndup(val, val_len);
+                omp_pack_int64(pck, atoll(tmp_str));
+                free(tmp_str);
+                break;
+            case T_HEX:
+                tmp_str = strndup(val, val_len);
+                omp_pack_uint64(pck, strtoull(tmp_str, NULL, 16));
+                free(tmp_str);
+                break;
+            case T_FLOAT:
+                tmp_str = strndup(val, val_len);
+                omp_pack_double(pck, atof(tmp_str));
+                free(tmp_str);
+                break;
+            case T_BOOL:
+                if (val_len >= 4 && !strncasecmp(val, "true", 4)) omp_pack_bool(pck, 1);
+                else if (val_len >= 5 && !strncasecmp(val, "false", 5)) omp_pack_bool(pck, 0);
+                else error = 1;
+                break;
+            case T_STRING:
+                omp_pack_str_with_body(pck, val, val_len);
+                break;
+            default:
+                error = 1;
+            }
+            if (error) omp_pack_str_with_body(pck, val, val_len);
+            break;
+        }
+    }
+    if (!casted) {
+        omp_pack_str_with_body(pck, key, key_len);
+        omp_pack_str_with_body(pck, val, val_len);
+    }
+}
+
+/*
+ * src/flb_parser_regex.c:114-227 flb_parser_regex_do (+ cb_results :44-112, and the group
+ * iteration of src/flb_regex.c:28-58,182-231,294-313).  Returns last byte consumed or -1.
+ * *out is malloc'd.
+ */
+int oflb_parser_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
+                   int64_t *out_sec, int64_t *out_nsec)
+{
+    int beg[ORX_MAX_GROUPS], end[ORX_MAX_GROUPS];
+    int nregs, n, i, k, last_pos = -1, num_skipped = 0;
+    time_t time_lookup_v = 0;
+    double time_frac = 0;
+    omp_buf pck;
+    orx_t *rx = parser->regex->rx;
+
+    nregs = orx_search(rx, buf, (int) length, beg, end, ORX_MAX_GROUPS);
+    if (nregs < 0) return -1;
+    n = nregs - 1;                           /* flb_regex_do returns num_regs - 1 */
+    if (n <= 0) return -1;                   /* flb_parser_regex_do: if (n <= 0) return -1 */
+
+    omp_buf_init(&pck);
+    omp_pack_map(&pck, n);
+
+    for (i = 0; i < orx_num_names(rx); i++) {
+        const char *name = orx_name(rx, i);
+        int len = (int) strlen(name);
+        for (k = 0; k < orx_name_ngroups(rx, i); k++) {
+            int gn = orx_name_group(rx, i, k);
+            const char *value = buf + beg[gn];
+            size_t vlen = (size_t) (end[gn] - beg[gn]);
+            int done = 0;
+            /* cb_onig_named: last_pos updated after the callback when end >= 0 */
+            /* ---- cb_results */
+            if (vlen == 0 && parser->skip_empty) { num_skipped++; done = 1; }
+            if (!done && parser->time_fmt) {
+                const char *time_key = parser->time_key ? parser->time_key : "time";
+                if (strcmp(name, time_key) == 0) {
+                    struct otm tm;
+                    double frac = 0;
+                    memset(&tm, 0, sizeof(tm));
+                    if (time_lookup(value, vlen, 0, parser, &tm, &frac) == -1) {
+                        num_skipped++;
+                        done = 1;
+                    }
+                    else {
+                        time_frac = frac;
+                        time_lookup_v = tm2time(&tm);
+                        if (!parser->time_keep) { num_skipped++; done = 1; }
+                    }
+                }
+            }
+            if (!done) {
+                if (parser->types_len != 0) typecast(parser, name, len, value, (int) vlen, &pck);
+                else {
+                    omp_pack_str_with_body(&pck, name, len);
+                    omp_pack_str_with_body(&pck, value, vlen);
+                }
+            }
+            if (end[gn] >= 0) last_pos = end[gn];
+        }
+    }
+    if (last_pos == -1) { omp_buf_free(&pck); return -1; }
+
+    if (num_skipped > 0) {
+        /* header patched in place, width kept (src/flb_parser_regex.c:182-199) */
+        int arr_size = n - num_skipped;
+        unsigned char *t = (unsigned char *) pck.data;
+        unsigned char h = t[0];
+        if (h >> 4 == 0x8) t[0] = (unsigned char) ((0x8 << 4) | (unsigned char) arr_size);
+        else if (h == 0xde) { t[1] = (unsigned char) (arr_size >> 8); t[2] = (unsigned char) arr_size; }
+        else if (h == 0xdf) { t[1] = (unsigned char) (arr_size >> 24); t[2] = (unsigned char) (arr_size >> 16);
+                              t[3] = (unsigned char) (arr_size >> 8); t[4] = (unsigned char) arr_size; }
+    }
+    *out = pck.data;
+    *out_size = pck.size;
+    *out_sec = (int64_t) time_lookup_v;
+    *out_nsec = (int64_t) (long) (time_frac * 1000000000);
+    return last_pos;
+}
+
+/* ------------------------------------------------------------------ record accessor (subset) */
+struct ra_sub { int is_index; int index; char *str; int len; };
+typedef struct ora {
+    char *key; int key_len;       /* NULL key => never matches ($TAG, $0.. forms) */
+    struct ra_sub *subs; int nsubs;
+} ora;
+
+/* grammar: src/record_accessor/ra.l:54-67, ra.y:60-99 */
+static ora *ora_create(const char *pat)
+{
+    ora *ra = calloc(1, sizeof(*ra));
+    const char *p = pat, *q;
+    if (*p != '$') { free(ra); return NULL; }
+    p++;
+    if (!((*p >= 'A' && *p <= 'Z') || (*p >= 'a' && *p <= 'z') || *p == '_')) { free(ra); return NULL; }
+    q = p;
+    while ((*q >= 'A' && *q <= 'Z') || (*q >= 'a' && *q <= 'z') || (*q >= '0' && *q <= '9') || *q == '_'
+           || *q == '.' || *q == '-' || *q == '/') q++;
+    ra->key = strndup(p, q - p);
+    ra->key_len = (int) (q - p);
+    p = q;
+    while (*p == '[') {
+        struct ra_sub s;
+        memset(&s, 0, sizeof(s));
+        p++;
+        if (*p == '\'') {
+            char *o;
+            p++;
+            s.str = malloc(strlen(p) + 1);
+            o = s.str;
+            for (;;) {
+                if (*p == '\0') goto bad;
+                if (*p == '\'') {
+                    if (p[1] == '\'') { *o++ = '\''; p += 2; continue; }
+                    p++;
+                    break;
+                }
+                *o++ = *p++;
+            }
+            *o = 0;
+            s.len = (int) (o - s.str);
+        }
+        else if (*p >= '0' && *p <= '9') {
+            s.is_index = 1;
+            s.index = atoi(p);
+            while (*p >= '0' && *p <= '9') p++;
+        }
+        else goto bad;
+        if (*p != ']') { free(s.str); goto bad; }
+        p++;
+        ra->subs = realloc(ra->subs, sizeof(s) * (ra->nsubs + 1));
+        ra->subs[ra->nsubs++] = s;
+    }
+    if (*p != '\0') goto bad;
+    return ra;
+bad:
+    free(ra->key); free(ra->subs); free(ra);
+    return NULL;
+}
+
+static void ora_destroy(ora *ra)
+{
+    int i;
+    if (!ra) return;
+    for (i = 0; i < ra->nsubs; i++) free(ra->subs[i].str);
+    free(ra->subs); free(ra->key); free(ra);
+}
+
+/* src/flb_ra_key.c:108-135: scans the map BACKWARDS, STR keys only */
+static int ra_key_val_id(const char *ckey, int klen, const omp_obj *map)
+{
+    int i;
+    if (map->type != OMP_MAP) return -1;
+    for (i = (int) map->via.map.size - 1; i >= 0; i--) {
+        const omp_obj *key = &map->via.map.ptr[i].key;
+        if (key->type != OMP_STR) continue;
+        if ((int) key->via.str.size != klen || memcmp(key->via.str.ptr, ckey, klen) != 0) continue;
+        return i;
+    }
+    return -1;
+}
+
+/* src/flb_ra_key.c:151-236 */
+static int subkey_to_object(const omp_obj *map, const ora *ra, const omp_obj **out_val)
+{
+    int i, levels = ra->nsubs, matched = 0, s;
+    const omp_obj *val = NULL;
+    omp_obj cur;
+    if (levels == 0) return -1;
+    cur = *map;
+    for (s = 0; s < ra->nsubs; s++) {
+        const struct ra_sub *e = &ra->subs[s];
+        if (e->is_index) {
+            if (cur.type != OMP_ARRAY) return -1;
+            if (e->index == INT_MAX || (uint32_t) e->index >= cur.via.array.size) return -1;
+            val = &cur.via.array.ptr[e->index];
+            cur = *val;
+            matched++;
+            if (levels == matched) break;
+            continue;
+        }
+        if (cur.type != OMP_MAP) break;
+        i = ra_key_val_id(e->str, e->len, &cur);
+        if (i == -1) continue;
+        val = &cur.via.map.ptr[i].val;
+        cur = *val;
+        matched++;
+        if (levels == matched) break;
+    }
+    if (matched == 0 || (matched > 0 && levels != matched)) return -1;
+    *out_val = val;
+    return 0;
+}
+
+/* src/flb_ra_key.c:374-434 with result == NULL, via src/flb_record_accessor.c:753-765 */
+static int ra_regex_match(const ora *ra, const omp_obj *map, oflb_regex *regex)
+{
+    int i;
+    const omp_obj *val, *out_val;
+    if (ra->key == NULL) return -1;
+    i = ra_key_val_id(ra->key, ra->key_len, map);
+    if (i == -1) return -1;
+    val = &map->via.map.ptr[i].val;
+    if ((val->type == OMP_MAP || val->type == OMP_ARRAY) && ra->nsubs > 0) {
+        if (subkey_to_object(val, ra, &out_val) == 0) {
+            if (out_val->type != OMP_STR) return -1;
+            return oflb_regex_match(regex, out_val->via.str.ptr, out_val->via.str.size);
+        }
+        return -1;
+    }
+    if (val->type != OMP_STR) return -1;
+    return oflb_regex_match(regex, val->via.str.ptr, val->via.str.size);
+}
+
+/* flb_ra_get_value_object for the filter_parser '$key' form (src/flb_record_accessor.c:803-814,
+ * src/flb_ra_key.c:238-300): value of key (+subkeys) or NULL */
+static const omp_obj *ra_get_value(const ora *ra, const omp_obj *map)
+{
+    int i;
+    const omp_obj *val, *out_val;
+    if (ra->key == NULL) return NULL;
+    i = ra_key_val_id(ra->key, ra->key_len, map);
+    if (i == -1) return NULL;
+    val = &map->via.map.ptr[i].val;
+    if ((val->type == OMP_MAP || val->type == OMP_ARRAY) && ra->nsubs > 0) {
+        if (subkey_to_object(val, ra, &out_val) == 0) return out_val;
+        return NULL;
+    }
+    return val;
+}
+
+/* ------------------------------------------------------------------ filter_grep */
+enum { GREP_REGEX = 1, GREP_EXCLUDE = 2 };
+enum { OP_LEGACY = 0, OP_OR = 1, OP_AND = 2 };
+
+struct grep_rule { int type; ora *ra; oflb_regex *regex; };
+typedef struct oflb_grep { int logical_op; struct grep_rule *rules; int nrules; } oflb_grep;
+
+void oflb_grep_destroy(oflb_grep *g)
+{
+    int i;
+    if (!g) return;
+    for (i = 0; i < g->nrules; i++) { ora_destroy(g->rules[i].ra); oflb_regex_destroy(g->rules[i].regex); }
+    free(g->rules); free(g);
+}
+
+/* plugins/filter_grep/grep.c:56-164 set_rules + :196-248 cb_grep_init.
+ * kinds[i] is the property key ("regex"/"exclude", case-insensitive), vals[i] "<key> <regex>" */
+oflb_grep *oflb_grep_create(int n, const char **kinds, const char **vals, const char *logical_op)
+{
+    oflb_grep *g = calloc(1, sizeof(*g));
+    int i, first_rule = 0;
+    g->logical_op = OP_LEGACY;
+    if (logical_op) {
+        size_t len = strlen(logical_op);
+        if (len == 3 && strncasecmp("AND", logical_op, 3) == 0) g->logical_op = OP_AND;
+        else if (len == 2 && strncasecmp("OR", logical_op, 2) == 0) g->logical_op = OP_OR;
+    }
+    g->rules = calloc(n ? n : 1, sizeof(struct grep_rule));
+    for (i = 0; i < n; i++) {
+        struct grep_rule *r = &g->rules[g->nrules];
+        const char *v = vals[i], *sp;
+        char *field, *rafield;
+        int flen;
+        if (strcasecmp(kinds[i], "regex") == 0) r->type = GREP_REGEX;
+        else if (strcasecmp(kinds[i], "exclude") == 0) r->type = GREP_EXCLUDE;
+        else continue;
+        if (g->logical_op != OP_LEGACY && first_rule != 0 && first_rule != r->type) goto fail;
+        first_rule = r->type;
+        /* flb_utils_split(val, ' ', 1): src/flb_utils.c:386-462 */
+        while (*v == ' ') v++;
+        sp = strchr(v, ' ');
+        if (!sp || sp == v || sp[1] == '\0') goto fail;      /* need exactly 2 tokens */
+        flen = (int) (sp - v);
+        field = strndup(v, flen);
+        if (field[0] == '$') rafield = strdup(field);
+        else { rafield = malloc(flen + 2); rafield[0] = '$'; memcpy(rafield + 1, field, flen + 1); }
+        free(field);
+        r->ra = ora_create(rafield);
+        free(rafield);
+        if (!r->ra) goto fail;
+        r->regex = oflb_regex_create(sp + 1);
+        if (!r->regex) { ora_destroy(r->ra); r->ra = NULL; goto fail; }
+        g->nrules++;
+    }
+    return g;
+fail:
+    oflb_grep_destroy(g);
+    return NULL;
+}
+
+#define GREP_RET_KEEP 0
+#define GREP_RET_EXCLUDE 1
+
+/* plugins/filter_grep/grep.c:167-194 */
+static int grep_filter_data(const omp_obj *map, oflb_grep *ctx)
+{
+    int i;
+    for (i = 0; i < ctx->nrules; i++) {
+        struct grep_rule *rule = &ctx->rules[i];
+        int ret = ra_regex_match(rule->ra, map, rule->regex);
+        if (ret <= 0) {
+            if (rule->type == GREP_REGEX) return GREP_RET_EXCLUDE;
+        }
+        else {
+            if (rule->type == GREP_EXCLUDE) return GREP_RET_EXCLUDE;
+            return GREP_RET_KEEP;
+        }
+    }
+    return GREP_RET_KEEP;
+}
+
+/* plugins/filter_grep/grep.c:250-284 */
+static int grep_filter_data_and_or(const omp_obj *map, oflb_grep *ctx)
+{
+    int i, found = 0;
+    struct grep_rule *rule = NULL;
+    for (i = 0; i < ctx->nrules; i++) {
+        int ra_ret;
+        found = 0;
+        rule = &ctx->rules[i];
+        ra_ret = ra_regex_match(rule->ra, map, rule->regex);
+        if (ra_ret > 0) found = 1;
+        if (ctx->logical_op == OP_OR && found) break;
+        if (ctx->logical_op == OP_AND && !found) break;
+    }
+    if (rule == NULL) return GREP_RET_KEEP;     /* no rules: the reference would deref an
+                                                   uninitialised pointer; not reachable via config */
+    if (rule->type == GREP_REGEX) return found ? GREP_RET_KEEP : GREP_RET_EXCLUDE;
+    return found ? GREP_RET_EXCLUDE : GREP_RET_KEEP;
+}
+
+/* plugins/filter_grep/grep.c:286-392.  *out malloc'd on MODIFIED. */
+int oflb_grep_filter(oflb_grep *ctx, const char *data, size_t bytes, char **out, size_t *out_size)
+{
+    oev_decoder dec;
+    oev_event ev;
+    omp_buf enc;
+    int ret, old_size = 0, new_size = 0;
+    oev_decoder_init(&dec, data, bytes);
+    omp_buf_init(&enc);
+    while ((ret = oev_decoder_next(&dec, &ev)) == OEV_SUCCESS) {
+        old_size++;
+        if (ctx->logical_op == OP_LEGACY) ret = grep_filter_data(ev.body, ctx);
+        else ret = grep_filter_data_and_or(ev.body, ctx);
+        if (ret == GREP_RET_KEEP) {
+            omp_buf_write(&enc, ev.record_base, ev.record_length);
+            new_size++;
+        }
+    }
+    if (ret == OEV_ERR_INSUFFICIENT_DATA && dec.off == bytes) ret = 0;
+    oev_decoder_destroy(&dec);
+    if (old_size == new_size) { omp_buf_free(&enc); return FLB_FILTER_NOTOUCH; }
+    if (ret == 0) {
+        *out = enc.data;
+        *out_size = enc.size;
+        return FLB_FILTER_MODIFIED;
+    }
+    omp_buf_free(&enc);
+    return FLB_FILTER_NOTOUCH;
+}
+
+/* ------------------------------------------------------------------ filter_parser */
+typedef struct oflb_fparser {
+    char *key_name; int key_name_len;
+    ora *ra_key;
+    int reserve_data, preserve_key;
+    oflb_parser **parsers; int nparsers;
+} oflb_fparser;
+
+/* plugins/filter_parser/filter_parser.c:96-149; parsers are borrowed */
+oflb_fparser *oflb_fparser_create(const char *key_name, int reserve_data, int preserve_key,
+                                  int nparsers, oflb_parser **parsers)
+{
+    oflb_fparser *f;
+    if (!key_name || nparsers == 0) return NULL;
+    f = calloc(1, sizeof(*f));
+    f->key_name = strdup(key_name);
+    f->key_name_len = (int) strlen(key_name);
+    f->reserve_data = reserve_data;
+    f->preserve_key = preserve_key;
+    if (key_name[0] == '$') {
+        f->ra_key = ora_create(key_name);
+        if (!f->ra_key) { free(f->key_name); free(f); return NULL; }
+    }
+    f->parsers = malloc(sizeof(*parsers) * nparsers);
+    memcpy(f->parsers, parsers, sizeof(*parsers) * nparsers);
+    f->nparsers = nparsers;
+    return f;
+}
+
+void oflb_fparser_destroy(oflb_fparser *f)
+{
+    if (!f) return;
+    ora_destroy(f->ra_key); free(f->key_name); free(f->parsers); free(f);
+}
+
+static int obj2char(const omp_obj *o, const char **s, int *n)
+{
+    if (o->type == OMP_STR || o->type == OMP_BIN) { *s = o->via.str.ptr; *n = (int) o->via.str.size; return 0; }
+    return -1;
+}
+
+/* flb_time_is_valid_eventtime: include/fluent-bit/flb_time.h:88-97 */
+static int valid_eventtime(const oev_time *t)
+{
+    if (t->sec < 0 || (uint64_t) t->sec > 0xffffffffULL || t->nsec < 0 || t->nsec >= 1000000000L) return 0;
+    return 1;
+}
+
+/* plugins/filter_parser/filter_parser.c:174-442 */
+int oflb_fparser_filter(oflb_fparser *ctx, const char *data, size_t bytes, char **out, size_t *out_size)
+{
+    oev_decoder dec;
+    oev_event ev;
+    omp_buf enc;
+    int ret, parse_ret = -1;
+    omp_arena tmp_arena;
+
+    oev_decoder_init(&dec, data, bytes);
+    omp_buf_init(&enc);
+    omp_arena_init(&tmp_arena);
+
+    while ((ret = oev_decoder_next(&dec, &ev)) == OEV_SUCCESS) {
+        char *out_buf = NULL;
+        size_t out_sz = 0;
+        oev_time tm = ev.ts;
+        const omp_obj *obj = ev.body;
+        int map_num = (int) obj->via.map.size, i, p;
+        const omp_kv **append_arr = NULL;
+        size_t append_arr_len;
+        int encoder_ok = 1;
+        const char *val_str; int val_len;
+        const char *key_str; int key_len;
+
+        append_arr_len = ctx->reserve_data ? (size_t) map_num : 0;
+        if (ctx->preserve_key && !ctx->reserve_data) append_arr_len = 1;
+        if (append_arr_len > 0) {
+            append_arr = calloc(append_arr_len, sizeof(*append_arr));
+            if (ctx->reserve_data) for (i = 0; i < map_num; i++) append_arr[i] = &obj->via.map.ptr[i];
+        }
+
+        if (ctx->ra_key) {
+            const omp_obj *rval = ra_get_value(ctx->ra_key, obj);
+            if (rval && obj2char(rval, &val_str, &val_len) == 0) {
+                for (p = 0; p < ctx->nparsers; p++) {
+                    int64_t ps = 0, pn = 0;
+                    char *ob = NULL; size_t os = 0;
+                    parse_ret = oflb_parser_do(ctx->parsers[p], val_str, val_len, &ob, &os, &ps, &pn);
+                    if (parse_ret >= 0) {
+                        free(out_buf);           /* (the reference leaks here; bytes are the same) */
+                        out_buf = ob; out_sz = os;
+                        if ((uint64_t) ps * 1000000000ULL + (uint64_t) pn != 0) { tm.sec = ps; tm.nsec = pn; }
+                        break;
+                    }
+                }
+            }
+        }
+        else {
+            for (i = 0; i < map_num; i++) {
+                const omp_kv *kv = &obj->via.map.ptr[i];
+                if (obj2char(&kv->key, &key_str, &key_len) < 0) continue;
+                if (key_len == ctx->key_name_len && !strncmp(key_str, ctx->key_name, key_len)) {
+                    if (obj2char(&kv->val, &val_str, &val_len) < 0) continue;
+                    for (p = 0; p < ctx->nparsers; p++) {
+                        int64_t ps = 0, pn = 0;
+                        char *ob = NULL; size_t os = 0;
+                        parse_ret = oflb_parser_do(ctx->parsers[p], val_str, val_len, &ob, &os, &ps, &pn);
+                        if (parse_ret >= 0) {
+                            free(out_buf);
+                            out_buf = ob; out_sz = os;
+                            if ((uint64_t) ps * 1000000000ULL + (uint64_t) pn != 0) { tm.sec = ps; tm.nsec = pn; }
+                            if (append_arr != NULL) {
+                                if (!ctx->preserve_key) append_arr[i] = NULL;
+                                else if (!ctx->reserve_data) append_arr[0] = kv;
+                            }
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+
+        /* encoder: begin_record / set_timestamp / set_metadata_from_msgpack_object */
+        if (!valid_eventtime(&tm)) encoder_ok = 0;   /* src/flb_log_event_encoder.c:345-363 */
+
+        if (out_buf != NULL && parse_ret >= 0) {
+            if (append_arr != NULL && append_arr_len > 0) {
+                size_t valid = 0, j;
+                for (j = 0; j < append_arr_len; j++) if (append_arr[j] != NULL) valid++;
+                if (valid > 0) {
+                    /* flb_msgpack_expand_map: src/flb_pack.c:1664-1738 */
+                    omp_obj m;
+                    size_t off = 0;
+                    omp_buf nb;
+                    uint32_t q;
+                    omp_arena_reset(&tmp_arena);
+                    if (omp_unpack_next(&tmp_arena, &m, out_buf, out_sz, &off) != OMP_UNPACK_SUCCESS || m.type != OMP_MAP) {
+                        free(out_buf); free(append_arr);
+                        oev_decoder_destroy(&dec); omp_buf_free(&enc); omp_arena_free(&tmp_arena);
+                        return FLB_FILTER_NOTOUCH;
+                    }
+                    omp_buf_init(&nb);
+                    omp_pack_map(&nb, m.via.map.size + valid);
+                    for (q = 0; q < m.via.map.size; q++) {
+                        omp_pack_object(&nb, &m.via.map.ptr[q].key);
+                        omp_pack_object(&nb, &m.via.map.ptr[q].val);
+                    }
+                    for (j = 0; j < append_arr_len; j++) {
+                        if (append_arr[j] == NULL) continue;
+                        omp_pack_object(&nb, &append_arr[j]->key);
+                        omp_pack_object(&nb, &append_arr[j]->val);
+                    }
+                    free(out_buf);
+                    out_buf = nb.data; out_sz = nb.size;
+                }
+            }
+            if (encoder_ok) {
+                /* emit_record direct path: src/flb_log_event_encoder.c:195-217 */
+                unsigned char hdr[12];
+                uint32_t s = (uint32_t) tm.sec, ns = (uint32_t) tm.nsec;
+                hdr[0] = 0x92; hdr[1] = 0x92; hdr[2] = 0xd7; hdr[3] = 0x00;
+                hdr[4] = s >> 24; hdr[5] = s >> 16; hdr[6] = s >> 8; hdr[7] = s;
+                hdr[8] = ns >> 24; hdr[9] = ns >> 16; hdr[10] = ns >> 8; hdr[11] = ns;
+                omp_buf_write(&enc, hdr, 12);
+                omp_pack_object(&enc, ev.metadata);
+                omp_buf_write(&enc, out_buf, out_sz);
+            }
+            free(out_buf);
+        }
+        else {
+            free(out_buf);     /* reference leaks when a later duplicate key fails after a success */
+            if (encoder_ok) {
+                unsigned char hdr[12];
+                uint32_t s = (uint32_t) tm.sec, ns = (uint32_t) tm.nsec;
+                hdr[0] = 0x92; hdr[1] = 0x92; hdr[2] = 0xd7; hdr[3] = 0x00;
+                hdr[4] = s >> 24; hdr[5] = s >> 16; hdr[6] = s >> 8; hdr[7] = s;
+                hdr[8] = ns >> 24; hdr[9] = ns >> 16; hdr[10] = ns >> 8; hdr[11] = ns;
+                omp_buf_write(&enc, hdr, 12);
+                omp_pack_object(&enc, ev.metadata);
+                omp_pack_object(&enc, ev.body);
+            }
+        }
+        free(append_arr);
+    }
+
+    oev_decoder_destroy(&dec);
+    omp_arena_free(&tmp_arena);
+    if (enc.size > 0) {
+        *out = enc.data;
+        *out_size = enc.size;
+        return FLB_FILTER_MODIFIED;
+    }
+    omp_buf_free(&enc);
+    return FLB_FILTER_NOTOUCH;
+}
+
+/* ------------------------------------------------------------------ helpers for tests/bench */
+void oflb_free(void *p) { free(p); }
+
+int oflb_count_records(const char *data, size_t bytes) { return oev_count_records(data, bytes); }
+
+/* canonical re-pack of one object (msgpack_pack_object) -- used by parity tests */
+int oflb_repack(const char *data, size_t bytes, char **out, size_t *out_size)
+{
+    omp_arena a;
+    omp_obj o;
+    omp_buf b;
+    size_t off = 0;
+    omp_arena_init(&a);
+    omp_buf_init(&b);
+    while (omp_unpack_next(&a, &o, data, bytes, &off) == OMP_UNPACK_SUCCESS) omp_pack_object(&b, &o);
+    omp_arena_free(&a);
+    *out = b.data; *out_size = b.size;
+    return (int) off;
+}
+
+/* timing loops (clock_gettime(CLOCK_MONOTONIC), as benchmarks/pack_json.c:138-166) */
+double oflb_bench_fparser(oflb_fparser *ctx, const char *data, size_t bytes, int iters, size_t *out_bytes)
+{
+    struct timespec t0, t1;
+    int i;
+    size_t total = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (i = 0; i < iters; i++) {
+        char *o = NULL; size_t os = 0;
+        if (oflb_fparser_filter(ctx, data, bytes, &o, &os) == FLB_FILTER_MODIFIED) { total += os; free(o); }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *out_bytes = total;
+    return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+double oflb_bench_grep(oflb_grep *ctx, const char *data, size_t bytes, int iters, size_t *out_bytes)
+{
+    struct timespec t0, t1;
+    int i;
+    size_t total = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (i = 0; i < iters; i++) {
+        char *o = NULL; size_t os = 0;
+        if (oflb_grep_filter(ctx, data, bytes, &o, &os) == FLB_FILTER_MODIFIED) { total += os; free(o); }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *out_bytes = total;
+    return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+}
+
+/* test hook: flb_parser_time_lookup + flb_parser_tm2time as driven by
+ * tests/internal/parser.c:228-290 (test_parser_time_lookup).  toff_enc < 0 keeps the parser's
+ * own offset, else (toff_enc - 2^20) replaces it for this call. */
+int oflb_time_lookup(oflb_parser *p, const char *s, size_t len, int64_t now, int toff_enc,
+                     int64_t *sec, double *frac)
+{
+    struct otm tm;
+    int saved = p->time_offset, r;
+    memset(&tm, 0, sizeof(tm));
+    if (toff_enc >= 0) p->time_offset = toff_enc - (1 << 20);
+    r = time_lookup(s, len, (time_t) now, p, &tm, frac);
+    p->time_offset = saved;
+    if (r == 0) *sec = (int64_t) tm2time(&tm);
+    return r;
+}

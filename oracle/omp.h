@@ -1,0 +1,123 @@
+/*
+ * oracle/omp.h -- TEST INFRASTRUCTURE ONLY.  CPU restatement (oracle) of the msgpack
+ * object model the reference hot path is written against (lib/msgpack-c) and of the log
+ * event decoder/encoder (src/flb_log_event_decoder.c, src/flb_log_event_encoder.c).
+ *
+ * Nothing in fluent-bit_amd/ may include or link this file: it is the checker, not the product.
+ */
+#ifndef ORACLE_OMP_H
+#define ORACLE_OMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+/* object types: lib/msgpack-c/include/msgpack/object.h:27-43 */
+enum {
+    OMP_NIL = 0, OMP_BOOL = 1, OMP_POS = 2, OMP_NEG = 3, OMP_F64 = 4, OMP_STR = 5,
+    OMP_ARRAY = 6, OMP_MAP = 7, OMP_BIN = 8, OMP_EXT = 9, OMP_F32 = 10
+};
+
+struct omp_kv;
+typedef struct omp_obj {
+    int type;
+    union {
+        int b;
+        uint64_t u64;
+        int64_t i64;
+        double f64;
+        struct { uint32_t size; const char *ptr; } str;          /* str, bin */
+        struct { uint32_t size; const char *ptr; int8_t type; } ext;
+        struct { uint32_t size; struct omp_obj *ptr; } array;
+        struct { uint32_t size; struct omp_kv *ptr; } map;
+    } via;
+} omp_obj;
+
+typedef struct omp_kv { omp_obj key; omp_obj val; } omp_kv;
+
+/* bump arena for object trees */
+typedef struct omp_arena {
+    char *base;
+    size_t cap;
+    size_t used;
+    struct omp_arena_chunk *chunks;
+} omp_arena;
+
+void omp_arena_init(omp_arena *a);
+void omp_arena_reset(omp_arena *a);
+void omp_arena_free(omp_arena *a);
+
+/* unpack results: lib/msgpack-c/include/msgpack/unpack.h msgpack_unpack_return */
+#define OMP_UNPACK_SUCCESS      2
+#define OMP_UNPACK_CONTINUE     0
+#define OMP_UNPACK_PARSE_ERROR (-1)
+
+int omp_unpack_next(omp_arena *a, omp_obj *out, const char *data, size_t len, size_t *off);
+
+/* growable output buffer (msgpack_sbuffer) */
+typedef struct omp_buf {
+    char *data;
+    size_t size;
+    size_t cap;
+} omp_buf;
+
+void omp_buf_init(omp_buf *b);
+void omp_buf_free(omp_buf *b);
+void omp_buf_write(omp_buf *b, const void *p, size_t n);
+
+/* packers: lib/msgpack-c/cmake/pack_template.h.in (smallest-encoding rules) */
+void omp_pack_nil(omp_buf *b);
+void omp_pack_bool(omp_buf *b, int v);
+void omp_pack_uint64(omp_buf *b, uint64_t v);
+void omp_pack_int64(omp_buf *b, int64_t v);
+void omp_pack_float(omp_buf *b, float v);
+void omp_pack_double(omp_buf *b, double v);
+void omp_pack_str(omp_buf *b, size_t n);
+void omp_pack_str_with_body(omp_buf *b, const char *s, size_t n);
+void omp_pack_bin(omp_buf *b, size_t n);
+void omp_pack_ext(omp_buf *b, size_t n, int8_t type);
+void omp_pack_array(omp_buf *b, size_t n);
+void omp_pack_map(omp_buf *b, size_t n);
+void omp_pack_object(omp_buf *b, const omp_obj *o);   /* lib/msgpack-c/src/objectc.c:39-126 */
+
+/* ---- log event decoder: src/flb_log_event_decoder.c ---- */
+/* values: include/fluent-bit/flb_log_event_decoder.h:31-43 */
+#define OEV_SUCCESS                      0
+#define OEV_ERR_WRONG_ROOT_TYPE         (-4)
+#define OEV_ERR_WRONG_ROOT_SIZE         (-5)
+#define OEV_ERR_WRONG_HEADER_TYPE       (-6)
+#define OEV_ERR_WRONG_HEADER_SIZE       (-7)
+#define OEV_ERR_WRONG_TIMESTAMP_TYPE    (-8)
+#define OEV_ERR_WRONG_METADATA_TYPE     (-9)
+#define OEV_ERR_WRONG_BODY_TYPE         (-10)
+#define OEV_ERR_DESERIALIZATION         (-11)
+#define OEV_ERR_INSUFFICIENT_DATA       (-12)
+
+typedef struct oev_time { int64_t sec; int64_t nsec; } oev_time;
+
+typedef struct oev_event {
+    oev_time ts;
+    omp_obj *metadata;      /* NULL => synthetic empty map (legacy format) */
+    omp_obj *body;
+    omp_obj *root;
+    const char *record_base;
+    size_t record_length;
+} oev_event;
+
+typedef struct oev_decoder {
+    const char *buf;
+    size_t len;
+    size_t off;
+    int last_result;
+    omp_arena arena;
+    omp_obj root;
+    omp_obj empty_map;
+} oev_decoder;
+
+void oev_decoder_init(oev_decoder *d, const char *buf, size_t len);
+void oev_decoder_destroy(oev_decoder *d);
+int oev_decoder_next(oev_decoder *d, oev_event *ev);   /* skips group markers (read_groups off) */
+
+/* flb_mp_count_log_records: src/flb_mp.c:49-72 */
+int oev_count_records(const char *buf, size_t len);
+
+#endif

@@ -1,0 +1,111 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes, os
+from ctypes import c_char_p, c_int, c_void_p, c_size_t, c_int64, c_double, POINTER, byref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODIFIED, NOTOUCH = 1, 2
+
+_L = None
+
+def lib():
+    global _L
+    if _L is None:
+        L = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.oflb_parser_create.restype = c_void_p
+        L.oflb_parser_create.argtypes = [c_char_p, c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_char_p]
+        L.oflb_parser_destroy.argtypes = [c_void_p]
+        L.oflb_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t),
+                                     POINTER(c_int64), POINTER(c_int64)]
+        L.oflb_grep_create.restype = c_void_p
+        L.oflb_grep_create.argtypes = [c_int, POINTER(c_char_p), POINTER(c_char_p), c_char_p]
+        L.oflb_grep_destroy.argtypes = [c_void_p]
+        L.oflb_grep_filter.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]
+        L.oflb_fparser_create.restype = c_void_p
+        L.oflb_fparser_create.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]
+        L.oflb_fparser_destroy.argtypes = [c_void_p]
+        L.oflb_fparser_filter.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]
+        L.oflb_free.argtypes = [c_void_p]
+        L.oflb_count_records.argtypes = [c_char_p, c_size_t]
+        L.oflb_repack.argtypes = [c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]
+        L.oflb_bench_fparser.restype = c_double
+        L.oflb_bench_fparser.argtypes = [c_void_p, c_char_p, c_size_t, c_int, POINTER(c_size_t)]
+        L.oflb_bench_grep.restype = c_double
+        L.oflb_bench_grep.argtypes = [c_void_p, c_char_p, c_size_t, c_int, POINTER(c_size_t)]
+        L.oflb_regex_create.restype = c_void_p
+        L.oflb_regex_create.argtypes = [c_char_p]
+        L.oflb_regex_match.argtypes = [c_void_p, c_char_p, c_size_t]
+        L.oflb_time_lookup.argtypes = [c_void_p, c_char_p, c_size_t, c_int64, c_int, POINTER(c_int64), POINTER(c_double)]
+        _L = L
+    return _L
+
+def _take(ptr, size):
+    data = ctypes.string_at(ptr, size.value) if ptr.value else b""
+    if ptr.value:
+        lib().oflb_free(ptr)
+    return data
+
+class Parser:
+    """mirrors flb_parser_create(name, "regex", regex, skip_empty, time_fmt, time_key, time_offset,
+    time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.
+    Defaults are the conf-file defaults (src/flb_parser.c:1277-1304)."""
+    def __init__(self, regex, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
+                 time_strict=True, skip_empty=True, types=None):
+        e = lambda s: s.encode() if isinstance(s, str) else s
+        self.h = lib().oflb_parser_create(e(regex), int(skip_empty), e(time_fmt), e(time_key), e(time_offset),
+                                          int(time_keep), int(time_strict), e(types))
+        if not self.h:
+            raise ValueError("oracle: parser create failed")
+    def do(self, buf):
+        out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()
+        r = lib().oflb_parser_do(self.h, buf, len(buf), byref(out), byref(sz), byref(sec), byref(nsec))
+        if r < 0:
+            return r, None, None
+        return r, _take(out, sz), (sec.value, nsec.value)
+    def time_lookup(self, s, now=0, time_offset=None):
+        sec = c_int64(); frac = c_double()
+        r = lib().oflb_time_lookup(self.h, s, len(s), now, -1 if time_offset is None else time_offset + (1 << 20),
+                                   byref(sec), byref(frac))
+        return r, sec.value, frac.value
+
+class Grep:
+    """rules: list of ("regex"|"exclude", "<key> <pattern>") in config order (plugins/filter_grep/grep.c:56-164)"""
+    def __init__(self, rules, logical_op=None):
+        n = len(rules)
+        kinds = (c_char_p * max(n, 1))(*[k.encode() if isinstance(k, str) else k for k, _ in rules])
+        vals = (c_char_p * max(n, 1))(*[v.encode() if isinstance(v, str) else v for _, v in rules])
+        self.h = lib().oflb_grep_create(n, kinds, vals, logical_op.encode() if logical_op else None)
+        if not self.h:
+            raise ValueError("oracle: grep create failed")
+    def filter(self, data):
+        out = c_void_p(); sz = c_size_t()
+        r = lib().oflb_grep_filter(self.h, data, len(data), byref(out), byref(sz))
+        return r, (_take(out, sz) if r == MODIFIED else None)
+    def bench(self, data, iters):
+        ob = c_size_t()
+        return lib().oflb_bench_grep(self.h, data, len(data), iters, byref(ob)), ob.value
+
+class FilterParser:
+    """mirrors filter_parser's Key_Name / Parser / Reserve_Data / Preserve_Key
+    (plugins/filter_parser/filter_parser.c:460-489)"""
+    def __init__(self, key_name, parsers, reserve_data=False, preserve_key=False):
+        self.parsers = parsers
+        arr = (c_void_p * len(parsers))(*[p.h for p in parsers])
+        k = key_name.encode() if isinstance(key_name, str) else key_name
+        self.h = lib().oflb_fparser_create(k, int(reserve_data), int(preserve_key), len(parsers), arr)
+        if not self.h:
+            raise ValueError("oracle: filter_parser create failed")
+    def filter(self, data):
+        out = c_void_p(); sz = c_size_t()
+        r = lib().oflb_fparser_filter(self.h, data, len(data), byref(out), byref(sz))
+        return r, (_take(out, sz) if r == MODIFIED else None)
+    def bench(self, data, iters):
+        ob = c_size_t()
+        return lib().oflb_bench_fparser(self.h, data, len(data), iters, byref(ob)), ob.value
+
+def count_records(data):
+    return lib().oflb_count_records(data, len(data))
+
+def repack(data):
+    out = c_void_p(); sz = c_size_t()
+    lib().oflb_repack(data, len(data), byref(out), byref(sz))
+    return _take(out, sz)
