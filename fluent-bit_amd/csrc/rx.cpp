@@ -1,0 +1,1175 @@
+// rx.cpp -- regex front-end + table compiler (see rx.hpp).
+//
+// Semantics implemented are those the reference gets from Onigmo 6.2.0 under
+// ONIG_SYNTAX_RUBY / ONIG_ENCODING_UTF8 / ONIG_OPTION_DEFAULT (src/flb_regex.c:142-145):
+//   ^ $ are line anchors, \A \z string anchors, '.' excludes \n unless (?m);
+//   \d \s \w \h and POSIX brackets are ASCII-range (ONIG_OPTION_ASCII_RANGE is forced for Ruby
+//   syntax: lib/onigmo/regcomp.c:5842-5850), their negations contain every non-ASCII code point;
+//   plain groups do not capture once a named group exists (lib/onigmo/regparse.c:971-984);
+//   an empty iteration of an unbounded loop leaves the loop (OP_NULL_CHECK_END, regexec.c).
+// Constructs that need a stack (back-references, look-around, atomic/possessive, absent, calls,
+// conditionals) are rejected: the filter fails to initialise rather than fall back to a CPU path.
+#include "rx.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <unordered_map>
+
+namespace rx {
+namespace {
+
+// ---------------------------------------------------------------- code point sets
+using Range = std::pair<uint32_t, uint32_t>;
+constexpr uint32_t MAXCP = 0x10FFFF;
+
+struct CodeSet {
+    std::vector<Range> r;
+    void add(uint32_t lo, uint32_t hi) { if (lo <= hi) r.emplace_back(lo, hi); }
+    void norm() {
+        std::sort(r.begin(), r.end());
+        std::vector<Range> o;
+        for (auto &x : r) {
+            if (!o.empty() && x.first <= o.back().second + 1) o.back().second = std::max(o.back().second, x.second);
+            else o.push_back(x);
+        }
+        r.swap(o);
+    }
+    void negate() {
+        norm();
+        std::vector<Range> o;
+        uint32_t next = 0;
+        for (auto &x : r) {
+            if (x.first > next) o.emplace_back(next, x.first - 1);
+            next = x.second + 1;
+        }
+        if (next <= MAXCP) o.emplace_back(next, MAXCP);
+        r.swap(o);
+    }
+    void merge(const CodeSet &s) { r.insert(r.end(), s.r.begin(), s.r.end()); }
+    bool has(uint32_t c) const {
+        for (auto &x : r) if (c >= x.first && c <= x.second) return true;
+        return false;
+    }
+    void fold_ascii_case() {
+        size_t n = r.size();
+        for (size_t i = 0; i < n; i++) {
+            uint32_t lo = r[i].first, hi = r[i].second;
+            uint32_t a = std::max<uint32_t>(lo, 'a'), b = std::min<uint32_t>(hi, 'z');
+            if (a <= b) add(a - 32, b - 32);
+            a = std::max<uint32_t>(lo, 'A'); b = std::min<uint32_t>(hi, 'Z');
+            if (a <= b) add(a + 32, b + 32);
+        }
+    }
+};
+
+void add_ctype(CodeSet &s, char t) {
+    switch (t) {
+    case 'd': s.add('0', '9'); break;
+    case 'w': s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); s.add('_', '_'); break;
+    case 's': s.add(9, 13); s.add(' ', ' '); break;
+    case 'h': s.add('0', '9'); s.add('A', 'F'); s.add('a', 'f'); break;
+    }
+}
+
+bool add_posix(CodeSet &s, const std::string &n) {
+    if (n == "alpha") { s.add('A', 'Z'); s.add('a', 'z'); }
+    else if (n == "digit") s.add('0', '9');
+    else if (n == "alnum") { s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); }
+    else if (n == "upper") s.add('A', 'Z');
+    else if (n == "lower") s.add('a', 'z');
+    else if (n == "space") { s.add(9, 13); s.add(' ', ' '); }
+    else if (n == "blank") { s.add(9, 9); s.add(' ', ' '); }
+    else if (n == "cntrl") { s.add(0, 31); s.add(127, 127); }
+    else if (n == "punct") { s.add(33, 47); s.add(58, 64); s.add(91, 96); s.add(123, 126); }
+    else if (n == "graph") s.add(33, 126);
+    else if (n == "print") s.add(32, 126);
+    else if (n == "xdigit") { s.add('0', '9'); s.add('A', 'F'); s.add('a', 'f'); }
+    else if (n == "word") { s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); s.add('_', '_'); }
+    else if (n == "ascii") s.add(0, 127);
+    else return false;
+    return true;
+}
+
+// ---------------------------------------------------------------- AST
+enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB };
+
+struct Ast {
+    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR } t = EMPTY;
+    CodeSet set;
+    std::vector<std::unique_ptr<Ast>> kids;
+    int cap = 0;
+    int min = 0, max = 0;       // max < 0: unbounded
+    bool greedy = true;
+    AnchorKind anchor = A_BOL;
+};
+using AstP = std::unique_ptr<Ast>;
+
+AstP mk(Ast::T t) { AstP a(new Ast); a->t = t; return a; }
+
+struct Syntax {
+    const unsigned char *s, *e, *p;
+    bool has_named = false;
+    int ncap = 0;
+    std::string err;
+    std::vector<std::string> names;
+    std::vector<std::vector<int>> name_groups;
+
+    bool fail(const char *m) { if (err.empty()) { err = m; err += " (offset " + std::to_string(p - s) + ")"; } return false; }
+    bool failed() const { return !err.empty(); }
+    bool eof() const { return p >= e; }
+
+    uint32_t take_cp() {
+        uint32_t c = *p++;
+        int n = 0;
+        if (c < 0x80) return c;
+        if (c >= 0xc2 && c <= 0xdf) { n = 1; c &= 0x1f; }
+        else if (c >= 0xe0 && c <= 0xef) { n = 2; c &= 0x0f; }
+        else if (c >= 0xf0 && c <= 0xf4) { n = 3; c &= 0x07; }
+        else { fail("invalid UTF-8 in pattern"); return 0xfffd; }
+        while (n-- > 0) {
+            if (eof() || (*p & 0xc0) != 0x80) { fail("invalid UTF-8 in pattern"); return 0xfffd; }
+            c = (c << 6) | (*p++ & 0x3f);
+        }
+        return c;
+    }
+
+    static int hexv(int c) {
+        if (c >= '0' && c <= '9') return c - '0';
+        if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+        if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+        return -1;
+    }
+
+    // after the backslash: escapes denoting one code point
+    bool escape_cp(uint32_t &out, bool in_class) {
+        int c = *p;
+        switch (c) {
+        case 't': p++; out = 9; return true;
+        case 'n': p++; out = 10; return true;
+        case 'r': p++; out = 13; return true;
+        case 'f': p++; out = 12; return true;
+        case 'v': p++; out = 11; return true;
+        case 'a': p++; out = 7; return true;
+        case 'e': p++; out = 27; return true;
+        case 'x': {
+            uint32_t v = 0; int n = 0;
+            p++;
+            if (!eof() && *p == '{') {
+                p++;
+                while (!eof() && hexv(*p) >= 0 && n < 8) { v = v * 16 + hexv(*p++); n++; }
+                if (eof() || *p != '}' || n == 0) { fail("bad \\x{...}"); return true; }
+                p++;
+            } else {
+                while (!eof() && hexv(*p) >= 0 && n < 2) { v = v * 16 + hexv(*p++); n++; }
+                if (n == 0) { fail("bad \\x"); return true; }
+                if (v >= 0x80) { fail("raw byte escapes >= 0x80 are not supported"); return true; }
+            }
+            out = v; return true;
+        }
+        case 'u': {
+            uint32_t v = 0; int n = 0;
+            p++;
+            while (!eof() && hexv(*p) >= 0 && n < 4) { v = v * 16 + hexv(*p++); n++; }
+            if (n != 4) { fail("bad \\u"); return true; }
+            out = v; return true;
+        }
+        case '0': {
+            uint32_t v = 0; int n = 0;
+            while (!eof() && *p >= '0' && *p <= '7' && n < 3) { v = v * 8 + (*p++ - '0'); n++; }
+            if (v >= 0x80) { fail("raw byte escapes >= 0x80 are not supported"); return true; }
+            out = v; return true;
+        }
+        case 'c': case 'C': case 'M':
+            fail("control/meta escapes are not supported"); return true;
+        }
+        if (in_class && c == 'b') { p++; out = 8; return true; }
+        return false;
+    }
+
+    void skip_extended(unsigned opts) {
+        if (!(opts & OPT_EXTEND)) return;
+        while (!eof()) {
+            int c = *p;
+            if (c == ' ' || (c >= 9 && c <= 13)) p++;
+            else if (c == '#') { while (!eof() && *p != '\n') p++; }
+            else break;
+        }
+    }
+
+    void note_name(const std::string &n, int group) {
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == n) { name_groups[i].push_back(group); return; }
+        names.push_back(n);
+        name_groups.push_back({group});
+    }
+
+    // '[' already consumed
+    bool char_class(CodeSet &out, unsigned opts) {
+        bool neg = false, first = true;
+        CodeSet s;
+        if (!eof() && *p == '^') { neg = true; p++; }
+        for (;;) {
+            uint32_t lo = 0, hi;
+            bool have = false;
+            if (eof()) return fail("premature end of char-class");
+            if (*p == ']') {
+                if (!first) { p++; break; }
+                p++; lo = ']'; have = true;
+            }
+            first = false;
+            if (!have) {
+                if (*p == '[') {
+                    if (p + 1 < e && p[1] == ':') {
+                        const unsigned char *q = p + 2;
+                        bool pneg = false;
+                        if (q < e && *q == '^') { pneg = true; q++; }
+                        const unsigned char *nm = q;
+                        while (q < e && *q >= 'a' && *q <= 'z') q++;
+                        if (q + 1 < e && q[0] == ':' && q[1] == ']') {
+                            CodeSet t;
+                            if (!add_posix(t, std::string((const char *) nm, q - nm))) return fail("unknown POSIX bracket");
+                            t.norm();
+                            if (pneg) t.negate();
+                            s.merge(t);
+                            p = q + 2;
+                            continue;
+                        }
+                    }
+                    p++;
+                    CodeSet t;
+                    if (!char_class(t, opts)) return false;
+                    s.merge(t);
+                    continue;
+                }
+                if (*p == '&' && p + 1 < e && p[1] == '&') return fail("class intersection (&&) is not supported");
+                if (*p == '\\') {
+                    p++;
+                    if (eof()) return fail("end pattern at escape");
+                    int c = *p;
+                    if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c); continue; }
+                    if (c == 'D' || c == 'W' || c == 'S' || c == 'H') {
+                        CodeSet t;
+                        p++;
+                        add_ctype(t, (char) (c + 32));
+                        t.negate();
+                        s.merge(t);
+                        continue;
+                    }
+                    if (c == 'p' || c == 'P' || c == 'R' || c == 'X') return fail("property escapes are not supported");
+                    if (escape_cp(lo, true)) { if (failed()) return false; }
+                    else if (c >= '1' && c <= '7') {
+                        uint32_t v = 0; int n = 0;
+                        while (!eof() && *p >= '0' && *p <= '7' && n < 3) { v = v * 8 + (*p++ - '0'); n++; }
+                        if (v >= 0x80) return fail("raw byte escapes >= 0x80 are not supported");
+                        lo = v;
+                    }
+                    else lo = take_cp();
+                }
+                else lo = take_cp();
+                if (failed()) return false;
+            }
+            hi = lo;
+            if (p + 1 < e && p[0] == '-' && p[1] != ']') {
+                const unsigned char *save = p;
+                p++;
+                if (*p == '[') p = save;
+                else if (*p == '\\') {
+                    p++;
+                    if (eof()) return fail("end pattern at escape");
+                    if (strchr("dwshDWSHpP", *p)) p = save;
+                    else if (escape_cp(hi, true)) { if (failed()) return false; }
+                    else hi = take_cp();
+                }
+                else hi = take_cp();
+                if (failed()) return false;
+                if (hi < lo) return fail("empty range in char class");
+            }
+            s.add(lo, hi);
+        }
+        if (opts & OPT_IGNORECASE) s.fold_ascii_case();
+        s.norm();
+        if (neg) s.negate();
+        out.merge(s);
+        return true;
+    }
+
+    AstP literal(uint32_t c, unsigned opts) {
+        AstP a = mk(Ast::SET);
+        if ((opts & OPT_IGNORECASE) && c >= 0x80) { fail("case-insensitive non-ASCII literals are not supported"); return a; }
+        a->set.add(c, c);
+        if (opts & OPT_IGNORECASE) a->set.fold_ascii_case();
+        a->set.norm();
+        return a;
+    }
+
+    int number() {
+        long v = 0; int n = 0;
+        while (!eof() && *p >= '0' && *p <= '9') { v = v * 10 + (*p++ - '0'); n++; if (v > 100000) v = 100001; }
+        return n ? (int) v : -1;
+    }
+
+    AstP alternation(unsigned opts, int depth);
+
+    AstP atom(unsigned &opts, int depth, bool &is_group_tail) {
+        is_group_tail = false;
+        skip_extended(opts);
+        if (eof()) return nullptr;
+        int c = *p;
+        if (c == '|' || c == ')') return nullptr;
+        if (c == '(') {
+            p++;
+            if (depth > 100) { fail("nesting too deep"); return nullptr; }
+            AstP g = mk(Ast::GROUP);
+            if (!eof() && *p == '?') {
+                p++;
+                if (eof()) { fail("end pattern in group"); return nullptr; }
+                c = *p;
+                if (c == '#') {
+                    while (!eof() && *p != ')') p++;
+                    if (eof()) { fail("end pattern in group"); return nullptr; }
+                    p++;
+                    return mk(Ast::EMPTY);
+                }
+                if (c == ':') { p++; g->kids.push_back(alternation(opts, depth + 1)); }
+                else if (c == '=' || c == '!') { fail("look-ahead is not supported on the GPU path"); return nullptr; }
+                else if (c == '>') { fail("atomic groups are not supported on the GPU path"); return nullptr; }
+                else if (c == '<' || c == '\'') {
+                    int term = c == '<' ? '>' : '\'';
+                    if (c == '<' && p + 1 < e && (p[1] == '=' || p[1] == '!')) { fail("look-behind is not supported on the GPU path"); return nullptr; }
+                    p++;
+                    const unsigned char *nm = p;
+                    while (!eof() && *p != term) {
+                        int ch = *p;
+                        if (!((ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '_' || ch >= 0x80)) { fail("invalid group name"); return nullptr; }
+                        p++;
+                    }
+                    if (eof() || p == nm || (*nm >= '0' && *nm <= '9')) { fail("invalid group name"); return nullptr; }
+                    g->cap = ++ncap;
+                    note_name(std::string((const char *) nm, p - nm), g->cap);
+                    p++;
+                    g->kids.push_back(alternation(opts, depth + 1));
+                }
+                else if (c == '~' || c == '(' || c == '&' || c == 'P') { fail("unsupported group construct"); return nullptr; }
+                else {
+                    unsigned o = opts;
+                    bool on = true;
+                    for (;;) {
+                        if (eof()) { fail("end pattern in group"); return nullptr; }
+                        c = *p;
+                        if (c == 'i') { if (on) o |= OPT_IGNORECASE; else o &= ~OPT_IGNORECASE; }
+                        else if (c == 'm') { if (on) o |= OPT_MULTILINE; else o &= ~OPT_MULTILINE; }
+                        else if (c == 'x') { if (on) o |= OPT_EXTEND; else o &= ~OPT_EXTEND; }
+                        else if (c == '-') on = false;
+                        else if (c == ')' || c == ':') break;
+                        else { fail("undefined group option"); return nullptr; }
+                        p++;
+                    }
+                    p++;
+                    if (c == ')') {
+                        // isolated option: the REST of the enclosing group, alternation included,
+                        // becomes the body (lib/onigmo/regparse.c parse_exp "option only")
+                        g->kids.push_back(alternation(o, depth + 1));
+                        is_group_tail = true;
+                        return g;
+                    }
+                    g->kids.push_back(alternation(o, depth + 1));
+                }
+            }
+            else {
+                if (!has_named) g->cap = ++ncap;
+                g->kids.push_back(alternation(opts, depth + 1));
+            }
+            if (failed()) return nullptr;
+            if (eof() || *p != ')') { fail("end pattern with unmatched parenthesis"); return nullptr; }
+            p++;
+            return g;
+        }
+        if (c == '[') {
+            p++;
+            AstP a = mk(Ast::SET);
+            if (!char_class(a->set, opts)) return nullptr;
+            a->set.norm();
+            return a;
+        }
+        if (c == '.') {
+            p++;
+            AstP a = mk(Ast::SET);
+            if (opts & OPT_MULTILINE) a->set.add(0, MAXCP);
+            else { a->set.add(0, 9); a->set.add(11, MAXCP); }
+            return a;
+        }
+        if (c == '^') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BOL; return a; }
+        if (c == '$') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_EOL; return a; }
+        if (c == '*' || c == '+' || c == '?') { fail("target of repeat operator is not specified"); return nullptr; }
+        if (c == '\\') {
+            p++;
+            if (eof()) { fail("end pattern at escape"); return nullptr; }
+            c = *p;
+            if (strchr("dwshDWSH", c)) {
+                p++;
+                AstP a = mk(Ast::SET);
+                add_ctype(a->set, (char) (c | 32));
+                a->set.norm();
+                if (!(c & 32)) a->set.negate();
+                return a;
+            }
+            if (c == 'A') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BOS; return a; }
+            if (c == 'z') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_EOS; return a; }
+            if (c == 'b') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_WORDB; return a; }
+            if (c == 'B') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_NWORDB; return a; }
+            if (c == 'Z') { fail("\\Z is not supported on the GPU path"); return nullptr; }
+            if (strchr("GKRXkgpP", c)) { fail("unsupported escape"); return nullptr; }
+            if (c >= '1' && c <= '9') { fail("back-references are not supported on the GPU path"); return nullptr; }
+            uint32_t v;
+            if (escape_cp(v, false)) { if (failed()) return nullptr; return literal(v, opts); }
+            v = take_cp();
+            return literal(v, opts);
+        }
+        return literal(take_cp(), opts);
+    }
+
+    AstP piece(unsigned &opts, int depth, bool &tail) {
+        AstP a = atom(opts, depth, tail);
+        if (!a || failed() || tail) return a;
+        for (;;) {
+            skip_extended(opts);
+            if (eof()) break;
+            int c = *p, lo, hi;
+            bool brace = false;
+            const unsigned char *save = p;
+            if (c == '*') { lo = 0; hi = -1; p++; }
+            else if (c == '+') { lo = 1; hi = -1; p++; }
+            else if (c == '?') { lo = 0; hi = 1; p++; }
+            else if (c == '{') {
+                p++;
+                lo = number();
+                if (!eof() && *p == ',') {
+                    p++;
+                    hi = number();
+                    if (lo < 0 && hi < 0) { p = save; break; }
+                    if (lo < 0) lo = 0;
+                }
+                else {
+                    if (lo < 0) { p = save; break; }
+                    hi = lo;
+                }
+                if (eof() || *p != '}') { p = save; break; }
+                p++;
+                if (lo > 100000 || hi > 100000) { fail("too big number for repeat range"); return nullptr; }
+                if (hi >= 0 && lo > hi) { fail("upper is smaller than lower in repeat range"); return nullptr; }
+                brace = true;
+            }
+            else break;
+            if (a->t == Ast::ANCHOR) { fail("target of repeat operator is invalid"); return nullptr; }
+            AstP r = mk(Ast::REPEAT);
+            r->min = lo; r->max = hi;
+            if (!eof() && *p == '?') { p++; r->greedy = false; }
+            else if (!brace && !eof() && *p == '+') { fail("possessive repeats are not supported on the GPU path"); return nullptr; }
+            r->kids.push_back(std::move(a));
+            a = std::move(r);
+        }
+        return a;
+    }
+
+    AstP concat(unsigned &opts, int depth) {
+        AstP cat = mk(Ast::CAT);
+        for (;;) {
+            bool tail = false;
+            AstP r = piece(opts, depth, tail);
+            if (failed()) return cat;
+            if (!r) break;
+            cat->kids.push_back(std::move(r));
+            if (tail) break;
+        }
+        return cat;
+    }
+};
+
+AstP Syntax::alternation(unsigned opts, int depth) {
+    unsigned o = opts;
+    AstP first = concat(o, depth);
+    if (failed() || eof() || *p != '|') return first;
+    AstP alt = mk(Ast::ALT);
+    alt->kids.push_back(std::move(first));
+    while (!eof() && *p == '|') {
+        p++;
+        alt->kids.push_back(concat(o, depth));
+        if (failed()) break;
+    }
+    return alt;
+}
+
+bool scan_named(const unsigned char *s, const unsigned char *e) {
+    int in_class = 0;
+    for (const unsigned char *p = s; p < e;) {
+        if (*p == '\\') { p += 2; continue; }
+        if (in_class) {
+            if (*p == '[') in_class++;
+            else if (*p == ']') in_class--;
+            p++;
+            continue;
+        }
+        if (*p == '[') { in_class = 1; p++; if (p < e && *p == '^') p++; if (p < e && *p == ']') p++; continue; }
+        if (*p == '(' && p + 2 < e && p[1] == '?' &&
+            ((p[2] == '<' && p + 3 < e && p[3] != '=' && p[3] != '!') || p[2] == '\'')) return true;
+        p++;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- byte-level NFA
+struct ByteSet {
+    uint64_t w[4] = {0, 0, 0, 0};
+    void set(int b) { w[b >> 6] |= 1ull << (b & 63); }
+    void set_range(int lo, int hi) { for (int b = lo; b <= hi; b++) set(b); }
+    bool has(int b) const { return (w[b >> 6] >> (b & 63)) & 1; }
+    bool empty() const { return !(w[0] | w[1] | w[2] | w[3]); }
+};
+
+enum NType { N_CONSUME, N_SPLIT, N_ASSERT, N_SAVE, N_MATCH };
+
+struct NNode {
+    NType t;
+    ByteSet set;              // CONSUME
+    int next = -1;            // CONSUME / ASSERT / SAVE
+    std::vector<int> outs;    // SPLIT (priority order)
+    AnchorKind akind = A_BOL; // ASSERT
+    int slot = 0;             // SAVE
+    bool is_loop = false;     // SPLIT heading an unbounded repeat
+    int exit = -1;            // loop: the edge leaving the loop
+    int pos = -1;             // CONSUME: position id
+};
+
+constexpr int MAX_NODES = 6000;
+
+struct Nfa {
+    std::vector<NNode> n;
+    int npos = 0;
+    int start = -1;
+    bool uses_nl = false, uses_word = false;
+    std::string err;
+
+    int add(NNode x) {
+        if ((int) n.size() >= MAX_NODES) { if (err.empty()) err = "pattern too large for the GPU tables"; return 0; }
+        n.push_back(std::move(x));
+        return (int) n.size() - 1;
+    }
+    int consume(const ByteSet &s, int next) {
+        NNode x; x.t = N_CONSUME; x.set = s; x.next = next; x.pos = npos++;
+        return add(std::move(x));
+    }
+    int split(std::vector<int> outs) { NNode x; x.t = N_SPLIT; x.outs = std::move(outs); return add(std::move(x)); }
+};
+
+// UTF-8 encoding of a code point set as alternatives of byte-range sequences
+struct Seq { int n; uint8_t lo[4], hi[4]; };
+
+void utf8_split(uint32_t lo, uint32_t hi, std::vector<Seq> &out) {
+    if (lo > hi) return;
+    static const uint32_t lim[3] = {0x7f, 0x7ff, 0xffff};
+    for (uint32_t l : lim) if (lo <= l && l < hi) { utf8_split(lo, l, out); utf8_split(l + 1, hi, out); return; }
+    if (hi < 0x80) { Seq s; s.n = 1; s.lo[0] = (uint8_t) lo; s.hi[0] = (uint8_t) hi; out.push_back(s); return; }
+    int n = lo < 0x800 ? 2 : lo < 0x10000 ? 3 : 4;
+    for (int i = 1; i < n; i++) {
+        uint32_t m = (1u << (6 * i)) - 1;
+        if ((lo & ~m) != (hi & ~m)) {
+            if ((lo & m) != 0) { utf8_split(lo, lo | m, out); utf8_split((lo | m) + 1, hi, out); return; }
+            if ((hi & m) != m) { utf8_split(lo, (hi & ~m) - 1, out); utf8_split(hi & ~m, hi, out); return; }
+        }
+    }
+    auto enc = [n](uint32_t c, uint8_t *b) {
+        if (n == 2) { b[0] = 0xc0 | (c >> 6); b[1] = 0x80 | (c & 0x3f); }
+        else if (n == 3) { b[0] = 0xe0 | (c >> 12); b[1] = 0x80 | ((c >> 6) & 0x3f); b[2] = 0x80 | (c & 0x3f); }
+        else { b[0] = 0xf0 | (c >> 18); b[1] = 0x80 | ((c >> 12) & 0x3f); b[2] = 0x80 | ((c >> 6) & 0x3f); b[3] = 0x80 | (c & 0x3f); }
+    };
+    Seq s; s.n = n;
+    enc(lo, s.lo); enc(hi, s.hi);
+    out.push_back(s);
+}
+
+struct Builder {
+    Nfa &nfa;
+    bool ascii_only;
+    Builder(Nfa &n, bool ascii) : nfa(n), ascii_only(ascii) {}
+
+    // node matching one character of `set`, continuing at `next`
+    int build_set(const CodeSet &set, int next) {
+        ByteSet ascii;
+        std::vector<Seq> seqs;
+        for (auto &r : set.r) {
+            uint32_t lo = r.first, hi = std::min(r.second, MAXCP);
+            if (lo <= 0x7f) { ascii.set_range((int) lo, (int) std::min<uint32_t>(hi, 0x7f)); lo = 0x80; }
+            if (lo > hi || ascii_only) continue;
+            // surrogates are not encodable
+            if (lo <= 0xd7ff) utf8_split(lo, std::min<uint32_t>(hi, 0xd7ff), seqs);
+            if (hi >= 0xe000) utf8_split(std::max<uint32_t>(lo, 0xe000), hi, seqs);
+        }
+        // bytes that can never start a well-formed sequence are 1-byte characters whose code is
+        // the byte value (Onigmo: mbc_enc_len INVALID => length 1, mbc_to_code => the byte)
+        ByteSet single = ascii;
+        for (int b = 0x80; b <= 0xff; b++) {
+            bool never_lead = (b <= 0xbf) || b == 0xc0 || b == 0xc1 || b >= 0xf5;
+            if (never_lead && !ascii_only && set.has((uint32_t) b)) single.set(b);
+        }
+        std::vector<int> alts;
+        if (!single.empty()) alts.push_back(nfa.consume(single, next));
+        // share continuation chains between sequences with identical tails
+        std::map<std::vector<uint8_t>, int> tails;
+        // group sequences by (tail signature) so leads with the same tail merge into one CONSUME
+        std::map<std::vector<uint8_t>, ByteSet> lead_by_tail;
+        for (auto &s : seqs) {
+            std::vector<uint8_t> sig;
+            for (int i = 1; i < s.n; i++) { sig.push_back(s.lo[i]); sig.push_back(s.hi[i]); }
+            ByteSet &ls = lead_by_tail[sig];
+            ls.set_range(s.lo[0], s.hi[0]);
+        }
+        for (auto &kv : lead_by_tail) {
+            const std::vector<uint8_t> &sig = kv.first;
+            int cont = next;
+            for (int i = (int) sig.size() / 2 - 1; i >= 0; i--) {
+                std::vector<uint8_t> tsig(sig.begin() + 2 * i, sig.end());
+                auto it = tails.find(tsig);
+                if (it != tails.end()) { cont = it->second; }
+                else {
+                    ByteSet bs; bs.set_range(sig[2 * i], sig[2 * i + 1]);
+                    cont = nfa.consume(bs, cont);
+                    tails[tsig] = cont;
+                }
+            }
+            alts.push_back(nfa.consume(kv.second, cont));
+        }
+        if (alts.empty()) {
+            ByteSet none;
+            return nfa.consume(none, next);      // matches nothing
+        }
+        if (alts.size() == 1) return alts[0];
+        return nfa.split(alts);
+    }
+
+    int build(const Ast *a, int next) {
+        if (!nfa.err.empty()) return next;
+        switch (a->t) {
+        case Ast::EMPTY: return next;
+        case Ast::SET: return build_set(a->set, next);
+        case Ast::CAT: {
+            int cur = next;
+            for (int i = (int) a->kids.size() - 1; i >= 0; i--) cur = build(a->kids[i].get(), cur);
+            return cur;
+        }
+        case Ast::ALT: {
+            std::vector<int> outs;
+            for (auto &k : a->kids) outs.push_back(build(k.get(), next));
+            return nfa.split(outs);
+        }
+        case Ast::GROUP: {
+            if (!a->cap) return build(a->kids[0].get(), next);
+            NNode close; close.t = N_SAVE; close.slot = 2 * a->cap + 1; close.next = next;
+            int c = nfa.add(close);
+            int body = build(a->kids[0].get(), c);
+            NNode open; open.t = N_SAVE; open.slot = 2 * a->cap; open.next = body;
+            return nfa.add(open);
+        }
+        case Ast::ANCHOR: {
+            NNode x; x.t = N_ASSERT; x.akind = a->anchor; x.next = next;
+            if (a->anchor == A_BOL || a->anchor == A_EOL) nfa.uses_nl = true;
+            if (a->anchor == A_WORDB || a->anchor == A_NWORDB) nfa.uses_word = true;
+            return nfa.add(x);
+        }
+        case Ast::REPEAT: {
+            const Ast *body = a->kids[0].get();
+            int cur;
+            if (a->max < 0) {
+                // unbounded tail: L = SPLIT(body -> L, exit)
+                NNode l; l.t = N_SPLIT; l.is_loop = true; l.exit = next;
+                int L = nfa.add(l);
+                int b = build(body, L);
+                if (a->greedy) nfa.n[L].outs = {b, next};
+                else nfa.n[L].outs = {next, b};
+                cur = L;
+            }
+            else {
+                cur = next;
+                for (int i = a->min; i < a->max; i++) {
+                    int b = build(body, cur);
+                    cur = a->greedy ? nfa.split({b, next}) : nfa.split({next, b});
+                }
+            }
+            for (int i = 0; i < a->min; i++) cur = build(body, cur);
+            return cur;
+        }
+        }
+        return next;
+    }
+};
+
+// ---------------------------------------------------------------- closure lists
+enum Kind { K_OTHER = 0, K_NL = 1, K_WORD = 2, K_EDGE = 3, NKIND = 4 };
+constexpr int T_MATCH = -1;
+
+struct Target { int pos; int tagseq; };   // pos == T_MATCH for MATCH
+
+struct Tables {
+    const Nfa &nfa;
+    std::vector<int> core_node;                       // core x -> NFA node to start the closure at
+    std::vector<int> pos_node;                        // position -> CONSUME node
+    std::map<std::vector<uint8_t>, int> tag_ids;
+    std::vector<std::vector<uint8_t>> tag_seqs;
+    std::vector<std::vector<Target>> lists;           // [(x * NKIND + pk) * NKIND + nk]
+    std::vector<char> have;
+
+    explicit Tables(const Nfa &n) : nfa(n) {
+        pos_node.resize(nfa.npos);
+        for (size_t i = 0; i < nfa.n.size(); i++) if (nfa.n[i].t == N_CONSUME) pos_node[nfa.n[i].pos] = (int) i;
+        for (int p = 0; p < nfa.npos; p++) core_node.push_back(nfa.n[pos_node[p]].next);
+        core_node.push_back(nfa.start);               // START core
+        lists.resize(core_node.size() * NKIND * NKIND);
+        have.assign(lists.size(), 0);
+        intern({});
+    }
+    int ncores() const { return (int) core_node.size(); }
+    int start_core() const { return (int) core_node.size() - 1; }
+
+    int intern(const std::vector<uint8_t> &t) {
+        auto it = tag_ids.find(t);
+        if (it != tag_ids.end()) return it->second;
+        int id = (int) tag_seqs.size();
+        tag_ids[t] = id;
+        tag_seqs.push_back(t);
+        return id;
+    }
+
+    static bool assert_ok(AnchorKind a, int pk, int nk) {
+        switch (a) {
+        case A_BOL: return pk == K_EDGE || (pk == K_NL && nk != K_EDGE);   // OP_BEGIN_LINE
+        case A_EOL: return nk == K_EDGE || nk == K_NL;                     // OP_END_LINE
+        case A_BOS: return pk == K_EDGE;
+        case A_EOS: return nk == K_EDGE;
+        case A_WORDB: return (pk == K_WORD) != (nk == K_WORD);
+        case A_NWORDB: return (pk == K_WORD) == (nk == K_WORD);
+        }
+        return false;
+    }
+
+    long budget = 0;
+
+    void dfs(int node, int pk, int nk, std::vector<char> &visited, std::vector<char> &onstack,
+             std::vector<uint8_t> &tags, std::vector<Target> &out) {
+        const NNode &nd = nfa.n[node];
+        if (++budget > 4000000) return;
+        if (nd.t == N_SPLIT && nd.is_loop && onstack[node]) {
+            // the loop body matched the empty string: leave the loop (OP_NULL_CHECK_END)
+            dfs(nd.exit, pk, nk, visited, onstack, tags, out);
+            return;
+        }
+        if (visited[node]) return;
+        visited[node] = 1;
+        switch (nd.t) {
+        case N_CONSUME: out.push_back({nd.pos, intern(tags)}); break;
+        case N_MATCH: out.push_back({T_MATCH, intern(tags)}); break;
+        case N_SAVE:
+            tags.push_back((uint8_t) nd.slot);
+            dfs(nd.next, pk, nk, visited, onstack, tags, out);
+            tags.pop_back();
+            break;
+        case N_ASSERT:
+            if (assert_ok(nd.akind, pk, nk)) dfs(nd.next, pk, nk, visited, onstack, tags, out);
+            break;
+        case N_SPLIT:
+            if (!nd.is_loop) {
+                for (int o : nd.outs) dfs(o, pk, nk, visited, onstack, tags, out);
+                break;
+            }
+            onstack[node] = 1;
+            for (int o : nd.outs) {
+                if (o == nd.exit) { dfs(o, pk, nk, visited, onstack, tags, out); continue; }
+                // A new iteration entered at this boundary may legitimately pass through nodes an
+                // earlier (higher-priority) path already visited: a backtracking engine would try
+                // them again with this iteration's captures, and the empty-iteration exit above
+                // makes the outcome path-dependent.  Explore the body with a fresh visited set.
+                std::vector<char> saved = visited;
+                std::fill(visited.begin(), visited.end(), 0);
+                visited[node] = 1;
+                dfs(o, pk, nk, visited, onstack, tags, out);
+                for (size_t i = 0; i < visited.size(); i++) visited[i] |= saved[i];
+            }
+            onstack[node] = 0;
+            break;
+        }
+    }
+
+    const std::vector<Target> &list(int x, int pk, int nk) {
+        size_t idx = ((size_t) x * NKIND + pk) * NKIND + nk;
+        if (!have[idx]) {
+            std::vector<char> visited(nfa.n.size(), 0), onstack(nfa.n.size(), 0);
+            std::vector<uint8_t> tags;
+            std::vector<Target> raw;
+            dfs(core_node[x], pk, nk, visited, onstack, tags, raw);
+            std::vector<char> seen(nfa.npos + 1, 0);
+            for (const Target &t : raw) {           // only the first (highest priority) occurrence
+                int k = t.pos == T_MATCH ? nfa.npos : t.pos;
+                if (seen[k]) continue;
+                seen[k] = 1;
+                lists[idx].push_back(t);
+                if (t.pos == T_MATCH) break;        // nothing after MATCH can ever be chosen
+            }
+            have[idx] = 1;
+        }
+        return lists[idx];
+    }
+};
+
+struct VecHash {
+    size_t operator()(const std::vector<uint64_t> &v) const {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (uint64_t x : v) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; }
+        return (size_t) h;
+    }
+};
+
+inline bool bit(const std::vector<uint64_t> &v, int i) { return (v[i >> 6] >> (i & 63)) & 1; }
+inline void setbit(std::vector<uint64_t> &v, int i) { v[i >> 6] |= 1ull << (i & 63); }
+
+constexpr int MAX_DFA_STATES = 20000;
+
+}  // namespace
+
+// ---------------------------------------------------------------- public: /pat/flags splitting
+void split_flb_pattern(const char *pattern, const char **start, const char **end, unsigned *options) {
+    // src/flb_regex.c:60-152 check_option() + str_to_regex()
+    size_t len = strlen(pattern);
+    const char *s = pattern, *e = pattern + len, *new_end = nullptr;
+    unsigned opt = 0;
+    if (s[0] == '/') {
+        const char *chr = strrchr(s, '/');
+        if (chr && chr != s && chr != e) {
+            bool ok = true;
+            new_end = chr;
+            for (chr++; chr != e && *chr; chr++) {
+                if (*chr == 'm') opt |= OPT_MULTILINE;
+                else if (*chr == 'i') opt |= OPT_IGNORECASE;
+                else if (*chr == 'x') opt |= OPT_EXTEND;
+                else if (*chr == 'o') { }
+                else { ok = false; break; }
+            }
+            if (!ok || opt == 0) { new_end = nullptr; opt = 0; }
+        }
+    }
+    if (len > 1 && pattern[0] == '/' && pattern[len - 1] == '/') { s++; e--; }
+    if (new_end) { s = pattern + 1; e = new_end; }
+    *start = s; *end = e; *options = opt;
+}
+
+// ---------------------------------------------------------------- compile
+namespace {
+
+bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool want_capture, TableSet &out, std::string &err) {
+    Nfa nfa;
+    {
+        NNode m; m.t = N_MATCH;
+        int match = nfa.add(m);
+        NNode close; close.t = N_SAVE; close.slot = 1; close.next = match;     // group 0 end
+        int c = nfa.add(close);
+        Builder b(nfa, ascii_only);
+        nfa.start = b.build(root, c);           // group 0 begin is the start boundary itself
+    }
+    if (!nfa.err.empty()) { err = nfa.err; return false; }
+    if (nfa.npos > 4000) { err = "pattern too large for the GPU tables (positions)"; return false; }
+    out = TableSet();
+    out.ascii_only = ascii_only;
+
+    // ---- context kinds actually distinguished by this pattern
+    bool any_assert = false;
+    for (auto &nd : nfa.n) if (nd.t == N_ASSERT) any_assert = true;
+    int kmap[NKIND];                         // canonical kind -> compact index
+    {
+        int n = 0;
+        kmap[K_OTHER] = n++;
+        kmap[K_NL] = nfa.uses_nl ? n++ : kmap[K_OTHER];
+        kmap[K_WORD] = nfa.uses_word ? n++ : kmap[K_OTHER];
+        kmap[K_EDGE] = any_assert ? n++ : kmap[K_OTHER];
+        out.NK = n;
+        out.kind_edge = kmap[K_EDGE];
+    }
+    int kinv[NKIND];                         // compact index -> a canonical kind
+    for (int k = NKIND - 1; k >= 0; k--) kinv[kmap[k]] = k;
+    auto kind_of_byte = [&](int b) -> int {
+        if (nfa.uses_nl && b == '\n') return K_NL;
+        if (nfa.uses_word && ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_')) return K_WORD;
+        return K_OTHER;
+    };
+
+    Tables tb(nfa);
+    const int P = nfa.npos;
+    {
+        std::map<std::vector<uint64_t>, int> sig2cls;
+        std::vector<uint64_t> sig((P + 63) / 64 + 1);
+        for (int b = 0; b < 256; b++) {
+            std::fill(sig.begin(), sig.end(), 0);
+            for (int p = 0; p < P; p++) if (nfa.n[tb.pos_node[p]].set.has(b)) setbit(sig, p);
+            sig.back() = (uint64_t) kind_of_byte(b) | ((ascii_only && b >= 0x80) ? 16u : 0u);
+            auto it = sig2cls.find(sig);
+            int id;
+            if (it == sig2cls.end()) { id = (int) sig2cls.size(); sig2cls[sig] = id; }
+            else id = it->second;
+            out.cls[b] = (uint8_t) id;
+            if (ascii_only && b >= 0x80) out.high_cls = id;
+        }
+        out.ncls = (int) sig2cls.size();
+        if (out.ncls > 255) { err = "too many byte classes"; return false; }
+    }
+    std::vector<int> rep(out.ncls, -1);
+    for (int b = 255; b >= 0; b--) rep[out.cls[b]] = b;
+    std::vector<std::vector<int>> pos_of_cls(out.ncls);
+    for (int c = 0; c < out.ncls; c++)
+        for (int p = 0; p < P; p++) if (nfa.n[tb.pos_node[p]].set.has(rep[c])) pos_of_cls[c].push_back(p);
+    std::vector<int> kind_cls(out.ncls);     // canonical kinds
+    for (int c = 0; c < out.ncls; c++) kind_cls[c] = kind_of_byte(rep[c]);
+
+    const int X = tb.ncores(), START = tb.start_core();
+    const int W = (X + 63) / 64;
+
+    // ---- match-only forward DFA over sets of cores
+    if (want_match_dfa) {
+        std::unordered_map<std::vector<uint64_t>, int, VecHash> ids;
+        std::vector<std::vector<uint64_t>> states;
+        auto intern = [&](std::vector<uint64_t> &k) -> int {
+            auto it = ids.find(k);
+            if (it != ids.end()) return it->second;
+            int id = (int) states.size();
+            ids.emplace(k, id);
+            states.push_back(k);
+            return id;
+        };
+        std::vector<uint64_t> k0(W + 1, 0);
+        setbit(k0, START);
+        k0[W] = (uint64_t) kinv[kmap[K_EDGE]];
+        out.d_init = intern(k0);
+        for (size_t si = 0; si < states.size(); si++) {
+            if ((int) states.size() > MAX_DFA_STATES) { err = "match DFA exceeds the state budget"; return false; }
+            std::vector<uint64_t> S = states[si];
+            int pk = (int) S[W];
+            out.ddelta.resize((si + 1) * out.ncls);
+            for (int c = 0; c < out.ncls; c++) {
+                if (c == out.high_cls) { out.ddelta[si * out.ncls + c] = D_POISON; continue; }
+                int nk = kind_cls[c];
+                bool accept = false;
+                std::vector<uint64_t> N(W + 1, 0);
+                setbit(N, START);
+                for (int x = 0; x < X && !accept; x++) {
+                    if (!bit(S, x)) continue;
+                    for (const Target &t : tb.list(x, pk, nk)) {
+                        if (t.pos == T_MATCH) { accept = true; break; }
+                        if (nfa.n[tb.pos_node[t.pos]].set.has(rep[c])) setbit(N, t.pos);
+                    }
+                }
+                if (accept) { out.ddelta[si * out.ncls + c] = D_ACCEPT; continue; }
+                N[W] = (uint64_t) kinv[kmap[nk]];
+                int id = intern(N);
+                if (id >= 0xFFF0) { err = "match DFA exceeds the state budget"; return false; }
+                out.ddelta[si * out.ncls + c] = (uint16_t) id;
+            }
+            bool fin = false;
+            for (int x = 0; x < X && !fin; x++) {
+                if (!bit(S, x)) continue;
+                for (const Target &t : tb.list(x, pk, K_EDGE)) if (t.pos == T_MATCH) { fin = true; break; }
+            }
+            out.d_final.push_back(fin ? 1 : 0);
+        }
+        out.nD = (int) states.size();
+    }
+    if (tb.budget > 4000000) { err = "pattern too complex (nested empty loops)"; return false; }
+    if (!want_capture) return true;
+
+    // ---- reverse DFA over sets of viable positions
+    const int WP = (P + 63) / 64 + 1;          // last word: next-kind (canonical)
+    std::unordered_map<std::vector<uint64_t>, int, VecHash> ids;
+    std::vector<std::vector<uint64_t>> states;
+    auto intern = [&](std::vector<uint64_t> &k) -> int {
+        auto it = ids.find(k);
+        if (it != ids.end()) return it->second;
+        int id = (int) states.size();
+        ids.emplace(k, id);
+        states.push_back(k);
+        return id;
+    };
+    auto ok = [&](int x, int pk, int nk, const std::vector<uint64_t> &V) -> bool {
+        for (const Target &t : tb.list(x, pk, nk)) if (t.pos == T_MATCH || bit(V, t.pos)) return true;
+        return false;
+    };
+    std::vector<uint64_t> k0(WP, 0);
+    k0[WP - 1] = (uint64_t) kinv[kmap[K_EDGE]];
+    out.r_init = intern(k0);
+    for (size_t si = 0; si < states.size(); si++) {
+        if ((int) states.size() > MAX_DFA_STATES) { err = "capture automaton exceeds the state budget"; return false; }
+        std::vector<uint64_t> S = states[si];
+        int nk = (int) S[WP - 1];
+        out.rdelta.resize((si + 1) * out.ncls);
+        for (int c = 0; c < out.ncls; c++) {
+            if (c == out.high_cls) { out.rdelta[si * out.ncls + c] = R_POISON; continue; }
+            int pk = kind_cls[c];
+            std::vector<uint64_t> N(WP, 0);
+            for (int p : pos_of_cls[c]) if (ok(p, pk, nk, S)) setbit(N, p);
+            N[WP - 1] = (uint64_t) kinv[kmap[kind_cls[c]]];
+            bool startok = ok(START, pk, nk, S);
+            int id = intern(N);
+            if (id >= 0x7FF0) { err = "capture automaton exceeds the state budget"; return false; }
+            out.rdelta[si * out.ncls + c] = (uint16_t) (id | (startok ? 0x8000 : 0));
+        }
+        out.r_info.push_back((uint8_t) (kmap[nk] | (ok(START, K_EDGE, nk, S) ? 0x80 : 0)));
+    }
+    out.nR = (int) states.size();
+    out.P = P;
+    out.VW = (P + 31) / 32;
+    if (out.VW == 0) out.VW = 1;
+    out.vmask.assign((size_t) out.nR * out.VW, 0);
+    for (int r = 0; r < out.nR; r++)
+        for (int p = 0; p < P; p++) if (bit(states[r], p)) out.vmask[(size_t) r * out.VW + (p >> 5)] |= 1u << (p & 31);
+
+    // ---- forward candidate lists per (core, prev kind, next kind)
+    out.nX = X;
+    out.kind_of_cls.resize(out.ncls);
+    for (int c = 0; c < out.ncls; c++) out.kind_of_cls[c] = (uint8_t) kmap[kind_cls[c]];
+    out.list_off.push_back(0);
+    for (int x = 0; x < X; x++)
+        for (int pk = 0; pk < out.NK; pk++)
+            for (int nk = 0; nk < out.NK; nk++) {
+                for (const Target &t : tb.list(x, kinv[pk], kinv[nk]))
+                    out.list_ent.push_back((t.pos == T_MATCH ? (uint32_t) F_MATCH : (uint32_t) t.pos) | ((uint32_t) t.tagseq << 16));
+                out.list_off.push_back((uint32_t) out.list_ent.size());
+            }
+    if (tb.budget > 4000000) { err = "pattern too complex (nested empty loops)"; return false; }
+    if (tb.tag_seqs.size() > 0xFFFF) { err = "too many tag sequences"; return false; }
+    out.tag_off.push_back(0);
+    for (auto &t : tb.tag_seqs) {
+        out.tag_data.insert(out.tag_data.end(), t.begin(), t.end());
+        out.tag_off.push_back((uint32_t) out.tag_data.size());
+    }
+    out.has_capture = true;
+    return true;
+}
+
+}  // namespace
+
+bool compile(const char *pattern, size_t len, unsigned options, bool want_captures, Program &out, std::string &err) {
+    Syntax sx;
+    sx.s = sx.p = (const unsigned char *) pattern;
+    sx.e = sx.s + len;
+    sx.has_named = scan_named(sx.s, sx.e);
+    AstP root = sx.alternation(options & (OPT_IGNORECASE | OPT_EXTEND | OPT_MULTILINE), 0);
+    if (!sx.failed() && !sx.eof()) sx.fail(*sx.p == ')' ? "unmatched close parenthesis" : "trailing garbage");
+    if (sx.failed()) { err = sx.err; return false; }
+    if (sx.ncap > 31) { err = "more than 31 capture groups"; return false; }
+    out = Program();
+    out.ngroups = sx.ncap;
+    out.names = sx.names;
+    out.name_groups = sx.name_groups;
+    if (!build_tables(root.get(), true, true, want_captures, out.ascii, err)) return false;
+    if (!build_tables(root.get(), false, false, true, out.utf8, err)) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------- host simulation of the tables
+int utf8_seq_len(const uint8_t *s, int i, int len) {
+    // well-formed UTF-8 (the transition table of lib/onigmo/enc/utf_8.c); a prefix-valid
+    // sequence cut by the end of the text counts with its full length (NEEDMORE)
+    int b0 = s[i], rem = len - i - 1;
+    int need, lo1 = 0x80, hi1 = 0xbf;
+    if (b0 >= 0xc2 && b0 <= 0xdf) need = 1;
+    else if (b0 >= 0xe0 && b0 <= 0xef) { need = 2; if (b0 == 0xe0) lo1 = 0xa0; if (b0 == 0xed) hi1 = 0x9f; }
+    else if (b0 >= 0xf0 && b0 <= 0xf4) { need = 3; if (b0 == 0xf0) lo1 = 0x90; if (b0 == 0xf4) hi1 = 0x8f; }
+    else return 1;
+    for (int k = 1; k <= need; k++) {
+        if (k > rem) return need + 1;                 // truncated by end of text
+        int b = s[i + k];
+        if (k == 1) { if (b < lo1 || b > hi1) return 1; }
+        else if (b < 0x80 || b > 0xbf) return 1;
+    }
+    return need + 1;
+}
+
+namespace {
+
+// returns 1 match, 0 no match, -3 poisoned (needs the utf8 tables)
+int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *beg, int *end) {
+    std::vector<uint16_t> rid(len + 1);
+    int R = t.r_init, best = -1;
+    int h1 = -1, h2 = -1, h3 = -1;            // best as it was 1/2/3 boundaries to the right
+    rid[len] = (uint16_t) R;
+    for (int i = len - 1; i >= 0; i--) {
+        uint16_t e = t.rdelta[(size_t) R * t.ncls + t.cls[s[i]]];
+        if ((e & 0x7FFF) == R_POISON) return -3;
+        int before = best;
+        if (e & 0x8000) best = i + 1;
+        R = e & 0x7FFF;
+        rid[i] = (uint16_t) R;
+        if (!t.ascii_only && s[i] >= 0xc2) {
+            // a match may only start on a character boundary (onig_search advances by enclen):
+            // boundaries strictly inside the sequence that starts here are not start candidates
+            int L = utf8_seq_len(s, i, len);
+            if (L == 2) best = before;
+            else if (L == 3) best = h1;
+            else if (L == 4) best = h2;
+        }
+        h3 = h2; h2 = h1; h1 = before;
+        (void) h3;
+    }
+    if (t.r_info[R] & 0x80) best = 0;
+    if (best < 0) return 0;
+    std::vector<int> slot(2 * (ngroups + 1), -1);
+    slot[0] = best;
+    int x = t.nX - 1, j = best;
+    int pk = j == 0 ? t.kind_edge : t.kind_of_cls[t.cls[s[j - 1]]];
+    for (;;) {
+        int r = rid[j];
+        int nk = t.r_info[r] & 7;
+        size_t li = ((size_t) x * t.NK + pk) * t.NK + nk;
+        uint32_t pick = 0xFFFFFFFFu;
+        for (uint32_t k = t.list_off[li]; k < t.list_off[li + 1]; k++) {
+            uint32_t ent = t.list_ent[k];
+            uint32_t tg = ent & 0xFFFF;
+            if (tg == F_MATCH || ((t.vmask[(size_t) r * t.VW + (tg >> 5)] >> (tg & 31)) & 1)) { pick = ent; break; }
+        }
+        if (pick == 0xFFFFFFFFu) return -2;      // table inconsistency (must never happen)
+        uint32_t ts = pick >> 16;
+        for (uint32_t k = t.tag_off[ts]; k < t.tag_off[ts + 1]; k++) slot[t.tag_data[k]] = j;
+        if ((pick & 0xFFFF) == F_MATCH) break;
+        x = (int) (pick & 0xFFFF);
+        pk = t.kind_of_cls[t.cls[s[j]]];
+        j++;
+        if (j > len) return -2;
+    }
+    for (int g = 0; g <= ngroups; g++) {
+        if (slot[2 * g] >= 0 && slot[2 * g + 1] >= 0) { beg[g] = slot[2 * g]; end[g] = slot[2 * g + 1]; }
+        else { beg[g] = -1; end[g] = -1; }
+    }
+    return 1;
+}
+
+}  // namespace
+
+int simulate_match(const Program &p, const uint8_t *s, int len) {
+    const TableSet &t = p.ascii;
+    int st = t.d_init;
+    for (int i = 0; i < len; i++) {
+        uint16_t n = t.ddelta[(size_t) st * t.ncls + t.cls[s[i]]];
+        if (n == D_ACCEPT) return 1;
+        if (n == D_POISON) {
+            std::vector<int> b(p.ngroups + 1), e(p.ngroups + 1);
+            int r = run_capture(p.utf8, p.ngroups, s, len, b.data(), e.data());
+            return r < 0 ? r : r;
+        }
+        st = n;
+    }
+    return t.d_final[st];
+}
+
+int simulate_capture(const Program &p, const uint8_t *s, int len, int *beg, int *end) {
+    int r = p.ascii.has_capture ? run_capture(p.ascii, p.ngroups, s, len, beg, end) : -3;
+    if (r == -3) r = run_capture(p.utf8, p.ngroups, s, len, beg, end);
+    if (r == 1) return p.ngroups + 1;
+    if (r == 0) return -1;
+    return r;
+}
+
+}  // namespace rx

@@ -1,0 +1,105 @@
+// rx.hpp -- host-side regex compiler for the MI355X filter path.
+//
+// Turns an Onigmo/Ruby-syntax pattern (the dialect src/flb_regex.c:116-152 hands to
+// onig_new with ONIG_ENCODING_UTF8 / ONIG_SYNTAX_RUBY) into flat tables the HIP kernels step
+// one input byte per lane:
+//
+//   * byte classes            cls[256]
+//   * match-only forward DFA  ddelta[nD][ncls]            (filter_grep / log_to_metrics gate:
+//                                                          flb_regex_match, src/flb_regex.c:270)
+//   * capture program         rdelta[nR][ncls]  reverse DFA over "viable position" bit sets
+//                             vmask[nR][VW]     the bit sets themselves (the bit-NFA state)
+//                             list_ent[]        per (core, context) priority-ordered targets
+//                             tag sequences     group open/close slots crossed per step
+//                                                         (flb_regex_do + flb_regex_parse,
+//                                                          src/flb_regex.c:182-231,294-313)
+//
+// The capture program reproduces backtracking (leftmost-first) semantics exactly without a
+// stack: pass 1 runs the reversed automaton from the end of the value and records, per byte
+// boundary, which NFA positions can still reach a match; pass 2 walks forward from the leftmost
+// viable start always taking the highest-priority transition whose target is viable, so the
+// first choice is the one a backtracking engine would have settled on.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rx {
+
+constexpr unsigned OPT_IGNORECASE = 1u;   // ONIG_OPTION_IGNORECASE
+constexpr unsigned OPT_EXTEND = 2u;       // ONIG_OPTION_EXTEND
+constexpr unsigned OPT_MULTILINE = 4u;    // ONIG_OPTION_MULTILINE ('.' matches \n)
+
+constexpr uint16_t D_ACCEPT = 0xFFFF;     // match-only DFA: sticky accept
+
+constexpr uint16_t D_POISON = 0xFFFE;     // ASCII tables: a byte >= 0x80 was seen -> UTF-8 tables
+constexpr uint16_t R_POISON = 0x7FFF;     // same, reverse automaton (low 15 bits of the entry)
+constexpr uint16_t F_MATCH = 0xFFFF;      // forward list entry: low half == MATCH reached
+
+// One set of tables.  Two sets are built per pattern: `ascii` assumes every input byte is
+// < 0x80 (any other byte maps to the HIGH class whose transitions are POISON; the kernels then
+// re-run that record on the `utf8` set), `utf8` expands every character class to well-formed
+// UTF-8 byte sequences (+ the never-valid lead bytes as 1-byte characters, as Onigmo's
+// mbc_enc_len does).  Logs are overwhelmingly ASCII, and the ASCII automata are 3-6x smaller,
+// small enough to be staged in LDS.
+struct TableSet {
+    bool ascii_only = false;
+    uint8_t cls[256];
+    int ncls = 0;
+    int high_cls = -1;
+
+    // match-only forward DFA (built for the ascii set only)
+    int nD = 0, d_init = 0;
+    std::vector<uint16_t> ddelta;             // [nD][ncls]
+    std::vector<uint8_t> d_final;             // [nD]
+
+    // capture program
+    bool has_capture = false;
+    int nR = 0, r_init = 0;
+    std::vector<uint16_t> rdelta;             // [nR][ncls]; bit15 = a match may START at the
+                                              // boundary right of the consumed byte
+    std::vector<uint8_t> r_info;              // [nR] bits0-2: kind of the byte right of the
+                                              // boundary (ctx next-kind), bit7: start viable at
+                                              // boundary 0 (beginning of text)
+    int P = 0, VW = 0;
+    std::vector<uint32_t> vmask;              // [nR][VW] viable-position bit sets
+    int nX = 0;                               // cores: positions 0..P-1, START = P
+    int NK = 1;                               // number of context kinds in use
+    int kind_edge = 0;                        // kind index of beginning/end of text
+    std::vector<uint8_t> kind_of_cls;         // [ncls]
+    std::vector<uint32_t> list_off;           // [(x*NK + pk)*NK + nk] -> range in list_ent
+    std::vector<uint32_t> list_ent;           // target core | tagseq << 16, priority order
+    std::vector<uint32_t> tag_off;            // [ntagseq+1]
+    std::vector<uint8_t> tag_data;            // capture slots (2*g, 2*g+1)
+};
+
+struct Program {
+    int ngroups = 0;                          // capture groups excluding group 0
+    std::vector<std::string> names;           // first-appearance order (onig_foreach_name)
+    std::vector<std::vector<int>> name_groups;
+    TableSet ascii;                           // match DFA (+ capture program when requested)
+    TableSet utf8;                            // capture program (also answers match-only)
+};
+
+// Compiles `pattern` (already stripped of the /../flags wrapper).  want_captures=false skips the
+// capture program (grep rules).  Returns false and fills err when the pattern uses a construct
+// the tables cannot express (back-references, look-around, atomic groups, ...) or exceeds the
+// table budget.  The caller must then FAIL LOUDLY: there is no CPU fallback in the product.
+bool compile(const char *pattern, size_t len, unsigned options, bool want_captures, Program &out,
+             std::string &err);
+
+// src/flb_regex.c:60-152: "/pat/imx" option syntax.  Returns the inner pattern range and options.
+void split_flb_pattern(const char *pattern, const char **start, const char **end, unsigned *options);
+
+// Host execution of the SAME tables the kernels use (debug/self-test aid, exercised by the CPU
+// unit tests; never called by the filters).
+//   returns -1 on mismatch else number of registers; beg/end sized ngroups+1.
+//   Both try the ascii set first and re-run on the utf8 set when a byte >= 0x80 poisons it,
+//   exactly as the kernels do.
+int simulate_capture(const Program &p, const uint8_t *s, int len, int *beg, int *end);
+int simulate_match(const Program &p, const uint8_t *s, int len);
+// UTF-8 sequence length rule shared with the kernels: length (2..4) of the well-formed or
+// end-truncated sequence starting at s[i], else 1
+int utf8_seq_len(const uint8_t *s, int i, int len);
+
+}  // namespace rx
