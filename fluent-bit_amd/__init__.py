@@ -1,0 +1,198 @@
+"""fluent-bit_amd -- MI355X-native Fluent Bit filter hot path (filter_parser / filter_grep /
+regex parsers) behind the C ABI of include/flb_gpu.h.
+
+This module is a thin ctypes binding used by tests/, bench.py and __graft_entry__.py.  The
+product is csrc/libflbgpu.so (hand-written HIP kernels + C++ host code); nothing here computes
+on the CPU and nothing here touches oracle/.  If the shared library is missing, import fails
+loudly -- there is no fallback path.
+
+The directory name contains a hyphen, so load it with `flbamd_loader.load()` (repo root) or
+importlib; it registers itself as `fluent_bit_amd`.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int64, c_size_t, c_uint,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libflbgpu.so")
+
+MODIFIED, NOTOUCH = 1, 2
+
+
+def build(force=False):
+    """Compile every HIP/C++ source for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, "all"], check=True)
+
+
+class DevChunk(Structure):
+    _fields_ = [("data", c_void_p), ("row_off", c_void_p), ("n", c_uint64), ("bytes", c_uint64)]
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `make -C %s` (hipcc, gfx950). There is no CPU fallback." % (LIB_PATH, CSRC))
+    L = ctypes.CDLL(LIB_PATH)
+    L.flbgpu_init.argtypes = [c_int]
+    L.flbgpu_last_error.restype = c_char_p
+    L.flbgpu_parser_create.restype = c_void_p
+    L.flbgpu_parser_create.argtypes = [c_char_p, c_char_p, c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_char_p]
+    L.flbgpu_parser_destroy.argtypes = [c_void_p]
+    L.flbgpu_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int64), POINTER(c_int64)]
+    L.flbgpu_filter_parser_create.restype = c_void_p
+    L.flbgpu_filter_parser_create.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]
+    L.flbgpu_filter_grep_create.restype = c_void_p
+    L.flbgpu_filter_grep_create.argtypes = [c_int, POINTER(c_char_p), POINTER(c_char_p), c_char_p]
+    L.flbgpu_filter_destroy.argtypes = [c_void_p]
+    L.flbgpu_filter_run.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]
+    L.flbgpu_filter_run_dev.argtypes = [c_void_p, POINTER(DevChunk), POINTER(DevChunk), c_void_p]
+    L.flbgpu_filter_last_counts.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64)]
+    L.flbgpu_filter_profile.argtypes = [c_void_p, c_int]
+    L.flbgpu_filter_profile_read.argtypes = [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_uint64)]
+    L.flbgpu_index_host.restype = c_int64
+    L.flbgpu_index_host.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.flbgpu_dev_alloc.restype = c_void_p
+    L.flbgpu_dev_alloc.argtypes = [c_size_t]
+    L.flbgpu_dev_free.argtypes = [c_void_p]
+    L.flbgpu_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_size_t]
+    L.flbgpu_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_size_t]
+    L.flbgpu_rx_compile.restype = c_void_p
+    L.flbgpu_rx_compile.argtypes = [c_char_p, c_int, c_uint, c_int, c_char_p, c_int]
+    L.flbgpu_rx_free.argtypes = [c_void_p]
+    L.flbgpu_rx_simulate_capture.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int)]
+    L.flbgpu_rx_simulate_match.argtypes = [c_void_p, c_char_p, c_int]
+    L.flbgpu_rx_info.argtypes = [c_void_p, POINTER(c_int)]
+    L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
+    _L = L
+    return L
+
+
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [c_void_p]
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+def last_error():
+    return lib().flbgpu_last_error().decode(errors="replace")
+
+
+_inited = False
+
+
+def init(device=0):
+    """Bind the process to one GPU.  Raises when no HIP device exists (no CPU path)."""
+    global _inited
+    if lib().flbgpu_init(device) != 0:
+        raise RuntimeError("flbgpu_init: " + last_error())
+    _inited = True
+
+
+class Parser:
+    """struct flb_parser for Format regex (include/fluent-bit/flb_parser.h:41-70); arguments as
+    flb_parser_create.  Defaults are the parsers-file defaults (src/flb_parser.c:1277-1304)."""
+
+    def __init__(self, regex, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
+                 time_strict=True, skip_empty=True, types=None, name="parser"):
+        self.h = lib().flbgpu_parser_create(_b(name), _b(regex), int(skip_empty), _b(time_fmt), _b(time_key),
+                                            _b(time_offset), int(time_keep), int(time_strict), _b(types))
+        if not self.h:
+            raise ValueError("flbgpu_parser_create: " + last_error())
+
+    def do(self, buf):
+        out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()
+        r = lib().flbgpu_parser_do(self.h, buf, len(buf), byref(out), byref(sz), byref(sec), byref(nsec))
+        if r < 0:
+            return r, None, None
+        data = ctypes.string_at(out, sz.value)
+        _libc.free(out)
+        return r, data, (sec.value, nsec.value)
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_parser_destroy(self.h)
+            self.h = None
+
+
+class _Filter:
+    h = None
+
+    def filter(self, data):
+        """cb_filter on a host buffer: returns (MODIFIED|NOTOUCH, bytes|None)"""
+        out = c_void_p(); sz = c_size_t()
+        r = lib().flbgpu_filter_run(self.h, data, len(data), byref(out), byref(sz))
+        if r != MODIFIED:
+            return r, None
+        b = ctypes.string_at(out, sz.value) if sz.value else b""
+        _libc.free(out)
+        return r, b
+
+    def filter_dev(self, chunk, stream=None):
+        """cb_filter on a device-resident chunk: returns (ret, DevChunk)"""
+        out = DevChunk()
+        r = lib().flbgpu_filter_run_dev(self.h, byref(chunk), byref(out), stream)
+        return r, out
+
+    def counts(self):
+        a = c_uint64(); b = c_uint64()
+        lib().flbgpu_filter_last_counts(self.h, byref(a), byref(b))
+        return a.value, b.value
+
+    def profile(self, enable=True):
+        lib().flbgpu_filter_profile(self.h, int(enable))
+
+    def profile_read(self):
+        names = (c_char_p * 16)(); ms = (c_double * 16)(); ln = (c_uint64 * 16)()
+        n = lib().flbgpu_filter_profile_read(self.h, 16, names, ms, ln)
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(n)}
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_filter_destroy(self.h)
+            self.h = None
+
+
+class FilterParser(_Filter):
+    """filter_parser: Key_Name / Parser* / Reserve_Data / Preserve_Key
+    (plugins/filter_parser/filter_parser.c:460-489)"""
+
+    def __init__(self, key_name, parsers, reserve_data=False, preserve_key=False):
+        self.parsers = list(parsers)
+        arr = (c_void_p * len(parsers))(*[p.h for p in parsers])
+        self.h = lib().flbgpu_filter_parser_create(_b(key_name), int(reserve_data), int(preserve_key), len(parsers), arr)
+        if not self.h:
+            raise ValueError("flbgpu_filter_parser_create: " + last_error())
+
+
+class FilterGrep(_Filter):
+    """filter_grep: rules = [("regex"|"exclude", "<key> <pattern>"), ...] in configuration order,
+    logical_op None|"legacy"|"AND"|"OR" (plugins/filter_grep/grep.c:407-424)"""
+
+    def __init__(self, rules, logical_op=None):
+        n = len(rules)
+        kinds = (c_char_p * max(n, 1))(*[_b(k) for k, _ in rules])
+        vals = (c_char_p * max(n, 1))(*[_b(v) for _, v in rules])
+        self.h = lib().flbgpu_filter_grep_create(n, kinds, vals, _b(logical_op))
+        if not self.h:
+            raise ValueError("flbgpu_filter_grep_create: " + last_error())
+
+
+def index_host(data):
+    """record boundaries of a host chunk: (n, offsets list[n+1], consumed)"""
+    import numpy as np
+    off = np.zeros(len(data) // 3 + 2, dtype=np.uint64)
+    consumed = c_size_t()
+    n = lib().flbgpu_index_host(data, len(data), off.ctypes.data, off.size, byref(consumed))
+    return n, off[: n + 1], consumed.value

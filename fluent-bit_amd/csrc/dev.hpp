@@ -1,0 +1,186 @@
+// dev.hpp -- structures shared by the host side (flbgpu.cpp) and the HIP kernels (kernels.hip).
+#pragma once
+#include <cstdint>
+
+namespace flbgpu {
+
+// ---- capture tables of one rx::TableSet, as device pointers
+struct DevCap {
+    const uint8_t *cls;            // [256]
+    const uint16_t *rdelta;        // [nR][ncls]
+    const uint8_t *r_info;         // [nR]
+    const uint32_t *vmask;         // [nR][VW]
+    const uint32_t *list_off;      // [nX*NK*NK + 1]
+    const uint32_t *list_ent;
+    const uint32_t *tag_off;
+    const uint8_t *tag_data;
+    const uint8_t *kind_of_cls;    // [ncls]
+    int ncls, nR, r_init, VW, nX, NK, kind_edge, ascii_only;
+    // LDS staging plan (bytes); 0 => tables are read from global memory
+    uint32_t lds_bytes;
+    uint32_t n_list_off, n_list_ent;
+};
+
+// ---- match-only DFA
+struct DevDfa {
+    const uint8_t *cls;            // [256]
+    const uint16_t *ddelta;        // [nD][ncls]
+    const uint8_t *d_final;        // [nD]
+    int ncls, nD, d_init;
+    uint32_t lds_bytes;
+};
+
+constexpr int MAX_GROUPS = 32;           // capture registers incl. group 0
+constexpr int MAX_NAMES = 32;
+constexpr int MAX_TIMEFMT = 96;
+constexpr int MAX_KEY = 128;
+constexpr int MAX_SUBKEYS = 8;
+
+// Types cast (src/flb_parser.c:2067-2164)
+enum { TY_NONE = 0, TY_INT = 1, TY_FLOAT = 2, TY_BOOL = 3, TY_STRING = 4, TY_HEX = 5 };
+
+// ---- one regex parser (struct flb_parser, include/fluent-bit/flb_parser.h:41-70)
+struct DevParser {
+    DevCap ascii, utf8;
+    int ngroups;
+    // named groups in onig_foreach_name order, one entry per (name, group) pair
+    int nfields;
+    int field_group[MAX_NAMES];
+    int field_name_off[MAX_NAMES];       // into names[]
+    int field_name_len[MAX_NAMES];
+    int field_is_time[MAX_NAMES];        // strcmp(name, time_key) == 0 and a time format exists
+    int field_type[MAX_NAMES];           // TY_*
+    char names[1024];
+    int nregs_minus1;                    // flb_regex_do return value (num_regs - 1)
+    int skip_empty;
+    int has_time;
+    int time_keep, time_strict, time_with_tz, time_offset;
+    int has_frac;                        // %L present: fmt2 is the part after it
+    char fmt1[MAX_TIMEFMT];              // expanded to primitive directives, NUL terminated
+    char fmt2[MAX_TIMEFMT];
+    uint8_t slot2cap[2 * MAX_GROUPS];    // capture slot -> index in the caps row (0xFF: not a named field)
+};
+
+// ---- record accessor / key
+struct DevKey {
+    int is_ra;                           // '$key['a'][1]' form (backward lookup, STR keys only)
+    int key_len;
+    char key[MAX_KEY];
+    int nsub;
+    int sub_is_index[MAX_SUBKEYS];
+    int sub_index[MAX_SUBKEYS];
+    int sub_off[MAX_SUBKEYS], sub_len[MAX_SUBKEYS];
+    char sub_str[256];
+};
+
+// per-record result of the parser match pass
+struct RecInfo {
+    uint32_t flags;
+    uint32_t val_off;                    // value offset relative to record start
+    uint32_t val_len;
+    uint32_t key_index;                  // index of the parsed kv in the body map
+    uint32_t ts_sec, ts_nsec;            // timestamp to emit
+    uint32_t body_off, body_len, meta_off, meta_len;   // relative to record start; meta_len 0 => {}
+    int32_t parser_idx;
+    uint32_t nkept;                      // fields that will be packed (map count after skips)
+};
+// capture spans live in a separate column: caps[rec][2*field + {0,1}] (begin/end relative to the
+// value, 0xFFFFFFFF = group did not participate), field = index in DevParser::field_group
+
+enum {
+    RF_VALID = 1,          // well-formed log event
+    RF_SKIP = 2,           // group marker / negative timestamp: hidden by the decoder
+    RF_PARSED = 4,         // a parser matched
+    RF_BADTS = 8,          // timestamp outside the EventTime range: encoder error, record dropped
+    RF_BAD = 16,           // decoder error: processing stops here
+};
+
+constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
+
+// ---- filter_parser configuration (plugins/filter_parser/filter_parser.c:460-489)
+struct FParserCfg {
+    DevKey key;
+    int reserve_data, preserve_key;
+    int nparsers;
+};
+
+struct ParserMatchArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    FParserCfg cfg;
+    const DevParser *parsers;
+    RecInfo *info;
+    uint32_t *caps;             // [n][caps_stride]
+    uint32_t caps_stride;
+    uint64_t *null_mask;        // [n]
+    uint32_t *out_len;          // [n]
+    uint16_t *rid;              // scratch: [slots][rid_len][64]
+    uint32_t rid_len;           // boundaries per lane (max value length + 1)
+    unsigned long long *first_bad;   // min index of a record that stops the decoder loop
+    unsigned long long *counts;      // [0] decoded log records, [1] records emitted
+};
+
+struct ParserEmitArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    FParserCfg cfg;
+    const DevParser *parsers;
+    const RecInfo *info;
+    const uint32_t *caps;
+    uint32_t caps_stride;
+    const uint64_t *null_mask;
+    const uint32_t *out_len;
+    const uint64_t *out_off;    // exclusive scan of out_len, [n+1]
+    uint8_t *out;
+};
+
+// ---- filter_grep (plugins/filter_grep/grep.c)
+constexpr int MAX_RULES = 64;
+enum { GREP_REGEX = 1, GREP_EXCLUDE = 2 };
+enum { OP_LEGACY = 0, OP_OR = 1, OP_AND = 2 };
+
+struct GrepRule {
+    int type;
+    DevKey key;
+    DevDfa dfa;
+    DevCap utf8;
+};
+
+struct GrepArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    const GrepRule *rules;
+    int nrules;
+    int logical_op;
+    uint32_t *keep_len;         // [n] record length when kept, else 0
+    uint32_t *status;           // [n] RF_* flags
+    unsigned long long *first_bad;
+    unsigned long long *counts; // [0] = decoded (non-skipped) records, [1] = kept records
+};
+
+struct GatherArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    const uint32_t *keep_len;
+    const uint64_t *out_off;
+    uint8_t *out;
+};
+
+}  // namespace flbgpu
+
+// launchers implemented in kernels.hip
+#include <hip/hip_runtime_api.h>
+namespace flbgpu {
+void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st);
+void launch_parser_emit(const ParserEmitArgs &a, hipStream_t st);
+void launch_grep_match(const GrepArgs &a, hipStream_t st);
+void launch_gather(const GatherArgs &a, hipStream_t st);
+size_t scan_tmp_elems(uint64_t n);
+void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st);
+void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st);
+
+}  // namespace flbgpu

@@ -1,0 +1,789 @@
+// flbgpu.cpp -- host side of libflbgpu.so: the C ABI declared in include/flb_gpu.h.
+//
+// Mirrors the reference's host-side structure for the filter hot path:
+//   flbgpu_parser        ~ struct flb_parser            (include/fluent-bit/flb_parser.h:41-70)
+//   flbgpu_filter(grep)  ~ struct grep_ctx + rules      (plugins/filter_grep/grep.h)
+//   flbgpu_filter(parser)~ struct filter_parser_ctx     (plugins/filter_parser/filter_parser.h)
+//   flbgpu_filter_run    ~ cb_filter                    (include/fluent-bit/flb_filter.h:57-81)
+// Configuration-time work (regex compile, rule parsing, time-format analysis) happens here on the
+// host exactly once; per-record work happens only in kernels.hip.  There is no CPU data path.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+#include "../../include/flb_gpu.h"
+#include "dev.hpp"
+#include "rx.hpp"
+
+using namespace flbgpu;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int g_cus = 0;
+
+static void set_err(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (getenv("FLBGPU_DEBUG")) fprintf(stderr, "[flbgpu] %s\n", buf);
+}
+
+#define HIPOK(call)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return false;                                                                        \
+        }                                                                                        \
+    } while (0)
+
+extern "C" const char *flbgpu_last_error(void) { return g_err.c_str(); }
+
+extern "C" int flbgpu_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_err("no HIP device available (%s): libflbgpu has no CPU path", e != hipSuccess ? hipGetErrorString(e) : "count=0");
+        return -1;
+    }
+    if (device < 0 || device >= n) { set_err("device %d out of range (0..%d)", device, n - 1); return -1; }
+    if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return -1; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) g_cus = prop.multiProcessorCount;
+    return 0;
+}
+
+extern "C" int flbgpu_device_cus(void) { return g_cus; }
+
+// ------------------------------------------------------------------------------------------ device buffers
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIPOK(hipMalloc(&p, want));
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *) p; }
+};
+
+// uploads vectors of one table set into a single device allocation
+struct TableBlob {
+    void *dev = nullptr;
+    ~TableBlob() { if (dev) (void) hipFree(dev); }
+};
+
+template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vector<T> &v) {
+    size_t off = (blob.size() + 15) & ~(size_t) 15;
+    blob.resize(off + v.size() * sizeof(T) + 16);
+    if (!v.empty()) memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+static bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
+    std::vector<uint8_t> b;
+    std::vector<uint8_t> cls(t.cls, t.cls + 256);
+    size_t o_cls = put(b, cls), o_rd = put(b, t.rdelta), o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
+    size_t o_lo = put(b, t.list_off), o_le = put(b, t.list_ent), o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
+    size_t o_kc = put(b, t.kind_of_cls);
+    HIPOK(hipMalloc(&blob.dev, b.size()));
+    HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
+    const uint8_t *d = (const uint8_t *) blob.dev;
+    memset(&out, 0, sizeof(out));
+    out.cls = d + o_cls; out.rdelta = (const uint16_t *) (d + o_rd); out.r_info = d + o_ri;
+    out.vmask = (const uint32_t *) (d + o_vm); out.list_off = (const uint32_t *) (d + o_lo);
+    out.list_ent = (const uint32_t *) (d + o_le); out.tag_off = (const uint32_t *) (d + o_to);
+    out.tag_data = d + o_td; out.kind_of_cls = d + o_kc;
+    out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK;
+    out.kind_edge = t.kind_edge; out.ascii_only = t.ascii_only ? 1 : 0;
+    out.n_list_off = (uint32_t) t.list_off.size(); out.n_list_ent = (uint32_t) t.list_ent.size();
+    return true;
+}
+
+static bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
+    std::vector<uint8_t> b;
+    std::vector<uint8_t> cls(t.cls, t.cls + 256);
+    size_t o_cls = put(b, cls), o_dd = put(b, t.ddelta), o_df = put(b, t.d_final);
+    HIPOK(hipMalloc(&blob.dev, b.size()));
+    HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
+    const uint8_t *d = (const uint8_t *) blob.dev;
+    memset(&out, 0, sizeof(out));
+    out.cls = d + o_cls; out.ddelta = (const uint16_t *) (d + o_dd); out.d_final = d + o_df;
+    out.ncls = t.ncls; out.nD = t.nD; out.d_init = t.d_init;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ parser
+struct flbgpu_parser {
+    std::string name;
+    rx::Program prog;
+    TableBlob blob_ascii, blob_utf8;
+    DevParser dev;                 // host copy (device pointers inside)
+    flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
+};
+
+// src/flb_parser.c:1806-1870 flb_parser_tzone_offset
+static int tzone_offset(const char *str, int len, int *tmdiff) {
+    const char *p = str;
+    *tmdiff = 0;
+    if (*p == 'Z') return 0;
+    if (*p != '+' && *p != '-') return -1;
+    if (len < 4) return -1;
+    int neg = (*p++ == '-');
+    const char *end = str + len;
+    long hour = ((p[0] - '0') * 10) + (p[1] - '0'), min;
+    if (end - p == 5 && p[2] == ':') min = ((p[3] - '0') * 10) + (p[4] - '0');
+    else min = ((p[2] - '0') * 10) + (p[3] - '0');
+    if (hour < 0 || hour > 59 || min < 0 || min > 59) return -1;
+    *tmdiff = (int) (hour * 3600 + min * 60);
+    if (neg) *tmdiff = -*tmdiff;
+    return 0;
+}
+
+// expands the composite strptime directives (src/flb_strptime.c:300-355) and checks that only
+// directives implemented by the device interpreter remain
+static bool expand_time_fmt(const char *fmt, std::string &out, std::string &why) {
+    for (const char *p = fmt; *p; p++) {
+        if (*p != '%') { out += *p; continue; }
+        p++;
+        while (*p == 'E' || *p == 'O') p++;
+        switch (*p) {
+        case 'T': case 'X': out += "%H:%M:%S"; break;
+        case 'D': case 'x': out += "%m/%d/%y"; break;
+        case 'F': out += "%Y-%m-%d"; break;
+        case 'R': out += "%H:%M"; break;
+        case 'r': out += "%I:%M:%S %p"; break;
+        case 'c': out += "%a %b %e %H:%M:%S %Y"; break;
+        case 'Z': why = "%Z (time zone abbreviations) is not supported on the GPU path"; return false;
+        case '\0': why = "dangling % in time format"; return false;
+        default:
+            if (!strchr("%AaBbhCedkHlIjMmpSsUWVwugGYyznt", *p)) { why = std::string("unsupported time directive %") + *p; return false; }
+            out += '%'; out += *p;
+        }
+    }
+    return true;
+}
+
+extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int skip_empty,
+                                               const char *time_fmt, const char *time_key, const char *time_offset,
+                                               int time_keep, int time_strict, const char *types) {
+    if (!regex) { set_err("parser '%s': missing regex", name ? name : ""); return nullptr; }
+    auto *p = new flbgpu_parser();
+    p->name = name ? name : "";
+    const char *s, *e;
+    unsigned opts;
+    rx::split_flb_pattern(regex, &s, &e, &opts);
+    std::string err;
+    if (!rx::compile(s, (size_t) (e - s), opts, true, p->prog, err)) {
+        set_err("parser '%s': cannot compile regex for the GPU path: %s", p->name.c_str(), err.c_str());
+        delete p;
+        return nullptr;
+    }
+    DevParser &d = p->dev;
+    memset(&d, 0, sizeof(d));
+    if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_cap(p->prog.utf8, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
+    d.ngroups = p->prog.ngroups;
+    d.nregs_minus1 = p->prog.ngroups;
+    d.skip_empty = skip_empty;
+    d.time_keep = time_keep;
+    d.time_strict = time_strict;
+    memset(d.slot2cap, 0xFF, sizeof(d.slot2cap));
+    // time format analysis: src/flb_parser.c:906-1040
+    if (time_fmt && time_fmt[0]) {
+        std::string tf = time_fmt;
+        bool with_year = tf.find("%Y") != std::string::npos || tf.find("%y") != std::string::npos || tf.find("%s") != std::string::npos;
+        if (!with_year) {
+            set_err("parser '%s': year-less Time_Format depends on the wall clock (src/flb_parser.c:1945-2001) and is not supported on the GPU path", p->name.c_str());
+            delete p;
+            return nullptr;
+        }
+        d.has_time = 1;
+        d.time_with_tz = (tf.find("%z") != std::string::npos || tf.find("%Z") != std::string::npos ||
+                          tf.find("%SZ") != std::string::npos || tf.find("%S.%LZ") != std::string::npos) ? 1 : 0;
+        std::string f1 = tf, f2;
+        size_t lpos = tf.find("%L");
+        if (lpos != std::string::npos) { f1 = tf.substr(0, lpos); f2 = tf.substr(lpos + 2); d.has_frac = 1; }
+        std::string x1, x2, why;
+        if (!expand_time_fmt(f1.c_str(), x1, why) || !expand_time_fmt(f2.c_str(), x2, why)) {
+            set_err("parser '%s': %s", p->name.c_str(), why.c_str());
+            delete p;
+            return nullptr;
+        }
+        if (x1.size() >= MAX_TIMEFMT || x2.size() >= MAX_TIMEFMT) { set_err("parser '%s': Time_Format too long", p->name.c_str()); delete p; return nullptr; }
+        strcpy(d.fmt1, x1.c_str());
+        strcpy(d.fmt2, x2.c_str());
+        if (time_offset && time_offset[0]) {
+            int diff = 0;
+            if (tzone_offset(time_offset, (int) strlen(time_offset), &diff) == -1) { set_err("parser '%s': invalid Time_Offset", p->name.c_str()); delete p; return nullptr; }
+            d.time_offset = diff;
+        }
+    }
+    // Types: src/flb_parser.c:1130-1182
+    std::vector<std::pair<std::string, int>> tys;
+    if (types && types[0]) {
+        const char *q = types;
+        while (*q) {
+            while (*q == ' ') q++;
+            if (!*q) break;
+            const char *sp = strchr(q, ' ');
+            if (!sp) sp = q + strlen(q);
+            const char *colon = (const char *) memchr(q, ':', sp - q);
+            if (colon) {
+                std::string key(q, colon - q), ty(colon + 1, sp - colon - 1);
+                int t = TY_STRING;
+                if (!strcasecmp(ty.c_str(), "integer")) t = TY_INT;
+                else if (!strcasecmp(ty.c_str(), "bool")) t = TY_BOOL;
+                else if (!strcasecmp(ty.c_str(), "float")) t = TY_FLOAT;
+                else if (!strcasecmp(ty.c_str(), "hex")) t = TY_HEX;
+                if (t == TY_FLOAT) {
+                    set_err("parser '%s': Types float (libc atof) is not implemented on the GPU path yet", p->name.c_str());
+                    delete p;
+                    return nullptr;
+                }
+                tys.emplace_back(key, t);
+            }
+            q = *sp ? sp + 1 : sp;
+        }
+    }
+    // named fields in onig_foreach_name order
+    const char *tkey = (time_key && time_key[0]) ? time_key : "time";
+    size_t noff = 0;
+    for (size_t i = 0; i < p->prog.names.size(); i++) {
+        for (int g : p->prog.name_groups[i]) {
+            if (d.nfields >= MAX_NAMES || noff + p->prog.names[i].size() > sizeof(d.names)) { set_err("parser '%s': too many named groups", p->name.c_str()); delete p; return nullptr; }
+            int f = d.nfields++;
+            d.field_group[f] = g;
+            d.field_name_off[f] = (int) noff;
+            d.field_name_len[f] = (int) p->prog.names[i].size();
+            memcpy(d.names + noff, p->prog.names[i].data(), p->prog.names[i].size());
+            noff += p->prog.names[i].size();
+            d.field_is_time[f] = (d.has_time && p->prog.names[i] == tkey) ? 1 : 0;
+            d.field_type[f] = TY_NONE;
+            for (auto &ty : tys) if (ty.first == p->prog.names[i]) { d.field_type[f] = ty.second; break; }   // first match wins
+            d.slot2cap[2 * g] = (uint8_t) (2 * f);
+            d.slot2cap[2 * g + 1] = (uint8_t) (2 * f + 1);
+        }
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------ keys
+// grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
+static bool parse_ra(const char *pat, DevKey &k, std::string &why) {
+    memset(&k, 0, sizeof(k));
+    k.is_ra = 1;
+    const char *p = pat;
+    if (*p != '$') { why = "record accessor must start with $"; return false; }
+    p++;
+    if (!((*p >= 'A' && *p <= 'Z') || (*p >= 'a' && *p <= 'z') || *p == '_')) { why = "unsupported record accessor (only $key['sub'][n] forms are on the GPU path)"; return false; }
+    const char *q = p;
+    while ((*q >= 'A' && *q <= 'Z') || (*q >= 'a' && *q <= 'z') || (*q >= '0' && *q <= '9') || *q == '_' || *q == '.' || *q == '-' || *q == '/') q++;
+    if (q - p >= MAX_KEY) { why = "key too long"; return false; }
+    if ((q - p) == 3 && !strncmp(p, "TAG", 3)) { why = "$TAG accessors are not on the GPU path"; return false; }
+    memcpy(k.key, p, q - p);
+    k.key_len = (int) (q - p);
+    p = q;
+    size_t so = 0;
+    while (*p == '[') {
+        if (k.nsub >= MAX_SUBKEYS) { why = "too many subkeys"; return false; }
+        p++;
+        int s = k.nsub;
+        if (*p == '\'') {
+            p++;
+            k.sub_off[s] = (int) so;
+            for (;;) {
+                if (!*p) { why = "unterminated subkey string"; return false; }
+                if (*p == '\'') {
+                    if (p[1] == '\'') { if (so >= sizeof(k.sub_str)) { why = "subkeys too long"; return false; } k.sub_str[so++] = '\''; p += 2; continue; }
+                    p++;
+                    break;
+                }
+                if (so >= sizeof(k.sub_str)) { why = "subkeys too long"; return false; }
+                k.sub_str[so++] = *p++;
+            }
+            k.sub_len[s] = (int) so - k.sub_off[s];
+        }
+        else if (*p >= '0' && *p <= '9') {
+            k.sub_is_index[s] = 1;
+            k.sub_index[s] = atoi(p);
+            while (*p >= '0' && *p <= '9') p++;
+        }
+        else { why = "bad subkey"; return false; }
+        if (*p != ']') { why = "bad subkey"; return false; }
+        p++;
+        k.nsub++;
+    }
+    if (*p) { why = "trailing characters in record accessor"; return false; }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ filters
+enum { F_PARSER = 1, F_GREP = 2 };
+
+struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
+
+struct flbgpu_filter {
+    int kind = 0;
+    hipStream_t stream = nullptr;
+    // filter_parser
+    FParserCfg pcfg;
+    std::vector<flbgpu_parser *> parsers;
+    DevBuf d_parsers;
+    uint32_t caps_stride = 0;
+    // filter_grep
+    std::vector<GrepRule> rules;
+    std::vector<TableBlob *> rule_blobs;
+    DevBuf d_rules;
+    int logical_op = 0;
+    // working buffers
+    DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_misc, d_status, d_out_off;
+    DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
+    uint64_t last_in = 0, last_out = 0;
+    // profiling
+    bool prof = false;
+    std::vector<KernelProf> kp;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~flbgpu_filter() {
+        for (auto *b : rule_blobs) delete b;
+        DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid,
+                         &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
+        for (auto *b : all) b->release();
+        if (ev0) (void) hipEventDestroy(ev0);
+        if (ev1) (void) hipEventDestroy(ev1);
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+static bool filter_common_init(flbgpu_filter *f) {
+    HIPOK(hipStreamCreate(&f->stream));
+    HIPOK(hipEventCreate(&f->ev0));
+    HIPOK(hipEventCreate(&f->ev1));
+    return true;
+}
+
+struct ProfScope {
+    flbgpu_filter *f; hipStream_t st; const char *name; bool on;
+    ProfScope(flbgpu_filter *f_, hipStream_t st_, const char *n) : f(f_), st(st_), name(n), on(f_->prof) {
+        if (on) (void) hipEventRecord(f->ev0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void) hipEventRecord(f->ev1, st);
+        (void) hipEventSynchronize(f->ev1);
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, f->ev0, f->ev1);
+        for (auto &k : f->kp) if (!strcmp(k.name, name)) { k.ms += ms; k.launches++; return; }
+        KernelProf k; k.name = name; k.ms = ms; k.launches = 1;
+        f->kp.push_back(k);
+    }
+};
+
+extern "C" void flbgpu_filter_profile(flbgpu_filter *f, int enable) { f->prof = enable != 0; f->kp.clear(); }
+
+extern "C" int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char **names, double *ms, uint64_t *launches) {
+    int n = 0;
+    for (auto &k : f->kp) {
+        if (n >= max) break;
+        names[n] = k.name; ms[n] = k.ms; launches[n] = k.launches; n++;
+    }
+    return n;
+}
+
+extern "C" void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t *out_records) {
+    if (in_records) *in_records = f->last_in;
+    if (out_records) *out_records = f->last_out;
+}
+
+extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int reserve_data, int preserve_key,
+                                                      int nparsers, flbgpu_parser **parsers) {
+    if (!key_name) { set_err("filter_parser: missing 'key_name'"); return nullptr; }
+    if (nparsers <= 0) { set_err("filter_parser: Invalid 'parser'"); return nullptr; }
+    auto *f = new flbgpu_filter();
+    f->kind = F_PARSER;
+    memset(&f->pcfg, 0, sizeof(f->pcfg));
+    f->pcfg.reserve_data = reserve_data;
+    f->pcfg.preserve_key = preserve_key;
+    f->pcfg.nparsers = nparsers;
+    if (key_name[0] == '$') {
+        std::string why;
+        if (!parse_ra(key_name, f->pcfg.key, why)) { set_err("filter_parser: invalid record accessor pattern '%s': %s", key_name, why.c_str()); delete f; return nullptr; }
+    }
+    else {
+        size_t n = strlen(key_name);
+        if (n >= MAX_KEY) { set_err("filter_parser: key_name too long"); delete f; return nullptr; }
+        memcpy(f->pcfg.key.key, key_name, n);
+        f->pcfg.key.key_len = (int) n;
+    }
+    std::vector<DevParser> dp;
+    for (int i = 0; i < nparsers; i++) {
+        f->parsers.push_back(parsers[i]);
+        dp.push_back(parsers[i]->dev);
+        if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
+    }
+    if (f->caps_stride == 0) f->caps_stride = 2;
+    if (!filter_common_init(f) || !f->d_parsers.ensure(dp.size() * sizeof(DevParser))) { delete f; return nullptr; }
+    if (hipMemcpy(f->d_parsers.p, dp.data(), dp.size() * sizeof(DevParser), hipMemcpyHostToDevice) != hipSuccess) { set_err("upload failed"); delete f; return nullptr; }
+    return f;
+}
+
+extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *const *kinds, const char *const *values,
+                                                    const char *logical_op) {
+    auto *f = new flbgpu_filter();
+    f->kind = F_GREP;
+    f->logical_op = OP_LEGACY;
+    if (logical_op) {
+        size_t len = strlen(logical_op);
+        if (len == 3 && !strncasecmp("AND", logical_op, 3)) f->logical_op = OP_AND;
+        else if (len == 2 && !strncasecmp("OR", logical_op, 2)) f->logical_op = OP_OR;
+    }
+    int first_rule = 0;
+    for (int i = 0; i < nrules; i++) {
+        GrepRule r;
+        memset(&r, 0, sizeof(r));
+        if (!strcasecmp(kinds[i], "regex")) r.type = GREP_REGEX;
+        else if (!strcasecmp(kinds[i], "exclude")) r.type = GREP_EXCLUDE;
+        else continue;
+        if (f->logical_op != OP_LEGACY && first_rule != 0 && first_rule != r.type) {
+            set_err("filter_grep: Both 'regex' and 'exclude' are set.");
+            delete f;
+            return nullptr;
+        }
+        first_rule = r.type;
+        // flb_utils_split(val, ' ', 1): src/flb_utils.c:386-462
+        const char *v = values[i];
+        while (*v == ' ') v++;
+        const char *sp = strchr(v, ' ');
+        if (!sp || sp == v || !sp[1]) { set_err("filter_grep: invalid regex, expected field and regular expression"); delete f; return nullptr; }
+        std::string field(v, sp - v);
+        if (field[0] != '$') field = "$" + field;
+        std::string why;
+        if (!parse_ra(field.c_str(), r.key, why)) { set_err("filter_grep: invalid record accessor? '%s': %s", field.c_str(), why.c_str()); delete f; return nullptr; }
+        const char *ps, *pe;
+        unsigned opts;
+        rx::split_flb_pattern(sp + 1, &ps, &pe, &opts);
+        rx::Program prog;
+        std::string err;
+        if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) {
+            set_err("filter_grep: could not compile regex pattern '%s' for the GPU path: %s", sp + 1, err.c_str());
+            delete f;
+            return nullptr;
+        }
+        auto *b1 = new TableBlob(), *b2 = new TableBlob();
+        f->rule_blobs.push_back(b1);
+        f->rule_blobs.push_back(b2);
+        if (!upload_dfa(prog.ascii, *b1, r.dfa) || !upload_cap(prog.utf8, *b2, r.utf8)) { delete f; return nullptr; }
+        if ((int) f->rules.size() >= MAX_RULES) { set_err("filter_grep: more than %d rules", MAX_RULES); delete f; return nullptr; }
+        f->rules.push_back(r);
+    }
+    if (!filter_common_init(f) || !f->d_rules.ensure(std::max<size_t>(1, f->rules.size()) * sizeof(GrepRule))) { delete f; return nullptr; }
+    if (!f->rules.empty() &&
+        hipMemcpy(f->d_rules.p, f->rules.data(), f->rules.size() * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) {
+        set_err("upload failed");
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+
+extern "C" void flbgpu_filter_destroy(flbgpu_filter *f) { delete f; }
+
+extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
+    if (!p) return;
+    if (p->self_filter) delete p->self_filter;
+    delete p;
+}
+
+// ------------------------------------------------------------------------------------------ run (device level)
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[2]; };
+
+static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
+    uint64_t n = in->n;
+    *ret = FLBGPU_FILTER_NOTOUCH;
+    f->last_in = 0; f->last_out = 0;
+    if (n == 0) return true;
+    if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
+    MiscWords *dm = f->d_misc.as<MiscWords>();
+    MiscWords hm;
+    const uint64_t *row_off = in->row_off;
+    const uint8_t *data = (const uint8_t *) in->data;
+    // scratch sizing: one state id per byte boundary of the longest record
+    memset(&hm, 0, sizeof(hm));
+    hm.first_bad = ~0ull;
+    HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+    launch_max_row_len(row_off, n, &dm->max_row, st);
+    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    uint32_t rid_len = (uint32_t) hm.max_row + 2;
+    int cus = g_cus > 0 ? g_cus : 256;
+    int grid = cus * 8;                                     // 8 blocks of 4 waves per CU
+    uint64_t need_blocks = (n + 255) / 256;
+    if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
+    // bound the scratch to ~2 GiB by shrinking the grid for very long records
+    while (grid > 1 && (size_t) grid * 4 * 64 * rid_len * sizeof(uint16_t) > ((size_t) 2 << 30)) grid /= 2;
+    if (!f->d_rid.ensure((size_t) grid * 4 * 64 * rid_len * sizeof(uint16_t))) return false;
+    if (!f->d_info.ensure(n * sizeof(RecInfo)) || !f->d_caps.ensure(n * f->caps_stride * sizeof(uint32_t)) ||
+        !f->d_null.ensure(n * sizeof(uint64_t)) || !f->d_len.ensure(n * sizeof(uint32_t)) ||
+        !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
+        return false;
+    ParserMatchArgs ma;
+    ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
+    ma.info = f->d_info.as<RecInfo>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
+    ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.rid = f->d_rid.as<uint16_t>();
+    ma.rid_len = rid_len; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    { ProfScope ps(f, st, "k_parser_match"); launch_parser_match(ma, grid, st); }
+    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
+    if (n == 0) return true;
+    { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
+    uint64_t total = 0;
+    HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    f->last_in = hm.counts[0];
+    if (total == 0) return true;                            // encoder produced nothing: NOTOUCH (+ error log)
+    if (!f->d_out.ensure(total + 16)) return false;
+    ParserEmitArgs ea;
+    ea.data = data; ea.row_off = row_off; ea.n = n; ea.cfg = f->pcfg; ea.parsers = f->d_parsers.as<DevParser>();
+    ea.info = f->d_info.as<RecInfo>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
+    ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
+    ea.out = f->d_out.as<uint8_t>();
+    { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, st); }
+    HIPOK(hipStreamSynchronize(st));
+    out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
+    f->last_out = hm.counts[1];   // rows with length 0 (dropped/skipped) remain as empty rows
+    *ret = FLBGPU_FILTER_MODIFIED;
+    return true;
+}
+
+static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret,
+                         bool trailing_garbage) {
+    uint64_t n = in->n;
+    *ret = FLBGPU_FILTER_NOTOUCH;
+    f->last_in = 0; f->last_out = 0;
+    if (n == 0) return true;
+    if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
+    MiscWords *dm = f->d_misc.as<MiscWords>();
+    MiscWords hm;
+    memset(&hm, 0, sizeof(hm));
+    hm.first_bad = ~0ull;
+    HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+    if (!f->d_len.ensure(n * sizeof(uint32_t)) || !f->d_status.ensure(n * sizeof(uint32_t)) ||
+        !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
+        return false;
+    GrepArgs ga;
+    ga.data = (const uint8_t *) in->data; ga.row_off = in->row_off; ga.n = n; ga.rules = f->d_rules.as<GrepRule>();
+    ga.nrules = (int) f->rules.size(); ga.logical_op = f->logical_op; ga.keep_len = f->d_len.as<uint32_t>();
+    ga.status = f->d_status.as<uint32_t>(); ga.first_bad = &dm->first_bad; ga.counts = dm->counts;
+    { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, st); }
+    { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
+    uint64_t total = 0;
+    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    f->last_in = hm.counts[0];
+    f->last_out = hm.counts[0];
+    // Any decoder error (bad event shape, truncated or malformed msgpack) ends the reference's
+    // loop with an error code: whatever was kept, the filter answers NOTOUCH
+    // (plugins/filter_grep/grep.c:356-385).  "we keep everything" compares RECORD COUNTS, and
+    // group markers are not records (old_size == new_size, :362-371).
+    if (hm.first_bad != ~0ull || trailing_garbage) return true;
+    if (hm.counts[0] == hm.counts[1]) return true;
+    f->last_out = hm.counts[1];
+    if (!f->d_out.ensure(total + 16)) return false;
+    GatherArgs ta;
+    ta.data = (const uint8_t *) in->data; ta.row_off = in->row_off; ta.n = n; ta.keep_len = f->d_len.as<uint32_t>();
+    ta.out_off = f->d_off.as<uint64_t>(); ta.out = f->d_out.as<uint8_t>();
+    { ProfScope ps(f, st, "k_gather"); launch_gather(ta, st); }
+    HIPOK(hipStreamSynchronize(st));
+    out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
+    *ret = FLBGPU_FILTER_MODIFIED;
+    return true;
+}
+
+extern "C" int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream) {
+    hipStream_t st = stream ? (hipStream_t) stream : f->stream;
+    int ret = FLBGPU_FILTER_NOTOUCH;
+    bool ok = f->kind == F_PARSER ? run_parser_dev(f, in, out, st, &ret) : run_grep_dev(f, in, out, st, &ret, false);
+    if (!ok) return FLBGPU_FILTER_NOTOUCH;      // errors degrade to NOTOUCH (SURVEY 8b "Errors")
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------ host indexer
+static inline bool h_skip(const uint8_t *d, size_t len, size_t *pos) {
+    size_t p = *pos;
+    uint64_t remaining = 1;
+    while (remaining > 0) {
+        if (p >= len) return false;
+        uint8_t c = d[p++];
+        size_t need = 0, payload = 0;
+        uint64_t kids = 0;
+        if (c <= 0x7f || c >= 0xe0) { }
+        else if (c >= 0xa0 && c <= 0xbf) payload = c & 31;
+        else if (c >= 0x90 && c <= 0x9f) kids = c & 15;
+        else if (c >= 0x80 && c <= 0x8f) kids = 2ull * (c & 15);
+        else {
+            int kind = 0;   // 1 payload-length, 2 array count, 3 map count, 4 ext
+            switch (c) {
+            case 0xc0: case 0xc2: case 0xc3: break;
+            case 0xc1: return false;
+            case 0xc4: need = 1; kind = 1; break;
+            case 0xc5: need = 2; kind = 1; break;
+            case 0xc6: need = 4; kind = 1; break;
+            case 0xc7: need = 1; kind = 4; break;
+            case 0xc8: need = 2; kind = 4; break;
+            case 0xc9: need = 4; kind = 4; break;
+            case 0xca: payload = 4; break;
+            case 0xcb: payload = 8; break;
+            case 0xcc: case 0xd0: payload = 1; break;
+            case 0xcd: case 0xd1: payload = 2; break;
+            case 0xce: case 0xd2: payload = 4; break;
+            case 0xcf: case 0xd3: payload = 8; break;
+            case 0xd4: payload = 2; break;
+            case 0xd5: payload = 3; break;
+            case 0xd6: payload = 5; break;
+            case 0xd7: payload = 9; break;
+            case 0xd8: payload = 17; break;
+            case 0xd9: need = 1; kind = 1; break;
+            case 0xda: need = 2; kind = 1; break;
+            case 0xdb: need = 4; kind = 1; break;
+            case 0xdc: need = 2; kind = 2; break;
+            case 0xdd: need = 4; kind = 2; break;
+            case 0xde: need = 2; kind = 3; break;
+            case 0xdf: need = 4; kind = 3; break;
+            }
+            if (need) {
+                if (len - p < need) return false;
+                uint64_t v = 0;
+                for (size_t i = 0; i < need; i++) v = (v << 8) | d[p + i];
+                p += need;
+                if (kind == 1) payload = (size_t) v;
+                else if (kind == 2) kids = v;
+                else if (kind == 3) kids = 2 * v;
+                else payload = (size_t) v + 1;
+            }
+        }
+        if (len - p < payload) return false;
+        p += payload;
+        remaining--;
+        remaining += kids;
+        if (kids > len - p) return false;          // every element needs at least one byte
+    }
+    *pos = p;
+    return true;
+}
+
+extern "C" int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap, size_t *consumed) {
+    const uint8_t *d = (const uint8_t *) data;
+    size_t pos = 0;
+    int64_t n = 0;
+    while (pos < bytes) {
+        size_t q = pos;
+        if (!h_skip(d, bytes, &q)) break;
+        if ((size_t) n + 1 >= cap) break;
+        row_off[n++] = pos;
+        pos = q;
+    }
+    if (cap > 0) row_off[n] = pos;
+    if (consumed) *consumed = pos;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------ run (host level)
+extern "C" int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **out_buf, size_t *out_size) {
+    if (bytes == 0) return FLBGPU_FILTER_NOTOUCH;
+    // record boundaries: worst case one record per 3 bytes
+    std::vector<uint64_t> off(bytes / 3 + 2);
+    size_t consumed = 0;
+    int64_t n = flbgpu_index_host(data, bytes, off.data(), off.size(), &consumed);
+    bool garbage = consumed != bytes;
+    if (n == 0) return FLBGPU_FILTER_NOTOUCH;
+    hipStream_t st = f->stream;
+    if (!f->h_in_data.ensure(consumed + 16) || !f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return FLBGPU_FILTER_NOTOUCH;
+    if (hipMemcpyAsync(f->h_in_data.p, data, consumed, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(f->h_in_off.p, off.data(), (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+        set_err("host to device copy failed");
+        return FLBGPU_FILTER_NOTOUCH;
+    }
+    flbgpu_dev_chunk in, out;
+    in.data = f->h_in_data.p; in.row_off = f->h_in_off.as<uint64_t>(); in.n = (uint64_t) n; in.bytes = consumed;
+    memset(&out, 0, sizeof(out));
+    int ret = FLBGPU_FILTER_NOTOUCH;
+    bool ok = f->kind == F_PARSER ? run_parser_dev(f, &in, &out, st, &ret) : run_grep_dev(f, &in, &out, st, &ret, garbage);
+    if (!ok || ret != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
+    void *hb = malloc(out.bytes ? out.bytes : 1);
+    if (!hb) return FLBGPU_FILTER_NOTOUCH;
+    if (out.bytes && hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        free(hb);
+        set_err("device to host copy failed");
+        return FLBGPU_FILTER_NOTOUCH;
+    }
+    *out_buf = hb;
+    *out_size = out.bytes;
+    return FLBGPU_FILTER_MODIFIED;
+}
+
+// flb_parser_do on a batch of one: wraps the value as {"k": value} and runs filter_parser with
+// Key_Name k, then strips the event header from the output.
+extern "C" int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length, void **out_buf, size_t *out_size,
+                                int64_t *out_sec, int64_t *out_nsec) {
+    if (!p->self_filter) {
+        flbgpu_parser *arr[1] = {p};
+        p->self_filter = flbgpu_filter_parser_create("k", 0, 0, 1, arr);
+        if (!p->self_filter) return -1;
+    }
+    std::vector<uint8_t> rec;
+    const uint8_t hdr[] = {0x92, 0x92, 0xd7, 0x00, 0, 0, 0, 0, 0, 0, 0, 0, 0x80, 0x81, 0xa1, 'k', 0xdb};
+    rec.insert(rec.end(), hdr, hdr + sizeof(hdr));
+    for (int i = 3; i >= 0; i--) rec.push_back((uint8_t) (length >> (8 * i)));
+    rec.insert(rec.end(), (const uint8_t *) buf, (const uint8_t *) buf + length);
+    void *ob = nullptr;
+    size_t os = 0;
+    if (flbgpu_filter_run(p->self_filter, rec.data(), rec.size(), &ob, &os) != FLBGPU_FILTER_MODIFIED || os < 13) { free(ob); return -1; }
+    const uint8_t *o = (const uint8_t *) ob;
+    size_t body = 13;       // 92 92 d7 00 <8> 80
+    // an unparsed record comes back as the canonical re-pack of the wrapper body {"k": value}
+    bool parsed;
+    {
+        std::vector<uint8_t> canon = {0x81, 0xa1, 'k'};
+        if (length < 32) canon.push_back((uint8_t) (0xa0 | length));
+        else if (length < 256) { canon.push_back(0xd9); canon.push_back((uint8_t) length); }
+        else if (length < 65536) { canon.push_back(0xda); canon.push_back((uint8_t) (length >> 8)); canon.push_back((uint8_t) length); }
+        else { canon.push_back(0xdb); for (int i = 3; i >= 0; i--) canon.push_back((uint8_t) (length >> (8 * i))); }
+        parsed = !(os - body == canon.size() + length && !memcmp(o + body, canon.data(), canon.size()) &&
+                   !memcmp(o + body + canon.size(), buf, length));
+    }
+    if (!parsed) { free(ob); return -1; }
+    uint32_t sec = ((uint32_t) o[4] << 24) | (o[5] << 16) | (o[6] << 8) | o[7];
+    uint32_t nsec = ((uint32_t) o[8] << 24) | (o[9] << 16) | (o[10] << 8) | o[11];
+    *out_sec = sec; *out_nsec = nsec;
+    size_t ms = os - body;
+    void *m = malloc(ms ? ms : 1);
+    memcpy(m, o + body, ms);
+    free(ob);
+    *out_buf = m; *out_size = ms;
+    return (int) length;     // NOTE: the reference returns the end of the last named group
+}
+
+// ------------------------------------------------------------------------------------------ device helpers
+extern "C" void *flbgpu_dev_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_err("hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void flbgpu_dev_free(void *p) { if (p) (void) hipFree(p); }
+extern "C" int flbgpu_memcpy_h2d(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+extern "C" int flbgpu_memcpy_d2h(void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+extern "C" int flbgpu_sync(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }

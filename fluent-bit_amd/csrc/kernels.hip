@@ -1,0 +1,1322 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / MI355X) for the Fluent Bit filter hot path.
+//
+// Layout in HBM: a chunk is the reference wire format itself (concatenated msgpack log events,
+// src/flb_log_event_encoder.c:195-217) as one contiguous byte column plus a row-offset column
+// (u64 [n+1]).  One record is processed per lane; the automaton tables (byte classes, reverse
+// DFA, viable-position bit sets, priority lists) are staged in LDS and stepped one input byte
+// per lane.  Nothing here is a dense contraction, so there is no MFMA: the bound is HBM/LDS.
+//
+//   k_parser_match   filter_parser pass 1: decode event, locate Key_Name, run the parsers'
+//                    capture programs, parse the time field, compute the output size
+//                    (plugins/filter_parser/filter_parser.c:226-323, src/flb_parser_regex.c:114-227)
+//   k_parser_emit    filter_parser pass 2: write the V2 record at its scanned offset
+//                    (filter_parser.c:325-413, src/flb_log_event_encoder.c:195-217)
+//   k_grep_match     filter_grep: rule evaluation -> keep flag / kept length
+//                    (plugins/filter_grep/grep.c:167-194,250-284, src/flb_ra_key.c:374-434)
+//   k_gather         copy of the kept records (flb_log_event_encoder_emit_raw_record)
+//   k_scan_*         exclusive prefix sums (u32 -> u64) used for the write offsets
+//   k_index_*        record boundary discovery helpers
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev.hpp"
+
+namespace flbgpu {
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------
+// byte access
+// ------------------------------------------------------------------------------------------
+DEV uint32_t ld8(const uint8_t *p) { return *p; }
+DEV uint32_t ldbe16(const uint8_t *p) { return (ld8(p) << 8) | ld8(p + 1); }
+DEV uint32_t ldbe32(const uint8_t *p) { return (ld8(p) << 24) | (ld8(p + 1) << 16) | (ld8(p + 2) << 8) | ld8(p + 3); }
+DEV uint64_t ldbe64(const uint8_t *p) { return ((uint64_t) ldbe32(p) << 32) | ldbe32(p + 4); }
+
+// ------------------------------------------------------------------------------------------
+// output sinks: CountSink sizes, ByteSink writes
+// ------------------------------------------------------------------------------------------
+struct CountSink {
+    uint64_t n = 0;
+    DEV void put(uint32_t) { n++; }
+    DEV void copy(const uint8_t *, uint32_t len) { n += len; }
+    DEV void finish() {}
+};
+
+struct ByteSink {
+    uint8_t *p;
+    DEV explicit ByteSink(uint8_t *dst) : p(dst) {}
+    DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
+    DEV void copy(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = (uint8_t) ld8(src + i); }
+    DEV void finish() {}
+};
+
+// msgpack packers over a sink (lib/msgpack-c/cmake/pack_template.h.in smallest-encoding rules)
+template <class S> DEV void pk_be(S &s, uint64_t v, int n) { for (int i = n - 1; i >= 0; i--) s.put((uint32_t) (v >> (8 * i))); }
+template <class S> DEV void pk_uint(S &s, uint64_t v) {
+    if (v < 128) s.put((uint32_t) v);
+    else if (v < 256) { s.put(0xcc); s.put((uint32_t) v); }
+    else if (v < 65536) { s.put(0xcd); pk_be(s, v, 2); }
+    else if (v < (1ull << 32)) { s.put(0xce); pk_be(s, v, 4); }
+    else { s.put(0xcf); pk_be(s, v, 8); }
+}
+template <class S> DEV void pk_int(S &s, int64_t v) {
+    if (v >= 0) { pk_uint(s, (uint64_t) v); return; }
+    if (v >= -32) s.put((uint32_t) (uint8_t) v);
+    else if (v >= -128) { s.put(0xd0); s.put((uint32_t) (uint8_t) v); }
+    else if (v >= -32768) { s.put(0xd1); pk_be(s, (uint64_t) v, 2); }
+    else if (v >= -2147483648LL) { s.put(0xd2); pk_be(s, (uint64_t) v, 4); }
+    else { s.put(0xd3); pk_be(s, (uint64_t) v, 8); }
+}
+template <class S> DEV void pk_str_hdr(S &s, uint32_t n) {
+    if (n < 32) s.put(0xa0 | n);
+    else if (n < 256) { s.put(0xd9); s.put(n); }
+    else if (n < 65536) { s.put(0xda); pk_be(s, n, 2); }
+    else { s.put(0xdb); pk_be(s, n, 4); }
+}
+template <class S> DEV void pk_bin_hdr(S &s, uint32_t n) {
+    if (n < 256) { s.put(0xc4); s.put(n); }
+    else if (n < 65536) { s.put(0xc5); pk_be(s, n, 2); }
+    else { s.put(0xc6); pk_be(s, n, 4); }
+}
+template <class S> DEV void pk_ext_hdr(S &s, uint32_t n, uint32_t type) {
+    if (n == 1) s.put(0xd4);
+    else if (n == 2) s.put(0xd5);
+    else if (n == 4) s.put(0xd6);
+    else if (n == 8) s.put(0xd7);
+    else if (n == 16) s.put(0xd8);
+    else if (n < 256) { s.put(0xc7); s.put(n); }
+    else if (n < 65536) { s.put(0xc8); pk_be(s, n, 2); }
+    else { s.put(0xc9); pk_be(s, n, 4); }
+    s.put(type);
+}
+template <class S> DEV void pk_array_hdr(S &s, uint32_t n) {
+    if (n < 16) s.put(0x90 | n);
+    else if (n < 65536) { s.put(0xdc); pk_be(s, n, 2); }
+    else { s.put(0xdd); pk_be(s, n, 4); }
+}
+template <class S> DEV void pk_map_hdr(S &s, uint32_t n) {
+    if (n < 16) s.put(0x80 | n);
+    else if (n < 65536) { s.put(0xde); pk_be(s, n, 2); }
+    else { s.put(0xdf); pk_be(s, n, 4); }
+}
+
+// ------------------------------------------------------------------------------------------
+// msgpack token reader
+// ------------------------------------------------------------------------------------------
+enum { T_NIL, T_BOOL, T_UINT, T_NINT, T_F32, T_F64, T_STR, T_BIN, T_EXT, T_ARRAY, T_MAP, T_BAD };
+
+struct Tok {
+    int type;
+    uint32_t len;        // payload length (str/bin/ext) or element count (array/map)
+    uint64_t u;          // integer value bits / float bits / bool / ext type
+    const uint8_t *next; // first byte after the header (payload start for str/bin/ext)
+};
+
+// reads one token header at p (p < end); returns T_BAD on truncation or the reserved byte 0xc1
+DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
+    Tok t;
+    t.type = T_BAD; t.len = 0; t.u = 0; t.next = p;
+    if (p >= end) return t;
+    uint32_t c = ld8(p++);
+    uint32_t need = 0;
+    if (c <= 0x7f) { t.type = T_UINT; t.u = c; }
+    else if (c >= 0xe0) { t.type = T_NINT; t.u = (uint64_t) (int64_t) (int8_t) c; }
+    else if (c >= 0xa0 && c <= 0xbf) { t.type = T_STR; t.len = c & 31; }
+    else if (c >= 0x90 && c <= 0x9f) { t.type = T_ARRAY; t.len = c & 15; }
+    else if (c >= 0x80 && c <= 0x8f) { t.type = T_MAP; t.len = c & 15; }
+    else {
+        switch (c) {
+        case 0xc0: t.type = T_NIL; break;
+        case 0xc2: t.type = T_BOOL; t.u = 0; break;
+        case 0xc3: t.type = T_BOOL; t.u = 1; break;
+        case 0xc4: need = 1; t.type = T_BIN; break;
+        case 0xc5: need = 2; t.type = T_BIN; break;
+        case 0xc6: need = 4; t.type = T_BIN; break;
+        case 0xc7: need = 1; t.type = T_EXT; break;
+        case 0xc8: need = 2; t.type = T_EXT; break;
+        case 0xc9: need = 4; t.type = T_EXT; break;
+        case 0xca: need = 4; t.type = T_F32; break;
+        case 0xcb: need = 8; t.type = T_F64; break;
+        case 0xcc: need = 1; t.type = T_UINT; break;
+        case 0xcd: need = 2; t.type = T_UINT; break;
+        case 0xce: need = 4; t.type = T_UINT; break;
+        case 0xcf: need = 8; t.type = T_UINT; break;
+        case 0xd0: need = 1; t.type = T_NINT; break;
+        case 0xd1: need = 2; t.type = T_NINT; break;
+        case 0xd2: need = 4; t.type = T_NINT; break;
+        case 0xd3: need = 8; t.type = T_NINT; break;
+        case 0xd4: t.type = T_EXT; t.len = 1; break;
+        case 0xd5: t.type = T_EXT; t.len = 2; break;
+        case 0xd6: t.type = T_EXT; t.len = 4; break;
+        case 0xd7: t.type = T_EXT; t.len = 8; break;
+        case 0xd8: t.type = T_EXT; t.len = 16; break;
+        case 0xd9: need = 1; t.type = T_STR; break;
+        case 0xda: need = 2; t.type = T_STR; break;
+        case 0xdb: need = 4; t.type = T_STR; break;
+        case 0xdc: need = 2; t.type = T_ARRAY; break;
+        case 0xdd: need = 4; t.type = T_ARRAY; break;
+        case 0xde: need = 2; t.type = T_MAP; break;
+        case 0xdf: need = 4; t.type = T_MAP; break;
+        default: return t;      // 0xc1
+        }
+        if ((uint64_t) (end - p) < need) { t.type = T_BAD; return t; }
+        if (need) {
+            uint64_t v = need == 1 ? ld8(p) : need == 2 ? ldbe16(p) : need == 4 ? ldbe32(p) : ldbe64(p);
+            p += need;
+            if (t.type == T_UINT || t.type == T_F32 || t.type == T_F64) t.u = v;
+            else if (t.type == T_NINT) {
+                int64_t sv = need == 1 ? (int64_t) (int8_t) v : need == 2 ? (int64_t) (int16_t) v
+                           : need == 4 ? (int64_t) (int32_t) v : (int64_t) v;
+                // non-negative values of the signed family are POSITIVE_INTEGER
+                // (lib/msgpack-c/src/unpack.c template_callback_int*)
+                if (sv >= 0) t.type = T_UINT;
+                t.u = (uint64_t) sv;
+            }
+            else t.len = (uint32_t) v;
+        }
+        if (t.type == T_EXT) {
+            if (p >= end) { t.type = T_BAD; return t; }
+            t.u = ld8(p++);
+        }
+    }
+    if (t.type == T_STR || t.type == T_BIN || t.type == T_EXT) {
+        if ((uint64_t) (end - p) < t.len) { t.type = T_BAD; return t; }
+    }
+    t.next = p;
+    return t;
+}
+
+// skips one complete object; nullptr when malformed / truncated
+DEV const uint8_t *mp_skip(const uint8_t *p, const uint8_t *end) {
+    uint64_t remaining = 1;
+    while (remaining > 0) {
+        Tok t = mp_tok(p, end);
+        if (t.type == T_BAD) return nullptr;
+        remaining--;
+        p = t.next;
+        if (t.type == T_STR || t.type == T_BIN || t.type == T_EXT) p += t.len;
+        else if (t.type == T_ARRAY) remaining += t.len;
+        else if (t.type == T_MAP) remaining += 2ull * t.len;
+    }
+    return p;
+}
+
+// canonical re-pack of one object (msgpack_pack_object, lib/msgpack-c/src/objectc.c:39-126)
+template <class S> DEV const uint8_t *mp_canon(const uint8_t *p, const uint8_t *end, S &s) {
+    uint64_t remaining = 1;
+    while (remaining > 0) {
+        Tok t = mp_tok(p, end);
+        if (t.type == T_BAD) return nullptr;
+        remaining--;
+        p = t.next;
+        switch (t.type) {
+        case T_NIL: s.put(0xc0); break;
+        case T_BOOL: s.put(t.u ? 0xc3 : 0xc2); break;
+        case T_UINT: pk_uint(s, t.u); break;
+        case T_NINT: pk_int(s, (int64_t) t.u); break;
+        case T_F32: s.put(0xca); pk_be(s, t.u, 4); break;
+        case T_F64: s.put(0xcb); pk_be(s, t.u, 8); break;
+        case T_STR: pk_str_hdr(s, t.len); s.copy(p, t.len); p += t.len; break;
+        case T_BIN: pk_bin_hdr(s, t.len); s.copy(p, t.len); p += t.len; break;
+        case T_EXT: pk_ext_hdr(s, t.len, (uint32_t) t.u); s.copy(p, t.len); p += t.len; break;
+        case T_ARRAY: pk_array_hdr(s, t.len); remaining += t.len; break;
+        case T_MAP: pk_map_hdr(s, t.len); remaining += 2ull * t.len; break;
+        }
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// log event decode (src/flb_log_event_decoder.c:182-330)
+// ------------------------------------------------------------------------------------------
+struct Event {
+    uint32_t flags;               // RF_*
+    int64_t sec, nsec;
+    const uint8_t *meta;          // nullptr => synthetic empty map (legacy format)
+    const uint8_t *meta_end;
+    const uint8_t *body;          // at the map header
+    const uint8_t *body_end;
+};
+
+DEV Event decode_event(const uint8_t *rec, const uint8_t *end) {
+    Event ev;
+    ev.flags = RF_BAD; ev.sec = 0; ev.nsec = 0; ev.meta = nullptr; ev.meta_end = nullptr; ev.body = nullptr; ev.body_end = nullptr;
+    Tok root = mp_tok(rec, end);
+    if (root.type != T_ARRAY || root.len != 2) return ev;
+    const uint8_t *p = root.next;
+    Tok h = mp_tok(p, end);
+    if (h.type == T_BAD) return ev;
+    Tok ts;
+    const uint8_t *after_header;
+    if (h.type == T_ARRAY) {
+        if (h.len != 2) return ev;
+        ts = mp_tok(h.next, end);
+        if (ts.type == T_BAD) return ev;
+        const uint8_t *ts_end = ts.next + ((ts.type == T_EXT || ts.type == T_STR || ts.type == T_BIN) ? ts.len : 0);
+        if (ts.type == T_ARRAY || ts.type == T_MAP) return ev;      // wrong timestamp type
+        Tok m = mp_tok(ts_end, end);
+        if (m.type != T_MAP) return ev;
+        ev.meta = ts_end;
+        ev.meta_end = mp_skip(ts_end, end);
+        if (!ev.meta_end) return ev;
+        after_header = ev.meta_end;
+    }
+    else {
+        ts = h;
+        if (ts.type == T_MAP) return ev;
+        after_header = mp_skip(p, end);
+        if (!after_header) return ev;
+    }
+    if (ts.type != T_UINT && ts.type != T_F64 && ts.type != T_EXT) return ev;
+    Tok b = mp_tok(after_header, end);
+    if (b.type != T_MAP) return ev;
+    ev.body = after_header;
+    ev.body_end = mp_skip(after_header, end);
+    if (!ev.body_end) return ev;
+    // timestamp value (flb_log_event_decoder_decode_timestamp)
+    if (ts.type == T_UINT) { ev.sec = (int64_t) ts.u; ev.nsec = 0; }
+    else if (ts.type == T_F64) {
+        double f = __longlong_as_double((long long) ts.u);
+        ev.sec = (int64_t) f;
+        ev.nsec = (int64_t) ((f - (double) ev.sec) * 1000000000);
+    }
+    else {
+        if (ts.u != 0 || ts.len != 8) return ev;
+        uint32_t s = ldbe32(ts.next), ns = ldbe32(ts.next + 4);
+        if (s == 0xffffffffu || s == 0xfffffffeu) {
+            if (ns != 0) return ev;
+            ev.sec = s == 0xffffffffu ? -1 : -2;
+            ev.nsec = 0;
+        }
+        else {
+            if (ns >= 1000000000u) return ev;     // flb_time_is_valid_eventtime
+            ev.sec = s; ev.nsec = ns;
+        }
+    }
+    ev.flags = RF_VALID;
+    if (ev.sec < 0) ev.flags |= RF_SKIP;          // group markers / invalid negative markers
+    return ev;
+}
+
+// ------------------------------------------------------------------------------------------
+// key lookup
+// ------------------------------------------------------------------------------------------
+DEV bool bytes_eq(const uint8_t *a, const char *b, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) if (ld8(a + i) != (uint8_t) b[i]) return false;
+    return true;
+}
+
+// src/flb_ra_key.c:108-135: LAST entry whose key is a STR equal to `key`; returns the value ptr
+DEV const uint8_t *map_find_last(const uint8_t *map, const uint8_t *end, const char *key, uint32_t klen) {
+    Tok m = mp_tok(map, end);
+    if (m.type != T_MAP) return nullptr;
+    const uint8_t *p = m.next, *found = nullptr;
+    for (uint32_t i = 0; i < m.len; i++) {
+        Tok k = mp_tok(p, end);
+        if (k.type == T_BAD) return nullptr;
+        const uint8_t *kend = mp_skip(p, end);
+        if (!kend) return nullptr;
+        if (k.type == T_STR && k.len == klen && bytes_eq(k.next, key, klen)) found = kend;
+        p = mp_skip(kend, end);
+        if (!p) return nullptr;
+    }
+    return found;
+}
+
+// src/flb_ra_key.c:151-236 + :374-434: resolves `$key['a'][1]`; returns pointer to the value
+// object or nullptr.  *plain is set when the top-level value was used as is.
+DEV const uint8_t *ra_resolve(const DevKey &k, const uint8_t *body, const uint8_t *end) {
+    const uint8_t *val = map_find_last(body, end, k.key, (uint32_t) k.key_len);
+    if (!val) return nullptr;
+    Tok t = mp_tok(val, end);
+    if ((t.type == T_MAP || t.type == T_ARRAY) && k.nsub > 0) {
+        const uint8_t *cur = val;
+        int matched = 0;
+        for (int s = 0; s < k.nsub; s++) {
+            Tok c = mp_tok(cur, end);
+            if (k.sub_is_index[s]) {
+                if (c.type != T_ARRAY) return nullptr;
+                if ((uint32_t) k.sub_index[s] >= c.len) return nullptr;
+                const uint8_t *p = c.next;
+                for (int i = 0; i < k.sub_index[s]; i++) { p = mp_skip(p, end); if (!p) return nullptr; }
+                cur = p;
+                matched++;
+                if (matched == k.nsub) break;
+                continue;
+            }
+            if (c.type != T_MAP) break;
+            const uint8_t *v = map_find_last(cur, end, k.sub_str + k.sub_off[s], (uint32_t) k.sub_len[s]);
+            if (!v) continue;                      // "try next entry" (never completes the levels)
+            cur = v;
+            matched++;
+            if (matched == k.nsub) break;
+        }
+        if (matched == 0 || matched != k.nsub) return nullptr;
+        return cur;
+    }
+    return val;
+}
+
+// ------------------------------------------------------------------------------------------
+// regex: match-only DFA
+// ------------------------------------------------------------------------------------------
+constexpr int RX_NOMATCH = 0, RX_MATCH = 1, RX_POISON = 2;
+
+template <class T8, class T16>
+DEV int dfa_match(const T8 *cls, const T16 *ddelta, const uint8_t *d_final, int ncls, int d_init,
+                  const uint8_t *s, uint32_t len) {
+    uint32_t st = (uint32_t) d_init;
+    for (uint32_t i = 0; i < len; i++) {
+        uint32_t c = cls[ld8(s + i)];
+        uint32_t n = ddelta[st * (uint32_t) ncls + c];
+        if (n == 0xFFFF) return RX_MATCH;
+        if (n == 0xFFFE) return RX_POISON;
+        st = n;
+    }
+    return d_final[st] ? RX_MATCH : RX_NOMATCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// regex: capture program
+// ------------------------------------------------------------------------------------------
+DEV int utf8_seq_len_dev(const uint8_t *s, uint32_t i, uint32_t len) {
+    uint32_t b0 = ld8(s + i);
+    int rem = (int) (len - i - 1);
+    int need;
+    uint32_t lo1 = 0x80, hi1 = 0xbf;
+    if (b0 >= 0xc2 && b0 <= 0xdf) need = 1;
+    else if (b0 >= 0xe0 && b0 <= 0xef) { need = 2; if (b0 == 0xe0) lo1 = 0xa0; if (b0 == 0xed) hi1 = 0x9f; }
+    else if (b0 >= 0xf0 && b0 <= 0xf4) { need = 3; if (b0 == 0xf0) lo1 = 0x90; if (b0 == 0xf4) hi1 = 0x8f; }
+    else return 1;
+    for (int k = 1; k <= need; k++) {
+        if (k > rem) return need + 1;
+        uint32_t b = ld8(s + i + k);
+        if (k == 1) { if (b < lo1 || b > hi1) return 1; }
+        else if (b < 0x80 || b > 0xbf) return 1;
+    }
+    return need + 1;
+}
+
+// Views over a table set whose hot arrays may live in LDS (T = address-space qualified ptr)
+struct CapView {
+    const uint8_t *cls;
+    const uint16_t *rdelta;
+    const uint8_t *r_info;
+    const uint32_t *vmask;
+    const uint32_t *list_off;
+    const uint32_t *list_ent;
+    const uint32_t *tag_off;
+    const uint8_t *tag_data;
+    const uint8_t *kind_of_cls;
+    int ncls, r_init, VW, nX, NK, kind_edge, ascii_only;
+};
+
+DEV CapView view_of(const DevCap &d) {
+    CapView v;
+    v.cls = d.cls; v.rdelta = d.rdelta; v.r_info = d.r_info; v.vmask = d.vmask; v.list_off = d.list_off;
+    v.list_ent = d.list_ent; v.tag_off = d.tag_off; v.tag_data = d.tag_data; v.kind_of_cls = d.kind_of_cls;
+    v.ncls = d.ncls; v.r_init = d.r_init; v.VW = d.VW; v.nX = d.nX; v.NK = d.NK; v.kind_edge = d.kind_edge;
+    v.ascii_only = d.ascii_only;
+    return v;
+}
+
+// Pass 1 over one value: reverse automaton.  Stores the state id of every boundary 0..len into
+// `rid` (stride `rstride` elements between consecutive boundaries: the scratch is laid out
+// [boundary][lane] so that a wave's stores coalesce).  Returns the leftmost viable start
+// boundary, -1 for no match, -2 when a byte >= 0x80 poisoned the ASCII tables.
+template <bool STORE>
+DEV int rx_reverse(const CapView &t, const uint8_t *s, uint32_t len, uint16_t *rid, uint32_t rstride) {
+    uint32_t R = (uint32_t) t.r_init;
+    int best = -1, h1 = -1, h2 = -1;
+    if (STORE) rid[(size_t) len * rstride] = (uint16_t) R;
+    for (int i = (int) len - 1; i >= 0; i--) {
+        uint32_t b = ld8(s + i);
+        uint32_t e = t.rdelta[R * (uint32_t) t.ncls + t.cls[b]];
+        if ((e & 0x7FFF) == 0x7FFF) return -2;
+        int before = best;
+        if (e & 0x8000) best = i + 1;
+        R = e & 0x7FFF;
+        if (STORE) rid[(size_t) i * rstride] = (uint16_t) R;
+        if (!t.ascii_only) {
+            if (b >= 0xc2) {
+                int L = utf8_seq_len_dev(s, (uint32_t) i, len);
+                if (L == 2) best = before;
+                else if (L == 3) best = h1;
+                else if (L == 4) best = h2;
+            }
+            h2 = h1; h1 = before;
+        }
+    }
+    if (t.r_info[R] & 0x80) best = 0;
+    return best;
+}
+
+// Pass 2: deterministic leftmost-first walk from boundary `start`; writes the capture slots that
+// belong to named fields into caps[] (slot2cap maps a capture slot to its caps index or 0xFF).
+// Returns the end boundary of the match (>= 0) or -1 on a table inconsistency.
+DEV int rx_forward(const CapView &t, const uint8_t *s, uint32_t len, int start, const uint16_t *rid,
+                   uint32_t rstride, const uint8_t *slot2cap, uint32_t *caps) {
+    uint32_t x = (uint32_t) t.nX - 1;
+    uint32_t j = (uint32_t) start;
+    uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : t.kind_of_cls[t.cls[ld8(s + j - 1)]];
+    for (;;) {
+        uint32_t r = rid[(size_t) j * rstride];
+        uint32_t nk = t.r_info[r] & 7;
+        uint32_t li = (x * (uint32_t) t.NK + pk) * (uint32_t) t.NK + nk;
+        uint32_t k = t.list_off[li], kend = t.list_off[li + 1];
+        uint32_t pick = 0xFFFFFFFFu;
+        for (; k < kend; k++) {
+            uint32_t ent = t.list_ent[k];
+            uint32_t tg = ent & 0xFFFF;
+            if (tg == 0xFFFF || ((t.vmask[r * (uint32_t) t.VW + (tg >> 5)] >> (tg & 31)) & 1)) { pick = ent; break; }
+        }
+        if (pick == 0xFFFFFFFFu) return -1;
+        uint32_t ts = pick >> 16;
+        for (uint32_t q = t.tag_off[ts]; q < t.tag_off[ts + 1]; q++) {
+            uint32_t ci = slot2cap[t.tag_data[q]];
+            if (ci != 0xFF) caps[ci] = j;
+        }
+        if ((pick & 0xFFFF) == 0xFFFF) return (int) j;
+        x = pick & 0xFFFF;
+        pk = t.kind_of_cls[t.cls[ld8(s + j)]];
+        j++;
+        if (j > len) return -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// strptime (src/flb_strptime.c:253-907, C locale) + time lookup (src/flb_parser.c:1876-2065)
+// ------------------------------------------------------------------------------------------
+struct Tm {
+    int year, mon, mday, hour, min, sec, yday, wday;
+    long gmtoff;
+    int century, relyear, fields;
+    int have_epoch; int64_t epoch;      // %s
+};
+enum { F_MON = 1, F_MDAY = 2, F_WDAY = 4, F_YDAY = 8, F_YEAR = 16 };
+
+DEV bool d_isspace(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+DEV bool d_isdigit(uint32_t c) { return c >= '0' && c <= '9'; }
+DEV uint32_t d_lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
+
+// input text is [s, e); reads past e yield NUL (the reference works on a NUL-terminated copy)
+struct TStr {
+    const uint8_t *s, *e;
+    DEV uint32_t at(const uint8_t *p) const { return p < e ? ld8(p) : 0; }
+};
+
+DEV bool conv_num(const TStr &in, const uint8_t *&bp, int &dest, int llim, int ulim) {
+    int result = 0, rulim = ulim;
+    uint32_t c = in.at(bp);
+    if (c < '0' || c > '9') return false;
+    do {
+        result *= 10;
+        result += (int) (in.at(bp++) - '0');
+        rulim /= 10;
+        c = in.at(bp);
+    } while ((result * 10 <= ulim) && rulim && c >= '0' && c <= '9');
+    if (result < llim || result > ulim) return false;
+    dest = result;
+    return true;
+}
+
+DEV bool conv_num64(const TStr &in, const uint8_t *&bp, int64_t &dest) {
+    int64_t result = 0, rulim = INT64_MAX;
+    uint32_t c = in.at(bp);
+    if (c < '0' || c > '9') return false;
+    do {
+        if (result > 922337203685477580LL) return false;
+        result *= 10;
+        if (result > 9223372036854775760LL) return false;
+        result += (int64_t) (in.at(bp++) - '0');
+        rulim /= 10;
+        if (result >= 922337203685477580LL) return false;
+        c = in.at(bp);
+    } while (rulim && c >= '0' && c <= '9');      // result*10 <= INT64_MAX always holds here
+    dest = result;
+    return true;
+}
+
+__constant__ char c_mon_full[12][10] = { "january", "february", "march", "april", "may", "june", "july",
+                                         "august", "september", "october", "november", "december" };
+__constant__ char c_day_full[7][10] = { "sunday", "monday", "tuesday", "wednesday", "thursday", "friday", "saturday" };
+__constant__ int c_mon_len[2][12] = { { 31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 },
+                                      { 31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 } };
+
+// case-insensitive prefix match of a lower-case word; returns its length or 0
+DEV int match_word(const TStr &in, const uint8_t *bp, const char *w, int wl) {
+    for (int i = 0; i < wl; i++) if (d_lower(in.at(bp + i)) != (uint32_t) w[i]) return 0;
+    return wl;
+}
+DEV int cstrlen(const char *w) { int n = 0; while (w[n]) n++; return n; }
+
+DEV bool d_isleap(int y) { return (y % 4) == 0 && ((y % 100) != 0 || (y % 400) == 0); }
+DEV int leaps_thru_end_of(int y) {
+    if (y >= 0) return y / 4 - y / 100 + y / 400;
+    int z = -(y + 1);
+    return -((z / 4 - z / 100 + z / 400) + 1);
+}
+
+// days since 1970-01-01 of year/month(1..12)/day
+DEV int64_t days_from_civil(int64_t y, int m, int d) {
+    y -= m <= 2;
+    int64_t era = (y >= 0 ? y : y - 399) / 400;
+    int64_t yoe = y - era * 400;
+    int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + doe - 719468;
+}
+
+// one flb_strptime() call (initialize = 1).  fmt holds only primitive directives (the host
+// expands %T %D %F %R %r %c %x %X).  Returns the new input pointer or nullptr.
+DEV const uint8_t *d_strptime(const TStr &in, const uint8_t *bp, const char *fmt, Tm &tm) {
+    tm.century = 1900; tm.relyear = -1; tm.fields = 0; tm.gmtoff = 0;
+    uint32_t c;
+    int i;
+    while ((c = (uint8_t) *fmt) != 0) {
+        if (d_isspace(c)) {
+            while (d_isspace(in.at(bp))) bp++;
+            fmt++;
+            continue;
+        }
+        if (in.at(bp) == 0) return nullptr;
+        c = (uint8_t) *fmt++;
+        if (c != '%') {
+            if (c != in.at(bp++)) return nullptr;
+            continue;
+        }
+        c = (uint8_t) *fmt++;
+        while (c == 'E' || c == 'O') c = (uint8_t) *fmt++;
+        switch (c) {
+        case '%':
+            if (in.at(bp++) != '%') return nullptr;
+            break;
+        case 'A': case 'a': {
+            int len = 0;
+            for (i = 0; i < 7; i++) {
+                len = match_word(in, bp, c_day_full[i], cstrlen(c_day_full[i]));
+                if (len) break;
+                len = match_word(in, bp, c_day_full[i], 3);
+                if (len) break;
+            }
+            if (i == 7) return nullptr;
+            tm.wday = i; bp += len; tm.fields |= F_WDAY;
+            break;
+        }
+        case 'B': case 'b': case 'h': {
+            int len = 0;
+            for (i = 0; i < 12; i++) {
+                len = match_word(in, bp, c_mon_full[i], cstrlen(c_mon_full[i]));
+                if (len) break;
+                len = match_word(in, bp, c_mon_full[i], 3);
+                if (len) break;
+            }
+            if (i == 12) return nullptr;
+            tm.mon = i; bp += len; tm.fields |= F_MON;
+            break;
+        }
+        case 'C':
+            if (!conv_num(in, bp, i, 0, 99)) return nullptr;
+            tm.century = i * 100;
+            break;
+        case 'e':
+            if (d_isspace(in.at(bp))) bp++;
+            /* FALLTHROUGH */
+        case 'd':
+            if (!conv_num(in, bp, tm.mday, 1, 31)) return nullptr;
+            tm.fields |= F_MDAY;
+            break;
+        case 'k': case 'H':
+            if (!conv_num(in, bp, tm.hour, 0, 23)) return nullptr;
+            break;
+        case 'l': case 'I':
+            if (!conv_num(in, bp, tm.hour, 1, 12)) return nullptr;
+            break;
+        case 'j':
+            if (!conv_num(in, bp, tm.yday, 1, 366)) return nullptr;
+            tm.yday--;
+            tm.fields |= F_YDAY;
+            break;
+        case 'M':
+            if (!conv_num(in, bp, tm.min, 0, 59)) return nullptr;
+            break;
+        case 'm':
+            if (!conv_num(in, bp, tm.mon, 1, 12)) return nullptr;
+            tm.mon--;
+            tm.fields |= F_MON;
+            break;
+        case 'p':
+            if (d_lower(in.at(bp)) == 'a' && d_lower(in.at(bp + 1)) == 'm') {
+                if (tm.hour > 12) return nullptr;
+                else if (tm.hour == 12) tm.hour = 0;
+                bp += 2;
+                break;
+            }
+            if (d_lower(in.at(bp)) == 'p' && d_lower(in.at(bp + 1)) == 'm') {
+                if (tm.hour > 12) return nullptr;
+                else if (tm.hour < 12) tm.hour += 12;
+                bp += 2;
+                break;
+            }
+            return nullptr;
+        case 'S':
+            if (!conv_num(in, bp, tm.sec, 0, 60)) return nullptr;
+            break;
+        case 's': {
+            int64_t v;
+            if (!conv_num64(in, bp, v)) return nullptr;
+            if (v > 67767976233532799LL) return nullptr;         // gmtime_r overflows tm_year
+            tm.have_epoch = 1; tm.epoch = v;
+            tm.gmtoff = 0;
+            tm.fields = 0xffff;
+            break;
+        }
+        case 'U': case 'W': case 'V':
+            if (!conv_num(in, bp, i, 0, 53)) return nullptr;
+            break;
+        case 'w':
+            if (!conv_num(in, bp, tm.wday, 0, 6)) return nullptr;
+            tm.fields |= F_WDAY;
+            break;
+        case 'u':
+            if (!conv_num(in, bp, i, 1, 7)) return nullptr;
+            tm.wday = i % 7;
+            tm.fields |= F_WDAY;
+            break;
+        case 'g':
+            if (!conv_num(in, bp, i, 0, 99)) return nullptr;
+            break;
+        case 'G':
+            do bp++; while (d_isdigit(in.at(bp)));
+            break;
+        case 'Y':
+            if (!conv_num(in, bp, i, 0, 9999)) return nullptr;
+            tm.relyear = -1;
+            tm.year = i - 1900;
+            tm.fields |= F_YEAR;
+            break;
+        case 'y':
+            if (!conv_num(in, bp, tm.relyear, 0, 99)) return nullptr;
+            break;
+        case 'z': {
+            while (d_isspace(in.at(bp))) bp++;
+            int neg = 0;
+            uint32_t z = in.at(bp++);
+            if (z == 'G') {
+                if (in.at(bp++) != 'M') return nullptr;
+                if (in.at(bp++) != 'T') return nullptr;
+                tm.gmtoff = 0;
+                continue;
+            }
+            if (z == 'U') {
+                if (in.at(bp++) != 'T') return nullptr;
+                if (in.at(bp) == 'C') bp++;
+                tm.gmtoff = 0;
+                continue;
+            }
+            if (z == 'Z') { tm.gmtoff = 0; continue; }
+            if (z == '+') neg = 0;
+            else if (z == '-') neg = 1;
+            else {
+                --bp;
+                // RFC-822 North American zones: E/C/M/P + S/D + T
+                uint32_t a = d_lower(in.at(bp)), b2 = d_lower(in.at(bp + 1)), c2 = d_lower(in.at(bp + 2));
+                int zi = a == 'e' ? 0 : a == 'c' ? 1 : a == 'm' ? 2 : a == 'p' ? 3 : -1;
+                if (zi >= 0 && c2 == 't' && (b2 == 's' || b2 == 'd')) {
+                    tm.gmtoff = (b2 == 's' ? (-5 - zi) : (-4 - zi)) * 3600L;
+                    bp += 3;
+                    continue;
+                }
+                return nullptr;
+            }
+            if (!d_isdigit(in.at(bp)) || !d_isdigit(in.at(bp + 1))) return nullptr;
+            int offs = ((int) (in.at(bp) - '0') * 10 + (int) (in.at(bp + 1) - '0')) * 3600;
+            bp += 2;
+            if (in.at(bp) == ':') bp++;
+            if (d_isdigit(in.at(bp))) {
+                offs += (int) (in.at(bp++) - '0') * 10 * 60;
+                if (!d_isdigit(in.at(bp))) return nullptr;
+                offs += (int) (in.at(bp++) - '0') * 60;
+            }
+            if (neg) offs = -offs;
+            tm.gmtoff = offs;
+            continue;
+        }
+        case 'n': case 't':
+            while (d_isspace(in.at(bp))) bp++;
+            break;
+        default:
+            return nullptr;
+        }
+    }
+    if (tm.relyear != -1) {
+        if (tm.century == 1900) tm.year = tm.relyear <= 68 ? tm.relyear + 2000 - 1900 : tm.relyear;
+        else tm.year = tm.relyear + tm.century - 1900;
+        tm.fields |= F_YEAR;
+    }
+    if ((tm.fields & F_YEAR) && !tm.have_epoch) {
+        const int year = tm.year + 1900;
+        const int lp = d_isleap(year) ? 1 : 0;
+        if (!(tm.fields & F_YDAY) && (tm.fields & F_MON) && (tm.fields & F_MDAY)) {
+            tm.yday = tm.mday - 1;
+            for (i = 0; i < tm.mon; i++) tm.yday += c_mon_len[lp][i];
+            tm.fields |= F_YDAY;
+        }
+        if (tm.fields & F_YDAY) {
+            int days = tm.yday;
+            if (!(tm.fields & F_MON)) {
+                tm.mon = 0;
+                while (tm.mon < 12 && days >= c_mon_len[lp][tm.mon]) days -= c_mon_len[lp][tm.mon++];
+            }
+            if (!(tm.fields & F_MDAY)) tm.mday = days + 1;
+        }
+    }
+    (void) leaps_thru_end_of;
+    return bp;
+}
+
+// timegm(tm) - gmtoff (include/fluent-bit/flb_parser.h:80-94, use_system_timezone == FALSE)
+DEV int64_t tm2time(const Tm &tm) {
+    if (tm.have_epoch) return tm.epoch - tm.gmtoff;
+    int64_t y = (int64_t) tm.year + 1900 + (tm.mon >= 0 ? tm.mon / 12 : -((11 - tm.mon) / 12));
+    int m = tm.mon >= 0 ? tm.mon % 12 : 11 - ((11 - tm.mon) % 12);
+    int64_t days = days_from_civil(y, m + 1, 1) + (tm.mday - 1);
+    return days * 86400 + (int64_t) tm.hour * 3600 + (int64_t) tm.min * 60 + tm.sec - tm.gmtoff;
+}
+
+// flb_parser_time_lookup + tm2time for formats that carry the year.  Returns -1 (field is
+// dropped, time stays 0), or 0 with *sec / *frac set.
+DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_t *sec, double *frac) {
+    Tm tm;
+    tm.year = tm.mon = tm.mday = tm.hour = tm.min = tm.sec = tm.yday = tm.wday = 0;
+    tm.gmtoff = 0; tm.have_epoch = 0; tm.epoch = 0;
+    *frac = 0;
+    // the reference copies the text into a NUL-terminated buffer and works on strlen() of it:
+    // an embedded NUL ends the string
+    uint32_t n = 0;
+    while (n < vlen && ld8(v + n) != 0) n++;
+    TStr in;
+    in.s = v; in.e = v + n;
+    const uint8_t *p = d_strptime(in, v, ps.fmt1, tm);
+    bool ok = p != nullptr;
+    if (ok && ps.has_frac) {
+        // parse_subseconds: strtod("0." + up to 9 chars); digits only (hex/exp forms cannot
+        // appear after "0." + digits except an exponent, handled below)
+        uint32_t avail = (uint32_t) (in.e - p);
+        uint32_t digits = avail < 9 ? avail : 9, k = 0;
+        uint64_t num = 0;
+        while (k < digits && d_isdigit(in.at(p + k))) { num = num * 10 + (in.at(p + k) - '0'); k++; }
+        if (k == 0) ok = false;
+        else {
+            // correctly rounded: num < 2^53 and 10^k <= 1e9 are exact doubles, one IEEE division
+            double pw = 1.0;
+            for (uint32_t q = 0; q < k; q++) pw *= 10.0;
+            double f = (double) num / pw;
+            uint32_t consumed = k;
+            // strtod also accepts an exponent inside the 9-char window: e.g. "12e3"
+            if (k < digits && (in.at(p + k) == 'e' || in.at(p + k) == 'E')) {
+                uint32_t q = k + 1;
+                int eneg = 0;
+                if (q < digits && (in.at(p + q) == '+' || in.at(p + q) == '-')) { eneg = in.at(p + q) == '-'; q++; }
+                if (q < digits && d_isdigit(in.at(p + q))) {
+                    int ex = 0;
+                    while (q < digits && d_isdigit(in.at(p + q))) { ex = ex * 10 + (int) (in.at(p + q) - '0'); q++; }
+                    // rare; the scaled value is only exact for tiny exponents, which is all that
+                    // fits in the window
+                    double sc = 1.0;
+                    for (int z = 0; z < ex && z < 400; z++) sc *= 10.0;
+                    f = eneg ? f / sc : f * sc;
+                    consumed = q;
+                }
+            }
+            *frac = f;
+            p += consumed;
+            Tm tm2 = tm;
+            const uint8_t *p2 = d_strptime(in, p, ps.fmt2, tm2);
+            // the second call re-initialises gmtoff/century/relyear/fields but keeps the fields
+            tm = tm2;
+            if (!p2) ok = false;
+        }
+    }
+    if (!ok) {
+        if (ps.time_strict) return -1;
+        // non-strict: the reference returns 0 before applying the fixed offset and keeps
+        // whatever strptime filled in so far (src/flb_parser.c:2004-2013)
+        *sec = tm2time(tm);
+        return 0;
+    }
+    if (!ps.time_with_tz) tm.gmtoff = ps.time_offset;
+    *sec = tm2time(tm);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Types casts (src/flb_parser.c:2067-2164): atoll / strtoull(16) / bool
+// ------------------------------------------------------------------------------------------
+DEV int64_t d_atoll(const uint8_t *s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n && d_isspace(ld8(s + i))) i++;
+    bool neg = false;
+    if (i < n && (ld8(s + i) == '+' || ld8(s + i) == '-')) { neg = ld8(s + i) == '-'; i++; }
+    uint64_t v = 0;
+    bool ovf = false;
+    uint64_t lim = neg ? (uint64_t) 1 << 63 : (uint64_t) INT64_MAX;
+    while (i < n && d_isdigit(ld8(s + i))) {
+        uint32_t d = ld8(s + i) - '0';
+        if (v > (lim - d) / 10) ovf = true;
+        v = v * 10 + d;
+        i++;
+    }
+    if (ovf) return neg ? INT64_MIN : INT64_MAX;
+    return neg ? (int64_t) (0 - v) : (int64_t) v;
+}
+
+DEV uint64_t d_strtoull16(const uint8_t *s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n && d_isspace(ld8(s + i))) i++;
+    bool neg = false;
+    if (i < n && (ld8(s + i) == '+' || ld8(s + i) == '-')) { neg = ld8(s + i) == '-'; i++; }
+    auto hv = [](uint32_t c) -> int {
+        if (c >= '0' && c <= '9') return (int) c - '0';
+        if (c >= 'a' && c <= 'f') return (int) c - 'a' + 10;
+        if (c >= 'A' && c <= 'F') return (int) c - 'A' + 10;
+        return -1;
+    };
+    if (i + 1 < n && ld8(s + i) == '0' && (ld8(s + i + 1) == 'x' || ld8(s + i + 1) == 'X') &&
+        i + 2 < n && hv(ld8(s + i + 2)) >= 0) i += 2;
+    uint64_t v = 0;
+    bool ovf = false;
+    while (i < n && hv(ld8(s + i)) >= 0) {
+        if (v >> 60) ovf = true;
+        v = (v << 4) | (uint64_t) hv(ld8(s + i));
+        i++;
+    }
+    if (ovf) return UINT64_MAX;
+    return neg ? (0 - v) : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// parsed-record body writer shared by the size pass and the emit pass
+// ------------------------------------------------------------------------------------------
+template <class S>
+DEV void write_field_value(S &s, int type, const uint8_t *v, uint32_t vlen) {
+    switch (type) {
+    case TY_INT: pk_int(s, d_atoll(v, vlen)); break;
+    case TY_HEX: pk_uint(s, d_strtoull16(v, vlen)); break;
+    case TY_BOOL:
+        if (vlen >= 4 && d_lower(ld8(v)) == 't' && d_lower(ld8(v + 1)) == 'r' && d_lower(ld8(v + 2)) == 'u' && d_lower(ld8(v + 3)) == 'e') s.put(0xc3);
+        else if (vlen >= 5 && d_lower(ld8(v)) == 'f' && d_lower(ld8(v + 1)) == 'a' && d_lower(ld8(v + 2)) == 'l' && d_lower(ld8(v + 3)) == 's' && d_lower(ld8(v + 4)) == 'e') s.put(0xc2);
+        else { pk_str_hdr(s, vlen); s.copy(v, vlen); }
+        break;
+    default:
+        pk_str_hdr(s, vlen); s.copy(v, vlen);
+    }
+}
+
+
+// Writes (or sizes) the complete output record for `rec`.
+template <class S>
+DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
+                      const RecInfo &ri, const uint32_t *caps, uint64_t null_mask) {
+    // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
+    s.put(0x92); s.put(0x92); s.put(0xd7); s.put(0x00);
+    pk_be(s, ri.ts_sec, 4); pk_be(s, ri.ts_nsec, 4);
+    if (ri.meta_len) mp_canon(rec + ri.meta_off, rec + ri.meta_off + ri.meta_len, s);
+    else s.put(0x80);
+    const uint8_t *body = rec + ri.body_off, *body_end = body + ri.body_len;
+    if (!(ri.flags & RF_PARSED)) {
+        mp_canon(body, body_end, s);
+        return;
+    }
+    const DevParser &ps = parsers[ri.parser_idx];
+    // kvs to append after the parsed ones (filter_parser.c:343-395)
+    Tok bm = mp_tok(body, body_end);
+    uint32_t nappend = 0;
+    bool plain_key = !cfg.key.is_ra;
+    if (cfg.reserve_data) {
+        nappend = bm.len;
+        if (plain_key && !cfg.preserve_key) {
+            for (uint32_t i = 0; i < bm.len && i < 64; i++) if ((null_mask >> i) & 1) nappend--;
+        }
+    }
+    else if (cfg.preserve_key && plain_key) nappend = 1;
+    if (nappend > 0) pk_map_hdr(s, ri.nkept + nappend);      // flb_msgpack_expand_map repacks
+    else {
+        // header patched in place: width of the ORIGINAL count is kept (flb_parser_regex.c:182-199)
+        uint32_t n0 = (uint32_t) ps.nregs_minus1;
+        if (n0 < 16) s.put(0x80 | ri.nkept);
+        else if (n0 < 65536) { s.put(0xde); pk_be(s, ri.nkept, 2); }
+        else { s.put(0xdf); pk_be(s, ri.nkept, 4); }
+    }
+    const uint8_t *val = rec + ri.val_off;
+    for (int f = 0; f < ps.nfields; f++) {
+        uint32_t b = caps[2 * f], e = caps[2 * f + 1];
+        uint32_t vlen = (b == CAP_UNSET || e == CAP_UNSET) ? 0 : e - b;
+        const uint8_t *v = (b == CAP_UNSET || e == CAP_UNSET) ? val : val + b;
+        if (vlen == 0 && ps.skip_empty) continue;
+        if (ps.field_is_time[f]) {
+            // dropped when the time is unparsable, or parsed and !time_keep
+            int64_t sec; double frac;
+            if (time_lookup(ps, v, vlen, &sec, &frac) == -1) continue;
+            if (!ps.time_keep) continue;
+        }
+        pk_str_hdr(s, (uint32_t) ps.field_name_len[f]);
+        for (int q = 0; q < ps.field_name_len[f]; q++) s.put((uint8_t) ps.names[ps.field_name_off[f] + q]);
+        write_field_value(s, ps.field_type[f], v, vlen);
+    }
+    if (nappend > 0) {
+        const uint8_t *p = bm.next;
+        for (uint32_t i = 0; i < bm.len; i++) {
+            const uint8_t *kend = mp_skip(p, body_end);
+            const uint8_t *vend = kend ? mp_skip(kend, body_end) : nullptr;
+            if (!vend) return;
+            bool take;
+            if (cfg.reserve_data) take = !(plain_key && !cfg.preserve_key && i < 64 && ((null_mask >> i) & 1));
+            else take = (i == ri.key_index);
+            if (take) { mp_canon(p, kend, s); mp_canon(kend, vend, s); }
+            p = vend;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+// one parser attempt on one value.  Returns true on success (flb_parser_do >= 0).
+DEV bool try_parser(const DevParser &ps, const uint8_t *val, uint32_t vlen, uint16_t *rid, uint32_t rid_len,
+                    uint32_t *caps, int64_t *tsec, int64_t *tnsec, uint32_t *nkept) {
+    if (vlen + 1 > rid_len) return false;                 // scratch too small: host sizes it to fit
+    CapView va = view_of(ps.ascii);
+    const CapView *used = &va;
+    CapView vu;
+    int best = rx_reverse<true>(va, val, vlen, rid, 64);
+    if (best == -2) {
+        vu = view_of(ps.utf8);
+        used = &vu;
+        best = rx_reverse<true>(vu, val, vlen, rid, 64);
+    }
+    if (best < 0) return false;
+    if (ps.nregs_minus1 <= 0) return false;               // flb_parser_regex_do: n <= 0
+    for (int f = 0; f < 2 * ps.nfields; f++) caps[f] = CAP_UNSET;
+    const uint8_t *slot2cap = ps.slot2cap;
+    int endb = rx_forward(*used, val, vlen, best, rid, 64, slot2cap, caps);
+    if (endb < 0) return false;
+    // group 0 is not a named field; named groups that did not participate stay CAP_UNSET
+    bool any = false;
+    uint32_t kept = 0;
+    int64_t sec = 0; double frac = 0;
+    for (int f = 0; f < ps.nfields; f++) {
+        uint32_t b = caps[2 * f], e = caps[2 * f + 1];
+        bool set = (b != CAP_UNSET && e != CAP_UNSET);
+        if (!set) { caps[2 * f] = CAP_UNSET; caps[2 * f + 1] = CAP_UNSET; }
+        if (set) any = true;                               // last_pos (src/flb_regex.c:52-54)
+        uint32_t fl = set ? e - b : 0;
+        if (fl == 0 && ps.skip_empty) continue;
+        if (ps.field_is_time[f]) {
+            int64_t s2; double f2;
+            if (time_lookup(ps, set ? val + b : val, fl, &s2, &f2) == -1) continue;
+            sec = s2; frac = f2;
+            if (!ps.time_keep) continue;
+        }
+        kept++;
+    }
+    if (!any) return false;
+    *tsec = sec;
+    *tnsec = (int64_t) (frac * 1000000000);
+    *nkept = kept;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint16_t *rid = a.rid + ((size_t) wave_slot * a.rid_len) * 64 + lane;
+    for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
+        uint64_t r = base + lane;
+        if (r >= a.n) continue;
+        const uint8_t *rec = a.data + a.row_off[r];
+        const uint8_t *rec_end = a.data + a.row_off[r + 1];
+        RecInfo ri;
+        ri.flags = 0; ri.val_off = 0; ri.val_len = 0; ri.key_index = 0; ri.ts_sec = 0; ri.ts_nsec = 0;
+        ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0;
+        uint64_t null_mask = 0;
+        uint32_t *caps = a.caps + r * a.caps_stride;
+        Event ev = decode_event(rec, rec_end);
+        ri.flags = ev.flags;
+        if (ev.flags & RF_BAD) {
+            atomicMin(a.first_bad, (unsigned long long) r);
+            a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = 0;
+            continue;
+        }
+        if (ev.flags & RF_SKIP) { a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = 0; continue; }
+        atomicAdd(&a.counts[0], 1ull);
+        ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
+        if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
+        int64_t tsec = ev.sec, tnsec = ev.nsec;
+        bool have_out = false, last_ok = false;
+        if (a.cfg.key.is_ra) {
+            const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end);
+            if (v) {
+                Tok t = mp_tok(v, ev.body_end);
+                if (t.type == T_STR || t.type == T_BIN) {
+                    for (int p = 0; p < a.cfg.nparsers; p++) {
+                        int64_t ps = 0, pn = 0; uint32_t nk = 0;
+                        last_ok = try_parser(a.parsers[p], t.next, t.len, rid, a.rid_len, caps, &ps, &pn, &nk);
+                        if (last_ok) {
+                            have_out = true;
+                            ri.val_off = (uint32_t) (t.next - rec); ri.val_len = t.len; ri.parser_idx = p; ri.nkept = nk;
+                            if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        else {
+            Tok bm = mp_tok(ev.body, ev.body_end);
+            const uint8_t *p = bm.next;
+            for (uint32_t i = 0; i < bm.len; i++) {
+                Tok k = mp_tok(p, ev.body_end);
+                const uint8_t *kend = mp_skip(p, ev.body_end);
+                Tok v = mp_tok(kend, ev.body_end);
+                const uint8_t *vend = mp_skip(kend, ev.body_end);
+                if ((k.type == T_STR || k.type == T_BIN) && k.len == (uint32_t) a.cfg.key.key_len &&
+                    bytes_eq(k.next, a.cfg.key.key, k.len) && (v.type == T_STR || v.type == T_BIN)) {
+                    for (int q = 0; q < a.cfg.nparsers; q++) {
+                        int64_t ps = 0, pn = 0; uint32_t nk = 0;
+                        last_ok = try_parser(a.parsers[q], v.next, v.len, rid, a.rid_len, caps, &ps, &pn, &nk);
+                        if (last_ok) {
+                            have_out = true;
+                            ri.val_off = (uint32_t) (v.next - rec); ri.val_len = v.len; ri.parser_idx = q; ri.nkept = nk;
+                            ri.key_index = i;
+                            if (i < 64) null_mask |= 1ull << i;
+                            if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
+                            break;
+                        }
+                    }
+                }
+                p = vend;
+            }
+        }
+        if (have_out && last_ok) ri.flags |= RF_PARSED;
+        // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
+        if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
+            ri.flags |= RF_BADTS;
+            a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = null_mask;
+            continue;
+        }
+        ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
+        CountSink cs;
+        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        a.info[r] = ri;
+        a.null_mask[r] = null_mask;
+        a.out_len[r] = (uint32_t) cs.n;
+        atomicAdd(&a.counts[1], 1ull);
+    }
+}
+
+
+__global__ void __launch_bounds__(256) k_parser_emit(ParserEmitArgs a) {
+    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    if (a.out_len[r] == 0) return;
+    const uint8_t *rec = a.data + a.row_off[r];
+    const uint8_t *rec_end = a.data + a.row_off[r + 1];
+    ByteSink s(a.out + a.out_off[r]);
+    write_record(s, a.cfg, a.parsers, rec, rec_end, a.info[r], a.caps + r * a.caps_stride, a.null_mask[r]);
+}
+
+// ------------------------------------------------------------------------------------------
+// filter_grep
+// ------------------------------------------------------------------------------------------
+
+// flb_ra_regex_match (src/flb_record_accessor.c:753-765): > 0 match, <= 0 no match
+DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_end) {
+    const uint8_t *v = ra_resolve(ru.key, body, body_end);
+    if (!v) return -1;
+    Tok t = mp_tok(v, body_end);
+    if (t.type != T_STR) return -1;
+    int m = dfa_match(ru.dfa.cls, ru.dfa.ddelta, ru.dfa.d_final, ru.dfa.ncls, ru.dfa.d_init, t.next, t.len);
+    if (m == RX_POISON) {
+        CapView vu = view_of(ru.utf8);
+        int best = rx_reverse<false>(vu, t.next, t.len, nullptr, 0);
+        m = best >= 0 ? RX_MATCH : RX_NOMATCH;
+    }
+    return m == RX_MATCH ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_grep_match(GrepArgs a) {
+    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    const uint8_t *rec = a.data + a.row_off[r];
+    const uint8_t *rec_end = a.data + a.row_off[r + 1];
+    Event ev = decode_event(rec, rec_end);
+    a.status[r] = ev.flags;
+    if (ev.flags & RF_BAD) { atomicMin(a.first_bad, (unsigned long long) r); a.keep_len[r] = 0; return; }
+    if (ev.flags & RF_SKIP) { a.keep_len[r] = 0; return; }
+    bool keep = true;
+    if (a.logical_op == OP_LEGACY) {
+        // plugins/filter_grep/grep.c:167-194
+        for (int i = 0; i < a.nrules; i++) {
+            const GrepRule &ru = a.rules[i];
+            int ret = rule_match(ru, ev.body, ev.body_end);
+            if (ret <= 0) { if (ru.type == GREP_REGEX) { keep = false; break; } }
+            else { keep = (ru.type != GREP_EXCLUDE); break; }
+        }
+    }
+    else {
+        // plugins/filter_grep/grep.c:250-284
+        bool found = false;
+        int last = 0;
+        for (int i = 0; i < a.nrules; i++) {
+            last = i;
+            found = rule_match(a.rules[i], ev.body, ev.body_end) > 0;
+            if (a.logical_op == OP_OR && found) break;
+            if (a.logical_op == OP_AND && !found) break;
+        }
+        if (a.nrules > 0) keep = (a.rules[last].type == GREP_REGEX) ? found : !found;
+    }
+    a.keep_len[r] = keep ? (uint32_t) (rec_end - rec) : 0;
+    atomicAdd(&a.counts[0], 1ull);
+    if (keep) atomicAdd(&a.counts[1], 1ull);
+}
+
+// copy of the kept records: one wave per record, byte granular
+
+__global__ void __launch_bounds__(256) k_gather(GatherArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t r = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= a.n) return;
+    uint32_t len = a.keep_len[r];
+    if (!len) return;
+    const uint8_t *src = a.data + a.row_off[r];
+    uint8_t *dst = a.out + a.out_off[r];
+    for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan u32 -> u64 (three small kernels; n up to 2^32)
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;            // per thread
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *tile_sums) {
+    __shared__ uint64_t sh[SCAN_BLOCK / 64];
+    uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
+    uint64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        uint64_t i = base + (uint64_t) k * SCAN_BLOCK + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) t += sh[w];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of the tile sums in place; total written to tile_sums[ntiles]
+__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *tile_sums, uint64_t ntiles) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < ntiles; base += 1024) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < ntiles ? tile_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            uint64_t t = threadIdx.x >= (unsigned) o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint64_t incl = sh[threadIdx.x];
+        if (i < ntiles) tile_sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *tile_sums, uint64_t *out) {
+    __shared__ uint64_t sh[SCAN_BLOCK];
+    uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) { uint64_t i = base + k; v[k] = i < n ? in[i] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+        uint64_t t = threadIdx.x >= (unsigned) o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t run = tile_sums[blockIdx.x] + sh[threadIdx.x] - s;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        uint64_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLOCK - 1) out[n] = tile_sums[gridDim.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__global__ void k_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out) {
+    uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long m = 0;
+    for (; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        unsigned long long l = row_off[i + 1] - row_off[i];
+        if (l > m) m = l;
+    }
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_down(m, o, 64); if (t > m) m = t; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------
+void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_parser_match, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_parser_emit(const ParserEmitArgs &a, hipStream_t st) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_parser_emit, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_grep_match(const GrepArgs &a, hipStream_t st) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_grep_match, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_gather(const GatherArgs &a, hipStream_t st) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned) ((a.n * 64 + 255) / 256)), dim3(256), 0, st, a);
+}
+// exclusive scan: out[0..n] (n+1 entries); tmp must hold ntiles+1 u64
+size_t scan_tmp_elems(uint64_t n) { return (size_t) ((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
+void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st) {
+    uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (ntiles == 0) { (void) hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, ntiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp, out);
+}
+void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st) {
+    (void) hipMemsetAsync(out, 0, sizeof(unsigned long long), st);
+    if (n == 0) return;
+    unsigned grid = (unsigned) ((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_max_row_len, dim3(grid), dim3(256), 0, st, row_off, n, out);
+}
+
+}  // namespace flbgpu

@@ -1,0 +1,127 @@
+/*
+ * flb_gpu.h -- C ABI of libflbgpu.so: the MI355X-native implementation of Fluent Bit's per-record
+ * filter hot path (flb_filter_do -> cb_filter of filter_parser / filter_grep, flb_parser_do for
+ * regex parsers).  Plain pointers and sizes only; every entry point names the reference
+ * interface it replaces (paths relative to the fluent-bit source tree).
+ *
+ * Two call levels are offered for each filter:
+ *   - host level   : same contract as the reference callback (borrowed input buffer in host
+ *                    memory, malloc()'d output handed to the caller, FLB_FILTER_MODIFIED /
+ *                    FLB_FILTER_NOTOUCH return) -- this is what a plugin shim binds;
+ *   - device level : chunk bytes + row offsets already resident in HBM, output left in HBM --
+ *                    used to chain filters without a PCIe round trip and by bench.py.
+ *
+ * There is NO CPU fallback: a pattern/option the tables cannot express makes *_create() fail
+ * with a message, exactly like the reference fails cb_init on an invalid regex.
+ */
+#ifndef FLB_GPU_H
+#define FLB_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* include/fluent-bit/flb_filter.h:41-42 */
+#define FLBGPU_FILTER_MODIFIED 1
+#define FLBGPU_FILTER_NOTOUCH  2
+
+typedef struct flbgpu_parser flbgpu_parser;
+typedef struct flbgpu_filter flbgpu_filter;
+
+/* A chunk resident in device memory: the reference wire format (concatenated msgpack log events,
+ * src/flb_log_event_encoder.c:195-217) as one byte column + the row-offset column (n+1 entries,
+ * row_off[n] == bytes). */
+typedef struct flbgpu_dev_chunk {
+    const void *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    uint64_t bytes;
+} flbgpu_dev_chunk;
+
+/* ---- library -------------------------------------------------------------------------------- */
+/* Selects the HIP device for the calling process (one process per GPU). 0 on success. */
+int flbgpu_init(int device);
+/* Last error text of the calling thread ("" if none). */
+const char *flbgpu_last_error(void);
+/* Number of compute units of the selected device (0 before init). */
+int flbgpu_device_cus(void);
+
+/* ---- parsers: replaces flb_parser_create() / flb_parser_do() / flb_parser_destroy() ------------
+ * include/fluent-bit/flb_parser.h:99-149, src/flb_parser.c:805-1049, src/flb_parser_regex.c:114-227.
+ * Only Format regex is on this path.  Arguments keep the reference meaning; `types` is the
+ * "key:type key:type" string of the parsers file (src/flb_parser.c:1130-1182).  Conf-file defaults:
+ * skip_empty=1, time_keep=0, time_strict=1 (src/flb_parser.c:1277-1304). */
+flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int skip_empty,
+                                    const char *time_fmt, const char *time_key, const char *time_offset,
+                                    int time_keep, int time_strict, const char *types);
+void flbgpu_parser_destroy(flbgpu_parser *p);
+/* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
+ * consumed (>= 0) or -1.  Runs the same kernels on a batch of one. */
+int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length, void **out_buf, size_t *out_size,
+                     int64_t *out_sec, int64_t *out_nsec);
+
+/* ---- filter_parser: replaces cb_parser_init / cb_parser_filter / cb_parser_exit ----------------
+ * plugins/filter_parser/filter_parser.c:96-149,174-442.  Properties Key_Name / Parser (repeated) /
+ * Reserve_Data / Preserve_Key keep their names and meaning (:460-489). */
+flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int reserve_data, int preserve_key,
+                                           int nparsers, flbgpu_parser **parsers);
+
+/* ---- filter_grep: replaces cb_grep_init / cb_grep_filter / cb_grep_exit ------------------------
+ * plugins/filter_grep/grep.c:56-164,196-248,286-392.  kinds[i] is the property name ("regex" or
+ * "exclude", case-insensitive) and values[i] its value "<key> <pattern>" in configuration order;
+ * logical_op is NULL/"legacy"/"AND"/"OR". */
+flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *const *kinds, const char *const *values,
+                                         const char *logical_op);
+
+void flbgpu_filter_destroy(flbgpu_filter *f);
+
+/* cb_filter (include/fluent-bit/flb_filter.h:57-81): `data` is borrowed host memory.  On
+ * FLBGPU_FILTER_MODIFIED *out_buf is malloc()'d (release with free(), i.e. flb_free) and
+ * *out_size may be 0 (every record dropped).  On FLBGPU_FILTER_NOTOUCH they are left untouched. */
+int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **out_buf, size_t *out_size);
+
+/* Device-level cb_filter: `in` lives in HBM.  On MODIFIED, *out describes filter-owned device
+ * buffers that stay valid until the next call on the same filter (or its destruction).  `stream`
+ * is a hipStream_t (NULL = the filter's own stream); the call returns after the stream work it
+ * enqueued has completed (sizes are needed on the host to size the output). */
+int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream);
+
+/* Record accounting of the last run (what flb_filter_do derives with flb_mp_count_log_records,
+ * src/flb_filter.c:272): records decoded from the input / records in the output. */
+void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t *out_records);
+
+/* Kernel timing (HIP events recorded on the stream the kernels run on).  When enabled, every
+ * run accumulates the duration of each kernel; names[] is a NUL-separated list. */
+void flbgpu_filter_profile(flbgpu_filter *f, int enable);
+int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char **names, double *ms, uint64_t *launches);
+
+/* ---- record boundary discovery (flb_log_event_decoder_next loop, src/flb_log_event_decoder.c:342) --
+ * Walks concatenated msgpack objects in host memory; fills row_off[0..n] (capacity cap entries).
+ * Returns n; *consumed is the offset where decoding stopped (== bytes for a clean chunk). */
+int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap, size_t *consumed);
+
+/* ---- device memory helpers for callers that have no HIP binding of their own ------------------ */
+void *flbgpu_dev_alloc(size_t bytes);
+void flbgpu_dev_free(void *p);
+int flbgpu_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int flbgpu_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int flbgpu_sync(void);
+
+/* ---- diagnostics: regex table compiler ------------------------------------------------------
+ * flbgpu_rx_compile mirrors onig_new() as called by src/flb_regex.c:142-145 (options = ONIG_OPTION_*
+ * bits i=1,x=2,m=4).  The simulate_* calls execute the compiled tables on the host (self-test of
+ * the compiler on machines without a GPU); filters never use them. */
+void *flbgpu_rx_compile(const char *pattern, int len, unsigned options, int want_captures, char *err, int errlen);
+void flbgpu_rx_free(void *h);
+int flbgpu_rx_simulate_capture(void *h, const char *s, int len, int *beg, int *end);
+int flbgpu_rx_simulate_match(void *h, const char *s, int len);
+void flbgpu_rx_info(void *h, int *info12);
+int flbgpu_rx_names(void *h, char *buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""CPU-side checks of the product library (no GPU): the shared object loads, exports every
+symbol include/flb_gpu.h declares, fails loudly without a device, and its regex table compiler
+reproduces the real-Onigmo golden vectors when the tables are executed on the host."""
+import base64, ctypes, json, os, re
+import pytest
+import flbamd_loader
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def g():
+    return flbamd_loader.load()
+
+
+def test_exports_match_header(g):
+    hdr = open(os.path.join(ROOT, "include", "flb_gpu.h")).read()
+    names = sorted(set(re.findall(r"\b(flbgpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    L = g.lib()
+    for n in names:
+        assert hasattr(L, n), "libflbgpu.so does not export %s" % n
+
+
+def test_fails_loudly_without_gpu(g):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        g.init(0)
+    assert "no CPU path" in g.last_error()
+
+
+def test_unsupported_constructs_fail_at_create(g):
+    for rx in [r"(a)\1", r"(?=a)b", r"(?<=a)b", r"(?>a+)b", r"a*+", r"\p{Alpha}+"]:
+        with pytest.raises(ValueError):
+            g.Parser("^(?<x>" + rx + ")$")
+    with pytest.raises(ValueError):
+        g.Parser(r"^(?<time>.*)$", time_fmt="%b %d %H:%M:%S", time_key="time")     # year-less
+    with pytest.raises(ValueError):
+        g.FilterGrep([("regex", "log a"), ("exclude", "log b")], "AND")
+
+
+def test_regex_tables_against_golden(g):
+    L = g.lib()
+    kat = json.load(open(os.path.join(HERE, "golden", "regex_kat.json")))
+    checked = 0
+    for ent in kat:
+        pat = base64.b64decode(ent["pattern"])
+        if not ent["compiles"]:
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        if not h:
+            continue        # constructs rejected by design (look-around, atomic, possessive, \Z, octal)
+        buf = ctypes.create_string_buffer(4096)
+        L.flbgpu_rx_names(h, buf, 4096)
+        names = [[l.rsplit("=", 1)[0], int(l.rsplit("=", 1)[1])] for l in buf.value.decode().splitlines()]
+        assert names == ent["names"], pat
+        dev = any(t in pat for t in (rb'[[:', rb'\b', rb'\B'))
+        for s64, want in ent["cases"]:
+            s = base64.b64decode(s64)
+            if dev and any(c >= 0x80 for c in s):
+                continue
+            beg = (ctypes.c_int * 40)(); end = (ctypes.c_int * 40)()
+            n = L.flbgpu_rx_simulate_capture(h, s, len(s), beg, end)
+            got = None if n == -1 else [[beg[i], end[i]] for i in range(n)]
+            assert got == want, (pat, s)
+            assert L.flbgpu_rx_simulate_match(h, s, len(s)) == (0 if want is None else 1), (pat, s)
+            checked += 1
+        L.flbgpu_rx_free(h)
+    assert checked > 8000
+
+
+def test_index_host(g):
+    import synth
+    data, off, ep = synth.apache_records(100)
+    n, o, consumed = g.index_host(bytes(data))
+    assert n == 100 and consumed == len(data) and list(o) == list(off)
+    n, o, consumed = g.index_host(bytes(data) + b"\x92\x01")
+    assert n == 100 and consumed == len(data)
+    n, o, consumed = g.index_host(bytes(data[:277]) + b"\xc1" + bytes(data[277:]))
+    assert n == 1 and consumed == 277

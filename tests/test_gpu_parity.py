@@ -1,0 +1,191 @@
+"""GPU parity: the HIP path (through the C ABI of include/flb_gpu.h) against the CPU oracle on the
+same inputs -- bit-exact output bytes and return codes."""
+import os, random, struct
+import numpy as np
+import pytest
+import oracle_binding as ob
+import synth
+import flbamd_loader
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+APACHE2 = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$'
+APACHE = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^\"]*?)(?: +\S*)?)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>[^\"]*)")?$'
+TF = "%d/%b/%Y:%H:%M:%S %z"
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def both_parser(g, data, key, pargs_list, reserve=False, preserve=False):
+    op = [ob.Parser(**a) for a in pargs_list]
+    gp = [g.Parser(**a) for a in pargs_list]
+    ro, oo = ob.FilterParser(key, op, reserve, preserve).filter(data)
+    f = g.FilterParser(key, gp, reserve, preserve)
+    rg, og = f.filter(data)
+    f.close()
+    for p in gp:
+        p.close()
+    return (ro, oo), (rg, og)
+
+
+def both_grep(g, data, rules, op=None):
+    ro, oo = ob.Grep(rules, op).filter(data)
+    f = g.FilterGrep(rules, op)
+    rg, og = f.filter(data)
+    f.close()
+    return (ro, oo), (rg, og)
+
+
+def first_diff(a, b):
+    if a is None or b is None:
+        return "one side None"
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return "byte %d: oracle %r gpu %r (len %d vs %d)" % (i, a[max(0, i - 20):i + 20], b[max(0, i - 20):i + 20], len(a), len(b))
+    return "length %d vs %d" % (len(a), len(b))
+
+
+def test_parser_apache2_synthetic(g):
+    data, off, ep = synth.apache_records(20000)
+    o, q = both_parser(g, bytes(data), "log", [dict(regex=APACHE2, time_fmt=TF, time_key="time")])
+    assert o[0] == q[0] == ob.MODIFIED
+    assert o[1] == q[1], first_diff(o[1], q[1])
+
+
+def test_parser_apache_fixture_400(g):
+    data = open(os.path.join(HERE, "golden", "apache_400.mp"), "rb").read()
+    for rx in (APACHE2, APACHE):
+        o, q = both_parser(g, data, "log", [dict(regex=rx, time_fmt=TF, time_key="time")])
+        assert o[0] == q[0] and o[1] == q[1], first_diff(o[1], q[1])
+
+
+def test_grep_on_parser_output(g):
+    data, off, ep = synth.apache_records(20000)
+    o, q = both_parser(g, bytes(data), "log", [dict(regex=APACHE2, time_fmt=TF, time_key="time")])
+    parsed = o[1]
+    for rules, op in [([("regex", r"code ^5\d\d$")], None), ([("exclude", "method GET")], None),
+                      ([("regex", "code ^2"), ("regex", "agent curl")], "AND"),
+                      ([("regex", "code ^404$"), ("regex", "method ^P")], "OR"),
+                      ([("regex", "host .*")], None), ([("regex", "nokey x")], None)]:
+        a, b = both_grep(g, parsed, rules, op)
+        assert a[0] == b[0], (rules, a[0], b[0])
+        assert a[1] == b[1], (rules, first_diff(a[1], b[1]))
+
+
+def _rec(body, sec=1, nsec=0, meta=None):
+    return synth.v2_record(sec, nsec, body, meta)
+
+
+def test_grep_edge_cases(g):
+    recs = [_rec({"log": "aaa"}), _rec({"log": "bbb"}), _rec({"log": "abc", "x": "1"}), _rec({"other": "aaa"}),
+            _rec({"log": 5}), _rec(synth.KV([("log", "zzz"), ("log", "aaa")])), synth.legacy_record(5, {"log": "aaa"}),
+            synth.legacy_record(1.5, {"log": "xaax"}), _rec({"k": {"sub": ["x", "HELLO"]}}), _rec({"log": "héllo wörld"}),
+            _rec({"log": ""})]
+    grp = synth.mp([[synth.ext_ts(0xffffffff, 0), {}], {"g": 1}])
+    data = b"".join(recs)
+    cases = [([("regex", "log a")], None), ([("exclude", "log a")], None), ([("regex", "log .*")], None),
+             ([("regex", "log nomatch")], None), ([("regex", "$k['sub'][1] /hello/i")], None),
+             ([("regex", "log ^$")], None), ([("regex", "log é")], None), ([("regex", "log [^a-z ]")], None),
+             ([("exclude", "log a"), ("regex", "log b")], None)]
+    for rules, op in cases:
+        for d in (data, grp + data, data + b"\x92\x01", recs[0], grp + recs[0] + grp):
+            a, b = both_grep(g, d, rules, op)
+            assert a == b, (rules, d[:40], a[0], b[0], first_diff(a[1], b[1]))
+
+
+def test_filter_parser_semantics(g):
+    ty = dict(regex=r"^(?<INT>[^ ]+) (?<FLOAT>[^ ]+) (?<BOOL>[^ ]+) (?<STRING>.+)$", types="INT:integer BOOL:bool STRING:string")
+    src = _rec({"data": "100 0.5 true x", "extra": "y"}) + _rec({"data": "-7 1 nope zz zz", "n": {"a": [1, 2.5, None, True]}}) + _rec({"nodata": 1})
+    for reserve, preserve in [(False, False), (True, False), (True, True), (False, True)]:
+        o, q = both_parser(g, src, "data", [ty], reserve, preserve)
+        assert o == q, (reserve, preserve, first_diff(o[1], q[1]))
+    pt = dict(regex=r"^(?<time>[^ ]+) (?<msg>.*)$", time_fmt="%Y-%m-%dT%H:%M:%S.%L", time_key="time")
+    src = _rec({"log": "2017-11-01T22:25:21.648 hello"}) + _rec({"log": "2017-11-01T22:25:21 nofrac"}) + _rec({"log": "garbage here"})
+    for keep in (False, True):
+        o, q = both_parser(g, src, "log", [dict(pt, time_keep=keep)])
+        assert o == q, first_diff(o[1], q[1])
+    # map32 / int canonicalisation of unparsed bodies and metadata
+    raw = b"\x92\x92" + synth.ext_ts(7, 9).b + b"\xdf\x00\x00\x00\x01\xa1m\xd0\x05" + b"\xdf\x00\x00\x00\x01\xa3log\xd9\x03abc"
+    o, q = both_parser(g, raw + raw, "log", [pt])
+    assert o == q, first_diff(o[1], q[1])
+    # several parsers, skip_empty on/off, record accessor key, duplicate keys
+    pa = dict(regex=r"^(?<a>\d+)$"); pb = dict(regex=r"^(?<b>\w+)$")
+    o, q = both_parser(g, _rec({"log": "abc"}) + _rec({"log": "123"}) + _rec({"log": "!!"}), "log", [pa, pb])
+    assert o == q, first_diff(o[1], q[1])
+    for se in (True, False):
+        o, q = both_parser(g, _rec({"log": " yy"}) + _rec({"log": "xx "}), "log", [dict(regex=r"^(?<a>x*) (?<b>y*)$", skip_empty=se)])
+        assert o == q, first_diff(o[1], q[1])
+    o, q = both_parser(g, _rec({"k": {"in": "42"}}) + _rec({"k": "17"}), "$k['in']", [pa], True, True)
+    assert o == q, first_diff(o[1], q[1])
+    dup = _rec(synth.KV([("log", "12"), ("z", 1), ("log", "34")])) + _rec(synth.KV([("log", "12"), ("log", "xx")]))
+    for reserve, preserve in [(False, False), (True, False), (False, True)]:
+        o, q = both_parser(g, dup, "log", [pa], reserve, preserve)
+        assert o == q, first_diff(o[1], q[1])
+    # legacy records, group markers, float/int timestamps, bad tail
+    grp = synth.mp([[synth.ext_ts(0xffffffff, 0), {}], {"g": 1}])
+    mix = grp + synth.legacy_record(5, {"log": "77"}) + synth.legacy_record(1.25, {"log": "x"}) + _rec({"log": "9"}, 3, 4, {"m": 1})
+    o, q = both_parser(g, mix, "log", [pa])
+    assert o == q, first_diff(o[1], q[1])
+    o, q = both_parser(g, mix + b"\x93\x01\x02\x03" + _rec({"log": "5"}), "log", [pa])
+    assert o == q, first_diff(o[1], q[1])
+    o, q = both_parser(g, mix + b"\x92\x01", "log", [pa])
+    assert o == q, first_diff(o[1], q[1])
+
+
+def test_map16_header_width(g):
+    names = ["g%02d" % i for i in range(16)]
+    rx = "^" + " ".join("(?<%s>[a-z]*)" % n for n in names) + "$"
+    line = " ".join(["ab"] * 15 + [""])
+    o, q = both_parser(g, _rec({"log": line}) + _rec({"log": " ".join(["ab"] * 16)}), "log", [dict(regex=rx)])
+    assert o == q, first_diff(o[1], q[1])
+
+
+def test_random_mutations_parity(g):
+    """fuzz: mutated apache lines (ASCII and UTF-8 insertions) through parser then grep"""
+    rng = random.Random(11)
+    data, off, ep = synth.apache_records(4000)
+    lines = [bytes(data[int(off[i]) + 21:int(off[i + 1])]) for i in range(4000)]
+    recs = []
+    for ln in lines:
+        m = bytearray(ln)
+        for _ in range(rng.randint(0, 3)):
+            k = rng.randrange(len(m))
+            op = rng.random()
+            if op < 0.3: m[k] = rng.choice(b' "[]\n-x')
+            elif op < 0.5: del m[k]
+            elif op < 0.7: m[k:k] = rng.choice(["é", "日本", "ü"]).encode()
+            else: m = m[:max(k, 1)]
+        recs.append(_rec({"log": bytes(m)}, rng.randrange(2**31), rng.randrange(10**9)))
+    blob = b"".join(recs)
+    o, q = both_parser(g, blob, "log", [dict(regex=APACHE2, time_fmt=TF, time_key="time"), dict(regex=APACHE, time_fmt=TF, time_key="time")])
+    assert o == q, first_diff(o[1], q[1])
+    a, b = both_grep(g, o[1], [("regex", r"code ^[45]"), ("exclude", "agent curl")])
+    assert a == b, first_diff(a[1], b[1])
+
+
+def test_device_level_chain_matches_host_level(g):
+    data, off, ep = synth.apache_records(5000)
+    L = g.lib()
+    d_data = L.flbgpu_dev_alloc(len(data)); d_off = L.flbgpu_dev_alloc(off.nbytes)
+    L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, len(data)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+    p = g.Parser(APACHE2, time_fmt=TF, time_key="time")
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep([("regex", r"code ^5\d\d$")])
+    ch = g.DevChunk(d_data, d_off, 5000, len(data))
+    r1, o1 = fp.filter_dev(ch)
+    assert r1 == g.MODIFIED and fp.counts() == (5000, 5000)
+    r2, o2 = fg.filter_dev(o1)
+    assert r2 == g.MODIFIED
+    out = np.empty(o2.bytes, dtype=np.uint8)
+    L.flbgpu_memcpy_d2h(out.ctypes.data, o2.data, o2.bytes)
+    po = ob.Parser(APACHE2, time_fmt=TF, time_key="time")
+    _, want1 = ob.FilterParser("log", [po]).filter(bytes(data))
+    _, want2 = ob.Grep([("regex", r"code ^5\d\d$")]).filter(want1)
+    assert bytes(out) == want2
+    assert fg.counts() == (5000, ob.count_records(want2))
+    L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
