@@ -155,6 +155,8 @@ def test_random_mutations_parity(g):
     for ln in lines:
         m = bytearray(ln)
         for _ in range(rng.randint(0, 3)):
+            if len(m) < 2:
+                break
             k = rng.randrange(len(m))
             op = rng.random()
             if op < 0.3: m[k] = rng.choice(b' "[]\n-x')
