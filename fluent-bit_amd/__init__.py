@@ -17,7 +17,7 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libflbgpu.so")
+LIB_PATH = os.environ.get("FLBGPU_LIB") or os.path.join(CSRC, "libflbgpu.so")
 
 MODIFIED, NOTOUCH = 1, 2
 

@@ -6,19 +6,24 @@ namespace flbgpu {
 
 // ---- capture tables of one rx::TableSet, as device pointers
 struct DevCap {
-    const uint8_t *cls;            // [256]
-    const uint16_t *rdelta;        // [nR][ncls]
+    // hot tables (touched once per input byte); stored back to back so that a workgroup can
+    // stage them into LDS with one coalesced copy: [hot_base, hot_base + hot_bytes)
+    const uint16_t *rdelta;        // [nR + 1][1 << cls_shift]; bit15 = a match may start here
+    const uint32_t *ft;            // [nX * NKp][1 << wsh] forward table (encoding: rx.hpp)
+    const uint32_t *ft2;           // [nmulti][1 << fc_shift] one-byte-lookahead rows
+    const uint8_t *cls;            // [256] byte -> class
+    const uint8_t *col;            // [256] byte -> kind << fc_shift | class
+    // cold tables (only when several candidates remain for a byte)
     const uint8_t *r_info;         // [nR]
     const uint32_t *vmask;         // [nR][VW]
     const uint32_t *list_off;      // [nX*NK*NK + 1]
     const uint32_t *list_ent;
     const uint32_t *tag_off;
     const uint8_t *tag_data;
-    const uint8_t *kind_of_cls;    // [ncls]
-    int ncls, nR, r_init, VW, nX, NK, kind_edge, ascii_only;
-    // LDS staging plan (bytes); 0 => tables are read from global memory
-    uint32_t lds_bytes;
-    uint32_t n_list_off, n_list_ent;
+    int ncls, nR, r_init, VW, nX, NK, NKp, kind_edge, ascii_only, cls_shift, fc_shift, wsh, col_eot;
+    const uint8_t *hot_base;
+    uint32_t hot_bytes;
+    uint32_t off_rdelta, off_ft, off_ft2, off_cls, off_col;   // byte offsets inside the hot block
 };
 
 // ---- match-only DFA
@@ -83,6 +88,8 @@ struct RecInfo {
     uint32_t body_off, body_len, meta_off, meta_len;   // relative to record start; meta_len 0 => {}
     int32_t parser_idx;
     uint32_t nkept;                      // fields that will be packed (map count after skips)
+    uint32_t drop_mask;                  // bit f: named field f is not packed (empty+skip_empty,
+                                         // unparsable time, or time consumed and !time_keep)
 };
 // capture spans live in a separate column: caps[rec][2*field + {0,1}] (begin/end relative to the
 // value, 0xFFFFFFFF = group did not participate), field = index in DevParser::field_group
@@ -96,6 +103,9 @@ enum {
 };
 
 constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
+constexpr int CHK_STEP = 16;             // one reverse-DFA state id is kept every CHK_STEP boundaries
+constexpr uint32_t FT_SPECIAL = 0x80000000u, FT_CAPS = 1, FT_MATCH = 2, FT_LOOK = 3, FT_MULTI = 4, FT_DEAD = 5;
+constexpr uint32_t TG_MATCH = 0xFFFFFFFDu, TG_DEAD = 0xFFFFFFFFu;   // results of the slow-path resolver
 
 // ---- filter_parser configuration (plugins/filter_parser/filter_parser.c:460-489)
 struct FParserCfg {
@@ -115,8 +125,10 @@ struct ParserMatchArgs {
     uint32_t caps_stride;
     uint64_t *null_mask;        // [n]
     uint32_t *out_len;          // [n]
-    uint16_t *rid;              // scratch: [slots][rid_len][64]
-    uint32_t rid_len;           // boundaries per lane (max value length + 1)
+    uint16_t *chk;              // scratch: reverse-DFA state checkpoints [slots][chk_len][64]
+    uint32_t chk_len;           // checkpoints per lane (max value length / CHK_STEP + 2)
+    uint32_t lds_bytes;         // dynamic LDS: parser 0's hot ASCII tables are staged when > 0
+    uint32_t debug_skip;        // timing experiments only (FLBGPU_DEBUG_SKIP): results are wrong when != 0
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
     unsigned long long *counts;      // [0] decoded log records, [1] records emitted
 };
@@ -176,7 +188,8 @@ struct GatherArgs {
 #include <hip/hip_runtime_api.h>
 namespace flbgpu {
 void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st);
-void launch_parser_emit(const ParserEmitArgs &a, hipStream_t st);
+constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
+void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);

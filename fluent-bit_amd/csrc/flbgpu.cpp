@@ -96,20 +96,26 @@ template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vect
 static bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint8_t> b;
     std::vector<uint8_t> cls(t.cls, t.cls + 256);
-    size_t o_cls = put(b, cls), o_rd = put(b, t.rdelta), o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
+    // hot block first (staged into LDS as one piece): rdelta | ft | ft2 | cls | col
+    size_t o_rd = put(b, t.rdelta_p), o_ft = put(b, t.ft), o_f2 = put(b, t.ft2), o_cls = put(b, cls), o_col = put(b, t.col);
+    size_t hot_end = (b.size() + 15) & ~(size_t) 15;
+    b.resize(hot_end);
+    size_t o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
     size_t o_lo = put(b, t.list_off), o_le = put(b, t.list_ent), o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
-    size_t o_kc = put(b, t.kind_of_cls);
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     const uint8_t *d = (const uint8_t *) blob.dev;
     memset(&out, 0, sizeof(out));
-    out.cls = d + o_cls; out.rdelta = (const uint16_t *) (d + o_rd); out.r_info = d + o_ri;
-    out.vmask = (const uint32_t *) (d + o_vm); out.list_off = (const uint32_t *) (d + o_lo);
-    out.list_ent = (const uint32_t *) (d + o_le); out.tag_off = (const uint32_t *) (d + o_to);
-    out.tag_data = d + o_td; out.kind_of_cls = d + o_kc;
-    out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK;
-    out.kind_edge = t.kind_edge; out.ascii_only = t.ascii_only ? 1 : 0;
-    out.n_list_off = (uint32_t) t.list_off.size(); out.n_list_ent = (uint32_t) t.list_ent.size();
+    out.rdelta = (const uint16_t *) (d + o_rd); out.ft = (const uint32_t *) (d + o_ft); out.ft2 = (const uint32_t *) (d + o_f2);
+    out.cls = d + o_cls; out.col = d + o_col;
+    out.r_info = d + o_ri; out.vmask = (const uint32_t *) (d + o_vm); out.list_off = (const uint32_t *) (d + o_lo);
+    out.list_ent = (const uint32_t *) (d + o_le); out.tag_off = (const uint32_t *) (d + o_to); out.tag_data = d + o_td;
+    out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK; out.NKp = t.NKp;
+    out.kind_edge = t.kind_edge; out.ascii_only = t.ascii_only ? 1 : 0; out.cls_shift = t.cls_shift; out.fc_shift = t.fc_shift;
+    out.wsh = t.wsh; out.col_eot = t.col_eot;
+    out.hot_base = d; out.hot_bytes = (uint32_t) hot_end;
+    out.off_rdelta = (uint32_t) o_rd; out.off_ft = (uint32_t) o_ft; out.off_ft2 = (uint32_t) o_f2;
+    out.off_cls = (uint32_t) o_cls; out.off_col = (uint32_t) o_col;
     return true;
 }
 
@@ -201,6 +207,7 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
     d.time_keep = time_keep;
     d.time_strict = time_strict;
     memset(d.slot2cap, 0xFF, sizeof(d.slot2cap));
+    for (size_t i = 0; i < p->prog.slot2cap.size() && i < sizeof(d.slot2cap); i++) d.slot2cap[i] = p->prog.slot2cap[i];
     // time format analysis: src/flb_parser.c:906-1040
     if (time_fmt && time_fmt[0]) {
         std::string tf = time_fmt;
@@ -273,8 +280,6 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
             d.field_is_time[f] = (d.has_time && p->prog.names[i] == tkey) ? 1 : 0;
             d.field_type[f] = TY_NONE;
             for (auto &ty : tys) if (ty.first == p->prog.names[i]) { d.field_type[f] = ty.second; break; }   // first match wins
-            d.slot2cap[2 * g] = (uint8_t) (2 * f);
-            d.slot2cap[2 * g + 1] = (uint8_t) (2 * f + 1);
         }
     }
     return p;
@@ -526,14 +531,18 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     launch_max_row_len(row_off, n, &dm->max_row, st);
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
-    uint32_t rid_len = (uint32_t) hm.max_row + 2;
+    // scratch: one reverse-DFA state checkpoint per CHK_STEP bytes of the longest record, per lane
+    uint32_t chk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
     int cus = g_cus > 0 ? g_cus : 256;
-    int grid = cus * 8;                                     // 8 blocks of 4 waves per CU
-    uint64_t need_blocks = (n + 255) / 256;
+    // one 1024-thread workgroup (16 waves) per CU shares one LDS copy of parser 0's hot ASCII
+    // tables (160 KiB of LDS per CU); bigger tables are read through L2 instead
+    uint32_t lds_bytes = f->parsers[0]->dev.ascii.hot_bytes;
+    if (getenv("FLBGPU_NO_LDS")) lds_bytes = 0;
+    if (lds_bytes > 156 * 1024) lds_bytes = 0;
+    int grid = cus;
+    uint64_t need_blocks = (n + MATCH_BLOCK - 1) / MATCH_BLOCK;
     if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
-    // bound the scratch to ~2 GiB by shrinking the grid for very long records
-    while (grid > 1 && (size_t) grid * 4 * 64 * rid_len * sizeof(uint16_t) > ((size_t) 2 << 30)) grid /= 2;
-    if (!f->d_rid.ensure((size_t) grid * 4 * 64 * rid_len * sizeof(uint16_t))) return false;
+    if (!f->d_rid.ensure((size_t) grid * (MATCH_BLOCK / 64) * 64 * chk_len * sizeof(uint16_t))) return false;
     if (!f->d_info.ensure(n * sizeof(RecInfo)) || !f->d_caps.ensure(n * f->caps_stride * sizeof(uint32_t)) ||
         !f->d_null.ensure(n * sizeof(uint64_t)) || !f->d_len.ensure(n * sizeof(uint32_t)) ||
         !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
@@ -541,8 +550,8 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ParserMatchArgs ma;
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
     ma.info = f->d_info.as<RecInfo>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
-    ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.rid = f->d_rid.as<uint16_t>();
-    ma.rid_len = rid_len; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
+    ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     { ProfScope ps(f, st, "k_parser_match"); launch_parser_match(ma, grid, st); }
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -560,7 +569,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ea.info = f->d_info.as<RecInfo>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
     ea.out = f->d_out.as<uint8_t>();
-    { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, st); }
+    { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
     HIPOK(hipStreamSynchronize(st));
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     f->last_out = hm.counts[1];   // rows with length 0 (dropped/skipped) remain as empty rows

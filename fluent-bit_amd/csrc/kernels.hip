@@ -23,11 +23,20 @@
 namespace flbgpu {
 
 #define DEV __device__ __forceinline__
+#define LDS_AS __attribute__((address_space(3)))
+
+extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 
 // ------------------------------------------------------------------------------------------
 // byte access
 // ------------------------------------------------------------------------------------------
 DEV uint32_t ld8(const uint8_t *p) { return *p; }
+// unaligned 32-bit load: gfx950 global/flat loads accept any byte address, so a lane can fetch
+// four consecutive bytes with one instruction wherever they start
+DEV uint32_t ldu32(const uint8_t *p) {
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    return *(const u32u *) p;
+}
 DEV uint32_t ldbe16(const uint8_t *p) { return (ld8(p) << 8) | ld8(p + 1); }
 DEV uint32_t ldbe32(const uint8_t *p) { return (ld8(p) << 24) | (ld8(p + 1) << 16) | (ld8(p + 2) << 8) | ld8(p + 3); }
 DEV uint64_t ldbe64(const uint8_t *p) { return ((uint64_t) ldbe32(p) << 32) | ldbe32(p + 4); }
@@ -47,6 +56,23 @@ struct ByteSink {
     DEV explicit ByteSink(uint8_t *dst) : p(dst) {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = (uint8_t) ld8(src + i); }
+    DEV void finish() {}
+};
+
+// stages a record into LDS; source bytes are pulled through a one-dword cache
+struct LdsSink {
+    __attribute__((address_space(3))) uint8_t *p;
+    DEV explicit LdsSink(__attribute__((address_space(3))) uint8_t *dst) : p(dst) {}
+    DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
+    DEV void copy(const uint8_t *src, uint32_t len) {
+        uint32_t i = 0;
+        for (; i + 4 <= len; i += 4) {
+            uint32_t w = ldu32(src + i);
+            p[0] = (uint8_t) w; p[1] = (uint8_t) (w >> 8); p[2] = (uint8_t) (w >> 16); p[3] = (uint8_t) (w >> 24);
+            p += 4;
+        }
+        for (; i < len; i++) *p++ = (uint8_t) ld8(src + i);
+    }
     DEV void finish() {}
 };
 
@@ -112,12 +138,24 @@ struct Tok {
     const uint8_t *next; // first byte after the header (payload start for str/bin/ext)
 };
 
-// reads one token header at p (p < end); returns T_BAD on truncation or the reserved byte 0xc1
+DEV uint64_t ldu64(const uint8_t *p) {
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    return *(const u64u *) p;
+}
+
+// reads one token header at p (p < end); returns T_BAD on truncation or the reserved byte 0xc1.
+// The header (first byte + up to 4 length bytes + ext type) is fetched with ONE unaligned 8-byte
+// load whenever 8 bytes remain before `end`.
 DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
     Tok t;
     t.type = T_BAD; t.len = 0; t.u = 0; t.next = p;
     if (p >= end) return t;
-    uint32_t c = ld8(p++);
+    uint64_t w;
+    const uint32_t avail = (uint32_t) ((uint64_t) (end - p) < 9 ? (end - p) : 9);
+    if (avail >= 8) w = ldu64(p);
+    else { w = 0; for (uint32_t q = 0; q < avail; q++) w |= (uint64_t) ld8(p + q) << (8 * q); }
+    uint32_t c = (uint32_t) (w & 0xff);
+    p++;
     uint32_t need = 0;
     if (c <= 0x7f) { t.type = T_UINT; t.u = c; }
     else if (c >= 0xe0) { t.type = T_NINT; t.u = (uint64_t) (int64_t) (int8_t) c; }
@@ -161,7 +199,13 @@ DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
         }
         if ((uint64_t) (end - p) < need) { t.type = T_BAD; return t; }
         if (need) {
-            uint64_t v = need == 1 ? ld8(p) : need == 2 ? ldbe16(p) : need == 4 ? ldbe32(p) : ldbe64(p);
+            uint64_t v;
+            if (need == 8) v = ldbe64(p);                       // 64-bit ints / doubles (rare)
+            else {
+                // big-endian value of `need` bytes that follow the first byte, taken from w
+                uint32_t x = (uint32_t) (w >> 8);
+                v = need == 1 ? (x & 0xff) : need == 2 ? (((x & 0xff) << 8) | ((x >> 8) & 0xff)) : __builtin_bswap32(x);
+            }
             p += need;
             if (t.type == T_UINT || t.type == T_F32 || t.type == T_F64) t.u = v;
             else if (t.type == T_NINT) {
@@ -176,7 +220,9 @@ DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
         }
         if (t.type == T_EXT) {
             if (p >= end) { t.type = T_BAD; return t; }
-            t.u = ld8(p++);
+            // ext type byte: byte 1 + need of the header
+            t.u = (1 + need) < 8 ? (uint32_t) ((w >> (8 * (1 + need))) & 0xff) : ld8(p);
+            p++;
         }
     }
     if (t.type == T_STR || t.type == T_BIN || t.type == T_EXT) {
@@ -302,7 +348,13 @@ DEV Event decode_event(const uint8_t *rec, const uint8_t *end) {
 // key lookup
 // ------------------------------------------------------------------------------------------
 DEV bool bytes_eq(const uint8_t *a, const char *b, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) if (ld8(a + i) != (uint8_t) b[i]) return false;
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        uint32_t x = ldu32(a + i);
+        uint32_t y = (uint8_t) b[i] | ((uint32_t) (uint8_t) b[i + 1] << 8) | ((uint32_t) (uint8_t) b[i + 2] << 16) | ((uint32_t) (uint8_t) b[i + 3] << 24);
+        if (x != y) return false;
+    }
+    for (; i < n; i++) if (ld8(a + i) != (uint8_t) b[i]) return false;
     return true;
 }
 
@@ -397,49 +449,145 @@ DEV int utf8_seq_len_dev(const uint8_t *s, uint32_t i, uint32_t len) {
     return need + 1;
 }
 
-// Views over a table set whose hot arrays may live in LDS (T = address-space qualified ptr)
-struct CapView {
-    const uint8_t *cls;
-    const uint16_t *rdelta;
-    const uint8_t *r_info;
-    const uint32_t *vmask;
-    const uint32_t *list_off;
-    const uint32_t *list_ent;
-    const uint32_t *tag_off;
-    const uint8_t *tag_data;
-    const uint8_t *kind_of_cls;
-    int ncls, r_init, VW, nX, NK, kind_edge, ascii_only;
+// Hot tables of one table set: the arrays touched once per input byte.  The pointers refer
+// either to LDS (staged copy, address space 3 so that the compiler emits ds_read) or to global
+// memory.
+template <bool LDS> struct HotPtr;
+template <> struct HotPtr<true> {
+    typedef const LDS_AS uint8_t *p8; typedef const LDS_AS uint16_t *p16; typedef const LDS_AS uint32_t *p32;
+};
+template <> struct HotPtr<false> {
+    typedef const uint8_t *p8; typedef const uint16_t *p16; typedef const uint32_t *p32;
+};
+template <bool LDS> struct HotTabs {
+    typename HotPtr<LDS>::p8 cls;         // byte -> class (reverse pass)
+    typename HotPtr<LDS>::p8 col;         // byte -> kind << fc_shift | class (forward pass)
+    typename HotPtr<LDS>::p16 rdelta;     // rows of 1 << cls_shift entries
+    typename HotPtr<LDS>::p32 ft;         // rows of 1 << wsh entries
+    typename HotPtr<LDS>::p32 ft2;        // rows of 1 << fc_shift entries
+    int ncls, NK, NKp, kind_edge, r_init, nX, nR, ascii_only, cls_shift, fc_shift, wsh, col_eot;
 };
 
-DEV CapView view_of(const DevCap &d) {
-    CapView v;
-    v.cls = d.cls; v.rdelta = d.rdelta; v.r_info = d.r_info; v.vmask = d.vmask; v.list_off = d.list_off;
-    v.list_ent = d.list_ent; v.tag_off = d.tag_off; v.tag_data = d.tag_data; v.kind_of_cls = d.kind_of_cls;
-    v.ncls = d.ncls; v.r_init = d.r_init; v.VW = d.VW; v.nX = d.nX; v.NK = d.NK; v.kind_edge = d.kind_edge;
-    v.ascii_only = d.ascii_only;
-    return v;
+template <bool LDS> DEV void hot_scalars(HotTabs<LDS> &h, const DevCap &d) {
+    h.ncls = d.ncls; h.NK = d.NK; h.NKp = d.NKp; h.kind_edge = d.kind_edge; h.r_init = d.r_init; h.nX = d.nX; h.nR = d.nR;
+    h.ascii_only = d.ascii_only; h.cls_shift = d.cls_shift; h.fc_shift = d.fc_shift; h.wsh = d.wsh; h.col_eot = d.col_eot;
 }
 
-// Pass 1 over one value: reverse automaton.  Stores the state id of every boundary 0..len into
-// `rid` (stride `rstride` elements between consecutive boundaries: the scratch is laid out
-// [boundary][lane] so that a wave's stores coalesce).  Returns the leftmost viable start
-// boundary, -1 for no match, -2 when a byte >= 0x80 poisoned the ASCII tables.
-template <bool STORE>
-DEV int rx_reverse(const CapView &t, const uint8_t *s, uint32_t len, uint16_t *rid, uint32_t rstride) {
+DEV HotTabs<false> hot_global(const DevCap &d) {
+    HotTabs<false> h;
+    h.cls = d.cls; h.col = d.col; h.rdelta = d.rdelta; h.ft = d.ft; h.ft2 = d.ft2;
+    hot_scalars(h, d);
+    return h;
+}
+
+DEV HotTabs<true> hot_lds(const DevCap &d, LDS_AS uint8_t *lds) {
+    HotTabs<true> h;
+    h.rdelta = (const LDS_AS uint16_t *) (lds + d.off_rdelta);
+    h.ft = (const LDS_AS uint32_t *) (lds + d.off_ft);
+    h.ft2 = (const LDS_AS uint32_t *) (lds + d.off_ft2);
+    h.cls = lds + d.off_cls;
+    h.col = lds + d.off_col;
+    hot_scalars(h, d);
+    return h;
+}
+
+// 16 consecutive bytes with one unaligned dwordx4 load
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+DEV v4u32 ldu128(const uint8_t *p) {
+    typedef v4u32 v4u32u __attribute__((aligned(1)));
+    return *(const v4u32u *) p;
+}
+
+// bytes pos..pos+3 of s (little endian in the result); bytes at or beyond len read as zero and
+// are never dereferenced (no over-read past the value)
+DEV uint32_t load4(const uint8_t *s, uint32_t pos, uint32_t len) {
+    if (pos + 4 <= len) return ldu32(s + pos);
+    uint32_t w = 0;
+    for (uint32_t q = 0; q < 4; q++) if (pos + q < len) w |= ld8(s + pos + q) << (8 * q);
+    return w;
+}
+
+// bytes pos..pos+15 (zero beyond len, never dereferenced)
+DEV v4u32 load16(const uint8_t *s, uint32_t pos, uint32_t len) {
+    if (pos + 16 <= len) return ldu128(s + pos);
+    v4u32 r;
+    r.x = load4(s, pos, len); r.y = load4(s, pos + 4, len); r.z = load4(s, pos + 8, len); r.w = load4(s, pos + 12, len);
+    return r;
+}
+
+// Pass 1 over one value: the reverse automaton, one byte per step from the last byte to the
+// first.  Bytes are fetched four at a time with one unaligned dword load issued one group ahead
+// (its latency hides behind the previous group's steps); the four class lookups of a group are
+// independent and issue together, only the four state transitions form a dependent chain.  Every
+// CHK_STEP boundaries (counted from the END of the value, so that all lanes of a wave store in
+// the same iteration) the state id is kept in chk[(t / CHK_STEP) * 64] ([checkpoint][lane]
+// layout: a wave's stores coalesce).  Returns the leftmost viable start boundary, -1 for no
+// match, -2 when a byte >= 0x80 poisoned the ASCII tables.
+template <bool LDS>
+DEV int rx_reverse(const HotTabs<LDS> &t, const uint8_t *r_info, const uint8_t *s, uint32_t len, uint16_t *chk) {
     uint32_t R = (uint32_t) t.r_init;
     int best = -1, h1 = -1, h2 = -1;
-    if (STORE) rid[(size_t) len * rstride] = (uint16_t) R;
-    for (int i = (int) len - 1; i >= 0; i--) {
+    static_assert(CHK_STEP == 16, "the 16-byte reverse trip stores one checkpoint per trip");
+    const uint32_t sh = (uint32_t) t.cls_shift, poison = (uint32_t) t.nR;
+    if (chk) chk[0] = (uint16_t) R;
+    uint32_t tt = 0;
+    if (t.ascii_only) {
+        // one group = 4 bytes held in a dword; `top` is the index of the byte in its high lane
+#define RX_REV_GROUP(w, top)                                                                        \
+        {                                                                                           \
+            uint32_t c0 = t.cls[(w) >> 24], c1 = t.cls[((w) >> 16) & 255];                          \
+            uint32_t c2 = t.cls[((w) >> 8) & 255], c3 = t.cls[(w) & 255];                           \
+            uint32_t e0 = t.rdelta[(R << sh) + c0];                                                 \
+            uint32_t e1 = t.rdelta[((e0 & 0x7FFF) << sh) + c1];                                     \
+            uint32_t e2 = t.rdelta[((e1 & 0x7FFF) << sh) + c2];                                     \
+            uint32_t e3 = t.rdelta[((e2 & 0x7FFF) << sh) + c3];                                     \
+            if ((e0 | e1 | e2 | e3) & 0x8000) {          /* start candidates are rare */           \
+                if (e0 & 0x8000) best = (int) (top) + 1;                                            \
+                if (e1 & 0x8000) best = (int) (top);                                                \
+                if (e2 & 0x8000) best = (int) (top) - 1;                                            \
+                if (e3 & 0x8000) best = (int) (top) - 2;                                            \
+            }                                                                                       \
+            R = e3 & 0x7FFF;                                                                        \
+        }
+        // 16 bytes per trip: one unaligned dwordx4 load, issued one trip ahead
+        const uint32_t n16 = len / 16;
+        v4u32 wn = n16 ? ldu128(s + len - 16) : (v4u32) (0);
+        for (uint32_t g = 0; g < n16; g++) {
+            const v4u32 w = wn;
+            if (g + 1 < n16) wn = ldu128(s + len - 16 * (g + 2));
+            const uint32_t top = len - 1 - 16 * g;
+            RX_REV_GROUP(w.w, top)
+            RX_REV_GROUP(w.z, top - 4)
+            RX_REV_GROUP(w.y, top - 8)
+            RX_REV_GROUP(w.x, top - 12)
+            // POISON (row nR) is absorbing and carries no start flags: one test per trip
+            if (R == poison) return -2;
+            tt = 16 * (g + 1);                           // CHK_STEP == 16: a checkpoint every trip
+            if (chk) chk[(size_t) (tt / CHK_STEP) * 64] = (uint16_t) R;
+        }
+        tt = 16 * n16;
+        // remaining 4-byte groups
+        while (tt + 4 <= len) {
+            const uint32_t w = ldu32(s + len - tt - 4);
+            RX_REV_GROUP(w, len - 1 - tt)
+            if (R == poison) return -2;
+            tt += 4;
+            if (chk && (tt & (CHK_STEP - 1)) == 0) chk[(size_t) (tt / CHK_STEP) * 64] = (uint16_t) R;
+        }
+#undef RX_REV_GROUP
+    }
+    for (tt = tt + 1; tt <= len; tt++) {
+        uint32_t i = len - tt;
         uint32_t b = ld8(s + i);
-        uint32_t e = t.rdelta[R * (uint32_t) t.ncls + t.cls[b]];
-        if ((e & 0x7FFF) == 0x7FFF) return -2;
+        uint32_t e = t.rdelta[(R << sh) + t.cls[b]];
+        if ((e & 0x7FFF) == poison) return -2;
         int before = best;
-        if (e & 0x8000) best = i + 1;
+        if (e & 0x8000) best = (int) i + 1;
         R = e & 0x7FFF;
-        if (STORE) rid[(size_t) i * rstride] = (uint16_t) R;
+        if (chk && (tt & (CHK_STEP - 1)) == 0) chk[(size_t) (tt / CHK_STEP) * 64] = (uint16_t) R;
         if (!t.ascii_only) {
             if (b >= 0xc2) {
-                int L = utf8_seq_len_dev(s, (uint32_t) i, len);
+                int L = utf8_seq_len_dev(s, i, len);
                 if (L == 2) best = before;
                 else if (L == 3) best = h1;
                 else if (L == 4) best = h2;
@@ -447,40 +595,117 @@ DEV int rx_reverse(const CapView &t, const uint8_t *s, uint32_t len, uint16_t *r
             h2 = h1; h1 = before;
         }
     }
-    if (t.r_info[R] & 0x80) best = 0;
+    if (r_info[R] & 0x80) best = 0;
     return best;
 }
 
-// Pass 2: deterministic leftmost-first walk from boundary `start`; writes the capture slots that
-// belong to named fields into caps[] (slot2cap maps a capture slot to its caps index or 0xFF).
-// Returns the end boundary of the match (>= 0) or -1 on a table inconsistency.
-DEV int rx_forward(const CapView &t, const uint8_t *s, uint32_t len, int start, const uint16_t *rid,
-                   uint32_t rstride, const uint8_t *slot2cap, uint32_t *caps) {
-    uint32_t x = (uint32_t) t.nX - 1;
+// several candidates remain for this byte (or its capture writes do not fit the packed entry):
+// rebuild the reverse state of boundary j from the nearest checkpoint to its right, take the
+// first viable candidate and apply its tag sequence.  Returns the target core, TG_MATCH for
+// MATCH, TG_DEAD on inconsistency.
+template <bool LDS>
+DEV uint32_t rx_resolve_multi(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, uint32_t j, uint32_t li,
+                              const uint16_t *chk, const uint8_t *slot2cap, uint32_t *caps) {
+    uint32_t t0 = ((len - j) / CHK_STEP) * CHK_STEP, b0 = len - t0;
+    uint32_t r = chk[(size_t) (t0 / CHK_STEP) * 64];
+    for (uint32_t i = b0; i > j; i--) r = t.rdelta[(r << t.cls_shift) + t.cls[ld8(s + i - 1)]] & 0x7FFF;
+    for (uint32_t k = d.list_off[li]; k < d.list_off[li + 1]; k++) {
+        uint32_t ent = d.list_ent[k], tg = ent & 0xFFFF;
+        if (tg == 0xFFFF || ((d.vmask[r * (uint32_t) d.VW + (tg >> 5)] >> (tg & 31)) & 1)) {
+            uint32_t ts = ent >> 16;
+            for (uint32_t q = d.tag_off[ts]; q < d.tag_off[ts + 1]; q++) {
+                uint32_t ci = slot2cap[d.tag_data[q]];
+                if (ci != 0xFF) caps[ci] = j;
+            }
+            return tg == 0xFFFF ? TG_MATCH : tg;
+        }
+    }
+    return TG_DEAD;
+}
+
+// column codes of the four value bytes in w (positions pos..pos+3); positions at or beyond len
+// get the end-of-text column
+template <bool LDS>
+DEV uint32_t pack_col(const HotTabs<LDS> &t, uint32_t w, uint32_t pos, uint32_t len) {
+    uint32_t v0 = t.col[w & 255], v1 = t.col[(w >> 8) & 255], v2 = t.col[(w >> 16) & 255], v3 = t.col[w >> 24];
+    if (pos + 4 > len) {
+        const uint32_t eot = (uint32_t) t.col_eot;
+        if (pos >= len) v0 = eot;
+        if (pos + 1 >= len) v1 = eot;
+        if (pos + 2 >= len) v2 = eot;
+        v3 = eot;
+    }
+    return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+}
+
+// Pass 2: deterministic leftmost-first walk from boundary `start`.  Value bytes are fetched four
+// at a time (unaligned dword, issued two groups ahead) and turned into a packed queue of column
+// codes one group ahead, so that a plain step is: index = row << wsh | column, ONE dependent LDS
+// read, and the entry IS the next row.  Everything else (capture writes, MATCH, lookahead, the
+// rare multi-candidate resolution) sits behind one "special" bit test.  Returns the end boundary of
+// the match (>= 0) or -1 on a table inconsistency.
+template <bool LDS>
+DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, int start, const uint16_t *chk,
+                   const uint8_t *slot2cap, uint32_t *caps) {
     uint32_t j = (uint32_t) start;
-    uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : t.kind_of_cls[t.cls[ld8(s + j - 1)]];
+    const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
+    uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : (uint32_t) (t.col[ld8(s + j - 1)] >> fsh);
+    uint32_t S = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + pk;
+    // 16-byte windows of the value (one unaligned dwordx4 load each, issued a window ahead);
+    // every 4 steps the next dword of the window becomes a packed queue of 4 column codes
+    uint32_t gb = j;                                            // position of the current 4-byte group
+    v4u32 wc = load16(s, gb, len), wx = load16(s, gb + 16, len);
+    uint32_t vq = pack_col(t, wc.x, gb, len);                   // codes of positions gb..gb+3
+    uint32_t vqn = pack_col(t, wc.y, gb + 4, len);
+    uint32_t sub = 2;                                           // dword of the window feeding the NEXT refill
+    uint32_t k = 0;
     for (;;) {
-        uint32_t r = rid[(size_t) j * rstride];
-        uint32_t nk = t.r_info[r] & 7;
-        uint32_t li = (x * (uint32_t) t.NK + pk) * (uint32_t) t.NK + nk;
-        uint32_t k = t.list_off[li], kend = t.list_off[li + 1];
-        uint32_t pick = 0xFFFFFFFFu;
-        for (; k < kend; k++) {
-            uint32_t ent = t.list_ent[k];
-            uint32_t tg = ent & 0xFFFF;
-            if (tg == 0xFFFF || ((t.vmask[r * (uint32_t) t.VW + (tg >> 5)] >> (tg & 31)) & 1)) { pick = ent; break; }
+        const uint32_t colc = vq & 255;
+        uint32_t e = t.ft[(S << wsh) + colc];
+        if (e & FT_SPECIAL) {
+            uint32_t ty = (e >> 28) & 7;
+            if (ty == FT_LOOK) {
+                uint32_t cn = (k < 3 ? (vq >> 8) : vqn) & ((1u << fsh) - 1);   // class of the next byte / EOT
+                e = t.ft2[((e & 0xFFFFFF) << fsh) + cn];
+                ty = (e & FT_SPECIAL) ? (e >> 28) & 7 : 0;
+            }
+            if (ty == 0) S = e;
+            else if (ty == FT_CAPS || ty == FT_MATCH) {
+                uint32_t ca = (e >> 12) & 63, cb = (e >> 18) & 63;
+                if (ca) caps[ca - 1] = j;
+                if (cb) caps[cb - 1] = j;
+                if (ty == FT_MATCH) return (int) j;
+                S = e & 0xFFF;
+            }
+            else if (ty == FT_MULTI) {
+                uint32_t x = S / (uint32_t) t.NKp, pkk = S % (uint32_t) t.NKp, nk = colc >> fsh;
+                uint32_t li = (x * (uint32_t) t.NK + pkk) * (uint32_t) t.NK + nk;
+                uint32_t tg = rx_resolve_multi(d, t, s, len, j, li, chk, slot2cap, caps);
+                if (tg == TG_DEAD) return -1;
+                if (tg == TG_MATCH) return (int) j;
+                S = tg * (uint32_t) t.NKp + nk;
+            }
+            else return -1;
         }
-        if (pick == 0xFFFFFFFFu) return -1;
-        uint32_t ts = pick >> 16;
-        for (uint32_t q = t.tag_off[ts]; q < t.tag_off[ts + 1]; q++) {
-            uint32_t ci = slot2cap[t.tag_data[q]];
-            if (ci != 0xFF) caps[ci] = j;
-        }
-        if ((pick & 0xFFFF) == 0xFFFF) return (int) j;
-        x = pick & 0xFFFF;
-        pk = t.kind_of_cls[t.cls[ld8(s + j)]];
+        else S = e;
         j++;
-        if (j > len) return -1;
+        vq >>= 8;
+        if (++k == 4) {
+            if (j > len) return -1;
+            k = 0;
+            gb += 4;
+            vq = vqn;
+            // codes of positions gb+4..gb+7: dword `sub` of the current window, or the first dword
+            // of the next window once the current one is used up
+            if (sub == 4) {
+                wc = wx;
+                wx = load16(s, gb + 4 + 16, len);
+                sub = 0;
+            }
+            uint32_t w = sub == 0 ? wc.x : sub == 1 ? wc.y : sub == 2 ? wc.z : wc.w;
+            vqn = pack_col(t, w, gb + 4, len);
+            sub++;
+        }
     }
 }
 
@@ -950,16 +1175,10 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
     }
     const uint8_t *val = rec + ri.val_off;
     for (int f = 0; f < ps.nfields; f++) {
+        if ((ri.drop_mask >> f) & 1) continue;
         uint32_t b = caps[2 * f], e = caps[2 * f + 1];
         uint32_t vlen = (b == CAP_UNSET || e == CAP_UNSET) ? 0 : e - b;
         const uint8_t *v = (b == CAP_UNSET || e == CAP_UNSET) ? val : val + b;
-        if (vlen == 0 && ps.skip_empty) continue;
-        if (ps.field_is_time[f]) {
-            // dropped when the time is unparsable, or parsed and !time_keep
-            int64_t sec; double frac;
-            if (time_lookup(ps, v, vlen, &sec, &frac) == -1) continue;
-            if (!ps.time_keep) continue;
-        }
         pk_str_hdr(s, (uint32_t) ps.field_name_len[f]);
         for (int q = 0; q < ps.field_name_len[f]; q++) s.put((uint8_t) ps.names[ps.field_name_off[f] + q]);
         write_field_value(s, ps.field_type[f], v, vlen);
@@ -984,27 +1203,29 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
 // ------------------------------------------------------------------------------------------
 
 // one parser attempt on one value.  Returns true on success (flb_parser_do >= 0).
-DEV bool try_parser(const DevParser &ps, const uint8_t *val, uint32_t vlen, uint16_t *rid, uint32_t rid_len,
-                    uint32_t *caps, int64_t *tsec, int64_t *tnsec, uint32_t *nkept) {
-    if (vlen + 1 > rid_len) return false;                 // scratch too small: host sizes it to fit
-    CapView va = view_of(ps.ascii);
-    const CapView *used = &va;
-    CapView vu;
-    int best = rx_reverse<true>(va, val, vlen, rid, 64);
+// `hot` are parser ps's ASCII hot tables (LDS copy for parser 0, global otherwise).
+template <bool LDS>
+DEV bool try_parser(const DevParser &ps, const HotTabs<LDS> &hot, const uint8_t *val, uint32_t vlen, uint16_t *chk, uint32_t chk_len,
+                    uint32_t *caps, int64_t *tsec, int64_t *tnsec, uint32_t *nkept, uint32_t *drop_mask, uint32_t dbg) {
+    if (vlen / CHK_STEP + 2 > chk_len) return false;
+    if (dbg & 1) return false;      // scratch too small: the host sizes it to fit
+    bool use_utf8 = false;
+    int best = rx_reverse(hot, ps.ascii.r_info, val, vlen, chk);
+    HotTabs<false> hu = hot_global(ps.utf8);
     if (best == -2) {
-        vu = view_of(ps.utf8);
-        used = &vu;
-        best = rx_reverse<true>(vu, val, vlen, rid, 64);
+        use_utf8 = true;
+        best = rx_reverse(hu, ps.utf8.r_info, val, vlen, chk);
     }
     if (best < 0) return false;
     if (ps.nregs_minus1 <= 0) return false;               // flb_parser_regex_do: n <= 0
     for (int f = 0; f < 2 * ps.nfields; f++) caps[f] = CAP_UNSET;
-    const uint8_t *slot2cap = ps.slot2cap;
-    int endb = rx_forward(*used, val, vlen, best, rid, 64, slot2cap, caps);
+    if (dbg & 2) return false;
+    int endb = use_utf8 ? rx_forward(ps.utf8, hu, val, vlen, best, chk, ps.slot2cap, caps)
+                        : rx_forward(ps.ascii, hot, val, vlen, best, chk, ps.slot2cap, caps);
     if (endb < 0) return false;
-    // group 0 is not a named field; named groups that did not participate stay CAP_UNSET
+    // named groups that did not participate stay CAP_UNSET
     bool any = false;
-    uint32_t kept = 0;
+    uint32_t kept = 0, drop = 0;
     int64_t sec = 0; double frac = 0;
     for (int f = 0; f < ps.nfields; f++) {
         uint32_t b = caps[2 * f], e = caps[2 * f + 1];
@@ -1012,12 +1233,12 @@ DEV bool try_parser(const DevParser &ps, const uint8_t *val, uint32_t vlen, uint
         if (!set) { caps[2 * f] = CAP_UNSET; caps[2 * f + 1] = CAP_UNSET; }
         if (set) any = true;                               // last_pos (src/flb_regex.c:52-54)
         uint32_t fl = set ? e - b : 0;
-        if (fl == 0 && ps.skip_empty) continue;
-        if (ps.field_is_time[f]) {
+        if (fl == 0 && ps.skip_empty) { drop |= 1u << f; continue; }
+        if (ps.field_is_time[f] && !(dbg & 4)) {
             int64_t s2; double f2;
-            if (time_lookup(ps, set ? val + b : val, fl, &s2, &f2) == -1) continue;
+            if (time_lookup(ps, set ? val + b : val, fl, &s2, &f2) == -1) { drop |= 1u << f; continue; }
             sec = s2; frac = f2;
-            if (!ps.time_keep) continue;
+            if (!ps.time_keep) { drop |= 1u << f; continue; }
         }
         kept++;
     }
@@ -1025,14 +1246,30 @@ DEV bool try_parser(const DevParser &ps, const uint8_t *val, uint32_t vlen, uint
     *tsec = sec;
     *tnsec = (int64_t) (frac * 1000000000);
     *nkept = kept;
+    *drop_mask = drop;
     return true;
 }
 
-__global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
+template <bool LDS>
+__global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-    uint16_t *rid = a.rid + ((size_t) wave_slot * a.rid_len) * 64 + lane;
+    uint16_t *chk = a.chk + ((size_t) wave_slot * a.chk_len) * 64 + lane;
+
+    // stage parser 0's hot ASCII tables into LDS (one coalesced 16 B/lane copy per workgroup)
+    HotTabs<LDS> hot0;
+    if constexpr (LDS) {
+        const DevCap &c0 = a.parsers[0].ascii;
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u *src = (const v4u *) c0.hot_base;
+        LDS_AS v4u *dst = (LDS_AS v4u *) g_lds;
+        for (uint32_t i = threadIdx.x; i < a.lds_bytes / 16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+        hot0 = hot_lds(c0, (LDS_AS uint8_t *) g_lds);
+    }
+    else hot0 = hot_global(a.parsers[0].ascii);
+
     for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
         uint64_t r = base + lane;
         if (r >= a.n) continue;
@@ -1040,7 +1277,7 @@ __global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
         const uint8_t *rec_end = a.data + a.row_off[r + 1];
         RecInfo ri;
         ri.flags = 0; ri.val_off = 0; ri.val_len = 0; ri.key_index = 0; ri.ts_sec = 0; ri.ts_nsec = 0;
-        ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0;
+        ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0; ri.drop_mask = 0;
         uint64_t null_mask = 0;
         uint32_t *caps = a.caps + r * a.caps_stride;
         Event ev = decode_event(rec, rec_end);
@@ -1056,48 +1293,44 @@ __global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
         if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
         int64_t tsec = ev.sec, tnsec = ev.nsec;
         bool have_out = false, last_ok = false;
-        if (a.cfg.key.is_ra) {
-            const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end);
-            if (v) {
-                Tok t = mp_tok(v, ev.body_end);
-                if (t.type == T_STR || t.type == T_BIN) {
-                    for (int p = 0; p < a.cfg.nparsers; p++) {
-                        int64_t ps = 0, pn = 0; uint32_t nk = 0;
-                        last_ok = try_parser(a.parsers[p], t.next, t.len, rid, a.rid_len, caps, &ps, &pn, &nk);
-                        if (last_ok) {
-                            have_out = true;
-                            ri.val_off = (uint32_t) (t.next - rec); ri.val_len = t.len; ri.parser_idx = p; ri.nkept = nk;
-                            if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
-                            break;
-                        }
-                    }
+        // candidate values: the record accessor yields at most one; a plain Key_Name tries every
+        // kv whose key matches, in map order (filter_parser.c:259-323)
+        Tok bm = mp_tok(ev.body, ev.body_end);
+        const uint8_t *p = bm.next;
+        uint32_t nkv = a.cfg.key.is_ra ? 1 : bm.len;
+        for (uint32_t i = 0; i < nkv; i++) {
+            const uint8_t *vptr = nullptr;
+            uint32_t vlen = 0;
+            if (a.cfg.key.is_ra) {
+                const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end);
+                if (v) {
+                    Tok t = mp_tok(v, ev.body_end);
+                    if (t.type == T_STR || t.type == T_BIN) { vptr = t.next; vlen = t.len; }
                 }
             }
-        }
-        else {
-            Tok bm = mp_tok(ev.body, ev.body_end);
-            const uint8_t *p = bm.next;
-            for (uint32_t i = 0; i < bm.len; i++) {
-                Tok k = mp_tok(p, ev.body_end);
+            else {
+                Tok kt = mp_tok(p, ev.body_end);
                 const uint8_t *kend = mp_skip(p, ev.body_end);
-                Tok v = mp_tok(kend, ev.body_end);
-                const uint8_t *vend = mp_skip(kend, ev.body_end);
-                if ((k.type == T_STR || k.type == T_BIN) && k.len == (uint32_t) a.cfg.key.key_len &&
-                    bytes_eq(k.next, a.cfg.key.key, k.len) && (v.type == T_STR || v.type == T_BIN)) {
-                    for (int q = 0; q < a.cfg.nparsers; q++) {
-                        int64_t ps = 0, pn = 0; uint32_t nk = 0;
-                        last_ok = try_parser(a.parsers[q], v.next, v.len, rid, a.rid_len, caps, &ps, &pn, &nk);
-                        if (last_ok) {
-                            have_out = true;
-                            ri.val_off = (uint32_t) (v.next - rec); ri.val_len = v.len; ri.parser_idx = q; ri.nkept = nk;
-                            ri.key_index = i;
-                            if (i < 64) null_mask |= 1ull << i;
-                            if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
-                            break;
-                        }
+                Tok vt = mp_tok(kend, ev.body_end);
+                p = mp_skip(kend, ev.body_end);
+                if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
+                    bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) { vptr = vt.next; vlen = vt.len; }
+            }
+            if (!vptr) continue;
+            for (int q = 0; q < a.cfg.nparsers; q++) {
+                int64_t ps = 0, pn = 0; uint32_t nk = 0, dm = 0;
+                last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, caps, &ps, &pn, &nk, &dm, a.debug_skip)
+                                 : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, caps, &ps, &pn, &nk, &dm, a.debug_skip);
+                if (last_ok) {
+                    have_out = true;
+                    ri.val_off = (uint32_t) (vptr - rec); ri.val_len = vlen; ri.parser_idx = q; ri.nkept = nk; ri.drop_mask = dm;
+                    if (!a.cfg.key.is_ra) {
+                        ri.key_index = i;
+                        if (i < 64) null_mask |= 1ull << i;
                     }
+                    if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
+                    break;
                 }
-                p = vend;
             }
         }
         if (have_out && last_ok) ri.flags |= RF_PARSED;
@@ -1109,7 +1342,8 @@ __global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
         CountSink cs;
-        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        if (!(a.debug_skip & 8)) write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        else cs.n = 1;
         a.info[r] = ri;
         a.null_mask[r] = null_mask;
         a.out_len[r] = (uint32_t) cs.n;
@@ -1117,15 +1351,63 @@ __global__ void __launch_bounds__(256) k_parser_match(ParserMatchArgs a) {
     }
 }
 
+// Pass 2.  Each lane produces its record into a per-wave LDS staging area at the record's
+// offset inside the wave's (contiguous) output range; the wave then flushes the staged bytes with
+// 16 B per lane coalesced stores.  A record that does not fit the staging area is written directly.
+constexpr int EMIT_BLOCK = 256;
+constexpr int EMIT_STG = 18944;             // staging bytes per wave (64 records x 275 B + slack)
 
-__global__ void __launch_bounds__(256) k_parser_emit(ParserEmitArgs a) {
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n) return;
-    if (a.out_len[r] == 0) return;
-    const uint8_t *rec = a.data + a.row_off[r];
-    const uint8_t *rec_end = a.data + a.row_off[r + 1];
-    ByteSink s(a.out + a.out_off[r]);
-    write_record(s, a.cfg, a.parsers, rec, rec_end, a.info[r], a.caps + r * a.caps_stride, a.null_mask[r]);
+__global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LDS_AS uint8_t *stg = (LDS_AS uint8_t *) g_lds + (size_t) wave * EMIT_STG;
+    const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+        uint64_t r = base + lane;
+        uint32_t cnt = (uint32_t) ((a.n - base) < 64 ? (a.n - base) : 64);
+        uint64_t o0 = 0, o1 = 0;
+        if (lane < cnt) { o0 = a.out_off[r]; o1 = a.out_off[r + 1]; }
+        uint32_t lo = 0;
+        while (lo < cnt) {
+            uint64_t batch_base = __shfl(o0, (int) lo, 64);
+            uint32_t align = (uint32_t) (batch_base & 15);
+            bool fit = lane >= lo && lane < cnt && (o1 - batch_base + align) <= (uint64_t) EMIT_STG;
+            uint64_t mask = __ballot(fit) >> lo;
+            uint32_t m = (~mask == 0) ? 64 - lo : (uint32_t) __builtin_ctzll(~mask);
+            if (m > cnt - lo) m = cnt - lo;
+            if (m == 0) {
+                // one record larger than the staging area: straight to global memory
+                if (lane == lo && o1 > o0) {
+                    ByteSink s(a.out + o0);
+                    write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], a.info[r],
+                                 a.caps + r * a.caps_stride, a.null_mask[r]);
+                }
+                lo += 1;
+                continue;
+            }
+            if (lane >= lo && lane < lo + m && o1 > o0) {
+                LdsSink s(stg + align + (uint32_t) (o0 - batch_base));
+                write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], a.info[r],
+                             a.caps + r * a.caps_stride, a.null_mask[r]);
+            }
+            uint32_t total = (uint32_t) (__shfl(o1, (int) (lo + m - 1), 64) - batch_base);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // staged bytes visible to the wave
+            // flush [align, align + total) of the staging area to out[batch_base ...]
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            uint8_t *dst = a.out + (batch_base - align);               // 16 B aligned
+            uint32_t n16 = (align + total + 15) / 16;
+            for (uint32_t u = lane; u < n16; u += 64) {
+                uint32_t b0 = u * 16, b1 = b0 + 16;
+                if (b0 >= align && b1 <= align + total) *(v4u *) (dst + b0) = *(LDS_AS v4u *) (stg + b0);
+                else {
+                    uint32_t s0 = b0 < align ? align : b0, s1 = b1 > align + total ? align + total : b1;
+                    for (uint32_t q = s0; q < s1; q++) dst[q] = stg[q];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // staging area reusable
+            lo += m;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1140,8 +1422,8 @@ DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_
     if (t.type != T_STR) return -1;
     int m = dfa_match(ru.dfa.cls, ru.dfa.ddelta, ru.dfa.d_final, ru.dfa.ncls, ru.dfa.d_init, t.next, t.len);
     if (m == RX_POISON) {
-        CapView vu = view_of(ru.utf8);
-        int best = rx_reverse<false>(vu, t.next, t.len, nullptr, 0);
+        HotTabs<false> hu = hot_global(ru.utf8);
+        int best = rx_reverse(hu, ru.utf8.r_info, t.next, t.len, nullptr);
         m = best >= 0 ? RX_MATCH : RX_NOMATCH;
     }
     return m == RX_MATCH ? 1 : 0;
@@ -1288,11 +1570,26 @@ __global__ void k_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long
 // host-callable launchers
 // ------------------------------------------------------------------------------------------
 void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(k_parser_match, dim3(grid), dim3(256), 0, st, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_parser_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (a.lds_bytes) hipLaunchKernelGGL(k_parser_match<true>, dim3(grid), dim3(MATCH_BLOCK), a.lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_parser_match<false>, dim3(grid), dim3(MATCH_BLOCK), 0, st, a);
 }
-void launch_parser_emit(const ParserEmitArgs &a, hipStream_t st) {
+void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
-    hipLaunchKernelGGL(k_parser_emit, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, st, a);
+    static bool attr_set = false;
+    const size_t lds = (size_t) (EMIT_BLOCK / 64) * EMIT_STG;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_parser_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    uint64_t tiles = (a.n + 63) / 64, blocks = (tiles + EMIT_BLOCK / 64 - 1) / (EMIT_BLOCK / 64);
+    uint64_t cap = (uint64_t) cus * 2 * 4;                 // a few waves of tiles per CU, grid-stride over the rest
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_parser_emit, dim3((unsigned) blocks), dim3(EMIT_BLOCK), lds, st, a);
 }
 void launch_grep_match(const GrepArgs &a, hipStream_t st) {
     if (a.n == 0) return;

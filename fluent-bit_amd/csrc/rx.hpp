@@ -71,12 +71,54 @@ struct TableSet {
     std::vector<uint32_t> list_ent;           // target core | tagseq << 16, priority order
     std::vector<uint32_t> tag_off;            // [ntagseq+1]
     std::vector<uint8_t> tag_data;            // capture slots (2*g, 2*g+1)
+    // byte-resolved fast path of the forward walk: fastc[list][c] for byte class c (column ncls =
+    // end of text) is the ONLY candidate of that list whose byte set contains c (or MATCH), so
+    // no viability test is needed; FC_MULTI = several candidates remain (resolve with vmask),
+    // FC_DEAD = none.
+    std::vector<uint32_t> fastc;              // [nX*NK*NK][1 << fc_shift], column ncls = end of text
+    // Kernel-friendly encodings of the above (what is actually uploaded):
+    //   rdelta_p  rows padded to 1 << cls_shift entries, so the row offset is a shift; row nR is
+    //             the absorbing POISON state (replaces R_POISON)
+    //   ck[256]   byte -> class | kind << 6          (one lookup instead of two; ncls <= 64)
+    //   fastc     entry = target (12 bit, FC_TMATCH = match) | (capA+1) << 12 | (capB+1) << 18:
+    //             up to two capture-span writes of NAMED groups are carried inline, so the walk
+    //             needs no tag table; entries whose tag sequence does not fit are FC_MULTI
+    //   fast2     cells that stay ambiguous after one byte are usually decided by the NEXT byte
+    //             (delimiter-driven log patterns: "\S*\"" vs the closing quote): such a cell
+    //             holds FC_LOOK | m and fast2[m][class of byte j+1] is consulted (same encoding)
+    int cls_shift = 0, fc_shift = 0;
+    std::vector<uint16_t> rdelta_p;           // [nR + 1][1 << cls_shift]
+    std::vector<uint8_t> ck;                  // [256]
+    std::vector<uint32_t> fast2;              // [nmulti][1 << fc_shift]
+    // ---- what the kernels step through (derived from fastc/fast2 by encode_kernel_tables):
+    //   col[256]  byte -> column code  kind << fc_shift | class        (one lookup per byte)
+    //   ft        [nX * NKp][NKp << fc_shift]  row S = core * NKp + prev kind; a plain entry IS the
+    //             next row number (< 4096); entries with bit 31 are special, type in bits 28-30:
+    //               1 step + capture writes  (next row | (capA+1) << 12 | (capB+1) << 18)
+    //               2 MATCH (+ capture writes)   3 look at next byte: ft2[m][its class]
+    //               4 several candidates (resolve with vmask)   5 dead
+    //   ft2       [nmulti][1 << fc_shift], same encoding
+    int NKp = 1, wsh = 0;                     // NK rounded up to a power of two; row width shift
+    int col_eot = 0;                          // column code of "end of text"
+    std::vector<uint8_t> col;                 // [256]
+    std::vector<uint32_t> ft, ft2;
 };
+
+constexpr uint32_t FT_SPECIAL = 0x80000000u;
+constexpr uint32_t FT_CAPS = 1, FT_MATCH = 2, FT_LOOK = 3, FT_MULTI = 4, FT_DEAD = 5;
+inline uint32_t ft_type(uint32_t e) { return (e >> 28) & 7; }
+
+constexpr uint32_t FC_MULTI = 0xFFFFFFFEu;
+constexpr uint32_t FC_DEAD = 0xFFFFFFFFu;
+constexpr uint32_t FC_TMATCH = 0xFFFu;        // target field value meaning MATCH
+constexpr uint32_t FC_LOOK = 0xFE000000u;     // | m: resolve with fast2[m][next byte class]
 
 struct Program {
     int ngroups = 0;                          // capture groups excluding group 0
     std::vector<std::string> names;           // first-appearance order (onig_foreach_name)
     std::vector<std::vector<int>> name_groups;
+    std::vector<uint8_t> slot2cap;            // capture slot (2g, 2g+1) -> index in the caps row of
+                                              // the named fields (0xFF: not a named group's slot)
     TableSet ascii;                           // match DFA (+ capture program when requested)
     TableSet utf8;                            // capture program (also answers match-only)
 };
@@ -101,5 +143,7 @@ int simulate_match(const Program &p, const uint8_t *s, int len);
 // UTF-8 sequence length rule shared with the kernels: length (2..4) of the well-formed or
 // end-truncated sequence starting at s[i], else 1
 int utf8_seq_len(const uint8_t *s, int i, int len);
+// forward-walk step counters of simulate_capture since the last call: {fast, lookahead, slow}
+void debug_stats(long *out);
 
 }  // namespace rx

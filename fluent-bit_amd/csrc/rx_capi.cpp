@@ -43,6 +43,8 @@ void flbgpu_rx_info(void *h, int *info)
     info[10] = (int) p->utf8.list_ent.size(); info[11] = p->ngroups;
 }
 
+void flbgpu_rx_debug_stats(long *out3) { rx::debug_stats(out3); }
+
 /* "name=group\n" lines in onig_foreach_name order */
 int flbgpu_rx_names(void *h, char *buf, int cap)
 {
