@@ -79,7 +79,7 @@ struct DevKey {
 };
 
 // per-record result of the parser match pass
-struct RecInfo {
+struct alignas(16) RecInfo {
     uint32_t flags;
     uint32_t val_off;                    // value offset relative to record start
     uint32_t val_len;
@@ -90,6 +90,7 @@ struct RecInfo {
     uint32_t nkept;                      // fields that will be packed (map count after skips)
     uint32_t drop_mask;                  // bit f: named field f is not packed (empty+skip_empty,
                                          // unparsable time, or time consumed and !time_keep)
+    uint32_t pad_[3];                    // 64 bytes: four 16-byte stores
 };
 // capture spans live in a separate column: caps[rec][2*field + {0,1}] (begin/end relative to the
 // value, 0xFFFFFFFF = group did not participate), field = index in DevParser::field_group
@@ -128,6 +129,9 @@ struct ParserMatchArgs {
     uint16_t *chk;              // scratch: reverse-DFA state checkpoints [slots][chk_len][64]
     uint32_t chk_len;           // checkpoints per lane (max value length / CHK_STEP + 2)
     uint32_t lds_bytes;         // dynamic LDS: parser 0's hot ASCII tables are staged when > 0
+    uint32_t caps_lds_off;      // byte offset of the per-thread capture columns inside the dynamic LDS
+    uint32_t caps_in_lds;       // 0: spans are written straight to the global row
+    uint32_t lds_total;         // dynamic LDS bytes to request (tables + capture columns)
     uint32_t debug_skip;        // timing experiments only (FLBGPU_DEBUG_SKIP): results are wrong when != 0
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
     unsigned long long *counts;      // [0] decoded log records, [1] records emitted
@@ -164,6 +168,7 @@ struct GrepArgs {
     const uint8_t *data;
     const uint64_t *row_off;
     uint64_t n;
+    uint64_t bytes;             // chunk size (bounds the coalesced tile loads)
     const GrepRule *rules;
     int nrules;
     int logical_op;
@@ -190,7 +195,7 @@ namespace flbgpu {
 void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st);
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
-void launch_grep_match(const GrepArgs &a, hipStream_t st);
+void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);
 void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st);

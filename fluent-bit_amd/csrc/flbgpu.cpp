@@ -439,6 +439,7 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
     }
     if (f->caps_stride == 0) f->caps_stride = 2;
+    f->caps_stride = (f->caps_stride + 3) & ~3u;             // 16-byte rows
     if (!filter_common_init(f) || !f->d_parsers.ensure(dp.size() * sizeof(DevParser))) { delete f; return nullptr; }
     if (hipMemcpy(f->d_parsers.p, dp.data(), dp.size() * sizeof(DevParser), hipMemcpyHostToDevice) != hipSuccess) { set_err("upload failed"); delete f; return nullptr; }
     return f;
@@ -536,9 +537,16 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     int cus = g_cus > 0 ? g_cus : 256;
     // one 1024-thread workgroup (16 waves) per CU shares one LDS copy of parser 0's hot ASCII
     // tables (160 KiB of LDS per CU); bigger tables are read through L2 instead
-    uint32_t lds_bytes = f->parsers[0]->dev.ascii.hot_bytes;
-    if (getenv("FLBGPU_NO_LDS")) lds_bytes = 0;
-    if (lds_bytes > 156 * 1024) lds_bytes = 0;
+    uint32_t tab_bytes = f->parsers[0]->dev.ascii.hot_bytes;
+    uint32_t caps_bytes = (uint32_t) MATCH_BLOCK * (f->caps_stride + 1) * (uint32_t) sizeof(uint16_t);   // + dummy column
+    if (getenv("FLBGPU_NO_LDS")) tab_bytes = 0;
+    const uint32_t lds_cap = 160 * 1024;
+    if (tab_bytes + caps_bytes > lds_cap) {
+        // tables win the LDS when only one of the two fits
+        if (tab_bytes <= lds_cap) caps_bytes = 0;
+        else { tab_bytes = 0; if (caps_bytes > lds_cap) caps_bytes = 0; }
+    }
+    uint32_t lds_bytes = tab_bytes;                          // staged table bytes (0: tables stay in global memory)
     int grid = cus;
     uint64_t need_blocks = (n + MATCH_BLOCK - 1) / MATCH_BLOCK;
     if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
@@ -551,7 +559,8 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
     ma.info = f->d_info.as<RecInfo>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
-    ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
+    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     { ProfScope ps(f, st, "k_parser_match"); launch_parser_match(ma, grid, st); }
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -593,10 +602,10 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
         !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
         return false;
     GrepArgs ga;
-    ga.data = (const uint8_t *) in->data; ga.row_off = in->row_off; ga.n = n; ga.rules = f->d_rules.as<GrepRule>();
+    ga.data = (const uint8_t *) in->data; ga.row_off = in->row_off; ga.n = n; ga.bytes = in->bytes; ga.rules = f->d_rules.as<GrepRule>();
     ga.nrules = (int) f->rules.size(); ga.logical_op = f->logical_op; ga.keep_len = f->d_len.as<uint32_t>();
     ga.status = f->d_status.as<uint32_t>(); ga.first_bad = &dm->first_bad; ga.counts = dm->counts;
-    { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, st); }
+    { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     uint64_t total = 0;
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));

@@ -37,9 +37,12 @@ DEV uint32_t ldu32(const uint8_t *p) {
     typedef uint32_t u32u __attribute__((aligned(1)));
     return *(const u32u *) p;
 }
+DEV uint32_t ldbe32(const uint8_t *p) { return __builtin_bswap32(ldu32(p)); }
+DEV uint64_t ldbe64(const uint8_t *p) {
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    return __builtin_bswap64(*(const u64u *) p);
+}
 DEV uint32_t ldbe16(const uint8_t *p) { return (ld8(p) << 8) | ld8(p + 1); }
-DEV uint32_t ldbe32(const uint8_t *p) { return (ld8(p) << 24) | (ld8(p + 1) << 16) | (ld8(p + 2) << 8) | ld8(p + 3); }
-DEV uint64_t ldbe64(const uint8_t *p) { return ((uint64_t) ldbe32(p) << 32) | ldbe32(p + 4); }
 
 // ------------------------------------------------------------------------------------------
 // output sinks: CountSink sizes, ByteSink writes
@@ -65,10 +68,19 @@ struct LdsSink {
     DEV explicit LdsSink(__attribute__((address_space(3))) uint8_t *dst) : p(dst) {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) {
+        // gfx950 accepts unaligned dword accesses to LDS and to global memory alike
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        typedef v4 v4u __attribute__((aligned(1)));
         uint32_t i = 0;
+        for (; i + 16 <= len; i += 16) {
+            v4 w = *(const v4u *) (src + i);
+            *(LDS_AS u32u *) (p) = w.x; *(LDS_AS u32u *) (p + 4) = w.y;
+            *(LDS_AS u32u *) (p + 8) = w.z; *(LDS_AS u32u *) (p + 12) = w.w;
+            p += 16;
+        }
         for (; i + 4 <= len; i += 4) {
-            uint32_t w = ldu32(src + i);
-            p[0] = (uint8_t) w; p[1] = (uint8_t) (w >> 8); p[2] = (uint8_t) (w >> 16); p[3] = (uint8_t) (w >> 24);
+            *(LDS_AS u32u *) p = *(const u32u *) (src + i);
             p += 4;
         }
         for (; i < len; i++) *p++ = (uint8_t) ld8(src + i);
@@ -599,13 +611,30 @@ DEV int rx_reverse(const HotTabs<LDS> &t, const uint8_t *r_info, const uint8_t *
     return best;
 }
 
+// Where capture spans live while a value is being matched.  CapLds keeps them in LDS as u16
+// ([slot][thread] layout, conflict-free) -- no divergent global stores in the walk; CapGlobal
+// writes the u32 row in global memory directly (values of 65535 bytes or more).
+struct CapLds {
+    LDS_AS uint16_t *base;      // this thread's column; slot 0 is a dummy, span index ci lives in slot ci+1
+    uint32_t stride;            // threads per workgroup
+    DEV void set_raw(uint32_t slot, uint32_t j) { base[slot * stride] = (uint16_t) j; }
+    DEV void set(uint32_t ci, uint32_t j) { base[(ci + 1) * stride] = (uint16_t) j; }
+    DEV uint32_t get(uint32_t ci) const { uint32_t v = base[(ci + 1) * stride]; return v == 0xFFFF ? CAP_UNSET : v; }
+};
+struct CapGlobal {
+    uint32_t *row;
+    DEV void set_raw(uint32_t slot, uint32_t j) { if (slot) row[slot - 1] = j; }
+    DEV void set(uint32_t ci, uint32_t j) { row[ci] = j; }
+    DEV uint32_t get(uint32_t ci) const { return row[ci]; }
+};
+
 // several candidates remain for this byte (or its capture writes do not fit the packed entry):
 // rebuild the reverse state of boundary j from the nearest checkpoint to its right, take the
 // first viable candidate and apply its tag sequence.  Returns the target core, TG_MATCH for
 // MATCH, TG_DEAD on inconsistency.
-template <bool LDS>
+template <bool LDS, class CAP>
 DEV uint32_t rx_resolve_multi(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, uint32_t j, uint32_t li,
-                              const uint16_t *chk, const uint8_t *slot2cap, uint32_t *caps) {
+                              const uint16_t *chk, const uint8_t *slot2cap, CAP &caps) {
     uint32_t t0 = ((len - j) / CHK_STEP) * CHK_STEP, b0 = len - t0;
     uint32_t r = chk[(size_t) (t0 / CHK_STEP) * 64];
     for (uint32_t i = b0; i > j; i--) r = t.rdelta[(r << t.cls_shift) + t.cls[ld8(s + i - 1)]] & 0x7FFF;
@@ -615,7 +644,7 @@ DEV uint32_t rx_resolve_multi(const DevCap &d, const HotTabs<LDS> &t, const uint
             uint32_t ts = ent >> 16;
             for (uint32_t q = d.tag_off[ts]; q < d.tag_off[ts + 1]; q++) {
                 uint32_t ci = slot2cap[d.tag_data[q]];
-                if (ci != 0xFF) caps[ci] = j;
+                if (ci != 0xFF) caps.set(ci, j);
             }
             return tg == 0xFFFF ? TG_MATCH : tg;
         }
@@ -644,9 +673,9 @@ DEV uint32_t pack_col(const HotTabs<LDS> &t, uint32_t w, uint32_t pos, uint32_t 
 // read, and the entry IS the next row.  Everything else (capture writes, MATCH, lookahead, the
 // rare multi-candidate resolution) sits behind one "special" bit test.  Returns the end boundary of
 // the match (>= 0) or -1 on a table inconsistency.
-template <bool LDS>
+template <bool LDS, class CAP>
 DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, int start, const uint16_t *chk,
-                   const uint8_t *slot2cap, uint32_t *caps) {
+                   const uint8_t *slot2cap, CAP &caps) {
     uint32_t j = (uint32_t) start;
     const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
     uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : (uint32_t) (t.col[ld8(s + j - 1)] >> fsh);
@@ -669,25 +698,26 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
                 e = t.ft2[((e & 0xFFFFFF) << fsh) + cn];
                 ty = (e & FT_SPECIAL) ? (e >> 28) & 7 : 0;
             }
-            if (ty == 0) S = e;
-            else if (ty == FT_CAPS || ty == FT_MATCH) {
-                uint32_t ca = (e >> 12) & 63, cb = (e >> 18) & 63;
-                if (ca) caps[ca - 1] = j;
-                if (cb) caps[cb - 1] = j;
-                if (ty == FT_MATCH) return (int) j;
-                S = e & 0xFFF;
+            if (ty == FT_MATCH) {
+                caps.set_raw((e >> 12) & 63, j);
+                caps.set_raw((e >> 18) & 63, j);
+                return (int) j;
             }
-            else if (ty == FT_MULTI) {
+            if (ty == FT_MULTI) {
                 uint32_t x = S / (uint32_t) t.NKp, pkk = S % (uint32_t) t.NKp, nk = colc >> fsh;
                 uint32_t li = (x * (uint32_t) t.NK + pkk) * (uint32_t) t.NK + nk;
                 uint32_t tg = rx_resolve_multi(d, t, s, len, j, li, chk, slot2cap, caps);
                 if (tg == TG_DEAD) return -1;
                 if (tg == TG_MATCH) return (int) j;
-                S = tg * (uint32_t) t.NKp + nk;
+                e = tg * (uint32_t) t.NKp + nk;          // plain entry without capture writes
             }
-            else return -1;
+            else if (ty != 0) return -1;
         }
-        else S = e;
+        // plain step: capture writes are unconditional (column 0 is a dummy), so group boundaries
+        // cost no divergent branch
+        caps.set_raw((e >> 12) & 63, j);
+        caps.set_raw((e >> 18) & 63, j);
+        S = e & 0xFFF;
         j++;
         vq >>= 8;
         if (++k == 4) {
@@ -725,9 +755,22 @@ DEV bool d_isdigit(uint32_t c) { return c >= '0' && c <= '9'; }
 DEV uint32_t d_lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
 
 // input text is [s, e); reads past e yield NUL (the reference works on a NUL-terminated copy)
+// The text is read through a 16-byte register window (one unaligned dwordx4 load per 16 bytes
+// instead of one divergent byte load per character).
 struct TStr {
     const uint8_t *s, *e;
-    DEV uint32_t at(const uint8_t *p) const { return p < e ? ld8(p) : 0; }
+    mutable const uint8_t *wb = nullptr;     // window base, nullptr = empty
+    mutable v4u32 w;
+    DEV uint32_t at(const uint8_t *p) const {
+        if (p >= e) return 0;
+        if (wb == nullptr || p < wb || p >= wb + 16) {
+            wb = p;
+            w = load16(p, 0, (uint32_t) (e - p));
+        }
+        uint32_t o = (uint32_t) (p - wb);
+        uint32_t dw = o < 4 ? w.x : o < 8 ? w.y : o < 12 ? w.z : w.w;
+        return (dw >> (8 * (o & 3))) & 0xff;
+    }
 };
 
 DEV bool conv_num(const TStr &in, const uint8_t *&bp, int &dest, int llim, int ulim) {
@@ -1018,10 +1061,12 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
     *frac = 0;
     // the reference copies the text into a NUL-terminated buffer and works on strlen() of it:
     // an embedded NUL ends the string
-    uint32_t n = 0;
-    while (n < vlen && ld8(v + n) != 0) n++;
     TStr in;
-    in.s = v; in.e = v + n;
+    in.s = v; in.e = v + vlen;
+    uint32_t n = 0;
+    while (n < vlen && in.at(v + n) != 0) n++;
+    in.e = v + n;
+    in.wb = nullptr;
     const uint8_t *p = d_strptime(in, v, ps.fmt1, tm);
     bool ok = p != nullptr;
     if (ok && ps.has_frac) {
@@ -1204,11 +1249,11 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
 
 // one parser attempt on one value.  Returns true on success (flb_parser_do >= 0).
 // `hot` are parser ps's ASCII hot tables (LDS copy for parser 0, global otherwise).
-template <bool LDS>
+template <bool LDS, class CAP>
 DEV bool try_parser(const DevParser &ps, const HotTabs<LDS> &hot, const uint8_t *val, uint32_t vlen, uint16_t *chk, uint32_t chk_len,
-                    uint32_t *caps, int64_t *tsec, int64_t *tnsec, uint32_t *nkept, uint32_t *drop_mask, uint32_t dbg) {
-    if (vlen / CHK_STEP + 2 > chk_len) return false;
-    if (dbg & 1) return false;      // scratch too small: the host sizes it to fit
+                    CAP &caps, int64_t *tsec, int64_t *tnsec, uint32_t *nkept, uint32_t *drop_mask, uint32_t dbg) {
+    if (vlen / CHK_STEP + 2 > chk_len) return false;      // scratch too small: the host sizes it to fit
+    if (dbg & 1) return false;
     bool use_utf8 = false;
     int best = rx_reverse(hot, ps.ascii.r_info, val, vlen, chk);
     HotTabs<false> hu = hot_global(ps.utf8);
@@ -1218,7 +1263,7 @@ DEV bool try_parser(const DevParser &ps, const HotTabs<LDS> &hot, const uint8_t 
     }
     if (best < 0) return false;
     if (ps.nregs_minus1 <= 0) return false;               // flb_parser_regex_do: n <= 0
-    for (int f = 0; f < 2 * ps.nfields; f++) caps[f] = CAP_UNSET;
+    for (int f = 0; f < 2 * ps.nfields; f++) caps.set((uint32_t) f, CAP_UNSET);
     if (dbg & 2) return false;
     int endb = use_utf8 ? rx_forward(ps.utf8, hu, val, vlen, best, chk, ps.slot2cap, caps)
                         : rx_forward(ps.ascii, hot, val, vlen, best, chk, ps.slot2cap, caps);
@@ -1228,9 +1273,9 @@ DEV bool try_parser(const DevParser &ps, const HotTabs<LDS> &hot, const uint8_t 
     uint32_t kept = 0, drop = 0;
     int64_t sec = 0; double frac = 0;
     for (int f = 0; f < ps.nfields; f++) {
-        uint32_t b = caps[2 * f], e = caps[2 * f + 1];
+        uint32_t b = caps.get(2 * f), e = caps.get(2 * f + 1);
         bool set = (b != CAP_UNSET && e != CAP_UNSET);
-        if (!set) { caps[2 * f] = CAP_UNSET; caps[2 * f + 1] = CAP_UNSET; }
+        if (!set) { caps.set(2 * f, CAP_UNSET); caps.set(2 * f + 1, CAP_UNSET); }
         if (set) any = true;                               // last_pos (src/flb_regex.c:52-54)
         uint32_t fl = set ? e - b : 0;
         if (fl == 0 && ps.skip_empty) { drop |= 1u << f; continue; }
@@ -1269,6 +1314,11 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
         hot0 = hot_lds(c0, (LDS_AS uint8_t *) g_lds);
     }
     else hot0 = hot_global(a.parsers[0].ascii);
+    // capture spans of the value being matched: u16 column per thread in LDS
+    uint32_t n_dec = 0, n_emit = 0;
+    CapLds capl;
+    capl.base = (LDS_AS uint16_t *) (g_lds + a.caps_lds_off) + threadIdx.x;
+    capl.stride = blockDim.x;
 
     for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
         uint64_t r = base + lane;
@@ -1288,7 +1338,7 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
             continue;
         }
         if (ev.flags & RF_SKIP) { a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = 0; continue; }
-        atomicAdd(&a.counts[0], 1ull);
+        n_dec++;
         ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
         if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
         int64_t tsec = ev.sec, tnsec = ev.nsec;
@@ -1319,8 +1369,29 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
             if (!vptr) continue;
             for (int q = 0; q < a.cfg.nparsers; q++) {
                 int64_t ps = 0, pn = 0; uint32_t nk = 0, dm = 0;
-                last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, caps, &ps, &pn, &nk, &dm, a.debug_skip)
-                                 : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, caps, &ps, &pn, &nk, &dm, a.debug_skip);
+                const bool small = vlen < 0xFFFF && a.caps_in_lds;
+                if (small) {
+                    last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, capl, &ps, &pn, &nk, &dm, a.debug_skip)
+                                     : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capl, &ps, &pn, &nk, &dm, a.debug_skip);
+                    if (last_ok) {
+                        // publish the spans: one 16-byte aligned row per record
+                        const DevParser &pp = a.parsers[q];
+                        for (int f4 = 0; f4 < 2 * pp.nfields; f4 += 4) {
+                            v4u32 v;
+                            v.x = capl.get(f4);
+                            v.y = f4 + 1 < 2 * pp.nfields ? capl.get(f4 + 1) : CAP_UNSET;
+                            v.z = f4 + 2 < 2 * pp.nfields ? capl.get(f4 + 2) : CAP_UNSET;
+                            v.w = f4 + 3 < 2 * pp.nfields ? capl.get(f4 + 3) : CAP_UNSET;
+                            *(v4u32 *) (caps + f4) = v;
+                        }
+                    }
+                }
+                else {
+                    CapGlobal capg;
+                    capg.row = caps;
+                    last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, a.debug_skip)
+                                     : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, a.debug_skip);
+                }
                 if (last_ok) {
                     have_out = true;
                     ri.val_off = (uint32_t) (vptr - rec); ri.val_len = vlen; ri.parser_idx = q; ri.nkept = nk; ri.drop_mask = dm;
@@ -1347,7 +1418,14 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
         a.info[r] = ri;
         a.null_mask[r] = null_mask;
         a.out_len[r] = (uint32_t) cs.n;
-        atomicAdd(&a.counts[1], 1ull);
+        n_emit++;
+    }
+    // record accounting: per-thread counters -> wave reduction -> one atomic per wave leader into
+    // LDS-free block totals would need another barrier; 16 atomics per workgroup are negligible
+    for (int o = 32; o > 0; o >>= 1) { n_dec += __shfl_down(n_dec, o, 64); n_emit += __shfl_down(n_emit, o, 64); }
+    if (lane == 0) {
+        if (n_dec) atomicAdd(&a.counts[0], (unsigned long long) n_dec);
+        if (n_emit) atomicAdd(&a.counts[1], (unsigned long long) n_emit);
     }
 }
 
@@ -1429,15 +1507,8 @@ DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_
     return m == RX_MATCH ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_grep_match(GrepArgs a) {
-    uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n) return;
-    const uint8_t *rec = a.data + a.row_off[r];
-    const uint8_t *rec_end = a.data + a.row_off[r + 1];
-    Event ev = decode_event(rec, rec_end);
-    a.status[r] = ev.flags;
-    if (ev.flags & RF_BAD) { atomicMin(a.first_bad, (unsigned long long) r); a.keep_len[r] = 0; return; }
-    if (ev.flags & RF_SKIP) { a.keep_len[r] = 0; return; }
+// rule evaluation for one decoded event
+DEV bool grep_decide(const GrepArgs &a, const Event &ev) {
     bool keep = true;
     if (a.logical_op == OP_LEGACY) {
         // plugins/filter_grep/grep.c:167-194
@@ -1460,9 +1531,87 @@ __global__ void __launch_bounds__(256) k_grep_match(GrepArgs a) {
         }
         if (a.nrules > 0) keep = (a.rules[last].type == GREP_REGEX) ? found : !found;
     }
-    a.keep_len[r] = keep ? (uint32_t) (rec_end - rec) : 0;
-    atomicAdd(&a.counts[0], 1ull);
-    if (keep) atomicAdd(&a.counts[1], 1ull);
+    return keep;
+}
+
+// filter_grep.  One record per lane lets every lane touch its own cache lines ~20 times while it
+// walks the msgpack tokens; with hundreds of KB of such lines in flight per CU the 32 KB vector L1
+// thrashes and every touch goes back to L2/HBM (measured: 10x the chunk bytes fetched).  So the
+// wave first copies its 64 records -- one contiguous byte range of the chunk -- into LDS with
+// coalesced 16 B/lane loads (each chunk byte is read from HBM exactly once) and the lanes parse
+// their records out of LDS.
+constexpr int GREP_BLOCK = 256;
+constexpr int GREP_TILE = 18432;            // LDS bytes per wave (64 records of 277 B + slack)
+
+__global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LDS_AS uint8_t *tile = (LDS_AS uint8_t *) g_lds + (size_t) wave * GREP_TILE;
+    const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    const uint8_t *data_end = a.data + a.bytes;
+    uint32_t n_dec = 0, n_keep = 0;
+    for (uint64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+        const uint64_t r = base + lane;
+        const uint32_t cnt = (uint32_t) ((a.n - base) < 64 ? (a.n - base) : 64);
+        uint64_t o0 = 0, o1 = 0;
+        if (lane < cnt) { o0 = a.row_off[r]; o1 = a.row_off[r + 1]; }
+        uint32_t lo = 0;
+        while (lo < cnt) {
+            const uint64_t g0 = __shfl(o0, (int) lo, 64);
+            const uint32_t align = (uint32_t) (g0 & 15);
+            const bool fit = lane >= lo && lane < cnt && (o1 - g0 + align) <= (uint64_t) GREP_TILE;
+            const uint64_t mask = __ballot(fit) >> lo;
+            uint32_t m = (~mask == 0) ? 64 - lo : (uint32_t) __builtin_ctzll(~mask);
+            if (m > cnt - lo) m = cnt - lo;
+            const bool direct = (m == 0);                 // one record larger than the tile: parse it in place
+            if (direct) m = 1;
+            if (!direct) {
+                const uint32_t total = (uint32_t) (__shfl(o1, (int) (lo + m - 1), 64) - g0) + align;
+                const uint8_t *src = a.data + (g0 - align);
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                for (uint32_t u = lane; u * 16 < total; u += 64) {
+                    const uint8_t *p = src + (size_t) u * 16;
+                    v4 v;
+                    if (p + 16 <= data_end) v = *(const v4 *) p;
+                    else {
+                        uint32_t t4[4] = {0, 0, 0, 0};
+                        for (int q = 0; q < 16 && p + q < data_end; q++) t4[q >> 2] |= (uint32_t) p[q] << (8 * (q & 3));
+                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
+                    }
+                    *(LDS_AS v4 *) (tile + (size_t) u * 16) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            if (lane >= lo && lane < lo + m) {
+                const uint8_t *rec, *rec_end;
+                if (direct) { rec = a.data + o0; rec_end = a.data + o1; }
+                else {
+                    // generic pointer into the LDS aperture: the msgpack walkers are shared with
+                    // the kernels that read from global memory
+                    rec = (const uint8_t *) (tile + align + (uint32_t) (o0 - g0));
+                    rec_end = rec + (o1 - o0);
+                }
+                Event ev = decode_event(rec, rec_end);
+                a.status[r] = ev.flags;
+                if (ev.flags & RF_BAD) { atomicMin(a.first_bad, (unsigned long long) r); a.keep_len[r] = 0; }
+                else if (ev.flags & RF_SKIP) a.keep_len[r] = 0;
+                else {
+                    bool keep = grep_decide(a, ev);
+                    a.keep_len[r] = keep ? (uint32_t) (o1 - o0) : 0;
+                    n_dec++;
+                    if (keep) n_keep++;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            lo += m;
+        }
+    }
+    // one pair of atomics per wave (same-address atomics serialise at ~12 ns each)
+    for (int o = 32; o > 0; o >>= 1) { n_dec += __shfl_down(n_dec, o, 64); n_keep += __shfl_down(n_keep, o, 64); }
+    if (lane == 0) {
+        if (n_dec) atomicAdd(&a.counts[0], (unsigned long long) n_dec);
+        if (n_keep) atomicAdd(&a.counts[1], (unsigned long long) n_keep);
+    }
 }
 
 // copy of the kept records: one wave per record, byte granular
@@ -1575,8 +1724,13 @@ void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st) {
         (void) hipFuncSetAttribute((const void *) k_parser_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (a.lds_bytes) hipLaunchKernelGGL(k_parser_match<true>, dim3(grid), dim3(MATCH_BLOCK), a.lds_bytes, st, a);
-    else hipLaunchKernelGGL(k_parser_match<false>, dim3(grid), dim3(MATCH_BLOCK), 0, st, a);
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+        (void) hipFuncSetAttribute((const void *) k_parser_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set2 = true;
+    }
+    if (a.lds_bytes) hipLaunchKernelGGL(k_parser_match<true>, dim3(grid), dim3(MATCH_BLOCK), a.lds_total, st, a);
+    else hipLaunchKernelGGL(k_parser_match<false>, dim3(grid), dim3(MATCH_BLOCK), a.lds_total, st, a);
 }
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
@@ -1591,9 +1745,18 @@ void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_parser_emit, dim3((unsigned) blocks), dim3(EMIT_BLOCK), lds, st, a);
 }
-void launch_grep_match(const GrepArgs &a, hipStream_t st) {
+void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
-    hipLaunchKernelGGL(k_grep_match, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, st, a);
+    static bool attr_set = false;
+    const size_t lds = (size_t) (GREP_BLOCK / 64) * GREP_TILE;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_grep_match, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    uint64_t tiles = (a.n + 63) / 64, blocks = (tiles + GREP_BLOCK / 64 - 1) / (GREP_BLOCK / 64);
+    uint64_t cap = (uint64_t) cus * 2 * 4;                 // 2 resident workgroups per CU, a few rounds each
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_grep_match, dim3((unsigned) blocks), dim3(GREP_BLOCK), lds, st, a);
 }
 void launch_gather(const GatherArgs &a, hipStream_t st) {
     if (a.n == 0) return;

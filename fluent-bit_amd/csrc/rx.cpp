@@ -1165,8 +1165,8 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
             if ((e >> 24) == (FC_LOOK >> 24)) return FT_SPECIAL | (FT_LOOK << 28) | (e & 0xFFFFFF);
             uint32_t tg = e & 0xFFF, caps = e & 0xFFF000;
             if (tg == FC_TMATCH) return FT_SPECIAL | (FT_MATCH << 28) | caps;
-            uint32_t nextS = tg * (uint32_t) out.NKp + (uint32_t) nk;
-            return caps ? (FT_SPECIAL | (FT_CAPS << 28) | caps | nextS) : nextS;
+            // a plain step: next row | capture writes (slot 0 = the dummy "no write" column)
+            return (tg * (uint32_t) out.NKp + (uint32_t) nk) | caps;
         };
         out.ft.assign((size_t) X * out.NKp * W, FT_SPECIAL | (FT_DEAD << 28));
         out.ft2.assign(out.fast2.size(), FT_SPECIAL | (FT_DEAD << 28));
@@ -1315,7 +1315,6 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *
             if (pick == 0xFFFFFFFFu) return -2;
             // cross-check the packed capture writes against the tag sequence
             uint32_t ts0 = pick >> 16, want[2] = {(e >> 12) & 63, (e >> 18) & 63};
-            if (!(e & FT_SPECIAL)) { want[0] = want[1] = 0; }
             int q = 0;
             for (uint32_t k = t.tag_off[ts0]; k < t.tag_off[ts0 + 1]; k++) {
                 uint8_t sl = t.tag_data[k];

@@ -93,8 +93,9 @@ struct TableSet {
     // ---- what the kernels step through (derived from fastc/fast2 by encode_kernel_tables):
     //   col[256]  byte -> column code  kind << fc_shift | class        (one lookup per byte)
     //   ft        [nX * NKp][NKp << fc_shift]  row S = core * NKp + prev kind; a plain entry IS the
-    //             next row number (< 4096); entries with bit 31 are special, type in bits 28-30:
-    //               1 step + capture writes  (next row | (capA+1) << 12 | (capB+1) << 18)
+    //             next row number (bits 0-11) | (capA+1) << 12 | (capB+1) << 18  (capture span
+    //             writes of named groups, 0 = none); entries with bit 31 are special, type in
+    //             bits 28-30:
     //               2 MATCH (+ capture writes)   3 look at next byte: ft2[m][its class]
     //               4 several candidates (resolve with vmask)   5 dead
     //   ft2       [nmulti][1 << fc_shift], same encoding
