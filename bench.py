@@ -120,9 +120,12 @@ def main():
     value = total_records / dt
     # dominant kernel and its algorithmic bytes (DESIGN.md "Measurement")
     dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
+    value_bytes = in_bytes - 21 * n                      # the `log` values (277 B event = 21 B framing + 256 B line)
     alg_bytes_per_launch = {
-        "k_parser_match": in_bytes,                      # reads every chunk byte once
-        "k_parser_emit": in_bytes + parsed_bytes,        # re-reads the values, writes the output once
+        "k_parser_locate": in_bytes,                     # reads every chunk byte once
+        "k_parser_rx": value_bytes,                      # the capture program consumes each value byte once
+        "k_parser_finish": 8 * n,                        # time field + sizes
+        "k_parser_emit": value_bytes + parsed_bytes,     # re-reads the values, writes the output once
         "k_grep_match": parsed_bytes,
         "k_gather": 2 * kept_bytes,
     }

@@ -92,6 +92,7 @@ struct alignas(16) RecInfo {
                                          // unparsable time, or time consumed and !time_keep)
     uint32_t pad_[3];                    // 64 bytes: four 16-byte stores
 };
+constexpr int REC_NCOLS = 13;
 // capture spans live in a separate column: caps[rec][2*field + {0,1}] (begin/end relative to the
 // value, 0xFFFFFFFF = group did not participate), field = index in DevParser::field_group
 
@@ -101,6 +102,9 @@ enum {
     RF_PARSED = 4,         // a parser matched
     RF_BADTS = 8,          // timestamp outside the EventTime range: encoder error, record dropped
     RF_BAD = 16,           // decoder error: processing stops here
+    RF_CAND = 32,          // exactly one candidate value located (fast phases)
+    RF_RXOK = 64,          // parser 0's regex matched, spans published
+    RF_GENERIC = 128,      // needs k_parser_generic
 };
 
 constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
@@ -121,8 +125,9 @@ struct ParserMatchArgs {
     uint64_t n;
     FParserCfg cfg;
     const DevParser *parsers;
-    RecInfo *info;
-    uint32_t *caps;             // [n][caps_stride]
+    uint32_t *info;             // record columns: REC_NCOLS arrays of n u32 (structure of arrays:
+                                // a wave reads 64 consecutive words of a field, not 64 rows)
+    uint32_t *caps;             // [caps_stride][n] capture spans, one column per span end
     uint32_t caps_stride;
     uint64_t *null_mask;        // [n]
     uint32_t *out_len;          // [n]
@@ -134,7 +139,8 @@ struct ParserMatchArgs {
     uint32_t lds_total;         // dynamic LDS bytes to request (tables + capture columns)
     uint32_t debug_skip;        // timing experiments only (FLBGPU_DEBUG_SKIP): results are wrong when != 0
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
-    unsigned long long *counts;      // [0] decoded log records, [1] records emitted
+    unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel
+    uint64_t bytes;                  // chunk size (bounds the coalesced tile loads)
 };
 
 struct ParserEmitArgs {
@@ -143,8 +149,9 @@ struct ParserEmitArgs {
     uint64_t n;
     FParserCfg cfg;
     const DevParser *parsers;
-    const RecInfo *info;
-    const uint32_t *caps;
+    uint64_t n_cols;            // column length of info/caps (the n of the match pass, >= n)
+    const uint32_t *info;       // record columns (REC_NCOLS x n_cols)
+    const uint32_t *caps;       // [caps_stride][n]
     uint32_t caps_stride;
     const uint64_t *null_mask;
     const uint32_t *out_len;
@@ -192,7 +199,12 @@ struct GatherArgs {
 // launchers implemented in kernels.hip
 #include <hip/hip_runtime_api.h>
 namespace flbgpu {
-void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st);
+bool upload_time_tables();
+void launch_parser_locate(const ParserMatchArgs &a, int cus, hipStream_t st);
+void launch_parser_rx(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
+void launch_parser_finish(const ParserMatchArgs &a, int cus, hipStream_t st);
+void launch_parser_generic(const ParserMatchArgs &a, int grid, hipStream_t st);
+void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out, hipStream_t st);
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);

@@ -59,6 +59,7 @@ extern "C" int flbgpu_init(int device) {
     if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice(%d) failed", device); return -1; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) g_cus = prop.multiProcessorCount;
+    if (!upload_time_tables()) { set_err("uploading the strptime tables failed"); return -1; }
     return 0;
 }
 
@@ -354,7 +355,7 @@ struct flbgpu_filter {
     DevBuf d_rules;
     int logical_op = 0;
     // working buffers
-    DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_misc, d_status, d_out_off;
+    DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off;
     DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     uint64_t last_in = 0, last_out = 0;
     // profiling
@@ -363,7 +364,7 @@ struct flbgpu_filter {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~flbgpu_filter() {
         for (auto *b : rule_blobs) delete b;
-        DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid,
+        DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                          &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
         for (auto *b : all) b->release();
         if (ev0) (void) hipEventDestroy(ev0);
@@ -513,7 +514,7 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[2]; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[3]; };
 
 static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
     uint64_t n = in->n;
@@ -537,8 +538,10 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     int cus = g_cus > 0 ? g_cus : 256;
     // one 1024-thread workgroup (16 waves) per CU shares one LDS copy of parser 0's hot ASCII
     // tables (160 KiB of LDS per CU); bigger tables are read through L2 instead
+    int rx_threads = MATCH_BLOCK;
+    if (getenv("FLBGPU_RX_THREADS")) { rx_threads = atoi(getenv("FLBGPU_RX_THREADS")); if (rx_threads < 64 || rx_threads > MATCH_BLOCK || (rx_threads & 63)) rx_threads = MATCH_BLOCK; }
     uint32_t tab_bytes = f->parsers[0]->dev.ascii.hot_bytes;
-    uint32_t caps_bytes = (uint32_t) MATCH_BLOCK * (f->caps_stride + 1) * (uint32_t) sizeof(uint16_t);   // + dummy column
+    uint32_t caps_bytes = (uint32_t) rx_threads * (f->caps_stride + 1) * (uint32_t) sizeof(uint16_t);   // + dummy column
     if (getenv("FLBGPU_NO_LDS")) tab_bytes = 0;
     const uint32_t lds_cap = 160 * 1024;
     if (tab_bytes + caps_bytes > lds_cap) {
@@ -548,20 +551,35 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     }
     uint32_t lds_bytes = tab_bytes;                          // staged table bytes (0: tables stay in global memory)
     int grid = cus;
-    uint64_t need_blocks = (n + MATCH_BLOCK - 1) / MATCH_BLOCK;
+    uint64_t need_blocks = (n + rx_threads - 1) / rx_threads;
     if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
-    if (!f->d_rid.ensure((size_t) grid * (MATCH_BLOCK / 64) * 64 * chk_len * sizeof(uint16_t))) return false;
-    if (!f->d_info.ensure(n * sizeof(RecInfo)) || !f->d_caps.ensure(n * f->caps_stride * sizeof(uint32_t)) ||
+    if (!f->d_rid.ensure((size_t) grid * (rx_threads / 64) * 64 * chk_len * sizeof(uint16_t))) return false;
+    if (!f->d_info.ensure(n * REC_NCOLS * sizeof(uint32_t)) || !f->d_caps.ensure(n * f->caps_stride * sizeof(uint32_t)) ||
         !f->d_null.ensure(n * sizeof(uint64_t)) || !f->d_len.ensure(n * sizeof(uint32_t)) ||
         !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
         return false;
     ParserMatchArgs ma;
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
-    ma.info = f->d_info.as<RecInfo>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
+    ma.info = f->d_info.as<uint32_t>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
-    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
-    { ProfScope ps(f, st, "k_parser_match"); launch_parser_match(ma, grid, st); }
+    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.bytes = in->bytes;
+    { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
+    { ProfScope ps(f, st, "k_parser_rx"); launch_parser_rx(ma, grid, rx_threads, st); }
+    { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
+    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    if (hm.counts[2] > 0) {
+        // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...)
+        int ggrid = cus * 8;
+        while (ggrid > 1 && (size_t) ggrid * 4 * 64 * chk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
+        if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * chk_len * sizeof(uint16_t))) return false;
+        ParserMatchArgs mg = ma;
+        mg.chk = f->d_rid2.as<uint16_t>();
+        { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
+    }
+    launch_count_nonzero(f->d_len.as<uint32_t>(), hm.first_bad < n ? hm.first_bad : n, &dm->counts[1], st);
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
     if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
@@ -575,7 +593,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     if (!f->d_out.ensure(total + 16)) return false;
     ParserEmitArgs ea;
     ea.data = data; ea.row_off = row_off; ea.n = n; ea.cfg = f->pcfg; ea.parsers = f->d_parsers.as<DevParser>();
-    ea.info = f->d_info.as<RecInfo>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
+    ea.n_cols = in->n; ea.info = f->d_info.as<uint32_t>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
     ea.out = f->d_out.as<uint8_t>();
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }

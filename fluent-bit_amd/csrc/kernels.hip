@@ -6,8 +6,9 @@
 // DFA, viable-position bit sets, priority lists) are staged in LDS and stepped one input byte
 // per lane.  Nothing here is a dense contraction, so there is no MFMA: the bound is HBM/LDS.
 //
-//   k_parser_match   filter_parser pass 1: decode event, locate Key_Name, run the parsers'
-//                    capture programs, parse the time field, compute the output size
+//   k_parser_locate / k_parser_rx / k_parser_finish (/ k_parser_generic)
+//                    filter_parser pass 1 in phases: decode event + locate Key_Name, run the
+//                    capture program, parse the time field and compute the output size
 //                    (plugins/filter_parser/filter_parser.c:226-323, src/flb_parser_regex.c:114-227)
 //   k_parser_emit    filter_parser pass 2: write the V2 record at its scanned offset
 //                    (filter_parser.c:325-413, src/flb_log_event_encoder.c:195-217)
@@ -18,6 +19,7 @@
 //   k_index_*        record boundary discovery helpers
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "dev.hpp"
 
 namespace flbgpu {
@@ -157,7 +159,9 @@ DEV uint64_t ldu64(const uint8_t *p) {
 
 // reads one token header at p (p < end); returns T_BAD on truncation or the reserved byte 0xc1.
 // The header (first byte + up to 4 length bytes + ext type) is fetched with ONE unaligned 8-byte
-// load whenever 8 bytes remain before `end`.
+// load whenever 8 bytes remain before `end`; the 0xc0..0xdf family is decoded from two packed
+// nibble tables (type, number of length bytes) instead of a 32-way switch, which keeps this
+// function -- inlined at every token of every walker -- small.
 DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
     Tok t;
     t.type = T_BAD; t.len = 0; t.u = 0; t.next = p;
@@ -166,7 +170,7 @@ DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
     const uint32_t avail = (uint32_t) ((uint64_t) (end - p) < 9 ? (end - p) : 9);
     if (avail >= 8) w = ldu64(p);
     else { w = 0; for (uint32_t q = 0; q < avail; q++) w |= (uint64_t) ld8(p + q) << (8 * q); }
-    uint32_t c = (uint32_t) (w & 0xff);
+    const uint32_t c = (uint32_t) (w & 0xff);
     p++;
     uint32_t need = 0;
     if (c <= 0x7f) { t.type = T_UINT; t.u = c; }
@@ -175,40 +179,14 @@ DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
     else if (c >= 0x90 && c <= 0x9f) { t.type = T_ARRAY; t.len = c & 15; }
     else if (c >= 0x80 && c <= 0x8f) { t.type = T_MAP; t.len = c & 15; }
     else {
-        switch (c) {
-        case 0xc0: t.type = T_NIL; break;
-        case 0xc2: t.type = T_BOOL; t.u = 0; break;
-        case 0xc3: t.type = T_BOOL; t.u = 1; break;
-        case 0xc4: need = 1; t.type = T_BIN; break;
-        case 0xc5: need = 2; t.type = T_BIN; break;
-        case 0xc6: need = 4; t.type = T_BIN; break;
-        case 0xc7: need = 1; t.type = T_EXT; break;
-        case 0xc8: need = 2; t.type = T_EXT; break;
-        case 0xc9: need = 4; t.type = T_EXT; break;
-        case 0xca: need = 4; t.type = T_F32; break;
-        case 0xcb: need = 8; t.type = T_F64; break;
-        case 0xcc: need = 1; t.type = T_UINT; break;
-        case 0xcd: need = 2; t.type = T_UINT; break;
-        case 0xce: need = 4; t.type = T_UINT; break;
-        case 0xcf: need = 8; t.type = T_UINT; break;
-        case 0xd0: need = 1; t.type = T_NINT; break;
-        case 0xd1: need = 2; t.type = T_NINT; break;
-        case 0xd2: need = 4; t.type = T_NINT; break;
-        case 0xd3: need = 8; t.type = T_NINT; break;
-        case 0xd4: t.type = T_EXT; t.len = 1; break;
-        case 0xd5: t.type = T_EXT; t.len = 2; break;
-        case 0xd6: t.type = T_EXT; t.len = 4; break;
-        case 0xd7: t.type = T_EXT; t.len = 8; break;
-        case 0xd8: t.type = T_EXT; t.len = 16; break;
-        case 0xd9: need = 1; t.type = T_STR; break;
-        case 0xda: need = 2; t.type = T_STR; break;
-        case 0xdb: need = 4; t.type = T_STR; break;
-        case 0xdc: need = 2; t.type = T_ARRAY; break;
-        case 0xdd: need = 4; t.type = T_ARRAY; break;
-        case 0xde: need = 2; t.type = T_MAP; break;
-        case 0xdf: need = 4; t.type = T_MAP; break;
-        default: return t;      // 0xc1
-        }
+        const uint32_t sh = 4 * (c & 15);
+        const uint64_t ttab = c < 0xd0 ? 0x22225488877711b0ull : 0xaa99666888883333ull;      // type per first byte
+        const uint64_t ntab = c < 0xd0 ? 0x8421844214210000ull : 0x4242421000008421ull;      // length bytes per first byte
+        t.type = (int) ((ttab >> sh) & 15);
+        need = (uint32_t) ((ntab >> sh) & 15);
+        if (t.type == T_BAD) return t;                                  // 0xc1
+        if (c >= 0xd4 && c <= 0xd8) t.len = 1u << (c - 0xd4);           // fixext 1/2/4/8/16
+        if (c == 0xc3) t.u = 1;
         if ((uint64_t) (end - p) < need) { t.type = T_BAD; return t; }
         if (need) {
             uint64_t v;
@@ -622,10 +600,11 @@ struct CapLds {
     DEV uint32_t get(uint32_t ci) const { uint32_t v = base[(ci + 1) * stride]; return v == 0xFFFF ? CAP_UNSET : v; }
 };
 struct CapGlobal {
-    uint32_t *row;
-    DEV void set_raw(uint32_t slot, uint32_t j) { if (slot) row[slot - 1] = j; }
-    DEV void set(uint32_t ci, uint32_t j) { row[ci] = j; }
-    DEV uint32_t get(uint32_t ci) const { return row[ci]; }
+    uint32_t *base;             // [span][n] column block
+    uint64_t n, r;
+    DEV void set_raw(uint32_t slot, uint32_t j) { if (slot) base[(uint64_t) (slot - 1) * n + r] = j; }
+    DEV void set(uint32_t ci, uint32_t j) { base[(uint64_t) ci * n + r] = j; }
+    DEV uint32_t get(uint32_t ci) const { return base[(uint64_t) ci * n + r]; }
 };
 
 // several candidates remain for this byte (or its capture writes do not fit the packed entry):
@@ -741,6 +720,11 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
 
 // ------------------------------------------------------------------------------------------
 // strptime (src/flb_strptime.c:253-907, C locale) + time lookup (src/flb_parser.c:1876-2065)
+//
+// Written as a compact table-driven interpreter: every numeric directive goes through ONE
+// conv_num call site, the text through ONE windowed reader -- the straightforward "switch with a
+// conv_num per case" version inlines into tens of thousands of instructions and thrashes the
+// instruction cache.
 // ------------------------------------------------------------------------------------------
 struct Tm {
     int year, mon, mday, hour, min, sec, yday, wday;
@@ -754,14 +738,14 @@ DEV bool d_isspace(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 DEV bool d_isdigit(uint32_t c) { return c >= '0' && c <= '9'; }
 DEV uint32_t d_lower(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : c; }
 
-// input text is [s, e); reads past e yield NUL (the reference works on a NUL-terminated copy)
+// input text is [s, e); reads past e yield NUL (the reference works on a NUL-terminated copy).
 // The text is read through a 16-byte register window (one unaligned dwordx4 load per 16 bytes
 // instead of one divergent byte load per character).
 struct TStr {
     const uint8_t *s, *e;
-    mutable const uint8_t *wb = nullptr;     // window base, nullptr = empty
-    mutable v4u32 w;
-    DEV uint32_t at(const uint8_t *p) const {
+    const uint8_t *wb = nullptr;     // window base, nullptr = empty
+    v4u32 w;
+    DEV uint32_t at(const uint8_t *p) {
         if (p >= e) return 0;
         if (wb == nullptr || p < wb || p >= wb + 16) {
             wb = p;
@@ -773,57 +757,19 @@ struct TStr {
     }
 };
 
-DEV bool conv_num(const TStr &in, const uint8_t *&bp, int &dest, int llim, int ulim) {
-    int result = 0, rulim = ulim;
-    uint32_t c = in.at(bp);
-    if (c < '0' || c > '9') return false;
-    do {
-        result *= 10;
-        result += (int) (in.at(bp++) - '0');
-        rulim /= 10;
-        c = in.at(bp);
-    } while ((result * 10 <= ulim) && rulim && c >= '0' && c <= '9');
-    if (result < llim || result > ulim) return false;
-    dest = result;
-    return true;
-}
-
-DEV bool conv_num64(const TStr &in, const uint8_t *&bp, int64_t &dest) {
-    int64_t result = 0, rulim = INT64_MAX;
-    uint32_t c = in.at(bp);
-    if (c < '0' || c > '9') return false;
-    do {
-        if (result > 922337203685477580LL) return false;
-        result *= 10;
-        if (result > 9223372036854775760LL) return false;
-        result += (int64_t) (in.at(bp++) - '0');
-        rulim /= 10;
-        if (result >= 922337203685477580LL) return false;
-        c = in.at(bp);
-    } while (rulim && c >= '0' && c <= '9');      // result*10 <= INT64_MAX always holds here
-    dest = result;
-    return true;
-}
-
+// directive table, indexed by the conversion character (uniform across lanes => scalar loads)
+enum { DK_BAD = 0, DK_NUM, DK_NAME, DK_AMPM, DK_TZ, DK_EPOCH, DK_WS, DK_PCT, DK_G };
+enum { TF_MDAY = 0, TF_HOUR, TF_MIN, TF_SEC, TF_MON1, TF_YEAR, TF_RELYEAR, TF_CENTURY, TF_YDAY1, TF_WDAY, TF_WDAY7, TF_IGNORE,
+       TF_MONNAME, TF_DAYNAME };
+struct DirInfo { uint8_t kind, field, eatspace, pad; uint16_t lo, hi; };
+__constant__ DirInfo c_dir[128] = {};
 __constant__ char c_mon_full[12][10] = { "january", "february", "march", "april", "may", "june", "july",
                                          "august", "september", "october", "november", "december" };
 __constant__ char c_day_full[7][10] = { "sunday", "monday", "tuesday", "wednesday", "thursday", "friday", "saturday" };
 __constant__ int c_mon_len[2][12] = { { 31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 },
                                       { 31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 } };
 
-// case-insensitive prefix match of a lower-case word; returns its length or 0
-DEV int match_word(const TStr &in, const uint8_t *bp, const char *w, int wl) {
-    for (int i = 0; i < wl; i++) if (d_lower(in.at(bp + i)) != (uint32_t) w[i]) return 0;
-    return wl;
-}
-DEV int cstrlen(const char *w) { int n = 0; while (w[n]) n++; return n; }
-
 DEV bool d_isleap(int y) { return (y % 4) == 0 && ((y % 100) != 0 || (y % 400) == 0); }
-DEV int leaps_thru_end_of(int y) {
-    if (y >= 0) return y / 4 - y / 100 + y / 400;
-    int z = -(y + 1);
-    return -((z / 4 - z / 100 + z / 400) + 1);
-}
 
 // days since 1970-01-01 of year/month(1..12)/day
 DEV int64_t days_from_civil(int64_t y, int m, int d) {
@@ -837,155 +783,132 @@ DEV int64_t days_from_civil(int64_t y, int m, int d) {
 
 // one flb_strptime() call (initialize = 1).  fmt holds only primitive directives (the host
 // expands %T %D %F %R %r %c %x %X).  Returns the new input pointer or nullptr.
-DEV const uint8_t *d_strptime(const TStr &in, const uint8_t *bp, const char *fmt, Tm &tm) {
+DEV const uint8_t *d_strptime(TStr &in, const uint8_t *bp, const char *fmt, Tm &tm) {
     tm.century = 1900; tm.relyear = -1; tm.fields = 0; tm.gmtoff = 0;
     uint32_t c;
-    int i;
     while ((c = (uint8_t) *fmt) != 0) {
         if (d_isspace(c)) {
             while (d_isspace(in.at(bp))) bp++;
             fmt++;
             continue;
         }
-        if (in.at(bp) == 0) return nullptr;
+        uint32_t cur = in.at(bp);
+        if (cur == 0) return nullptr;
         c = (uint8_t) *fmt++;
         if (c != '%') {
-            if (c != in.at(bp++)) return nullptr;
+            if (c != cur) return nullptr;
+            bp++;
             continue;
         }
         c = (uint8_t) *fmt++;
         while (c == 'E' || c == 'O') c = (uint8_t) *fmt++;
-        switch (c) {
-        case '%':
-            if (in.at(bp++) != '%') return nullptr;
+        const DirInfo di = c_dir[c & 127];
+        switch (di.kind) {
+        case DK_PCT:
+            if (cur != '%') return nullptr;
+            bp++;
             break;
-        case 'A': case 'a': {
-            int len = 0;
-            for (i = 0; i < 7; i++) {
-                len = match_word(in, bp, c_day_full[i], cstrlen(c_day_full[i]));
-                if (len) break;
-                len = match_word(in, bp, c_day_full[i], 3);
-                if (len) break;
+        case DK_WS:
+            while (d_isspace(in.at(bp))) bp++;
+            break;
+        case DK_NUM: {
+            if (di.eatspace && d_isspace(cur)) { bp++; cur = in.at(bp); }
+            // _conv_num (src/flb_strptime.c:819-840)
+            int result = 0, rulim = di.hi;
+            if (cur < '0' || cur > '9') return nullptr;
+            for (;;) {
+                result = result * 10 + (int) (cur - '0');
+                bp++;
+                rulim /= 10;
+                cur = in.at(bp);
+                if (!((result * 10 <= (int) di.hi) && rulim && cur >= '0' && cur <= '9')) break;
             }
-            if (i == 7) return nullptr;
-            tm.wday = i; bp += len; tm.fields |= F_WDAY;
+            if (result < (int) di.lo || result > (int) di.hi) return nullptr;
+            switch (di.field) {
+            case TF_MDAY: tm.mday = result; tm.fields |= F_MDAY; break;
+            case TF_HOUR: tm.hour = result; break;
+            case TF_MIN: tm.min = result; break;
+            case TF_SEC: tm.sec = result; break;
+            case TF_MON1: tm.mon = result - 1; tm.fields |= F_MON; break;
+            case TF_YEAR: tm.relyear = -1; tm.year = result - 1900; tm.fields |= F_YEAR; break;
+            case TF_RELYEAR: tm.relyear = result; break;
+            case TF_CENTURY: tm.century = result * 100; break;
+            case TF_YDAY1: tm.yday = result - 1; tm.fields |= F_YDAY; break;
+            case TF_WDAY: tm.wday = result; tm.fields |= F_WDAY; break;
+            case TF_WDAY7: tm.wday = result % 7; tm.fields |= F_WDAY; break;
+            default: break;
+            }
             break;
         }
-        case 'B': case 'b': case 'h': {
-            int len = 0;
-            for (i = 0; i < 12; i++) {
-                len = match_word(in, bp, c_mon_full[i], cstrlen(c_mon_full[i]));
-                if (len) break;
-                len = match_word(in, bp, c_mon_full[i], 3);
-                if (len) break;
+        case DK_NAME: {
+            // full name first, then the 3-letter abbreviation, case-insensitively (:381-419)
+            const int count = di.field == TF_MONNAME ? 12 : 7;
+            int i, len = 0;
+            for (i = 0; i < count; i++) {
+                const char *w = di.field == TF_MONNAME ? c_mon_full[i] : c_day_full[i];
+                int wl = 0;
+                while (w[wl]) wl++;
+                int q = 0;
+                while (q < wl && d_lower(in.at(bp + q)) == (uint32_t) w[q]) q++;
+                if (q == wl) { len = wl; break; }
+                if (q >= 3) { len = 3; break; }
             }
-            if (i == 12) return nullptr;
-            tm.mon = i; bp += len; tm.fields |= F_MON;
+            if (i == count) return nullptr;
+            if (di.field == TF_MONNAME) { tm.mon = i; tm.fields |= F_MON; }
+            else { tm.wday = i; tm.fields |= F_WDAY; }
+            bp += len;
             break;
         }
-        case 'C':
-            if (!conv_num(in, bp, i, 0, 99)) return nullptr;
-            tm.century = i * 100;
+        case DK_AMPM: {
+            uint32_t c1 = d_lower(cur), c2 = d_lower(in.at(bp + 1));
+            if ((c1 != 'a' && c1 != 'p') || c2 != 'm') return nullptr;
+            if (tm.hour > 12) return nullptr;
+            if (c1 == 'a') { if (tm.hour == 12) tm.hour = 0; }
+            else if (tm.hour < 12) tm.hour += 12;
+            bp += 2;
             break;
-        case 'e':
-            if (d_isspace(in.at(bp))) bp++;
-            /* FALLTHROUGH */
-        case 'd':
-            if (!conv_num(in, bp, tm.mday, 1, 31)) return nullptr;
-            tm.fields |= F_MDAY;
-            break;
-        case 'k': case 'H':
-            if (!conv_num(in, bp, tm.hour, 0, 23)) return nullptr;
-            break;
-        case 'l': case 'I':
-            if (!conv_num(in, bp, tm.hour, 1, 12)) return nullptr;
-            break;
-        case 'j':
-            if (!conv_num(in, bp, tm.yday, 1, 366)) return nullptr;
-            tm.yday--;
-            tm.fields |= F_YDAY;
-            break;
-        case 'M':
-            if (!conv_num(in, bp, tm.min, 0, 59)) return nullptr;
-            break;
-        case 'm':
-            if (!conv_num(in, bp, tm.mon, 1, 12)) return nullptr;
-            tm.mon--;
-            tm.fields |= F_MON;
-            break;
-        case 'p':
-            if (d_lower(in.at(bp)) == 'a' && d_lower(in.at(bp + 1)) == 'm') {
-                if (tm.hour > 12) return nullptr;
-                else if (tm.hour == 12) tm.hour = 0;
-                bp += 2;
-                break;
+        }
+        case DK_EPOCH: {
+            // _conv_num64 (:842-876) + gmtime_r
+            int64_t result = 0, rulim = INT64_MAX;
+            if (cur < '0' || cur > '9') return nullptr;
+            for (;;) {
+                if (result > 922337203685477580LL) return nullptr;
+                result *= 10;
+                if (result > 9223372036854775760LL) return nullptr;
+                result += (int64_t) (cur - '0');
+                bp++;
+                rulim /= 10;
+                if (result >= 922337203685477580LL) return nullptr;
+                cur = in.at(bp);
+                if (!(rulim && cur >= '0' && cur <= '9')) break;
             }
-            if (d_lower(in.at(bp)) == 'p' && d_lower(in.at(bp + 1)) == 'm') {
-                if (tm.hour > 12) return nullptr;
-                else if (tm.hour < 12) tm.hour += 12;
-                bp += 2;
-                break;
-            }
-            return nullptr;
-        case 'S':
-            if (!conv_num(in, bp, tm.sec, 0, 60)) return nullptr;
-            break;
-        case 's': {
-            int64_t v;
-            if (!conv_num64(in, bp, v)) return nullptr;
-            if (v > 67767976233532799LL) return nullptr;         // gmtime_r overflows tm_year
-            tm.have_epoch = 1; tm.epoch = v;
+            if (result > 67767976233532799LL) return nullptr;        // gmtime_r overflows tm_year
+            tm.have_epoch = 1; tm.epoch = result;
             tm.gmtoff = 0;
             tm.fields = 0xffff;
             break;
         }
-        case 'U': case 'W': case 'V':
-            if (!conv_num(in, bp, i, 0, 53)) return nullptr;
-            break;
-        case 'w':
-            if (!conv_num(in, bp, tm.wday, 0, 6)) return nullptr;
-            tm.fields |= F_WDAY;
-            break;
-        case 'u':
-            if (!conv_num(in, bp, i, 1, 7)) return nullptr;
-            tm.wday = i % 7;
-            tm.fields |= F_WDAY;
-            break;
-        case 'g':
-            if (!conv_num(in, bp, i, 0, 99)) return nullptr;
-            break;
-        case 'G':
+        case DK_G:
             do bp++; while (d_isdigit(in.at(bp)));
             break;
-        case 'Y':
-            if (!conv_num(in, bp, i, 0, 9999)) return nullptr;
-            tm.relyear = -1;
-            tm.year = i - 1900;
-            tm.fields |= F_YEAR;
-            break;
-        case 'y':
-            if (!conv_num(in, bp, tm.relyear, 0, 99)) return nullptr;
-            break;
-        case 'z': {
+        case DK_TZ: {
             while (d_isspace(in.at(bp))) bp++;
-            int neg = 0;
             uint32_t z = in.at(bp++);
             if (z == 'G') {
                 if (in.at(bp++) != 'M') return nullptr;
                 if (in.at(bp++) != 'T') return nullptr;
                 tm.gmtoff = 0;
-                continue;
+                break;
             }
             if (z == 'U') {
                 if (in.at(bp++) != 'T') return nullptr;
                 if (in.at(bp) == 'C') bp++;
                 tm.gmtoff = 0;
-                continue;
+                break;
             }
-            if (z == 'Z') { tm.gmtoff = 0; continue; }
-            if (z == '+') neg = 0;
-            else if (z == '-') neg = 1;
-            else {
+            if (z == 'Z') { tm.gmtoff = 0; break; }
+            if (z != '+' && z != '-') {
                 --bp;
                 // RFC-822 North American zones: E/C/M/P + S/D + T
                 uint32_t a = d_lower(in.at(bp)), b2 = d_lower(in.at(bp + 1)), c2 = d_lower(in.at(bp + 2));
@@ -993,26 +916,25 @@ DEV const uint8_t *d_strptime(const TStr &in, const uint8_t *bp, const char *fmt
                 if (zi >= 0 && c2 == 't' && (b2 == 's' || b2 == 'd')) {
                     tm.gmtoff = (b2 == 's' ? (-5 - zi) : (-4 - zi)) * 3600L;
                     bp += 3;
-                    continue;
+                    break;
                 }
                 return nullptr;
             }
-            if (!d_isdigit(in.at(bp)) || !d_isdigit(in.at(bp + 1))) return nullptr;
-            int offs = ((int) (in.at(bp) - '0') * 10 + (int) (in.at(bp + 1) - '0')) * 3600;
+            uint32_t d0 = in.at(bp), d1 = in.at(bp + 1);
+            if (!d_isdigit(d0) || !d_isdigit(d1)) return nullptr;
+            int offs = ((int) (d0 - '0') * 10 + (int) (d1 - '0')) * 3600;
             bp += 2;
             if (in.at(bp) == ':') bp++;
-            if (d_isdigit(in.at(bp))) {
-                offs += (int) (in.at(bp++) - '0') * 10 * 60;
-                if (!d_isdigit(in.at(bp))) return nullptr;
-                offs += (int) (in.at(bp++) - '0') * 60;
+            d0 = in.at(bp);
+            if (d_isdigit(d0)) {
+                d1 = in.at(bp + 1);
+                if (!d_isdigit(d1)) return nullptr;
+                offs += ((int) (d0 - '0') * 10 + (int) (d1 - '0')) * 60;
+                bp += 2;
             }
-            if (neg) offs = -offs;
-            tm.gmtoff = offs;
-            continue;
-        }
-        case 'n': case 't':
-            while (d_isspace(in.at(bp))) bp++;
+            tm.gmtoff = z == '-' ? -offs : offs;
             break;
+        }
         default:
             return nullptr;
         }
@@ -1027,7 +949,7 @@ DEV const uint8_t *d_strptime(const TStr &in, const uint8_t *bp, const char *fmt
         const int lp = d_isleap(year) ? 1 : 0;
         if (!(tm.fields & F_YDAY) && (tm.fields & F_MON) && (tm.fields & F_MDAY)) {
             tm.yday = tm.mday - 1;
-            for (i = 0; i < tm.mon; i++) tm.yday += c_mon_len[lp][i];
+            for (int i = 0; i < tm.mon; i++) tm.yday += c_mon_len[lp][i];
             tm.fields |= F_YDAY;
         }
         if (tm.fields & F_YDAY) {
@@ -1039,7 +961,6 @@ DEV const uint8_t *d_strptime(const TStr &in, const uint8_t *bp, const char *fmt
             if (!(tm.fields & F_MDAY)) tm.mday = days + 1;
         }
     }
-    (void) leaps_thru_end_of;
     return bp;
 }
 
@@ -1066,24 +987,23 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
     uint32_t n = 0;
     while (n < vlen && in.at(v + n) != 0) n++;
     in.e = v + n;
-    in.wb = nullptr;
-    const uint8_t *p = d_strptime(in, v, ps.fmt1, tm);
-    bool ok = p != nullptr;
-    if (ok && ps.has_frac) {
-        // parse_subseconds: strtod("0." + up to 9 chars); digits only (hex/exp forms cannot
-        // appear after "0." + digits except an exponent, handled below)
-        uint32_t avail = (uint32_t) (in.e - p);
-        uint32_t digits = avail < 9 ? avail : 9, k = 0;
-        uint64_t num = 0;
-        while (k < digits && d_isdigit(in.at(p + k))) { num = num * 10 + (in.at(p + k) - '0'); k++; }
-        if (k == 0) ok = false;
-        else {
+    // the two flb_strptime() calls that bracket %L share ONE call site (pass 0: fmt1, pass 1: fmt2)
+    const uint8_t *p = v;
+    bool ok = true;
+    for (int pass = 0; pass < 2 && ok; pass++) {
+        if (pass == 1) {
+            if (!ps.has_frac) break;
+            // parse_subseconds: strtod("0." + up to 9 chars) -- digits (+ an exponent inside the window)
+            uint32_t avail = (uint32_t) (in.e - p);
+            uint32_t digits = avail < 9 ? avail : 9, k = 0;
+            uint64_t num = 0;
+            while (k < digits && d_isdigit(in.at(p + k))) { num = num * 10 + (in.at(p + k) - '0'); k++; }
+            if (k == 0) { ok = false; break; }
             // correctly rounded: num < 2^53 and 10^k <= 1e9 are exact doubles, one IEEE division
             double pw = 1.0;
             for (uint32_t q = 0; q < k; q++) pw *= 10.0;
             double f = (double) num / pw;
             uint32_t consumed = k;
-            // strtod also accepts an exponent inside the 9-char window: e.g. "12e3"
             if (k < digits && (in.at(p + k) == 'e' || in.at(p + k) == 'E')) {
                 uint32_t q = k + 1;
                 int eneg = 0;
@@ -1091,8 +1011,6 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
                 if (q < digits && d_isdigit(in.at(p + q))) {
                     int ex = 0;
                     while (q < digits && d_isdigit(in.at(p + q))) { ex = ex * 10 + (int) (in.at(p + q) - '0'); q++; }
-                    // rare; the scaled value is only exact for tiny exponents, which is all that
-                    // fits in the window
                     double sc = 1.0;
                     for (int z = 0; z < ex && z < 400; z++) sc *= 10.0;
                     f = eneg ? f / sc : f * sc;
@@ -1101,12 +1019,11 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
             }
             *frac = f;
             p += consumed;
-            Tm tm2 = tm;
-            const uint8_t *p2 = d_strptime(in, p, ps.fmt2, tm2);
-            // the second call re-initialises gmtoff/century/relyear/fields but keeps the fields
-            tm = tm2;
-            if (!p2) ok = false;
         }
+        // (the second call re-initialises gmtoff/century/relyear/fields but keeps the tm fields)
+        const uint8_t *p2 = d_strptime(in, p, pass == 0 ? ps.fmt1 : ps.fmt2, tm);
+        if (!p2) ok = false;
+        else p = p2;
     }
     if (!ok) {
         if (ps.time_strict) return -1;
@@ -1165,6 +1082,29 @@ DEV uint64_t d_strtoull16(const uint8_t *s, uint32_t n) {
     return neg ? (0 - v) : v;
 }
 
+// RecInfo lives in HBM as REC_NCOLS columns of n words each
+DEV void rec_store(uint32_t *cols, uint64_t n, uint64_t r, const RecInfo &ri) {
+    cols[0 * n + r] = ri.flags; cols[1 * n + r] = ri.val_off; cols[2 * n + r] = ri.val_len; cols[3 * n + r] = ri.key_index;
+    cols[4 * n + r] = ri.ts_sec; cols[5 * n + r] = ri.ts_nsec; cols[6 * n + r] = ri.body_off; cols[7 * n + r] = ri.body_len;
+    cols[8 * n + r] = ri.meta_off; cols[9 * n + r] = ri.meta_len; cols[10 * n + r] = (uint32_t) ri.parser_idx;
+    cols[11 * n + r] = ri.nkept; cols[12 * n + r] = ri.drop_mask;
+}
+DEV RecInfo rec_load(const uint32_t *cols, uint64_t n, uint64_t r) {
+    RecInfo ri;
+    ri.flags = cols[0 * n + r]; ri.val_off = cols[1 * n + r]; ri.val_len = cols[2 * n + r]; ri.key_index = cols[3 * n + r];
+    ri.ts_sec = cols[4 * n + r]; ri.ts_nsec = cols[5 * n + r]; ri.body_off = cols[6 * n + r]; ri.body_len = cols[7 * n + r];
+    ri.meta_off = cols[8 * n + r]; ri.meta_len = cols[9 * n + r]; ri.parser_idx = (int32_t) cols[10 * n + r];
+    ri.nkept = cols[11 * n + r]; ri.drop_mask = cols[12 * n + r];
+    ri.pad_[0] = ri.pad_[1] = ri.pad_[2] = 0;
+    return ri;
+}
+// one record's capture spans inside the [span][n] column block
+struct CapsView {
+    const uint32_t *base;
+    uint64_t n, r;
+    DEV uint32_t operator[](uint32_t i) const { return base[(uint64_t) i * n + r]; }
+};
+
 // ------------------------------------------------------------------------------------------
 // parsed-record body writer shared by the size pass and the emit pass
 // ------------------------------------------------------------------------------------------
@@ -1187,7 +1127,7 @@ DEV void write_field_value(S &s, int type, const uint8_t *v, uint32_t vlen) {
 // Writes (or sizes) the complete output record for `rec`.
 template <class S>
 DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
-                      const RecInfo &ri, const uint32_t *caps, uint64_t null_mask) {
+                      const RecInfo &ri, const CapsView &caps, uint64_t null_mask) {
     // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
     s.put(0x92); s.put(0x92); s.put(0xd7); s.put(0x00);
     pk_be(s, ri.ts_sec, 4); pk_be(s, ri.ts_nsec, 4);
@@ -1295,56 +1235,275 @@ DEV bool try_parser(const DevParser &ps, const HotTabs<LDS> &hot, const uint8_t 
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// filter_parser pass 1 is split into phase kernels so that every wave of a launch runs the same
+// small piece of code (register pressure and instruction-cache footprint of one phase only):
+//
+//   k_parser_locate   decode the event, find the value Key_Name designates, size the record as
+//                     if it stayed unparsed (records staged through LDS tiles, coalesced reads)
+//   k_parser_rx       parser 0's capture program on the located value (tables + spans in LDS)
+//   k_parser_finish   named fields, time lookup, size of the parsed record
+//   k_parser_generic  everything the fast phases do not cover (UTF-8 input, several parsers or
+//                     candidate keys, huge values): the complete per-record algorithm, run only
+//                     on the records flagged RF_GENERIC (normally none)
+// ------------------------------------------------------------------------------------------
+constexpr int LOC_BLOCK = 256;
+constexpr int LOC_TILE = 18432;             // LDS bytes per wave (64 records of 277 B + slack)
+
+DEV void recinfo_init(RecInfo &ri) {
+    ri.flags = 0; ri.val_off = 0; ri.val_len = 0; ri.key_index = 0; ri.ts_sec = 0; ri.ts_nsec = 0;
+    ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0; ri.drop_mask = 0;
+    ri.pad_[0] = ri.pad_[1] = ri.pad_[2] = 0;
+}
+
+// per-record part of k_parser_locate; rec may point into LDS (generic pointer)
+DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec, const uint8_t *rec_end, uint32_t &n_dec) {
+    RecInfo ri;
+    recinfo_init(ri);
+    Event ev = decode_event(rec, rec_end);
+    ri.flags = ev.flags;
+    if (ev.flags & RF_BAD) {
+        atomicMin(a.first_bad, (unsigned long long) r);
+        rec_store(a.info, a.n, r, ri);
+        return 0;
+    }
+    if (ev.flags & RF_SKIP) { rec_store(a.info, a.n, r, ri); return 0; }
+    n_dec++;
+    ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
+    if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
+    // candidate values (plugins/filter_parser/filter_parser.c:259-323)
+    uint32_t ncand = 0;
+    if (a.cfg.key.is_ra) {
+        const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end);
+        if (v) {
+            Tok t = mp_tok(v, ev.body_end);
+            if (t.type == T_STR || t.type == T_BIN) { ri.val_off = (uint32_t) (t.next - rec); ri.val_len = t.len; ncand = 1; }
+        }
+    }
+    else {
+        Tok bm = mp_tok(ev.body, ev.body_end);
+        const uint8_t *p = bm.next;
+        for (uint32_t i = 0; i < bm.len; i++) {
+            Tok kt = mp_tok(p, ev.body_end);
+            const uint8_t *kend = mp_skip(p, ev.body_end);
+            Tok vt = mp_tok(kend, ev.body_end);
+            p = mp_skip(kend, ev.body_end);
+            if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
+                bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) {
+                if (ncand == 0) { ri.val_off = (uint32_t) (vt.next - rec); ri.val_len = vt.len; ri.key_index = i; }
+                ncand++;
+            }
+        }
+    }
+    if (ncand == 1 && a.caps_in_lds && ri.val_len < 0xFFFF && (ri.val_len / CHK_STEP + 2) <= a.chk_len) ri.flags |= RF_CAND;
+    else if (ncand >= 1) { ri.flags |= RF_GENERIC; atomicAdd(&a.counts[2], 1ull); }
+    // size of the record if no parser matches: 12 + canonical metadata + canonical body; an event
+    // time outside the EventTime range makes the encoder reject the record
+    uint32_t out_len = 0;
+    if (ev.sec < 0 || (uint64_t) ev.sec > 0xffffffffull || ev.nsec < 0 || ev.nsec >= 1000000000LL) ri.flags |= RF_BADTS;
+    else {
+        ri.ts_sec = (uint32_t) ev.sec; ri.ts_nsec = (uint32_t) ev.nsec;
+        CountSink cs;
+        cs.n = 12;
+        if (ev.meta) mp_canon(ev.meta, ev.meta_end, cs); else cs.n += 1;
+        mp_canon(ev.body, ev.body_end, cs);
+        out_len = (uint32_t) cs.n;
+    }
+    rec_store(a.info, a.n, r, ri);
+    return out_len;
+}
+
+__global__ void __launch_bounds__(LOC_BLOCK) k_parser_locate(ParserMatchArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LDS_AS uint8_t *tile = (LDS_AS uint8_t *) g_lds + (size_t) wave * LOC_TILE;
+    const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    const uint8_t *data_end = a.data + a.bytes;
+    uint32_t n_dec = 0;
+    for (uint64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+        const uint64_t r = base + lane;
+        const uint32_t cnt = (uint32_t) ((a.n - base) < 64 ? (a.n - base) : 64);
+        uint64_t o0 = 0, o1 = 0;
+        if (lane < cnt) { o0 = a.row_off[r]; o1 = a.row_off[r + 1]; }
+        uint32_t lo = 0;
+        while (lo < cnt) {
+            const uint64_t g0 = __shfl(o0, (int) lo, 64);
+            const uint32_t align = (uint32_t) (g0 & 15);
+            const bool fit = lane >= lo && lane < cnt && (o1 - g0 + align) <= (uint64_t) LOC_TILE;
+            const uint64_t mask = __ballot(fit) >> lo;
+            uint32_t m = (~mask == 0) ? 64 - lo : (uint32_t) __builtin_ctzll(~mask);
+            if (m > cnt - lo) m = cnt - lo;
+            const bool direct = (m == 0);                 // one record larger than the tile: parse it in place
+            if (direct) m = 1;
+            if (!direct) {
+                const uint32_t total = (uint32_t) (__shfl(o1, (int) (lo + m - 1), 64) - g0) + align;
+                const uint8_t *src = a.data + (g0 - align);
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                for (uint32_t u = lane; u * 16 < total; u += 64) {
+                    const uint8_t *p = src + (size_t) u * 16;
+                    v4 v;
+                    if (p + 16 <= data_end) v = *(const v4 *) p;
+                    else {
+                        uint32_t t4[4] = {0, 0, 0, 0};
+                        for (int q = 0; q < 16 && p + q < data_end; q++) t4[q >> 2] |= (uint32_t) p[q] << (8 * (q & 3));
+                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
+                    }
+                    *(LDS_AS v4 *) (tile + (size_t) u * 16) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            if (lane >= lo && lane < lo + m) {
+                const uint8_t *rec, *rec_end;
+                if (direct) { rec = a.data + o0; rec_end = a.data + o1; }
+                else { rec = (const uint8_t *) (tile + align + (uint32_t) (o0 - g0)); rec_end = rec + (o1 - o0); }
+                a.out_len[r] = locate_one(a, r, rec, rec_end, n_dec);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            lo += m;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) n_dec += __shfl_down(n_dec, o, 64);
+    if (lane == 0 && n_dec) atomicAdd(&a.counts[0], (unsigned long long) n_dec);
+}
+
+// parser 0's capture program on the located values
 template <bool LDS>
-__global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a) {
+__global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
     uint16_t *chk = a.chk + ((size_t) wave_slot * a.chk_len) * 64 + lane;
-
-    // stage parser 0's hot ASCII tables into LDS (one coalesced 16 B/lane copy per workgroup)
+    const DevParser &ps = a.parsers[0];
+    // stage the hot ASCII tables into LDS (one coalesced 16 B/lane copy per workgroup)
     HotTabs<LDS> hot0;
     if constexpr (LDS) {
-        const DevCap &c0 = a.parsers[0].ascii;
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        const v4u *src = (const v4u *) c0.hot_base;
+        const v4u *src = (const v4u *) ps.ascii.hot_base;
         LDS_AS v4u *dst = (LDS_AS v4u *) g_lds;
         for (uint32_t i = threadIdx.x; i < a.lds_bytes / 16; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
-        hot0 = hot_lds(c0, (LDS_AS uint8_t *) g_lds);
+        hot0 = hot_lds(ps.ascii, (LDS_AS uint8_t *) g_lds);
     }
-    else hot0 = hot_global(a.parsers[0].ascii);
-    // capture spans of the value being matched: u16 column per thread in LDS
-    uint32_t n_dec = 0, n_emit = 0;
+    else hot0 = hot_global(ps.ascii);
     CapLds capl;
     capl.base = (LDS_AS uint16_t *) (g_lds + a.caps_lds_off) + threadIdx.x;
     capl.stride = blockDim.x;
+    const int ncap = 2 * ps.nfields;
+    uint32_t n_gen = 0;
+    for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
+        const uint64_t r = base + lane;
+        if (r >= a.n) continue;
+        const uint32_t flags = a.info[r];                     // column 0
+        if (!(flags & RF_CAND)) continue;
+        const uint32_t vlen = a.info[2 * a.n + r];
+        const uint8_t *val = a.data + a.row_off[r] + a.info[1 * a.n + r];
+        int best = rx_reverse(hot0, ps.ascii.r_info, val, vlen, chk);
+        int endb = -1;
+        if (best >= 0 && ps.nregs_minus1 > 0) {
+            for (int c = 0; c < ncap; c++) capl.set((uint32_t) c, CAP_UNSET);
+            endb = rx_forward(ps.ascii, hot0, val, vlen, best, chk, ps.slot2cap, capl);
+        }
+        if (endb >= 0) {
+            // publish the spans: [span][record] columns, a wave stores 64 consecutive words
+            for (int c = 0; c < ncap; c++) a.caps[(uint64_t) c * a.n + r] = capl.get((uint32_t) c);
+            a.info[r] = flags | RF_RXOK;
+        }
+        else if (best == -2 || a.cfg.nparsers > 1) {
+            // a byte >= 0x80 (UTF-8 tables) or more parsers to try: the generic kernel takes over
+            a.info[r] = flags | RF_GENERIC;
+            n_gen++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) n_gen += __shfl_down(n_gen, o, 64);
+    if (lane == 0 && n_gen) atomicAdd(&a.counts[2], (unsigned long long) n_gen);
+}
 
+// named fields, time lookup and size of the records parser 0 matched
+__global__ void __launch_bounds__(256) k_parser_finish(ParserMatchArgs a) {
+    const DevParser &ps = a.parsers[0];
+    uint32_t n_gen = 0;
+    for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * blockDim.x) {
+        const uint32_t fl0 = a.info[r];
+        if (!(fl0 & RF_RXOK) || (fl0 & RF_GENERIC)) { if (!(fl0 & RF_GENERIC)) a.null_mask[r] = 0; continue; }
+        RecInfo ri = rec_load(a.info, a.n, r);
+        const uint8_t *rec = a.data + a.row_off[r];
+        const uint8_t *rec_end = a.data + a.row_off[r + 1];
+        const uint8_t *val = rec + ri.val_off;
+        CapsView caps;
+        caps.base = a.caps; caps.n = a.n; caps.r = r;
+        bool any = false;
+        uint32_t kept = 0, drop = 0;
+        int64_t sec = 0; double frac = 0;
+        for (int f = 0; f < ps.nfields; f++) {
+            uint32_t b = caps[2 * f], e = caps[2 * f + 1];
+            bool set = (b != CAP_UNSET && e != CAP_UNSET);
+            if (set) any = true;                               // last_pos (src/flb_regex.c:52-54)
+            uint32_t fl = set ? e - b : 0;
+            if (fl == 0 && ps.skip_empty) { drop |= 1u << f; continue; }
+            if (ps.field_is_time[f]) {
+                int64_t s2; double f2;
+                if (time_lookup(ps, set ? val + b : val, fl, &s2, &f2) == -1) { drop |= 1u << f; continue; }
+                sec = s2; frac = f2;
+                if (!ps.time_keep) { drop |= 1u << f; continue; }
+            }
+            kept++;
+        }
+        if (!any) {
+            // flb_regex_parse found no participating named group: the parser fails
+            if (a.cfg.nparsers > 1) { a.info[r] = ri.flags | RF_GENERIC; n_gen++; }
+            else a.null_mask[r] = 0;
+            continue;
+        }
+        ri.flags |= RF_PARSED;
+        ri.flags &= ~(uint32_t) RF_BADTS;
+        ri.parser_idx = 0; ri.nkept = kept; ri.drop_mask = drop;
+        uint64_t null_mask = (!a.cfg.key.is_ra && ri.key_index < 64) ? 1ull << ri.key_index : 0;
+        int64_t tsec = ri.ts_sec, tnsec = ri.ts_nsec;
+        if (fl0 & RF_BADTS) { tsec = -1; tnsec = 0; }                        // the event time was out of range
+        int64_t psec = sec, pnsec = (int64_t) (frac * 1000000000);
+        bool have_parsed_time = ((uint64_t) psec * 1000000000ull + (uint64_t) pnsec) != 0;
+        if (have_parsed_time) { tsec = psec; tnsec = pnsec; }
+        a.null_mask[r] = null_mask;
+        // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
+        if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
+            ri.flags |= RF_BADTS;
+            rec_store(a.info, a.n, r, ri); a.out_len[r] = 0;
+            continue;
+        }
+        ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
+        CountSink cs;
+        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        rec_store(a.info, a.n, r, ri);
+        a.out_len[r] = (uint32_t) cs.n;
+    }
+    for (int o = 32; o > 0; o >>= 1) n_gen += __shfl_down(n_gen, o, 64);
+    if ((threadIdx.x & 63) == 0 && n_gen) atomicAdd(&a.counts[2], (unsigned long long) n_gen);
+}
+
+// The complete per-record algorithm (every candidate key, every parser, UTF-8 tables, values of
+// any length), for the records the fast phases flagged RF_GENERIC.
+__global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    uint16_t *chk = a.chk + ((size_t) wave_slot * a.chk_len) * 64 + lane;
     for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
         uint64_t r = base + lane;
         if (r >= a.n) continue;
+        if (!(a.info[r] & RF_GENERIC)) continue;
         const uint8_t *rec = a.data + a.row_off[r];
         const uint8_t *rec_end = a.data + a.row_off[r + 1];
         RecInfo ri;
-        ri.flags = 0; ri.val_off = 0; ri.val_len = 0; ri.key_index = 0; ri.ts_sec = 0; ri.ts_nsec = 0;
-        ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0; ri.drop_mask = 0;
+        recinfo_init(ri);
         uint64_t null_mask = 0;
-        uint32_t *caps = a.caps + r * a.caps_stride;
+        CapsView caps;
+        caps.base = a.caps; caps.n = a.n; caps.r = r;
         Event ev = decode_event(rec, rec_end);
-        ri.flags = ev.flags;
-        if (ev.flags & RF_BAD) {
-            atomicMin(a.first_bad, (unsigned long long) r);
-            a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = 0;
-            continue;
-        }
-        if (ev.flags & RF_SKIP) { a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = 0; continue; }
-        n_dec++;
+        ri.flags = ev.flags;                                  // valid, not skipped (checked by locate)
         ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
         if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
         int64_t tsec = ev.sec, tnsec = ev.nsec;
         bool have_out = false, last_ok = false;
-        // candidate values: the record accessor yields at most one; a plain Key_Name tries every
-        // kv whose key matches, in map order (filter_parser.c:259-323)
         Tok bm = mp_tok(ev.body, ev.body_end);
         const uint8_t *p = bm.next;
         uint32_t nkv = a.cfg.key.is_ra ? 1 : bm.len;
@@ -1369,29 +1528,9 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
             if (!vptr) continue;
             for (int q = 0; q < a.cfg.nparsers; q++) {
                 int64_t ps = 0, pn = 0; uint32_t nk = 0, dm = 0;
-                const bool small = vlen < 0xFFFF && a.caps_in_lds;
-                if (small) {
-                    last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, capl, &ps, &pn, &nk, &dm, a.debug_skip)
-                                     : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capl, &ps, &pn, &nk, &dm, a.debug_skip);
-                    if (last_ok) {
-                        // publish the spans: one 16-byte aligned row per record
-                        const DevParser &pp = a.parsers[q];
-                        for (int f4 = 0; f4 < 2 * pp.nfields; f4 += 4) {
-                            v4u32 v;
-                            v.x = capl.get(f4);
-                            v.y = f4 + 1 < 2 * pp.nfields ? capl.get(f4 + 1) : CAP_UNSET;
-                            v.z = f4 + 2 < 2 * pp.nfields ? capl.get(f4 + 2) : CAP_UNSET;
-                            v.w = f4 + 3 < 2 * pp.nfields ? capl.get(f4 + 3) : CAP_UNSET;
-                            *(v4u32 *) (caps + f4) = v;
-                        }
-                    }
-                }
-                else {
-                    CapGlobal capg;
-                    capg.row = caps;
-                    last_ok = q == 0 ? try_parser(a.parsers[0], hot0, vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, a.debug_skip)
-                                     : try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, a.debug_skip);
-                }
+                CapGlobal capg;
+                capg.base = a.caps; capg.n = a.n; capg.r = r;
+                last_ok = try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, 0u);
                 if (last_ok) {
                     have_out = true;
                     ri.val_off = (uint32_t) (vptr - rec); ri.val_len = vlen; ri.parser_idx = q; ri.nkept = nk; ri.drop_mask = dm;
@@ -1408,25 +1547,24 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_match(ParserMatchArgs a)
         // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
         if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
             ri.flags |= RF_BADTS;
-            a.info[r] = ri; a.out_len[r] = 0; a.null_mask[r] = null_mask;
+            rec_store(a.info, a.n, r, ri); a.out_len[r] = 0; a.null_mask[r] = null_mask;
             continue;
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
         CountSink cs;
-        if (!(a.debug_skip & 8)) write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
-        else cs.n = 1;
-        a.info[r] = ri;
+        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        rec_store(a.info, a.n, r, ri);
         a.null_mask[r] = null_mask;
         a.out_len[r] = (uint32_t) cs.n;
-        n_emit++;
     }
-    // record accounting: per-thread counters -> wave reduction -> one atomic per wave leader into
-    // LDS-free block totals would need another barrier; 16 atomics per workgroup are negligible
-    for (int o = 32; o > 0; o >>= 1) { n_dec += __shfl_down(n_dec, o, 64); n_emit += __shfl_down(n_emit, o, 64); }
-    if (lane == 0) {
-        if (n_dec) atomicAdd(&a.counts[0], (unsigned long long) n_dec);
-        if (n_emit) atomicAdd(&a.counts[1], (unsigned long long) n_emit);
-    }
+}
+
+// records with a non-empty output (flb_mp_count_log_records of the result)
+__global__ void __launch_bounds__(256) k_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) c += len[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long) c);
 }
 
 // Pass 2.  Each lane produces its record into a per-wave LDS staging area at the record's
@@ -1457,16 +1595,20 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
                 // one record larger than the staging area: straight to global memory
                 if (lane == lo && o1 > o0) {
                     ByteSink s(a.out + o0);
-                    write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], a.info[r],
-                                 a.caps + r * a.caps_stride, a.null_mask[r]);
+                    CapsView cv;
+                    cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
+                    write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r),
+                                 cv, a.null_mask[r]);
                 }
                 lo += 1;
                 continue;
             }
             if (lane >= lo && lane < lo + m && o1 > o0) {
                 LdsSink s(stg + align + (uint32_t) (o0 - batch_base));
-                write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], a.info[r],
-                             a.caps + r * a.caps_stride, a.null_mask[r]);
+                CapsView cv;
+                cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
+                write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r),
+                             cv, a.null_mask[r]);
             }
             uint32_t total = (uint32_t) (__shfl(o1, (int) (lo + m - 1), 64) - batch_base);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // staged bytes visible to the wave
@@ -1616,15 +1758,33 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
 
 // copy of the kept records: one wave per record, byte granular
 
+// One wave per 64 rows: the kept rows of the tile are copied one after the other, each by the
+// whole wave with 16 B per lane (unaligned vector loads/stores), so a 275 B record is one load
+// and one store instruction.
 __global__ void __launch_bounds__(256) k_gather(GatherArgs a) {
     const uint32_t lane = threadIdx.x & 63;
-    uint64_t r = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= a.n) return;
-    uint32_t len = a.keep_len[r];
-    if (!len) return;
-    const uint8_t *src = a.data + a.row_off[r];
-    uint8_t *dst = a.out + a.out_off[r];
-    for (uint32_t i = lane; i < len; i += 64) dst[i] = src[i];
+    const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    typedef v4 v4un __attribute__((aligned(1)));
+    for (uint64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
+        const uint64_t r = base + lane;
+        uint32_t len = 0;
+        uint64_t so = 0, dof = 0;
+        if (r < a.n) { len = a.keep_len[r]; if (len) { so = a.row_off[r]; dof = a.out_off[r]; } }
+        uint64_t mask = __ballot(len != 0);
+        while (mask) {
+            const int src_lane = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint32_t l = __shfl(len, src_lane, 64);
+            const uint8_t *src = a.data + __shfl(so, src_lane, 64);
+            uint8_t *dst = a.out + __shfl(dof, src_lane, 64);
+            for (uint32_t o = lane * 16; o < l; o += 64 * 16) {
+                if (o + 16 <= l) *(v4un *) (dst + o) = *(const v4un *) (src + o);
+                else for (uint32_t q = o; q < l; q++) dst[q] = src[q];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1718,19 +1878,64 @@ __global__ void k_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long
 // ------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------
-void launch_parser_match(const ParserMatchArgs &a, int grid, hipStream_t st) {
+// strptime directive table (src/flb_strptime.c:357-560: ranges of the numeric conversions)
+bool upload_time_tables() {
+    DirInfo h[128];
+    memset(h, 0, sizeof(h));
+    auto set = [&](char c, int kind, int field, int eat, int lo, int hi) {
+        h[(int) c].kind = (uint8_t) kind; h[(int) c].field = (uint8_t) field; h[(int) c].eatspace = (uint8_t) eat;
+        h[(int) c].lo = (uint16_t) lo; h[(int) c].hi = (uint16_t) hi;
+    };
+    set('d', DK_NUM, TF_MDAY, 0, 1, 31);   set('e', DK_NUM, TF_MDAY, 1, 1, 31);
+    set('H', DK_NUM, TF_HOUR, 0, 0, 23);   set('k', DK_NUM, TF_HOUR, 0, 0, 23);
+    set('I', DK_NUM, TF_HOUR, 0, 1, 12);   set('l', DK_NUM, TF_HOUR, 0, 1, 12);
+    set('j', DK_NUM, TF_YDAY1, 0, 1, 366); set('M', DK_NUM, TF_MIN, 0, 0, 59);
+    set('m', DK_NUM, TF_MON1, 0, 1, 12);   set('S', DK_NUM, TF_SEC, 0, 0, 60);
+    set('U', DK_NUM, TF_IGNORE, 0, 0, 53); set('W', DK_NUM, TF_IGNORE, 0, 0, 53); set('V', DK_NUM, TF_IGNORE, 0, 0, 53);
+    set('w', DK_NUM, TF_WDAY, 0, 0, 6);    set('u', DK_NUM, TF_WDAY7, 0, 1, 7);   set('g', DK_NUM, TF_IGNORE, 0, 0, 99);
+    set('Y', DK_NUM, TF_YEAR, 0, 0, 9999); set('y', DK_NUM, TF_RELYEAR, 0, 0, 99); set('C', DK_NUM, TF_CENTURY, 0, 0, 99);
+    set('A', DK_NAME, TF_DAYNAME, 0, 0, 0); set('a', DK_NAME, TF_DAYNAME, 0, 0, 0);
+    set('B', DK_NAME, TF_MONNAME, 0, 0, 0); set('b', DK_NAME, TF_MONNAME, 0, 0, 0); set('h', DK_NAME, TF_MONNAME, 0, 0, 0);
+    set('p', DK_AMPM, 0, 0, 0, 0); set('s', DK_EPOCH, 0, 0, 0, 0); set('z', DK_TZ, 0, 0, 0, 0);
+    set('n', DK_WS, 0, 0, 0, 0); set('t', DK_WS, 0, 0, 0, 0); set('%', DK_PCT, 0, 0, 0, 0); set('G', DK_G, 0, 0, 0, 0);
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_dir), h, sizeof(h)) == hipSuccess;
+}
+
+void launch_parser_locate(const ParserMatchArgs &a, int cus, hipStream_t st) {
     static bool attr_set = false;
+    const size_t lds = (size_t) (LOC_BLOCK / 64) * LOC_TILE;
     if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_parser_match<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) k_parser_locate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-        (void) hipFuncSetAttribute((const void *) k_parser_match<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set2 = true;
+    uint64_t tiles = (a.n + 63) / 64, blocks = (tiles + LOC_BLOCK / 64 - 1) / (LOC_BLOCK / 64);
+    uint64_t cap = (uint64_t) cus * 2 * 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_parser_locate, dim3((unsigned) blocks), dim3(LOC_BLOCK), lds, st, a);
+}
+void launch_parser_rx(const ParserMatchArgs &a, int grid, int threads, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_parser_rx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) k_parser_rx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
     }
-    if (a.lds_bytes) hipLaunchKernelGGL(k_parser_match<true>, dim3(grid), dim3(MATCH_BLOCK), a.lds_total, st, a);
-    else hipLaunchKernelGGL(k_parser_match<false>, dim3(grid), dim3(MATCH_BLOCK), a.lds_total, st, a);
+    if (a.lds_bytes) hipLaunchKernelGGL(k_parser_rx<true>, dim3(grid), dim3(threads), a.lds_total, st, a);
+    else hipLaunchKernelGGL(k_parser_rx<false>, dim3(grid), dim3(threads), a.lds_total, st, a);
+}
+void launch_parser_finish(const ParserMatchArgs &a, int cus, hipStream_t st) {
+    uint64_t blocks = (a.n + 255) / 256, cap = (uint64_t) cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_parser_finish, dim3((unsigned) blocks), dim3(256), 0, st, a);
+}
+void launch_parser_generic(const ParserMatchArgs &a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_parser_generic, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out, hipStream_t st) {
+    if (n == 0) return;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned) blocks), dim3(256), 0, st, len, n, out);
 }
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
@@ -1760,7 +1965,9 @@ void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st) {
 }
 void launch_gather(const GatherArgs &a, hipStream_t st) {
     if (a.n == 0) return;
-    hipLaunchKernelGGL(k_gather, dim3((unsigned) ((a.n * 64 + 255) / 256)), dim3(256), 0, st, a);
+    uint64_t tiles = (a.n + 63) / 64, blocks = (tiles + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_gather, dim3((unsigned) blocks), dim3(256), 0, st, a);
 }
 // exclusive scan: out[0..n] (n+1 entries); tmp must hold ntiles+1 u64
 size_t scan_tmp_elems(uint64_t n) { return (size_t) ((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
