@@ -539,23 +539,48 @@ DEV int rx_reverse(const HotTabs<LDS> &t, const uint8_t *r_info, const uint8_t *
             }                                                                                       \
             R = e3 & 0x7FFF;                                                                        \
         }
-        // 16 bytes per trip: one unaligned dwordx4 load, issued one trip ahead
-        const uint32_t n16 = len / 16;
-        v4u32 wn = n16 ? ldu128(s + len - 16) : (v4u32) (0);
-        for (uint32_t g = 0; g < n16; g++) {
-            const v4u32 w = wn;
-            if (g + 1 < n16) wn = ldu128(s + len - 16 * (g + 2));
-            const uint32_t top = len - 1 - 16 * g;
+        // 64 bytes per trip: four unaligned dwordx4 loads issued TOGETHER one trip ahead, so the
+        // 128-byte line they share is brought into the vector L1 once and the other three loads hit
+        // it before another wave evicts it (16 B loads spread over time re-fetched every line 8x)
+        const uint32_t n64 = len / 64;
+        v4u32 n0, n1, n2, n3;
+        n0 = n1 = n2 = n3 = (v4u32) (0);
+        if (n64) {
+            const uint8_t *q = s + len - 64;
+            n0 = ldu128(q); n1 = ldu128(q + 16); n2 = ldu128(q + 32); n3 = ldu128(q + 48);
+        }
+        for (uint32_t g = 0; g < n64; g++) {
+            const v4u32 w0 = n0, w1 = n1, w2 = n2, w3 = n3;
+            if (g + 1 < n64) {
+                const uint8_t *q = s + len - 64 * (g + 2);
+                n0 = ldu128(q); n1 = ldu128(q + 16); n2 = ldu128(q + 32); n3 = ldu128(q + 48);
+            }
+            const uint32_t top = len - 1 - 64 * g;
+#define RX_REV_16(vv, tp)                                                                           \
+            RX_REV_GROUP((vv).w, (tp)) RX_REV_GROUP((vv).z, (tp) - 4) RX_REV_GROUP((vv).y, (tp) - 8) \
+            RX_REV_GROUP((vv).x, (tp) - 12)                                                         \
+            if (chk) chk[(size_t) ((len - ((tp) - 15)) / CHK_STEP) * 64] = (uint16_t) R;
+            RX_REV_16(w3, top)
+            RX_REV_16(w2, top - 16)
+            RX_REV_16(w1, top - 32)
+            RX_REV_16(w0, top - 48)
+#undef RX_REV_16
+            // POISON (row nR) is absorbing and carries no start flags: one test per trip
+            if (R == poison) return -2;
+        }
+        tt = 64 * n64;
+        // remaining 16-byte groups
+        while (tt + 16 <= len) {
+            const v4u32 w = ldu128(s + len - tt - 16);
+            const uint32_t top = len - 1 - tt;
             RX_REV_GROUP(w.w, top)
             RX_REV_GROUP(w.z, top - 4)
             RX_REV_GROUP(w.y, top - 8)
             RX_REV_GROUP(w.x, top - 12)
-            // POISON (row nR) is absorbing and carries no start flags: one test per trip
             if (R == poison) return -2;
-            tt = 16 * (g + 1);                           // CHK_STEP == 16: a checkpoint every trip
+            tt += 16;                                    // CHK_STEP == 16: a checkpoint every 16 bytes
             if (chk) chk[(size_t) (tt / CHK_STEP) * 64] = (uint16_t) R;
         }
-        tt = 16 * n16;
         // remaining 4-byte groups
         while (tt + 4 <= len) {
             const uint32_t w = ldu32(s + len - tt - 4);
@@ -659,12 +684,14 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
     const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
     uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : (uint32_t) (t.col[ld8(s + j - 1)] >> fsh);
     uint32_t S = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + pk;
-    // 16-byte windows of the value (one unaligned dwordx4 load each, issued a window ahead);
-    // every 4 steps the next dword of the window becomes a packed queue of 4 column codes
+    // 64-byte windows of the value: four unaligned dwordx4 loads issued together (one L1 line
+    // fill), a window ahead of use; every 4 steps the next dword of the window becomes a packed
+    // queue of 4 column codes
     uint32_t gb = j;                                            // position of the current 4-byte group
-    v4u32 wc = load16(s, gb, len), wx = load16(s, gb + 16, len);
-    uint32_t vq = pack_col(t, wc.x, gb, len);                   // codes of positions gb..gb+3
-    uint32_t vqn = pack_col(t, wc.y, gb + 4, len);
+    v4u32 c0 = load16(s, gb, len), c1 = load16(s, gb + 16, len), c2 = load16(s, gb + 32, len), c3 = load16(s, gb + 48, len);
+    v4u32 x0 = load16(s, gb + 64, len), x1 = load16(s, gb + 80, len), x2 = load16(s, gb + 96, len), x3 = load16(s, gb + 112, len);
+    uint32_t vq = pack_col(t, c0.x, gb, len);                   // codes of positions gb..gb+3
+    uint32_t vqn = pack_col(t, c0.y, gb + 4, len);
     uint32_t sub = 2;                                           // dword of the window feeding the NEXT refill
     uint32_t k = 0;
     for (;;) {
@@ -706,12 +733,15 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
             vq = vqn;
             // codes of positions gb+4..gb+7: dword `sub` of the current window, or the first dword
             // of the next window once the current one is used up
-            if (sub == 4) {
-                wc = wx;
-                wx = load16(s, gb + 4 + 16, len);
+            if (sub == 16) {
+                c0 = x0; c1 = x1; c2 = x2; c3 = x3;
+                const uint32_t nb = gb + 4 + 64;
+                x0 = load16(s, nb, len); x1 = load16(s, nb + 16, len); x2 = load16(s, nb + 32, len); x3 = load16(s, nb + 48, len);
                 sub = 0;
             }
-            uint32_t w = sub == 0 ? wc.x : sub == 1 ? wc.y : sub == 2 ? wc.z : wc.w;
+            const uint32_t q4 = sub >> 2, q1 = sub & 3;
+            const v4u32 cv = q4 == 0 ? c0 : q4 == 1 ? c1 : q4 == 2 ? c2 : c3;
+            const uint32_t w = q1 == 0 ? cv.x : q1 == 1 ? cv.y : q1 == 2 ? cv.z : cv.w;
             vqn = pack_col(t, w, gb + 4, len);
             sub++;
         }
