@@ -10,6 +10,8 @@
  *   time lookup           src/flb_parser.c:1876-2065, include/fluent-bit/flb_parser.h:80-94
  *   typecast              src/flb_parser.c:2067-2164
  *   oflb_grep_*           plugins/filter_grep/grep.c:56-392, src/flb_ra_key.c:108-434
+ *   oflb_l2m_*            plugins/filter_log_to_metrics/log_to_metrics.c:216-343,355-595,970-1156,
+ *                         lib/cmetrics/src/cmt_histogram.c:328-361
  *   oflb_fparser_*        plugins/filter_parser/filter_parser.c:174-442,
  *                         src/flb_pack.c:1664-1738 (flb_msgpack_expand_map),
  *                         src/flb_log_event_encoder.c:172-363
@@ -900,6 +902,336 @@ int oflb_fparser_filter(oflb_fparser *ctx, const char *data, size_t bytes, char 
 }
 
 /* ------------------------------------------------------------------ helpers for tests/bench */
+
+/* ------------------------------------------------------------------ filter_log_to_metrics */
+/*
+ * plugins/filter_log_to_metrics/log_to_metrics.c restated:
+ *   set_rules            :216-312   rule field handed VERBATIM to flb_ra_create (no '$' prefixing)
+ *   grep_filter_data     :315-343   legacy rule evaluation
+ *   set_labels           :355-497   kubernetes labels first, then label_field / add_label in order
+ *   set_buckets          :540-595   strtod each "bucket", sort ascending
+ *   cb_log_to_metrics_filter :970-1156
+ * and the cmetrics arithmetic it drives:
+ *   cmt_counter_inc      lib/cmetrics/src/cmt_counter.c:100-116  (+1.0 on an f64)
+ *   cmt_gauge_set        lib/cmetrics/src/cmt_gauge.c
+ *   cmt_histogram_observe lib/cmetrics/src/cmt_histogram.c:328-361, default buckets :89-95
+ *   series identity      lib/cmetrics/src/cmt_map.c:377-452 (one series per label-value tuple, kept in
+ *                        insertion order; the 64-bit label hash is treated as collision free)
+ */
+#define L2M_COUNTER 0
+#define L2M_GAUGE 1
+#define L2M_HISTOGRAM 2
+#define L2M_MAX_LABEL_LENGTH 253      /* log_to_metrics.h:48 */
+#define L2M_MAX_LABEL_COUNT 128       /* log_to_metrics.h:50 */
+
+struct l2m_series {
+    char **labels;
+    double value;                 /* counter / gauge */
+    uint64_t *buckets;            /* [nb + 1] cumulative, last = +Inf */
+    uint64_t count;
+    double sum;
+};
+
+typedef struct oflb_l2m {
+    int mode;
+    int discard_logs;
+    struct grep_rule *rules; int nrules;
+    int label_count;
+    char **label_keys;
+    ora **label_ras;              /* NULL entry: label stays empty */
+    ora *value_ra;
+    int nb; double *bounds;
+    struct l2m_series *series; int nseries, cap;
+    int static_set;               /* label_count == 0: the map's static metric has been touched */
+} oflb_l2m;
+
+/* first parser entry of flb_ra_create(str): src/flb_record_accessor.c:74-232.  Text before the first
+ * '$' (or the whole string) is a STRING part whose name doubles as a top-level key
+ * (src/record_accessor/flb_ra_parser.c:224-249); '$TAG' / '$0' entries carry no key. */
+static ora *ora_create_first_part(const char *str, int *null_ok)
+{
+    const char *d = strchr(str, '$');
+    ora *ra;
+    *null_ok = 0;
+    if (str[0] != '$') {
+        size_t n = d ? (size_t) (d - str) : strlen(str);
+        if (n == 0) return NULL;
+        ra = calloc(1, sizeof(*ra));
+        ra->key = strndup(str, n);
+        ra->key_len = (int) n;
+        return ra;
+    }
+    if (str[1] == '\0') return NULL;
+    if ((str[1] >= '0' && str[1] <= '9') || strncmp(str + 1, "TAG", 3) == 0) {
+        *null_ok = 1;                         /* rp->key == NULL: lookups fail at run time */
+        return calloc(1, sizeof(*ra));
+    }
+    {
+        /* segment end: '.', ' ', ',', '"' outside quotes (:175-186) */
+        int quote = 0;
+        size_t end;
+        char *seg;
+        for (end = 1; str[end]; end++) {
+            if (str[end] == '\'') quote++;
+            else if (str[end] == '.' && (quote & 1)) continue;
+            else if (str[end] == '.' || str[end] == ' ' || str[end] == ',' || str[end] == '"') break;
+        }
+        seg = strndup(str, end);
+        ra = ora_create(seg);
+        free(seg);
+        return ra;
+    }
+}
+
+void oflb_l2m_destroy(oflb_l2m *c)
+{
+    int i, j;
+    if (!c) return;
+    for (i = 0; i < c->nrules; i++) { ora_destroy(c->rules[i].ra); oflb_regex_destroy(c->rules[i].regex); }
+    free(c->rules);
+    for (i = 0; i < c->label_count; i++) { free(c->label_keys[i]); ora_destroy(c->label_ras[i]); }
+    free(c->label_keys); free(c->label_ras);
+    ora_destroy(c->value_ra);
+    free(c->bounds);
+    for (i = 0; i < c->nseries; i++) {
+        for (j = 0; j < c->label_count; j++) free(c->series[i].labels[j]);
+        free(c->series[i].labels); free(c->series[i].buckets);
+    }
+    free(c->series);
+    free(c);
+}
+
+/* props: the filter's properties in configuration order as (key, value) pairs; the keys that matter
+ * are regex / exclude / label_field / add_label / bucket (all matched with strcasecmp, like the
+ * mk_list_foreach loops of set_rules/set_labels/set_buckets). */
+oflb_l2m *oflb_l2m_create(const char *mode, int nprops, const char **keys, const char **vals,
+                          int kubernetes_mode, const char *value_field, int discard_logs)
+{
+    static const char *k8s[5] = { "namespace_name", "pod_name", "container_name", "docker_id", "pod_id" };
+    oflb_l2m *c = calloc(1, sizeof(*c));
+    int i, n, null_ok;
+    c->discard_logs = discard_logs;
+    /* :731-749 */
+    if (mode == NULL || strcasecmp(mode, "counter") == 0) c->mode = L2M_COUNTER;
+    else if (strcasecmp(mode, "gauge") == 0) c->mode = L2M_GAUGE;
+    else if (strcasecmp(mode, "histogram") == 0) c->mode = L2M_HISTOGRAM;
+    else goto fail;
+    /* set_rules */
+    c->rules = calloc(nprops ? nprops : 1, sizeof(struct grep_rule));
+    for (i = 0; i < nprops; i++) {
+        struct grep_rule *r = &c->rules[c->nrules];
+        const char *v = vals[i], *sp;
+        char *field;
+        if (strcasecmp(keys[i], "regex") == 0) r->type = GREP_REGEX;
+        else if (strcasecmp(keys[i], "exclude") == 0) r->type = GREP_EXCLUDE;
+        else continue;
+        while (*v == ' ') v++;
+        sp = strchr(v, ' ');
+        if (!sp || sp == v || sp[1] == '\0') goto fail;
+        field = strndup(v, sp - v);
+        r->ra = ora_create_first_part(field, &null_ok);
+        free(field);
+        if (!r->ra) goto fail;
+        r->regex = oflb_regex_create(sp + 1);
+        if (!r->regex) { ora_destroy(r->ra); r->ra = NULL; goto fail; }
+        c->nrules++;
+    }
+    /* set_labels */
+    n = kubernetes_mode ? 5 : 0;
+    for (i = 0; i < nprops; i++)
+        if (strcasecmp(keys[i], "label_field") == 0 || strcasecmp(keys[i], "add_label") == 0) n++;
+    if (n > L2M_MAX_LABEL_COUNT) goto fail;
+    c->label_keys = calloc(n ? n : 1, sizeof(char *));
+    c->label_ras = calloc(n ? n : 1, sizeof(ora *));
+    if (kubernetes_mode) {
+        for (i = 0; i < 5; i++) {
+            char fmt[64];
+            snprintf(fmt, sizeof(fmt), "$kubernetes['%s']", k8s[i]);
+            c->label_keys[c->label_count] = strdup(k8s[i]);
+            c->label_ras[c->label_count++] = ora_create_first_part(fmt, &null_ok);
+        }
+    }
+    for (i = 0; i < nprops; i++) {
+        if (strcasecmp(keys[i], "label_field") == 0) {
+            c->label_keys[c->label_count] = strdup(vals[i]);
+            c->label_ras[c->label_count++] = ora_create_first_part(vals[i], &null_ok);
+        }
+        else if (strcasecmp(keys[i], "add_label") == 0) {
+            const char *v = vals[i], *sp;
+            while (*v == ' ') v++;
+            sp = strchr(v, ' ');
+            if (!sp || sp == v || sp[1] == '\0') goto fail;
+            c->label_keys[c->label_count] = strndup(v, sp - v);
+            c->label_ras[c->label_count++] = ora_create_first_part(sp + 1, &null_ok);
+        }
+    }
+    /* value_field: only for gauge / histogram (:794-808) */
+    if (c->mode > 0) {
+        if (!value_field || !*value_field) goto fail;
+        c->value_ra = ora_create_first_part(value_field, &null_ok);
+        if (!c->value_ra) goto fail;
+    }
+    /* set_buckets + defaults (:811-822) */
+    if (c->mode == L2M_HISTOGRAM) {
+        int nbk = 0, j;
+        for (i = 0; i < nprops; i++) if (strcasecmp(keys[i], "bucket") == 0) nbk++;
+        if (nbk == 0) {
+            static const double def[11] = { 0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1.0, 2.5, 5.0, 10.0 };
+            c->nb = 11;
+            c->bounds = malloc(sizeof(def));
+            memcpy(c->bounds, def, sizeof(def));
+        }
+        else {
+            c->bounds = calloc(nbk, sizeof(double));
+            for (i = 0; i < nprops; i++) {
+                char *end;
+                if (strcasecmp(keys[i], "bucket") != 0) continue;
+                c->bounds[c->nb] = strtod(vals[i], &end);
+                if (end == vals[i]) goto fail;
+                c->nb++;
+            }
+            for (i = 0; i < c->nb - 1; i++)
+                for (j = 0; j < c->nb - i - 1; j++)
+                    if (c->bounds[j] > c->bounds[j + 1]) { double t = c->bounds[j]; c->bounds[j] = c->bounds[j + 1]; c->bounds[j + 1] = t; }
+        }
+    }
+    return c;
+fail:
+    oflb_l2m_destroy(c);
+    return NULL;
+}
+
+static struct l2m_series *l2m_get_series(oflb_l2m *c, char **vals)
+{
+    int i, j;
+    struct l2m_series *s;
+    for (i = 0; i < c->nseries; i++) {
+        for (j = 0; j < c->label_count; j++) if (strcmp(c->series[i].labels[j], vals[j]) != 0) break;
+        if (j == c->label_count) return &c->series[i];
+    }
+    if (c->nseries == c->cap) { c->cap = c->cap ? 2 * c->cap : 16; c->series = realloc(c->series, c->cap * sizeof(*s)); }
+    s = &c->series[c->nseries++];
+    memset(s, 0, sizeof(*s));
+    s->labels = calloc(c->label_count ? c->label_count : 1, sizeof(char *));
+    for (j = 0; j < c->label_count; j++) s->labels[j] = strdup(vals[j]);
+    if (c->mode == L2M_HISTOGRAM) s->buckets = calloc(c->nb + 1, sizeof(uint64_t));
+    return s;
+}
+
+/* value of an accessor as the callback sees it: 0 none, 1 string, 2 float, 3 int, 4 other */
+static int l2m_value(const ora *ra, const omp_obj *map, char **str, double *f64, int64_t *i64)
+{
+    const omp_obj *o;
+    if (!ra || map->type != OMP_MAP) return 0;
+    o = ra_get_value(ra, map);
+    if (!o) return 0;
+    switch (o->type) {
+    case OMP_STR:
+        *str = malloc(o->via.str.size + 1);             /* flb_sds_create_len: NUL terminated copy */
+        memcpy(*str, o->via.str.ptr, o->via.str.size);
+        (*str)[o->via.str.size] = 0;
+        return 1;
+    case OMP_F64: case OMP_F32: *f64 = o->via.f64; return 2;
+    case OMP_POS: case OMP_NEG: *i64 = o->via.i64; return 3;
+    case OMP_BOOL: case OMP_MAP: case OMP_BIN: case OMP_NIL: return 4;
+    default: return 0;                                   /* array / ext: msgpack_object_to_ra_value == -1 */
+    }
+}
+
+int oflb_l2m_filter(oflb_l2m *c, const char *data, size_t bytes)
+{
+    omp_arena arena;
+    omp_obj root;
+    size_t off = 0;
+    double gauge_value = 0, histogram_value = 0;
+    char **vals = calloc(c->label_count ? c->label_count : 1, sizeof(char *));
+    char *buf = calloc(c->label_count ? c->label_count : 1, L2M_MAX_LABEL_LENGTH);
+    int i;
+    for (i = 0; i < c->label_count; i++) vals[i] = buf + (size_t) i * L2M_MAX_LABEL_LENGTH;
+    omp_arena_init(&arena);
+    for (;;) {
+        const omp_obj *map;
+        omp_obj nomap;
+        int keep = 1;
+        omp_arena_reset(&arena);
+        if (omp_unpack_next(&arena, &root, data, bytes, &off) != OMP_UNPACK_SUCCESS) break;
+        if (root.type != OMP_ARRAY) continue;
+        /* map = root.via.array.ptr[1]; an array shorter than 2 is read out of bounds by the
+         * reference -- restated as "not a map" (every accessor then fails) */
+        if (root.via.array.size >= 2) map = &root.via.array.ptr[1];
+        else { memset(&nomap, 0, sizeof(nomap)); nomap.type = OMP_NIL; map = &nomap; }
+        /* grep_filter_data :315-343 */
+        for (i = 0; i < c->nrules; i++) {
+            struct grep_rule *r = &c->rules[i];
+            int ret = map->type == OMP_MAP ? ra_regex_match(r->ra, map, r->regex) : -1;
+            if (ret <= 0) { if (r->type == GREP_REGEX) { keep = 0; break; } }
+            else { keep = (r->type != GREP_EXCLUDE); break; }
+        }
+        if (!keep) continue;
+        for (i = 0; i < c->label_count; i++) {
+            char *str = NULL; double f = 0; int64_t iv = 0;
+            int t;
+            vals[i][0] = '\0';
+            t = l2m_value(c->label_ras[i], map, &str, &f, &iv);
+            if (t == 1) { snprintf(vals[i], L2M_MAX_LABEL_LENGTH - 1, "%s", str); free(str); }
+            else if (t == 2) snprintf(vals[i], L2M_MAX_LABEL_LENGTH - 1, "%f", f);
+            else if (t == 3) snprintf(vals[i], L2M_MAX_LABEL_LENGTH - 1, "%ld", (long) iv);
+        }
+        if (c->mode == L2M_COUNTER) {
+            struct l2m_series *s = l2m_get_series(c, vals);
+            s->value += 1.0;
+            c->static_set = 1;
+        }
+        else {
+            char *str = NULL; double f = 0; int64_t iv = 0;
+            double *slot = c->mode == L2M_GAUGE ? &gauge_value : &histogram_value;
+            int t = l2m_value(c->value_ra, map, &str, &f, &iv);
+            struct l2m_series *s;
+            if (t == 0 || t == 4) continue;             /* missing / cannot convert: no update */
+            if (t == 1) { sscanf(str, "%lf", slot); free(str); }   /* failure keeps the previous value */
+            else if (t == 2) *slot = f;
+            else *slot = (double) iv;
+            s = l2m_get_series(c, vals);
+            c->static_set = 1;
+            if (c->mode == L2M_GAUGE) s->value = *slot;
+            else {
+                /* cmt_histogram_observe */
+                int b;
+                for (b = c->nb - 1; b >= 0; b--) {
+                    if (*slot > c->bounds[b]) break;
+                    s->buckets[b]++;
+                }
+                s->buckets[c->nb]++;
+                s->count++;
+                s->sum += *slot;
+            }
+        }
+    }
+    omp_arena_free(&arena);
+    free(buf); free(vals);
+    return c->discard_logs ? FLB_FILTER_MODIFIED : FLB_FILTER_NOTOUCH;
+}
+
+int oflb_l2m_info(oflb_l2m *c, int *label_count, int *nbuckets, double *bounds)
+{
+    int i;
+    *label_count = c->label_count;
+    *nbuckets = c->nb;
+    if (bounds) for (i = 0; i < c->nb; i++) bounds[i] = c->bounds[i];
+    return c->nseries;
+}
+const char *oflb_l2m_label_key(oflb_l2m *c, int i) { return c->label_keys[i]; }
+const char *oflb_l2m_series_label(oflb_l2m *c, int s, int i) { return c->series[s].labels[i]; }
+int oflb_l2m_series_get(oflb_l2m *c, int s, double *value, uint64_t *buckets, uint64_t *count, double *sum)
+{
+    int i;
+    *value = c->series[s].value;
+    *count = c->series[s].count;
+    *sum = c->series[s].sum;
+    if (buckets && c->series[s].buckets) for (i = 0; i <= c->nb; i++) buckets[i] = c->series[s].buckets[i];
+    return 0;
+}
+
 void oflb_free(void *p) { free(p); }
 
 int oflb_count_records(const char *data, size_t bytes) { return oev_count_records(data, bytes); }

@@ -35,6 +35,17 @@ def lib():
         L.oflb_regex_create.argtypes = [c_char_p]
         L.oflb_regex_match.argtypes = [c_void_p, c_char_p, c_size_t]
         L.oflb_time_lookup.argtypes = [c_void_p, c_char_p, c_size_t, c_int64, c_int, POINTER(c_int64), POINTER(c_double)]
+        L.oflb_l2m_create.restype = c_void_p
+        L.oflb_l2m_create.argtypes = [c_char_p, c_int, POINTER(c_char_p), POINTER(c_char_p), c_int, c_char_p, c_int]
+        L.oflb_l2m_destroy.argtypes = [c_void_p]
+        L.oflb_l2m_filter.argtypes = [c_void_p, c_char_p, c_size_t]
+        L.oflb_l2m_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_double)]
+        L.oflb_l2m_label_key.restype = c_char_p
+        L.oflb_l2m_label_key.argtypes = [c_void_p, c_int]
+        L.oflb_l2m_series_label.restype = c_char_p
+        L.oflb_l2m_series_label.argtypes = [c_void_p, c_int, c_int]
+        L.oflb_l2m_series_get.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(ctypes.c_uint64),
+                                          POINTER(ctypes.c_uint64), POINTER(c_double)]
         _L = L
     return _L
 
@@ -109,3 +120,34 @@ def repack(data):
     out = c_void_p(); sz = c_size_t()
     lib().oflb_repack(data, len(data), byref(out), byref(sz))
     return _take(out, sz)
+
+
+class L2M:
+    """filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c).  `props` is the list of
+    (key, value) properties in configuration order: regex / exclude / label_field / add_label / bucket;
+    the scalar options keep their property names."""
+    def __init__(self, metric_mode="counter", props=(), kubernetes_mode=False, value_field=None, discard_logs=False):
+        e = lambda s: s.encode() if isinstance(s, str) else s
+        n = len(props)
+        keys = (c_char_p * max(n, 1))(*[e(k) for k, _ in props])
+        vals = (c_char_p * max(n, 1))(*[e(v) for _, v in props])
+        self.h = lib().oflb_l2m_create(e(metric_mode), n, keys, vals, int(kubernetes_mode), e(value_field), int(discard_logs))
+        if not self.h:
+            raise ValueError("oracle: log_to_metrics create failed")
+    def filter(self, data):
+        return lib().oflb_l2m_filter(self.h, data, len(data))
+    def snapshot(self):
+        """-> (label_keys, bounds, [series]) with series = dict(labels=(..), value=, buckets=[..], count=, sum=)
+        in insertion order"""
+        lc = c_int(); nb = c_int()
+        bounds = (c_double * 1024)()
+        ns = lib().oflb_l2m_info(self.h, byref(lc), byref(nb), bounds)
+        keys = [lib().oflb_l2m_label_key(self.h, i).decode("latin1") for i in range(lc.value)]
+        out = []
+        for s in range(ns):
+            v = c_double(); cnt = ctypes.c_uint64(); sm = c_double()
+            bk = (ctypes.c_uint64 * (nb.value + 1))()
+            lib().oflb_l2m_series_get(self.h, s, byref(v), bk, byref(cnt), byref(sm))
+            out.append(dict(labels=tuple(lib().oflb_l2m_series_label(self.h, s, i) for i in range(lc.value)),
+                            value=v.value, buckets=list(bk), count=cnt.value, sum=sm.value))
+        return keys, list(bounds[: nb.value]), out
