@@ -73,6 +73,21 @@ def lib():
     L.flbgpu_rx_simulate_match.argtypes = [c_void_p, c_char_p, c_int]
     L.flbgpu_rx_info.argtypes = [c_void_p, POINTER(c_int)]
     L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
+    L.flbgpu_filter_l2m_create.restype = c_void_p
+    L.flbgpu_filter_l2m_create.argtypes = [c_char_p, c_int, POINTER(c_char_p), POINTER(c_char_p), c_int, c_char_p, c_int]
+    L.flbgpu_l2m_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+    L.flbgpu_l2m_label_key.restype = c_char_p
+    L.flbgpu_l2m_label_key.argtypes = [c_void_p, c_int]
+    L.flbgpu_l2m_bounds.argtypes = [c_void_p, POINTER(c_double)]
+    L.flbgpu_l2m_export.restype = c_int64
+    L.flbgpu_l2m_export.argtypes = [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.flbgpu_l2m_finalize_row.argtypes = [c_int, c_int, c_void_p, POINTER(c_double), c_void_p, POINTER(c_uint64), POINTER(c_double)]
+    L.flbgpu_l2m_set_index_base.argtypes = [c_void_p, c_uint64]
+    L.flbgpu_l2m_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+    L.flbgpu_nc_scan_double.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]
+    L.flbgpu_nc_fmt_f6.argtypes = [c_double, c_char_p, c_int]
+    L.flbgpu_nc_fmt_ld.argtypes = [ctypes.c_longlong, c_char_p]
+    L.flbgpu_nc_scan_double_dev.argtypes = [c_char_p, c_void_p, c_uint, c_int, c_void_p, c_void_p]
     _L = L
     return L
 
@@ -196,3 +211,127 @@ def index_host(data):
     consumed = c_size_t()
     n = lib().flbgpu_index_host(data, len(data), off.ctypes.data, off.size, byref(consumed))
     return n, off[: n + 1], consumed.value
+
+
+# ---- filter_log_to_metrics ---------------------------------------------------------------------
+COUNTER, GAUGE, HISTOGRAM = 0, 1, 2
+# word indices of a series row (csrc/dev.hpp): the first two merge by max, word 2 follows word 1,
+# everything else adds
+W_FIRST, W_LASTIDX, W_LASTVAL, W_COUNT = 0, 1, 2, 3
+
+
+def finalize_row(mode, nbuckets, row):
+    """one (merged) series row -> dict(value=, buckets=[cumulative.., +Inf], count=, sum=)"""
+    import numpy as np
+    row = np.ascontiguousarray(row, dtype=np.uint64)
+    v = c_double(); cnt = c_uint64(); sm = c_double()
+    bk = np.zeros(nbuckets + 1, dtype=np.uint64)
+    lib().flbgpu_l2m_finalize_row(mode, nbuckets, row.ctypes.data, byref(v), bk.ctypes.data, byref(cnt), byref(sm))
+    return dict(value=v.value, buckets=[int(x) for x in bk], count=cnt.value, sum=sm.value)
+
+
+class FilterLogToMetrics(_Filter):
+    """filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c).  `props` = the
+    instance properties in configuration order as (key, value): regex / exclude / label_field /
+    add_label / bucket; the scalar options keep their property names."""
+
+    def __init__(self, metric_mode="counter", props=(), kubernetes_mode=False, value_field=None, discard_logs=False):
+        n = len(props)
+        keys = (c_char_p * max(n, 1))(*[_b(k) for k, _ in props])
+        vals = (c_char_p * max(n, 1))(*[_b(v) for _, v in props])
+        self.h = lib().flbgpu_filter_l2m_create(_b(metric_mode), n, keys, vals, int(kubernetes_mode), _b(value_field),
+                                                int(discard_logs))
+        if not self.h:
+            raise ValueError("flbgpu_filter_l2m_create: " + last_error())
+        m = c_int(); lc = c_int(); nb = c_int(); w = c_int()
+        lib().flbgpu_l2m_info(self.h, byref(m), byref(lc), byref(nb), byref(w))
+        self.mode, self.label_count, self.nbuckets, self.row_words = m.value, lc.value, nb.value, w.value
+        self.label_keys = [lib().flbgpu_l2m_label_key(self.h, i).decode("latin1") for i in range(lc.value)]
+        b = (c_double * max(nb.value, 1))()
+        lib().flbgpu_l2m_bounds(self.h, b)
+        self.bounds = list(b[: nb.value])
+
+    def set_index_base(self, base):
+        lib().flbgpu_l2m_set_index_base(self.h, base)
+
+    def stats(self):
+        o = (c_uint64 * 5)()
+        lib().flbgpu_l2m_stats(self.h, o)
+        return dict(observations=o[0], deferred=o[1], stale=o[2], grows=o[3], slots=o[4])
+
+    def export(self):
+        """-> (keys: list[bytes], rows: np.uint64[n, row_words]) in first-appearance order; a key is the
+        series' label values, each NUL-terminated"""
+        import numpy as np
+        cap, kcap = 1024, 1 << 16
+        while True:
+            rows = np.zeros((cap, self.row_words), dtype=np.uint64)
+            off = np.zeros(cap + 1, dtype=np.uint64)
+            keys = ctypes.create_string_buffer(kcap)
+            need = c_size_t()
+            n = lib().flbgpu_l2m_export(self.h, cap, rows.ctypes.data, off.ctypes.data, keys, kcap, byref(need))
+            if n >= 0:
+                raw = keys.raw
+                return [raw[int(off[i]): int(off[i + 1])] for i in range(n)], rows[:n].copy()
+            if n == -1:
+                raise RuntimeError("flbgpu_l2m_export: " + last_error())
+            cap = max(cap, -n - 2)
+            kcap = max(kcap, need.value)
+
+    def snapshot(self, keys_rows=None):
+        """-> list of dict(labels=(bytes,..), value=, buckets=, count=, sum=) in first-appearance order"""
+        keys, rows = keys_rows if keys_rows is not None else self.export()
+        out = []
+        for k, r in zip(keys, rows):
+            d = finalize_row(self.mode, self.nbuckets, r)
+            d["labels"] = tuple(k.split(b"\0")[:-1]) if self.label_count else ()
+            out.append(d)
+        return out
+
+
+def l2m_all_reduce(flt, dist, device=None):
+    """Merges the series state of every rank's FilterLogToMetrics (same configuration on all ranks, each
+    fed its own shard of the records) -- SURVEY.md section 8e: one all-reduce of the partial
+    aggregates per flush.  Label dictionaries are made identical first (all-gather of the keys);
+    then the rows go through all_reduce: MAX for the two index words, SUM for the counts, bucket
+    counts and fixed-point sum digits (exact integers, so the merged result does not depend on the
+    rank count), and the gauge value is taken from the rank that owns the winning index.
+    `dist` is torch.distributed (backend nccl == RCCL over xGMI on the GPUs, gloo in the CPU tests).
+    Returns (keys, rows) as FilterLogToMetrics.export() does, identical on every rank."""
+    keys, rows = flt.export()
+    return l2m_merge(keys, rows, flt.row_words, dist, device)
+
+
+def l2m_merge(keys, rows, W, dist, device=None):
+    """the collective part of l2m_all_reduce on an exported (keys, rows) pair"""
+    import numpy as np
+    import torch
+    world = dist.get_world_size()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, keys)
+    # union of the label tuples; canonical order fixed after the reduce (first appearance)
+    index = {}
+    for ks in gathered:
+        for k in ks:
+            if k not in index:
+                index[k] = len(index)
+    n = len(index)
+    dense = np.zeros((n, W), dtype=np.uint64)
+    for k, r in zip(keys, rows):
+        dense[index[k]] = r
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    t = torch.from_numpy(dense.view(np.int64)).to(dev)
+    # max words: shift to signed order so that MAX on int64 is MAX on uint64
+    mx = t[:, :2].contiguous() ^ torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    mx = mx ^ torch.tensor(-2 ** 63, dtype=torch.int64, device=dev)
+    # the gauge value travels with the winning index: ranks that lost contribute 0
+    own = (t[:, 1] == mx[:, 1]) & (t[:, 1] != 0)
+    t[:, 2] = torch.where(own, t[:, 2], torch.zeros_like(t[:, 2]))
+    sm = t[:, 2:].contiguous()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    # two ranks can only tie on W_LASTIDX if they were given overlapping index ranges
+    merged = torch.cat([mx, sm], dim=1).cpu().numpy().view(np.uint64)
+    order = np.argsort(~merged[:, 0], kind="stable")
+    inv = sorted(index, key=index.get)
+    return [inv[i] for i in order], merged[order]

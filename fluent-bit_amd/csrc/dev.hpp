@@ -185,6 +185,78 @@ struct GrepArgs {
     unsigned long long *counts; // [0] = decoded (non-skipped) records, [1] = kept records
 };
 
+
+// ---- filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c)
+enum { L2M_COUNTER = 0, L2M_GAUGE = 1, L2M_HISTOGRAM = 2 };
+constexpr int L2M_MAX_LABELS = 128;          // MAX_LABEL_COUNT (log_to_metrics.h:50)
+constexpr int L2M_LABEL_MAX = 251;           // snprintf(buf, MAX_LABEL_LENGTH - 1, ...): at most 251 characters
+// One row of 64-bit words per series.  Every word merges across chunks, workgroups and GPUs with an
+// associative integer operation (max or add), which is what makes the result independent of the
+// order in which records are visited:
+//   [W_FIRST]    max of ~(global index of the record that created the series)   -> snapshot order
+//   [W_LASTIDX]  max of (global index + 1) of the record that last set the gauge
+//   [W_LASTVAL]  binary64 bits of the value that record carried (follows W_LASTIDX)
+//   [W_COUNT]    add: records counted (counter mode)
+//   [W_SPECIAL+0..2]  add: NaN / +Inf / -Inf observations (they do not fit the fixed-point sum)
+//   [W_LIMB + j] add: sum of the observed values as a fixed-point integer in 32-bit digits,
+//                digit j has weight 2^(32 j - 1074); exact, so the f64 sum is rounded once
+//   [W_BUCKET + b] add: observations whose smallest containing bucket is b (b == nb: above all bounds)
+constexpr int L2M_NLIMB = 68;
+constexpr int L2M_W_FIRST = 0, L2M_W_LASTIDX = 1, L2M_W_LASTVAL = 2, L2M_W_COUNT = 3, L2M_W_SPECIAL = 4,
+              L2M_W_LIMB = 7, L2M_W_BUCKET = L2M_W_LIMB + L2M_NLIMB;
+inline int l2m_row_words(int mode, int nb) { return mode == L2M_HISTOGRAM ? L2M_W_BUCKET + nb + 1 : L2M_W_SPECIAL; }
+
+constexpr uint32_t L2M_SID_NONE = 0xFFFFFFFFu;     // record makes no observation
+constexpr uint32_t L2M_SID_DEFER = 0xFFFFFFFEu;    // needs k_l2m_generic (float label, doubtful decimal)
+constexpr uint32_t L2M_SID_STALE = 0x80000000u;    // flag: value is the previous assigned value of this call
+
+// series dictionary: open addressing on the 64-bit hash of the label tuple; the tuple's bytes live
+// in an append-only arena and every lookup compares them (no reliance on the hash being unique)
+struct L2mTable {
+    unsigned long long *slot_hash;   // [cap]: 0 empty, 1 being published, else hash (>= 2)
+    uint32_t *slot_sid;              // [cap]
+    uint64_t cap_mask;
+    uint32_t max_series;
+    unsigned int *n_series;
+    uint8_t *arena;
+    unsigned long long *arena_used;
+    uint64_t arena_cap;
+    unsigned long long *key_off;     // [max_series]
+    uint32_t *key_len;               // [max_series]
+    unsigned long long *series_hash; // [max_series]
+    unsigned int *overflow;
+};
+
+struct L2mArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    uint64_t bytes;
+    const GrepRule *rules;
+    int nrules;
+    const DevKey *labels;            // key_len < 0: accessor without a key ($TAG, $0): always empty
+    int nlabels;
+    const DevKey *value_key;
+    int mode;
+    L2mTable t;
+    uint32_t *sid_col;               // [n]
+    uint64_t *val_col;               // [n] binary64 bits
+    unsigned long long *first_bad;
+    unsigned long long *counts;      // [0] observations, [1] deferred rows, [2] stale rows
+};
+
+struct L2mAggArgs {
+    const uint32_t *sid_col;
+    const uint64_t *val_col;
+    uint64_t n;
+    const unsigned long long *first_bad;
+    unsigned long long *rows;        // [max_series][W]
+    int W, mode, nb;
+    const double *bounds;            // [nb] ascending
+    uint64_t idx_base;               // global index of row 0
+    const unsigned int *n_series;
+};
+
 struct GatherArgs {
     const uint8_t *data;
     const uint64_t *row_off;
@@ -212,5 +284,12 @@ void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);
 void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st);
 void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st);
+void launch_l2m_extract(const L2mArgs &a, int cus, hipStream_t st);
+void launch_l2m_generic(const L2mArgs &a, hipStream_t st);
+void launch_l2m_stale(uint32_t *sid_col, uint64_t *val_col, uint64_t n, const unsigned long long *first_bad, uint64_t *tmp, hipStream_t st);
+size_t l2m_stale_tmp_elems(uint64_t n);
+void launch_l2m_aggregate(const L2mAggArgs &a, int cus, hipStream_t st);
+void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
+bool l2m_test_numconv(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *status);
 
 }  // namespace flbgpu

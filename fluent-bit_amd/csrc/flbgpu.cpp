@@ -7,19 +7,7 @@
 //   flbgpu_filter_run    ~ cb_filter                    (include/fluent-bit/flb_filter.h:57-81)
 // Configuration-time work (regex compile, rule parsing, time-format analysis) happens here on the
 // host exactly once; per-record work happens only in kernels.hip.  There is no CPU data path.
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <strings.h>
-#include <vector>
-
-#include "../../include/flb_gpu.h"
-#include "dev.hpp"
-#include "rx.hpp"
+#include "host_int.hpp"
 
 using namespace flbgpu;
 
@@ -27,7 +15,9 @@ using namespace flbgpu;
 static thread_local std::string g_err;
 static int g_cus = 0;
 
-static void set_err(const char *fmt, ...) {
+int flbgpu::device_cus() { return g_cus; }
+
+void flbgpu::set_err(const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
@@ -36,15 +26,6 @@ static void set_err(const char *fmt, ...) {
     g_err = buf;
     if (getenv("FLBGPU_DEBUG")) fprintf(stderr, "[flbgpu] %s\n", buf);
 }
-
-#define HIPOK(call)                                                                              \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);  \
-            return false;                                                                        \
-        }                                                                                        \
-    } while (0)
 
 extern "C" const char *flbgpu_last_error(void) { return g_err.c_str(); }
 
@@ -66,27 +47,6 @@ extern "C" int flbgpu_init(int device) {
 extern "C" int flbgpu_device_cus(void) { return g_cus; }
 
 // ------------------------------------------------------------------------------------------ device buffers
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    bool ensure(size_t bytes) {
-        if (bytes <= cap) return true;
-        if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        HIPOK(hipMalloc(&p, want));
-        cap = want;
-        return true;
-    }
-    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T *as() const { return (T *) p; }
-};
-
-// uploads vectors of one table set into a single device allocation
-struct TableBlob {
-    void *dev = nullptr;
-    ~TableBlob() { if (dev) (void) hipFree(dev); }
-};
-
 template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vector<T> &v) {
     size_t off = (blob.size() + 15) & ~(size_t) 15;
     blob.resize(off + v.size() * sizeof(T) + 16);
@@ -94,7 +54,7 @@ template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vect
     return off;
 }
 
-static bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
+bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint8_t> b;
     std::vector<uint8_t> cls(t.cls, t.cls + 256);
     // hot block first (staged into LDS as one piece): rdelta | ft | ft2 | cls | col
@@ -120,7 +80,7 @@ static bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     return true;
 }
 
-static bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
+bool flbgpu::upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
     std::vector<uint8_t> b;
     std::vector<uint8_t> cls(t.cls, t.cls + 256);
     size_t o_cls = put(b, cls), o_dd = put(b, t.ddelta), o_df = put(b, t.d_final);
@@ -288,7 +248,7 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
 
 // ------------------------------------------------------------------------------------------ keys
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
-static bool parse_ra(const char *pat, DevKey &k, std::string &why) {
+bool flbgpu::parse_ra(const char *pat, DevKey &k, std::string &why) {
     memset(&k, 0, sizeof(k));
     k.is_ra = 1;
     const char *p = pat;
@@ -337,65 +297,12 @@ static bool parse_ra(const char *pat, DevKey &k, std::string &why) {
 }
 
 // ------------------------------------------------------------------------------------------ filters
-enum { F_PARSER = 1, F_GREP = 2 };
-
-struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
-
-struct flbgpu_filter {
-    int kind = 0;
-    hipStream_t stream = nullptr;
-    // filter_parser
-    FParserCfg pcfg;
-    std::vector<flbgpu_parser *> parsers;
-    DevBuf d_parsers;
-    uint32_t caps_stride = 0;
-    // filter_grep
-    std::vector<GrepRule> rules;
-    std::vector<TableBlob *> rule_blobs;
-    DevBuf d_rules;
-    int logical_op = 0;
-    // working buffers
-    DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off;
-    DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
-    uint64_t last_in = 0, last_out = 0;
-    // profiling
-    bool prof = false;
-    std::vector<KernelProf> kp;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    ~flbgpu_filter() {
-        for (auto *b : rule_blobs) delete b;
-        DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                         &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
-        for (auto *b : all) b->release();
-        if (ev0) (void) hipEventDestroy(ev0);
-        if (ev1) (void) hipEventDestroy(ev1);
-        if (stream) (void) hipStreamDestroy(stream);
-    }
-};
-
-static bool filter_common_init(flbgpu_filter *f) {
+bool filter_common_init(flbgpu_filter *f) {
     HIPOK(hipStreamCreate(&f->stream));
     HIPOK(hipEventCreate(&f->ev0));
     HIPOK(hipEventCreate(&f->ev1));
     return true;
 }
-
-struct ProfScope {
-    flbgpu_filter *f; hipStream_t st; const char *name; bool on;
-    ProfScope(flbgpu_filter *f_, hipStream_t st_, const char *n) : f(f_), st(st_), name(n), on(f_->prof) {
-        if (on) (void) hipEventRecord(f->ev0, st);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        (void) hipEventRecord(f->ev1, st);
-        (void) hipEventSynchronize(f->ev1);
-        float ms = 0;
-        (void) hipEventElapsedTime(&ms, f->ev0, f->ev1);
-        for (auto &k : f->kp) if (!strcmp(k.name, name)) { k.ms += ms; k.launches++; return; }
-        KernelProf k; k.name = name; k.ms = ms; k.launches = 1;
-        f->kp.push_back(k);
-    }
-};
 
 extern "C" void flbgpu_filter_profile(flbgpu_filter *f, int enable) { f->prof = enable != 0; f->kp.clear(); }
 
@@ -446,6 +353,25 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
     return f;
 }
 
+bool flbgpu::compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why) {
+    std::string w2;
+    if (!parse_ra(ra_field.c_str(), r.key, w2)) { why = "invalid record accessor? '" + ra_field + "': " + w2; return false; }
+    const char *ps, *pe;
+    unsigned opts;
+    rx::split_flb_pattern(pattern, &ps, &pe, &opts);
+    rx::Program prog;
+    std::string err;
+    if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) {
+        why = std::string("could not compile regex pattern '") + pattern + "' for the GPU path: " + err;
+        return false;
+    }
+    auto *b1 = new TableBlob(), *b2 = new TableBlob();
+    blobs.push_back(b1);
+    blobs.push_back(b2);
+    if (!upload_dfa(prog.ascii, *b1, r.dfa) || !upload_cap(prog.utf8, *b2, r.utf8)) { why = flbgpu_last_error(); return false; }
+    return true;
+}
+
 extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *const *kinds, const char *const *values,
                                                     const char *logical_op) {
     auto *f = new flbgpu_filter();
@@ -477,21 +403,7 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
         std::string field(v, sp - v);
         if (field[0] != '$') field = "$" + field;
         std::string why;
-        if (!parse_ra(field.c_str(), r.key, why)) { set_err("filter_grep: invalid record accessor? '%s': %s", field.c_str(), why.c_str()); delete f; return nullptr; }
-        const char *ps, *pe;
-        unsigned opts;
-        rx::split_flb_pattern(sp + 1, &ps, &pe, &opts);
-        rx::Program prog;
-        std::string err;
-        if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) {
-            set_err("filter_grep: could not compile regex pattern '%s' for the GPU path: %s", sp + 1, err.c_str());
-            delete f;
-            return nullptr;
-        }
-        auto *b1 = new TableBlob(), *b2 = new TableBlob();
-        f->rule_blobs.push_back(b1);
-        f->rule_blobs.push_back(b2);
-        if (!upload_dfa(prog.ascii, *b1, r.dfa) || !upload_cap(prog.utf8, *b2, r.utf8)) { delete f; return nullptr; }
+        if (!compile_rule(field, sp + 1, r, f->rule_blobs, why)) { set_err("filter_grep: %s", why.c_str()); delete f; return nullptr; }
         if ((int) f->rules.size() >= MAX_RULES) { set_err("filter_grep: more than %d rules", MAX_RULES); delete f; return nullptr; }
         f->rules.push_back(r);
     }
@@ -652,7 +564,12 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
 extern "C" int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream) {
     hipStream_t st = stream ? (hipStream_t) stream : f->stream;
     int ret = FLBGPU_FILTER_NOTOUCH;
-    bool ok = f->kind == F_PARSER ? run_parser_dev(f, in, out, st, &ret) : run_grep_dev(f, in, out, st, &ret, false);
+    bool ok;
+    if (f->kind == F_L2M) {
+        ok = run_l2m_dev(f, in, st, &ret);
+        if (ok && ret == FLBGPU_FILTER_MODIFIED && out) memset(out, 0, sizeof(*out));   // discard_logs: every record dropped
+    }
+    else ok = f->kind == F_PARSER ? run_parser_dev(f, in, out, st, &ret) : run_grep_dev(f, in, out, st, &ret, false);
     if (!ok) return FLBGPU_FILTER_NOTOUCH;      // errors degrade to NOTOUCH (SURVEY 8b "Errors")
     return ret;
 }
@@ -757,7 +674,17 @@ extern "C" int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t byte
     in.data = f->h_in_data.p; in.row_off = f->h_in_off.as<uint64_t>(); in.n = (uint64_t) n; in.bytes = consumed;
     memset(&out, 0, sizeof(out));
     int ret = FLBGPU_FILTER_NOTOUCH;
-    bool ok = f->kind == F_PARSER ? run_parser_dev(f, &in, &out, st, &ret) : run_grep_dev(f, &in, &out, st, &ret, garbage);
+    bool ok;
+    if (f->kind == F_L2M) {
+        // cb_log_to_metrics_filter: *out_buf = NULL, *out_size = 0 with MODIFIED when discard_logs
+        // (plugins/filter_log_to_metrics/log_to_metrics.c:1141-1145)
+        ok = run_l2m_dev(f, &in, st, &ret);
+        if (!ok || ret != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
+        *out_buf = NULL;
+        *out_size = 0;
+        return FLBGPU_FILTER_MODIFIED;
+    }
+    ok = f->kind == F_PARSER ? run_parser_dev(f, &in, &out, st, &ret) : run_grep_dev(f, &in, &out, st, &ret, garbage);
     if (!ok || ret != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
     void *hb = malloc(out.bytes ? out.bytes : 1);
     if (!hb) return FLBGPU_FILTER_NOTOUCH;

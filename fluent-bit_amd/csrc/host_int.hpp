@@ -1,0 +1,123 @@
+// host_int.hpp -- internals shared by the host-side translation units of libflbgpu.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+#include "../../include/flb_gpu.h"
+#include "dev.hpp"
+#include "rx.hpp"
+
+namespace flbgpu {
+
+void set_err(const char *fmt, ...);
+int device_cus();
+
+#define HIPOK(call)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            ::flbgpu::set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return false;                                                                        \
+        }                                                                                        \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIPOK(hipMalloc(&p, want));
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *) p; }
+};
+
+// uploads vectors of one table set into a single device allocation
+struct TableBlob {
+    void *dev = nullptr;
+    ~TableBlob() { if (dev) (void) hipFree(dev); }
+};
+
+bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out);
+bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out);
+// grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
+bool parse_ra(const char *pat, DevKey &k, std::string &why);
+// "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)
+bool compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why);
+
+}  // namespace flbgpu
+
+struct L2mState;
+void l2m_state_destroy(L2mState *);
+
+struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
+
+enum { F_PARSER = 1, F_GREP = 2, F_L2M = 3 };
+
+struct flbgpu_filter {
+    int kind = 0;
+    hipStream_t stream = nullptr;
+    // filter_parser
+    flbgpu::FParserCfg pcfg;
+    std::vector<flbgpu_parser *> parsers;
+    flbgpu::DevBuf d_parsers;
+    uint32_t caps_stride = 0;
+    // filter_grep (and the rule gate of filter_log_to_metrics)
+    std::vector<flbgpu::GrepRule> rules;
+    std::vector<flbgpu::TableBlob *> rule_blobs;
+    flbgpu::DevBuf d_rules;
+    int logical_op = 0;
+    // filter_log_to_metrics
+    L2mState *l2m = nullptr;
+    // working buffers
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off;
+    flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
+    uint64_t last_in = 0, last_out = 0;
+    // profiling
+    bool prof = false;
+    std::vector<KernelProf> kp;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~flbgpu_filter() {
+        if (l2m) l2m_state_destroy(l2m);
+        for (auto *b : rule_blobs) delete b;
+        flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
+                                 &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
+        for (auto *b : all) b->release();
+        if (ev0) (void) hipEventDestroy(ev0);
+        if (ev1) (void) hipEventDestroy(ev1);
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+bool filter_common_init(flbgpu_filter *f);
+
+struct ProfScope {
+    flbgpu_filter *f; hipStream_t st; const char *name; bool on;
+    ProfScope(flbgpu_filter *f_, hipStream_t st_, const char *n) : f(f_), st(st_), name(n), on(f_->prof) {
+        if (on) (void) hipEventRecord(f->ev0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void) hipEventRecord(f->ev1, st);
+        (void) hipEventSynchronize(f->ev1);
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, f->ev0, f->ev1);
+        for (auto &k : f->kp) if (!strcmp(k.name, name)) { k.ms += ms; k.launches++; return; }
+        KernelProf k; k.name = name; k.ms = ms; k.launches = 1;
+        f->kp.push_back(k);
+    }
+};
+
+// filter_log_to_metrics entry used by flbgpu_filter_run / flbgpu_filter_run_dev
+bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, int *ret);

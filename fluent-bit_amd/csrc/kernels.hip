@@ -21,8 +21,15 @@
 #include <stdint.h>
 #include <string.h>
 #include "dev.hpp"
+#include "numconv.hpp"
 
 namespace flbgpu {
+
+namespace nc {
+__device__ const uint64_t g_pow5_dev[2 * (P5_QMAX - P5_QMIN + 1)] = {
+#include "pow5_table.inc"
+};
+}
 
 #define DEV __device__ __forceinline__
 #define LDS_AS __attribute__((address_space(3)))
@@ -2015,5 +2022,7 @@ void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long 
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_max_row_len, dim3(grid), dim3(256), 0, st, row_off, n, out);
 }
+
+#include "l2m_kernels.inc"
 
 }  // namespace flbgpu

@@ -1,0 +1,468 @@
+// l2m.cpp -- host side of filter_log_to_metrics (include/flb_gpu.h "filter_log_to_metrics").
+//
+//   flbgpu_filter_l2m_create  ~ cb_log_to_metrics_init: set_rules / set_labels / set_buckets
+//                               (plugins/filter_log_to_metrics/log_to_metrics.c:216-312,355-497,540-595,655-968)
+//   run_l2m_dev               ~ cb_log_to_metrics_filter (:970-1156), as kernel launches
+//   flbgpu_l2m_snapshot       ~ what the cmt context holds after the callback (cmt_counter / cmt_gauge /
+//                               cmt_histogram series, lib/cmetrics/src/cmt_map.c:377-452)
+//   flbgpu_l2m_export / _finalize_row   the mergeable integer state behind the snapshot, for the
+//                               all-reduce across GPUs
+// The hidden emitter input, the flush timer and the cmetrics msgpack encoding are engine plumbing
+// and stay with the engine (out of scope).
+#include "host_int.hpp"
+#include "numconv.hpp"
+
+#include <algorithm>
+
+using namespace flbgpu;
+
+struct L2mCtr { unsigned long long arena_used; unsigned int n_series; unsigned int overflow; };
+struct L2mMisc { unsigned long long first_bad; unsigned long long counts[3]; };
+
+struct L2mState {
+    int mode = 0, discard_logs = 0, nb = 0, W = 0;
+    std::vector<double> bounds;
+    std::vector<std::string> label_keys;
+    std::vector<DevKey> labels;
+    DevKey value_key;
+    DevBuf d_labels, d_value_key, d_bounds;
+    // series dictionary + rows
+    uint64_t cap = 0, arena_cap = 0;
+    uint32_t max_series = 0;
+    DevBuf d_slot_hash, d_slot_sid, d_arena, d_key_off, d_key_len, d_series_hash, d_rows, d_ctr;
+    // per-call columns
+    DevBuf d_sid, d_val, d_tmp, d_misc;
+    uint64_t idx_base = 0;
+    uint64_t last_obs = 0, last_deferred = 0, last_stale = 0, grows = 0;
+};
+
+void l2m_state_destroy(L2mState *s) {
+    if (!s) return;
+    DevBuf *all[] = {&s->d_labels, &s->d_value_key, &s->d_bounds, &s->d_slot_hash, &s->d_slot_sid, &s->d_arena, &s->d_key_off,
+                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc};
+    for (auto *b : all) b->release();
+    delete s;
+}
+
+// first parser entry of flb_ra_create(str) (src/flb_record_accessor.c:74-232): text before the
+// first '$' -- or the whole string -- is a STRING part whose name is looked up as a top-level key
+// (src/record_accessor/flb_ra_parser.c:224-249); "$TAG" / "$0" entries have no key.
+// returns 1 ok, 0 ok-but-keyless (lookups fail at run time), -1 invalid
+static int parse_first_part(const char *str, DevKey &k, std::string &why) {
+    memset(&k, 0, sizeof(k));
+    if (str[0] != '$') {
+        const char *d = strchr(str, '$');
+        size_t n = d ? (size_t) (d - str) : strlen(str);
+        if (n == 0) { why = "empty accessor"; return -1; }
+        if (n >= (size_t) MAX_KEY) { why = "key too long"; return -1; }
+        memcpy(k.key, str, n);
+        k.key_len = (int) n;
+        return 1;
+    }
+    if (!str[1]) { why = "empty accessor"; return -1; }
+    if ((str[1] >= '0' && str[1] <= '9') || !strncmp(str + 1, "TAG", 3)) { k.key_len = -1; return 0; }
+    int quote = 0;
+    size_t end;
+    for (end = 1; str[end]; end++) {                       // :175-186
+        if (str[end] == '\'') quote++;
+        else if (str[end] == '.' && (quote & 1)) continue;
+        else if (str[end] == '.' || str[end] == ' ' || str[end] == ',' || str[end] == '"') break;
+    }
+    std::string seg(str, end);
+    if (!parse_ra(seg.c_str(), k, why)) return -1;
+    return 1;
+}
+
+static bool zero_alloc(DevBuf &b, size_t bytes) {
+    if (!b.ensure(bytes)) return false;
+    HIPOK(hipMemset(b.p, 0, b.cap));
+    return true;
+}
+
+// grows `b` to new_bytes keeping the first `keep` bytes, zero-filling the rest
+static bool grow_keep(DevBuf &b, size_t new_bytes, size_t keep) {
+    DevBuf nb;
+    if (!zero_alloc(nb, new_bytes)) return false;
+    if (keep && b.p) HIPOK(hipMemcpy(nb.p, b.p, keep, hipMemcpyDeviceToDevice));
+    b.release();
+    b = nb;
+    return true;
+}
+
+static L2mTable table_of(L2mState *s) {
+    L2mTable t;
+    L2mCtr *c = s->d_ctr.as<L2mCtr>();
+    t.slot_hash = s->d_slot_hash.as<unsigned long long>();
+    t.slot_sid = s->d_slot_sid.as<uint32_t>();
+    t.cap_mask = s->cap - 1;
+    t.max_series = s->max_series;
+    t.n_series = &c->n_series;
+    t.arena = s->d_arena.as<uint8_t>();
+    t.arena_used = &c->arena_used;
+    t.arena_cap = s->arena_cap;
+    t.key_off = s->d_key_off.as<unsigned long long>();
+    t.key_len = s->d_key_len.as<uint32_t>();
+    t.series_hash = s->d_series_hash.as<unsigned long long>();
+    t.overflow = &c->overflow;
+    return t;
+}
+
+static bool table_init(L2mState *s) {
+    uint64_t cap = 1u << 16;
+    if (const char *e = getenv("FLBGPU_L2M_INIT_CAP")) {
+        uint64_t v = strtoull(e, nullptr, 10);
+        cap = 16;
+        while (cap < v) cap <<= 1;
+    }
+    s->cap = cap;
+    s->max_series = (uint32_t) (cap / 2);
+    s->arena_cap = std::max<uint64_t>(4096, cap * 32);
+    if (const char *e = getenv("FLBGPU_L2M_INIT_ARENA")) s->arena_cap = std::max<uint64_t>(64, strtoull(e, nullptr, 10) & ~7ull);
+    return zero_alloc(s->d_slot_hash, cap * 8) && zero_alloc(s->d_slot_sid, cap * 4) && zero_alloc(s->d_arena, s->arena_cap + 8) &&
+           zero_alloc(s->d_key_off, (size_t) s->max_series * 8) && zero_alloc(s->d_key_len, (size_t) s->max_series * 4) &&
+           zero_alloc(s->d_series_hash, (size_t) s->max_series * 8) &&
+           zero_alloc(s->d_rows, (size_t) s->max_series * s->W * 8) && zero_alloc(s->d_ctr, sizeof(L2mCtr));
+}
+
+// doubles whatever ran out (series capacity and/or arena) and rebuilds the slot array
+static bool table_grow(L2mState *s, hipStream_t st) {
+    L2mCtr c;
+    HIPOK(hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    const uint32_t ns = c.n_series;
+    bool series_full = (uint64_t) ns * 2 >= s->max_series;
+    bool arena_full = c.arena_used * 2 >= s->arena_cap;
+    if (!series_full && !arena_full) series_full = arena_full = true;       // long probe run or one very long key
+    if (series_full) {
+        const uint32_t old_max = s->max_series;
+        s->cap *= 2;
+        s->max_series = (uint32_t) (s->cap / 2);
+        s->d_slot_hash.release(); s->d_slot_sid.release();
+        if (!zero_alloc(s->d_slot_hash, s->cap * 8) || !zero_alloc(s->d_slot_sid, s->cap * 4)) return false;
+        if (!grow_keep(s->d_key_off, (size_t) s->max_series * 8, (size_t) old_max * 8) ||
+            !grow_keep(s->d_key_len, (size_t) s->max_series * 4, (size_t) old_max * 4) ||
+            !grow_keep(s->d_series_hash, (size_t) s->max_series * 8, (size_t) old_max * 8) ||
+            !grow_keep(s->d_rows, (size_t) s->max_series * s->W * 8, (size_t) old_max * s->W * 8)) return false;
+        L2mTable t = table_of(s);
+        launch_l2m_rehash(t, ns, st);
+        HIPOK(hipStreamSynchronize(st));
+    }
+    if (arena_full) {
+        const uint64_t old = s->arena_cap;
+        s->arena_cap *= 2;
+        if (!grow_keep(s->d_arena, s->arena_cap + 8, old)) return false;
+    }
+    s->grows++;
+    return true;
+}
+
+extern "C" flbgpu_filter *flbgpu_filter_l2m_create(const char *metric_mode, int nprops, const char *const *keys,
+                                                   const char *const *values, int kubernetes_mode, const char *value_field,
+                                                   int discard_logs) {
+    static const char *k8s[5] = {"namespace_name", "pod_name", "container_name", "docker_id", "pod_id"};   // :43-50
+    auto *f = new flbgpu_filter();
+    f->kind = F_L2M;
+    auto *s = new L2mState();
+    f->l2m = s;
+    s->discard_logs = discard_logs;
+    auto fail = [&](const char *fmt, const std::string &a) { set_err(fmt, a.c_str()); delete f; return (flbgpu_filter *) nullptr; };
+    // :731-757
+    if (!metric_mode || !strcasecmp(metric_mode, "counter")) s->mode = L2M_COUNTER;
+    else if (!strcasecmp(metric_mode, "gauge")) s->mode = L2M_GAUGE;
+    else if (!strcasecmp(metric_mode, "histogram")) s->mode = L2M_HISTOGRAM;
+    else return fail("log_to_metrics: invalid 'mode' value '%s'. Only 'counter', 'gauge' or 'histogram' types are allowed", metric_mode);
+    std::string why;
+    // set_rules :216-312 -- the field goes to flb_ra_create VERBATIM (no '$' is prepended)
+    for (int i = 0; i < nprops; i++) {
+        GrepRule r;
+        memset(&r, 0, sizeof(r));
+        if (!strcasecmp(keys[i], "regex")) r.type = GREP_REGEX;
+        else if (!strcasecmp(keys[i], "exclude")) r.type = GREP_EXCLUDE;
+        else continue;
+        const char *v = values[i];
+        while (*v == ' ') v++;
+        const char *sp = strchr(v, ' ');
+        if (!sp || sp == v || !sp[1]) return fail("log_to_metrics: invalid regex, expected field and regular expression%s", "");
+        std::string field(v, sp - v);
+        DevKey k;
+        int st = parse_first_part(field.c_str(), k, why);
+        if (st < 0) return fail("log_to_metrics: invalid record accessor? %s", "'" + field + "': " + why);
+        // compile_rule parses an accessor itself: hand it a placeholder and patch the key in
+        if (!compile_rule("$k", sp + 1, r, f->rule_blobs, why)) return fail("log_to_metrics: %s", why);
+        r.key = k;
+        if ((int) f->rules.size() >= MAX_RULES) return fail("log_to_metrics: too many rules%s", "");
+        f->rules.push_back(r);
+    }
+    // set_labels :355-497
+    auto add_label = [&](const std::string &name, const char *accessor) {
+        DevKey k;
+        std::string w;
+        if (parse_first_part(accessor, k, w) < 0) { memset(&k, 0, sizeof(k)); k.key_len = -1; }   // flb_warn + NULL accessor: label stays empty
+        s->label_keys.push_back(name);
+        s->labels.push_back(k);
+    };
+    if (kubernetes_mode)
+        for (int i = 0; i < 5; i++) add_label(k8s[i], (std::string("$kubernetes['") + k8s[i] + "']").c_str());
+    for (int i = 0; i < nprops; i++) {
+        if (!strcasecmp(keys[i], "label_field")) add_label(values[i], values[i]);
+        else if (!strcasecmp(keys[i], "add_label")) {
+            const char *v = values[i];
+            while (*v == ' ') v++;
+            const char *sp = strchr(v, ' ');
+            if (!sp || sp == v || !sp[1]) return fail("log_to_metrics: invalid label, expected name and key%s", "");
+            add_label(std::string(v, sp - v), sp + 1);
+        }
+    }
+    if ((int) s->labels.size() > L2M_MAX_LABELS) return fail("log_to_metrics: too many labels%s", "");
+    // value_field :794-808
+    memset(&s->value_key, 0, sizeof(s->value_key));
+    if (s->mode != L2M_COUNTER) {
+        if (!value_field || !*value_field) return fail("log_to_metrics: value_field is not set%s", "");
+        if (parse_first_part(value_field, s->value_key, why) < 0) return fail("log_to_metrics: invalid record accessor key for value_field: %s", why);
+    }
+    // set_buckets :540-595 + defaults :811-822
+    if (s->mode == L2M_HISTOGRAM) {
+        for (int i = 0; i < nprops; i++) {
+            if (strcasecmp(keys[i], "bucket")) continue;
+            char *end;
+            double d = strtod(values[i], &end);
+            if (end == values[i]) return fail("log_to_metrics: Error during conversion of bucket '%s'", values[i]);
+            s->bounds.push_back(d);
+        }
+        if (s->bounds.empty()) s->bounds = {0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1.0, 2.5, 5.0, 10.0};
+        else {
+            // sort_doubles_ascending: a bubble sort on '>' (NaN bounds stay where the comparisons leave them)
+            for (size_t i = 0; i + 1 < s->bounds.size(); i++)
+                for (size_t j = 0; j + 1 < s->bounds.size() - i; j++)
+                    if (s->bounds[j] > s->bounds[j + 1]) std::swap(s->bounds[j], s->bounds[j + 1]);
+        }
+        for (double b : s->bounds) if (b != b) return fail("log_to_metrics: NaN bucket bounds are not on the GPU path%s", "");
+    }
+    s->nb = (int) s->bounds.size();
+    s->W = l2m_row_words(s->mode, s->nb);
+    if (!filter_common_init(f)) { delete f; return nullptr; }
+    bool ok = f->d_rules.ensure(std::max<size_t>(1, f->rules.size()) * sizeof(GrepRule)) &&
+              s->d_labels.ensure(std::max<size_t>(1, s->labels.size()) * sizeof(DevKey)) && s->d_value_key.ensure(sizeof(DevKey)) &&
+              s->d_bounds.ensure(std::max<size_t>(1, s->bounds.size()) * sizeof(double)) && table_init(s);
+    if (ok && !f->rules.empty()) ok = hipMemcpy(f->d_rules.p, f->rules.data(), f->rules.size() * sizeof(GrepRule), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && !s->labels.empty()) ok = hipMemcpy(s->d_labels.p, s->labels.data(), s->labels.size() * sizeof(DevKey), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = hipMemcpy(s->d_value_key.p, &s->value_key, sizeof(DevKey), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && s->nb) ok = hipMemcpy(s->d_bounds.p, s->bounds.data(), s->nb * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { if (!*flbgpu_last_error()) set_err("log_to_metrics: device setup failed"); delete f; return nullptr; }
+    return f;
+}
+
+bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, int *ret) {
+    L2mState *s = f->l2m;
+    const uint64_t n = in->n;
+    *ret = s->discard_logs ? FLBGPU_FILTER_MODIFIED : FLBGPU_FILTER_NOTOUCH;
+    f->last_in = n; f->last_out = s->discard_logs ? 0 : n;
+    if (n == 0) return true;
+    if (!s->d_sid.ensure(n * 4) || !s->d_misc.ensure(sizeof(L2mMisc)) || !s->d_tmp.ensure(l2m_stale_tmp_elems(n) * 8)) return false;
+    if (s->mode != L2M_COUNTER && !s->d_val.ensure(n * 8)) return false;
+    L2mMisc hm;
+    L2mCtr hc;
+    const int cus = device_cus() > 0 ? device_cus() : 256;
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 40) { set_err("log_to_metrics: series dictionary keeps overflowing"); return false; }
+        memset(&hm, 0, sizeof(hm));
+        hm.first_bad = ~0ull;
+        HIPOK(hipMemcpyAsync(s->d_misc.p, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+        HIPOK(hipMemsetAsync(&s->d_ctr.as<L2mCtr>()->overflow, 0, sizeof(unsigned int), st));
+        L2mArgs a;
+        a.data = (const uint8_t *) in->data; a.row_off = in->row_off; a.n = n; a.bytes = in->bytes;
+        a.rules = f->d_rules.as<GrepRule>(); a.nrules = (int) f->rules.size();
+        a.labels = s->d_labels.as<DevKey>(); a.nlabels = (int) s->labels.size();
+        a.value_key = s->d_value_key.as<DevKey>(); a.mode = s->mode;
+        a.t = table_of(s);
+        a.sid_col = s->d_sid.as<uint32_t>(); a.val_col = s->d_val.as<uint64_t>();
+        a.first_bad = &s->d_misc.as<L2mMisc>()->first_bad; a.counts = s->d_misc.as<L2mMisc>()->counts;
+        { ProfScope ps(f, st, "k_l2m_extract"); launch_l2m_extract(a, cus, st); }
+        HIPOK(hipMemcpyAsync(&hm, s->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&hc, s->d_ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        if (!hc.overflow && hm.counts[1] > 0) {
+            { ProfScope ps(f, st, "k_l2m_generic"); launch_l2m_generic(a, st); }
+            HIPOK(hipMemcpyAsync(&hm, s->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipMemcpyAsync(&hc, s->d_ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+        }
+        if (!hc.overflow) break;
+        if (!table_grow(s, st)) return false;          // nothing was aggregated yet: the pass simply runs again
+    }
+    s->last_obs = hm.counts[0]; s->last_deferred = hm.counts[1]; s->last_stale = hm.counts[2];
+    if (hm.counts[2] > 0) {
+        ProfScope ps(f, st, "k_l2m_stale");
+        launch_l2m_stale(s->d_sid.as<uint32_t>(), s->d_val.as<uint64_t>(), n, &s->d_misc.as<L2mMisc>()->first_bad, s->d_tmp.as<uint64_t>(), st);
+    }
+    L2mAggArgs g;
+    g.sid_col = s->d_sid.as<uint32_t>(); g.val_col = s->d_val.as<uint64_t>(); g.n = n;
+    g.first_bad = &s->d_misc.as<L2mMisc>()->first_bad;
+    g.rows = s->d_rows.as<unsigned long long>(); g.W = s->W; g.mode = s->mode; g.nb = s->nb;
+    g.bounds = s->d_bounds.as<double>(); g.idx_base = s->idx_base; g.n_series = &s->d_ctr.as<L2mCtr>()->n_series;
+    { ProfScope ps(f, st, "k_l2m_aggregate"); launch_l2m_aggregate(g, cus, st); }
+    HIPOK(hipStreamSynchronize(st));
+    s->idx_base += n;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ results
+extern "C" int flbgpu_l2m_info(flbgpu_filter *f, int *mode, int *label_count, int *nbuckets, int *row_words) {
+    if (!f || f->kind != F_L2M) return -1;
+    L2mState *s = f->l2m;
+    if (mode) *mode = s->mode;
+    if (label_count) *label_count = (int) s->labels.size();
+    if (nbuckets) *nbuckets = s->nb;
+    if (row_words) *row_words = s->W;
+    return 0;
+}
+extern "C" const char *flbgpu_l2m_label_key(flbgpu_filter *f, int i) {
+    if (!f || f->kind != F_L2M || i < 0 || i >= (int) f->l2m->label_keys.size()) return nullptr;
+    return f->l2m->label_keys[i].c_str();
+}
+extern "C" int flbgpu_l2m_bounds(flbgpu_filter *f, double *bounds) {
+    if (!f || f->kind != F_L2M) return -1;
+    for (int i = 0; i < f->l2m->nb; i++) bounds[i] = f->l2m->bounds[i];
+    return f->l2m->nb;
+}
+extern "C" void flbgpu_l2m_set_index_base(flbgpu_filter *f, uint64_t base) { if (f && f->kind == F_L2M) f->l2m->idx_base = base; }
+extern "C" void flbgpu_l2m_stats(flbgpu_filter *f, uint64_t *out5) {
+    L2mState *s = f->l2m;
+    out5[0] = s->last_obs; out5[1] = s->last_deferred; out5[2] = s->last_stale; out5[3] = s->grows; out5[4] = s->cap;
+}
+
+// mergeable state of the series that exist (first-appearance order): rows[n][row_words] and the
+// label tuples as NUL-terminated strings back to back, key_off[n + 1] delimiting them.
+// Returns the number of series, or -(needed count) - 1 ... see header.
+extern "C" int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint64_t *rows, uint64_t *key_off, char *keys,
+                                     size_t keys_cap, size_t *keys_needed) {
+    if (!f || f->kind != F_L2M) return -1;
+    L2mState *s = f->l2m;
+    L2mCtr c;
+    if (hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return -1; }
+    const uint32_t ns = c.n_series;
+    std::vector<uint64_t> hrows((size_t) ns * s->W);
+    std::vector<unsigned long long> hoff(ns);
+    std::vector<uint32_t> hlen(ns);
+    std::vector<uint8_t> arena(c.arena_used);
+    bool ok = true;
+    if (ns) {
+        ok = hipMemcpy(hrows.data(), s->d_rows.p, hrows.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(hoff.data(), s->d_key_off.p, (size_t) ns * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(hlen.data(), s->d_key_len.p, (size_t) ns * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             (arena.empty() || hipMemcpy(arena.data(), s->d_arena.p, arena.size(), hipMemcpyDeviceToHost) == hipSuccess);
+    }
+    if (!ok) { set_err("log_to_metrics: device read failed"); return -1; }
+    // a series exists once a record touched it (dictionary entries created by rows behind a
+    // decode error never were)
+    std::vector<uint32_t> live;
+    for (uint32_t i = 0; i < ns; i++) if (hrows[(size_t) i * s->W + L2M_W_FIRST] != 0) live.push_back(i);
+    std::sort(live.begin(), live.end(), [&](uint32_t a, uint32_t b) {
+        return ~hrows[(size_t) a * s->W + L2M_W_FIRST] < ~hrows[(size_t) b * s->W + L2M_W_FIRST];
+    });
+    size_t need = 0;
+    for (uint32_t i : live) need += hlen[i];
+    if (keys_needed) *keys_needed = need;
+    if (live.size() > max_series || need > keys_cap) return -(int64_t) live.size() - 2;
+    size_t ko = 0;
+    for (size_t j = 0; j < live.size(); j++) {
+        uint32_t i = live[j];
+        memcpy(rows + j * s->W, &hrows[(size_t) i * s->W], (size_t) s->W * 8);
+        key_off[j] = ko;
+        memcpy(keys + ko, arena.data() + hoff[i], hlen[i]);
+        ko += hlen[i];
+    }
+    key_off[live.size()] = ko;
+    return (int64_t) live.size();
+}
+
+// one merged row -> the numbers cmetrics would hold.  Pure host arithmetic on integers.
+extern "C" int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
+                                       double *sum) {
+    *value = 0; *count = 0; *sum = 0;
+    if (mode == L2M_COUNTER) {
+        // cmt_counter_inc adds 1.0 to an f64 (lib/cmetrics/src/cmt_counter.c:100-116): exact up to 2^53, stuck there after
+        uint64_t c = row[L2M_W_COUNT];
+        if (c > (1ull << 53)) c = 1ull << 53;
+        *value = (double) c;
+        return 0;
+    }
+    if (mode == L2M_GAUGE) { memcpy(value, &row[L2M_W_LASTVAL], 8); return 0; }
+    // histogram: cumulative buckets (lib/cmetrics/src/cmt_histogram.c:344-356)
+    uint64_t run = 0;
+    for (int b = 0; b <= nbuckets; b++) { run += row[L2M_W_BUCKET + b]; buckets[b] = run; }
+    *count = run;
+    const uint64_t n_nan = row[L2M_W_SPECIAL], n_pinf = row[L2M_W_SPECIAL + 1], n_ninf = row[L2M_W_SPECIAL + 2];
+    uint64_t bits;
+    if (n_nan || (n_pinf && n_ninf)) bits = nc::DBL_NAN_BITS;
+    else if (n_pinf) bits = nc::DBL_INF_BITS;
+    else if (n_ninf) bits = nc::DBL_INF_BITS | nc::DBL_SIGN;
+    else {
+        // carry-propagate the digits (they may be sums over GPUs), then sign-magnitude
+        uint64_t d[L2M_NLIMB];
+        long long carry = 0;
+        for (int j = 0; j < L2M_NLIMB - 1; j++) {
+            long long t = (long long) row[L2M_W_LIMB + j] + carry;
+            long long lo = t & 0xFFFFFFFFll;
+            carry = (t - lo) >> 32;
+            d[j] = (uint64_t) lo;
+        }
+        long long top = (long long) row[L2M_W_LIMB + L2M_NLIMB - 1] + carry;
+        bool neg = top < 0;
+        uint64_t utop = (uint64_t) top;
+        if (neg) {
+            uint64_t c = 1;
+            for (int j = 0; j < L2M_NLIMB - 1; j++) { uint64_t t = (~d[j] & 0xFFFFFFFFull) + c; d[j] = t & 0xFFFFFFFFull; c = t >> 32; }
+            utop = ~utop + c;
+        }
+        d[L2M_NLIMB - 1] = utop;
+        // highest set bit; digit j has weight 2^(32 j - 1074), the top digit is a full 64-bit word
+        int hj = -1;
+        for (int j = L2M_NLIMB - 1; j >= 0; j--) if (d[j]) { hj = j; break; }
+        if (hj < 0) bits = 0;
+        else {
+            // gather the top 64 bits below (and including) the leading one + sticky
+            const int lead = 63 - __builtin_clzll(d[hj]);                 // bit inside digit hj
+            const int64_t top_pos = (int64_t) 32 * hj + lead;             // absolute bit index of the leading one
+            uint64_t m = 0;
+            bool sticky = false;
+            for (int64_t k = 0; k < 64; k++) {
+                int64_t pos = top_pos - k;
+                uint64_t bit = 0;
+                if (pos >= 0) {
+                    int j = (int) (pos / 32);
+                    if (j >= L2M_NLIMB - 1) bit = (d[L2M_NLIMB - 1] >> (pos - 32 * (L2M_NLIMB - 1))) & 1;
+                    else bit = (d[j] >> (pos % 32)) & 1;
+                }
+                m = (m << 1) | bit;
+            }
+            const int64_t low_pos = top_pos - 63;                         // weight of m's bit 0
+            for (int j = 0; j < L2M_NLIMB && !sticky; j++) {
+                const int64_t lo = (int64_t) 32 * j;
+                if (lo >= low_pos) break;
+                const int64_t width = j < L2M_NLIMB - 1 ? 32 : 64;
+                const int64_t below = std::min<int64_t>(low_pos - lo, width);     // bits of this digit under low_pos
+                const uint64_t mask = below >= 64 ? ~0ull : ((1ull << below) - 1);
+                if (d[j] & mask) sticky = true;
+            }
+            bits = nc::make_double_bits(m, low_pos - 1074, sticky) | (neg ? nc::DBL_SIGN : 0);
+        }
+    }
+    memcpy(sum, &bits, 8);
+    return 0;
+}
+
+// device instantiation check of numconv.hpp (tests only)
+extern "C" int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *consumed) {
+    if (n == 0) return 0;
+    void *d_s = nullptr, *d_o = nullptr, *d_b = nullptr, *d_c = nullptr;
+    bool ok = hipMalloc(&d_s, off[n] + 16) == hipSuccess && hipMalloc(&d_o, (n + 1) * 4) == hipSuccess &&
+              hipMalloc(&d_b, n * 8) == hipSuccess && hipMalloc(&d_c, n * 4) == hipSuccess;
+    ok = ok && hipMemcpy(d_s, strs, off[n], hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_o, off, (n + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && l2m_test_numconv((const char *) d_s, (const uint32_t *) d_o, n, mode, (uint64_t *) d_b, (int *) d_c);
+    ok = ok && hipMemcpy(bits, d_b, n * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(consumed, d_c, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    (void) hipFree(d_s); (void) hipFree(d_o); (void) hipFree(d_b); (void) hipFree(d_c);
+    if (!ok) set_err("numconv device self-test failed to run");
+    return ok ? 0 : -1;
+}

@@ -16,8 +16,9 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define NC_HD __host__ __device__ __forceinline__
-#define NC_HD_NOINL __host__ __device__
+#define NC_HD_NOINL __host__ __device__ inline
 #else
 #define NC_HD inline
 #define NC_HD_NOINL inline

@@ -1,7 +1,7 @@
 /*
  * flb_gpu.h -- C ABI of libflbgpu.so: the MI355X-native implementation of Fluent Bit's per-record
- * filter hot path (flb_filter_do -> cb_filter of filter_parser / filter_grep, flb_parser_do for
- * regex parsers).  Plain pointers and sizes only; every entry point names the reference
+ * filter hot path (flb_filter_do -> cb_filter of filter_parser / filter_grep / filter_log_to_metrics,
+ * flb_parser_do for regex parsers).  Plain pointers and sizes only; every entry point names the reference
  * interface it replaces (paths relative to the fluent-bit source tree).
  *
  * Two call levels are offered for each filter:
@@ -76,6 +76,43 @@ flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int reserve_dat
 flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *const *kinds, const char *const *values,
                                          const char *logical_op);
 
+/* ---- filter_log_to_metrics: replaces cb_log_to_metrics_init / cb_log_to_metrics_filter -----------
+ * plugins/filter_log_to_metrics/log_to_metrics.c:655-968,970-1156.  (keys[i], values[i]) are the
+ * instance's properties in configuration order; the ones read are regex / exclude (set_rules
+ * :216-312 -- the field is used verbatim, a name without '$' is a top-level key), label_field /
+ * add_label (set_labels :355-497) and bucket (set_buckets :540-595); metric_mode, kubernetes_mode,
+ * value_field and discard_logs keep their property names.  metric_name / namespace / subsystem /
+ * description, the tag, the emitter and the flush timer only label and ship the cmetrics context:
+ * they stay with the plugin shim.
+ * flbgpu_filter_run / flbgpu_filter_run_dev on this filter return NOTOUCH, or MODIFIED with an empty
+ * output when discard_logs is set (:1141-1145); the side effect is the series state below. */
+flbgpu_filter *flbgpu_filter_l2m_create(const char *metric_mode, int nprops, const char *const *keys,
+                                        const char *const *values, int kubernetes_mode, const char *value_field,
+                                        int discard_logs);
+/* mode 0 counter / 1 gauge / 2 histogram (log_to_metrics.h:41-43); row_words = 64-bit words of one
+ * series row in flbgpu_l2m_export */
+int flbgpu_l2m_info(flbgpu_filter *f, int *mode, int *label_count, int *nbuckets, int *row_words);
+const char *flbgpu_l2m_label_key(flbgpu_filter *f, int i);      /* ctx->label_keys[i] */
+int flbgpu_l2m_bounds(flbgpu_filter *f, double *bounds);        /* ascending upper bounds; returns nbuckets */
+/* Series state in first-appearance order (the order cmt_map keeps its metrics in,
+ * lib/cmetrics/src/cmt_map.c:377-452).  rows[n][row_words] are exact integer words that merge by
+ * max (words 0,1; word 2 follows word 1) or add (the rest) -- across chunks and across GPUs; keys
+ * holds each series' label values as NUL-terminated strings back to back, key_off[n+1] delimits them.
+ * Returns n, or -(n) - 2 when max_series / keys_cap are too small (*keys_needed = bytes wanted),
+ * -1 on error. */
+int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint64_t *rows, uint64_t *key_off, char *keys,
+                          size_t keys_cap, size_t *keys_needed);
+/* One (possibly merged) row -> what cmetrics holds: counter/gauge value, or cumulative buckets
+ * [nbuckets + 1] (+Inf last), count and sum (lib/cmetrics/src/cmt_histogram.c:328-361).  Host
+ * arithmetic on integers only; the sum is the exact sum of the observations rounded once. */
+int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
+                            double *sum);
+/* Global index of the next record (orders first-appearance / last-writer across shards). */
+void flbgpu_l2m_set_index_base(flbgpu_filter *f, uint64_t base);
+/* last run: observations, rows sent to the exact-arithmetic kernel, rows with a stale value; total
+ * dictionary growths; dictionary slots */
+void flbgpu_l2m_stats(flbgpu_filter *f, uint64_t *out5);
+
 void flbgpu_filter_destroy(flbgpu_filter *f);
 
 /* cb_filter (include/fluent-bit/flb_filter.h:57-81): `data` is borrowed host memory.  On
@@ -121,6 +158,16 @@ int flbgpu_rx_simulate_match(void *h, const char *s, int len);
 void flbgpu_rx_info(void *h, int *info12);
 int flbgpu_rx_names(void *h, char *buf, int cap);
 void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call: fast, lookahead, slow */
+
+/* ---- diagnostics: text <-> binary64 (csrc/numconv.hpp) ----------------------------------------
+ * strtod() (mode 0) / sscanf("%lf") (mode 1) and printf("%f") / ("%ld") as the kernels compute them;
+ * the host entry points run the host instantiation of the same header (CPU tests fuzz them against
+ * glibc), flbgpu_nc_scan_double_dev runs a batch on the device.  status: 0 no conversion, 1 ok,
+ * 2 = needs the exact path (only when exact == 0). */
+int flbgpu_nc_scan_double(const char *s, int len, int mode, int exact, double *out, int *consumed);
+int flbgpu_nc_fmt_f6(double v, char *buf, int cap);
+int flbgpu_nc_fmt_ld(long long v, char *buf);
+int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *consumed);
 
 #ifdef __cplusplus
 }

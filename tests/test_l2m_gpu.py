@@ -1,0 +1,306 @@
+"""GPU parity of filter_log_to_metrics: the HIP path through the C ABI against the CPU oracle.
+
+Bit-exact: series set and order, label bytes, counter values, gauge values, bucket counts, counts.
+Histogram sums: the device keeps the exact sum of the observations and rounds once, the reference
+adds sequentially in f64.  So the sum is compared (a) bit-exactly against math.fsum of the observed
+values, and (b) against the oracle bit-exactly whenever sequential addition is exact (integers /
+dyadic values) and within (n-1) * eps * sum|v| otherwise."""
+import math, os, random, struct, subprocess, sys
+import numpy as np
+import pytest
+import oracle_binding as ob
+import synth
+from synth import v2_record, legacy_record, mp, Raw
+import flbamd_loader
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+APACHE2 = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$'
+TF = "%d/%b/%Y:%H:%M:%S %z"
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def bits(x):
+    return struct.pack("<d", x)
+
+
+def same_f64(a, b):
+    return bits(a) == bits(b) or (math.isnan(a) and math.isnan(b))
+
+
+def check(g, mode, props, chunks, k8s=False, value_field=None, exact_sums=None, sum_mode="exact_or_bound", discard=False):
+    """runs the same chunks through oracle and product and compares the cmetrics state"""
+    o = ob.L2M(mode, props, kubernetes_mode=k8s, value_field=value_field, discard_logs=discard)
+    f = g.FilterLogToMetrics(mode, props, kubernetes_mode=k8s, value_field=value_field, discard_logs=discard)
+    for c in chunks:
+        ro = o.filter(c)
+        rg, out = f.filter(c)
+        assert ro == rg
+        if rg == g.MODIFIED:
+            assert out == b""
+    okeys, obounds, osn = o.snapshot()
+    assert okeys == f.label_keys
+    assert obounds == f.bounds
+    gsn = f.snapshot()
+    assert [s["labels"] for s in gsn] == [s["labels"] for s in osn]
+    for a, b in zip(gsn, osn):
+        if mode != "histogram":
+            assert same_f64(a["value"], b["value"]), (a, b)
+            continue
+        assert a["buckets"] == b["buckets"], (a, b)
+        assert a["count"] == b["count"]
+        if exact_sums is not None:
+            assert same_f64(a["sum"], exact_sums[a["labels"]]), (a["labels"], a["sum"], exact_sums[a["labels"]])
+        if sum_mode == "exact":
+            assert same_f64(a["sum"], b["sum"]), (a, b)
+        elif math.isnan(b["sum"]) or math.isinf(b["sum"]):
+            assert same_f64(a["sum"], b["sum"]), (a, b)
+        elif sum_mode != "none":
+            tol = max(a["count"] - 1, 0) * 2.0 ** -52 * max(abs(a["sum"]), abs(b["sum"]), 1e-300) * 4
+            assert abs(a["sum"] - b["sum"]) <= tol, (a, b)
+    st = f.stats()
+    f.close()
+    return gsn, st
+
+
+K8S = {"container_name": "mycontainer", "namespace_name": "k8s-dummy", "docker_id": "abc123",
+       "pod_name": "testpod", "pod_id": "def456"}
+
+
+def msg(message, direction, duration="20"):
+    return v2_record(1448403340, 0, {"message": message, "kubernetes": K8S, "duration": duration, "color": "red",
+                                     "direction": direction})
+
+
+LABELS = [("label_field", "color"), ("label_field", "direction")]
+
+
+def test_reference_runtime_cases(g):
+    # tests/runtime/filter_log_to_metrics.c, one call per pushed record like in_lib delivers them
+    m1, m2, m3 = msg("dummy", "right"), msg("dummy", "left"), msg("hello", "left")
+    s, _ = check(g, "counter", LABELS, [m1] * 5, k8s=True)
+    assert s[0]["value"] == 5.0 and s[0]["labels"][-2:] == (b"red", b"right")
+    s, _ = check(g, "counter", LABELS, [m1] * 5 + [m2] * 3, k8s=True)
+    assert [x["value"] for x in s] == [5.0, 3.0]
+    s, _ = check(g, "gauge", LABELS, [m1], value_field="duration")
+    assert s[0]["value"] == 20.0
+    s, _ = check(g, "histogram", LABELS, [m1] * 5, value_field="duration", sum_mode="exact")
+    assert s[0]["buckets"] == [0] * 11 + [5] and s[0]["sum"] == 100.0 and s[0]["count"] == 5
+    s, _ = check(g, "counter", LABELS + [("regex", "message .*el.*")], [m1, m3] * 3)
+    assert [(x["labels"], x["value"]) for x in s] == [((b"red", b"left"), 3.0)]
+    s, _ = check(g, "counter", [("regex", "message .*el.*")], [m3 * 3 + m1])
+    assert [(x["labels"], x["value"]) for x in s] == [((), 3.0)]
+    s, _ = check(g, "counter", [("add_label", "pod_name $kubernetes['pod_name']")], [m1 * 2])
+    assert [(x["labels"], x["value"]) for x in s] == [((b"testpod",), 2.0)]
+    check(g, "counter", [], [m1], discard=True)
+
+
+def test_label_formats(g):
+    recs = [{"a": "x" * 300}, {"a": b"ab\x00cd"}, {"a": 1.5}, {"a": -7}, {"a": 2 ** 64 - 1}, {"a": True}, {"a": None},
+            {"a": {"m": 1}}, {"a": [1, 2]}, {"b": 1}, {"a": 1e300}, {"a": 0.0000004}, {"a": Raw(b"\xca\x3f\xc0\x00\x00")},
+            {"a": -0.0}, {"a": float("inf")}, {"a": float("nan")}, {"a": 123456789.987654321}, {"a": 2 ** 63}, {"a": -2 ** 63},
+            {"a": 0}, {"a": 10 ** 18}, {"a": 5e-324}, {"a": 0.9999995}, {"a": 0.5000005}, {"a": 1e22}, {"a": 255.0000005}]
+    data = b"".join(v2_record(1, 0, r) for r in recs)
+    s, st = check(g, "counter", [("label_field", "a")], [data])
+    assert st["deferred"] >= 10            # the float labels went through the exact-arithmetic kernel
+    assert s[0]["labels"] == (b"x" * 251,) and s[1]["labels"] == (b"ab",)
+
+
+def rand_label(rng):
+    t = rng.randrange(10)
+    if t < 5: return rng.choice(["GET", "POST", "PUT", "a", "", "x" * rng.randrange(1, 40), "é", "200", "404"])
+    if t == 5: return rng.randrange(-1000, 1000)
+    if t == 6: return rng.choice([0.5, 2.25, -1.0, 1e6])
+    if t == 7: return rng.choice([True, None])
+    if t == 8: return {"in": rng.choice(["p", "q"]), "arr": [1, "z", {"k": "deep"}]}
+    return rng.choice([b"\xff\xfe", "tab\there"])
+
+
+def test_random_records_counter(g):
+    rng = random.Random(11)
+    chunks = []
+    for c in range(4):
+        recs = []
+        for i in range(3000):
+            body = {}
+            if rng.random() < 0.9: body["m"] = rand_label(rng)
+            if rng.random() < 0.8: body["code"] = rand_label(rng)
+            if rng.random() < 0.7: body["nest"] = {"in": rng.choice(["p", "q", 3]), "arr": [1, rng.choice(["z", "y"]), {"k": "deep"}]}
+            body["log"] = rng.choice(["an error here", "DEBUG noise", "fine", "DEBUG error", "érror"])
+            r = rng.random()
+            if r < 0.1: recs.append(legacy_record(rng.randrange(1, 2 ** 31), body))
+            elif r < 0.13: recs.append(v2_record(0xFFFFFFFF, 0, body))       # group marker: processed like any record
+            elif r < 0.15: recs.append(mp(rng.choice([1, "str", {"k": 1}])))  # not an array: skipped
+            elif r < 0.17: recs.append(mp([1]))                               # short array: no map
+            else: recs.append(v2_record(rng.randrange(1, 2 ** 31), rng.randrange(10 ** 9), body))
+        chunks.append(b"".join(recs))
+    props = [("exclude", "$log ^DEBUG"), ("label_field", "m"), ("add_label", "c $code"),
+             ("add_label", "deep $nest['arr'][2]['k']"), ("add_label", "in $nest['in']"), ("label_field", "$TAG"),
+             ("regex", "log err|fine|^.rror")]
+    s, st = check(g, "counter", props, chunks)
+    assert len(s) > 50 and st["deferred"] > 0
+
+
+def test_histogram_values_and_stale(g):
+    rng = random.Random(3)
+    vals = ["5", "abc", " 7e1xyz", "0x", "0x1p4", "1e400", "-3.25", True, None, 50, -2, 0.5, 1e-3, "", "inf", "nanx", "infinit",
+            "12345678901234567890123", "0.1", "1e22", "9007199254740993", "4.9e-324", ".5", "+.e1", Raw(b"\xca\x41\x20\x00\x00")]
+    chunks = []
+    for c in range(3):
+        recs = []
+        for i in range(4000):
+            body = {"k": rng.choice(["a", "b", "c"])}
+            if rng.random() < 0.95: body["v"] = rng.choice(vals)
+            recs.append(v2_record(1, 0, body))
+        chunks.append(b"".join(recs))
+    props = [("label_field", "k"), ("bucket", "10"), ("bucket", "0.5"), ("bucket", "100"), ("bucket", "-1"), ("bucket", "1e21")]
+    s, st = check(g, "histogram", props, chunks, value_field="v")
+    assert st["stale"] > 0
+    # gauge: last writer wins, stale values included
+    check(g, "gauge", [("label_field", "k")], chunks, value_field="v")
+    # a chunk that starts with failures observes 0.0 (gauge_value starts at 0 in every call)
+    c0 = b"".join(v2_record(1, 0, {"k": "a", "v": "zzz"}) for _ in range(10)) + v2_record(1, 0, {"k": "a", "v": "4"}) + \
+        v2_record(1, 0, {"k": "b", "v": "zzz"})
+    check(g, "histogram", [("label_field", "k")], [c0, c0], value_field="v", sum_mode="exact")
+    check(g, "gauge", [("label_field", "k")], [c0, c0], value_field="v")
+
+
+def test_histogram_exact_sum(g):
+    rng = random.Random(9)
+    recs, per = [], {}
+    for i in range(20000):
+        k = rng.choice([b"a", b"b", b"c", b"d"])
+        t = rng.random()
+        if t < 0.5: v = struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64) & 0xBFFFFFFFFFFFFFFF | (rng.randrange(900, 1150) << 52)))[0]
+        elif t < 0.7: v = rng.uniform(-1e6, 1e6)
+        elif t < 0.8: v = float(rng.randrange(-10 ** 15, 10 ** 15))
+        elif t < 0.9: v = struct.unpack("<d", struct.pack("<Q", rng.getrandbits(52) | (rng.getrandbits(1) << 63)))[0]   # subnormal
+        else: v = rng.choice([1e300, -1e300, 5e-324, 0.0, -0.0, 2.0 ** 1000, -2.0 ** 1000])
+        if not math.isfinite(v): continue
+        per.setdefault((k,), []).append(v)
+        recs.append(v2_record(1, 0, {"k": k, "v": v}))
+    exact = {k: math.fsum(v) for k, v in per.items()}
+    data = b"".join(recs)
+    n, off, _ = g.index_host(data)
+    cut = [0, int(off[n // 3]), int(off[2 * n // 3]), len(data)]
+    check(g, "histogram", [("label_field", "k")], [data[cut[i]:cut[i + 1]] for i in range(3)], value_field="v", exact_sums=exact,
+          sum_mode="none")
+    # non-finite observations
+    sp = [1.0, float("inf"), 2.0, float("nan"), float("-inf")]
+    for pick in ([0, 1, 2], [0, 4, 2], [0, 1, 4], [3, 0], [0, 2]):
+        d = b"".join(v2_record(1, 0, {"v": sp[i]}) for i in pick)
+        check(g, "histogram", [], [d], value_field="v", sum_mode="exact")
+
+
+def test_dictionary_growth(g):
+    # many series with a tiny initial dictionary/arena: the pass reruns after each growth
+    code = r'''
+import sys, random
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import flbamd_loader, oracle_binding as ob
+from synth import v2_record
+g = flbamd_loader.load(); g.init(0)
+rng = random.Random(1)
+chunks = []
+for c in range(3):
+    chunks.append(b"".join(v2_record(1, 0, {"a": "k%%d" %% rng.randrange(6000), "b": rng.randrange(3), "v": rng.randrange(100)}) for _ in range(20000)))
+props = [("label_field", "a"), ("label_field", "b")]
+o = ob.L2M("histogram", props, value_field="v"); f = g.FilterLogToMetrics("histogram", props, value_field="v")
+for c in chunks:
+    o.filter(c); f.filter(c)
+a = f.snapshot(); b = o.snapshot()[2]
+assert f.stats()["grows"] >= 5, f.stats()
+assert [x["labels"] for x in a] == [x["labels"] for x in b]
+assert all(x["buckets"] == y["buckets"] and x["sum"] == y["sum"] and x["count"] == y["count"] for x, y in zip(a, b))
+print("OK", len(a), f.stats())
+''' % (ROOT, HERE)
+    env = dict(os.environ, FLBGPU_L2M_INIT_CAP="16", FLBGPU_L2M_INIT_ARENA="64")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_decode_error_stops_the_call(g):
+    good = v2_record(1, 0, {"k": "a", "v": 1})
+    data = good * 100 + b"\xc1" + good * 50
+    s, _ = check(g, "counter", [("label_field", "k")], [data, good * 3])
+    assert s[0]["value"] == 103.0
+    # device chunk whose row 100 is not a valid object: rows behind it never ran (and create no series)
+    rows = [good] * 100 + [b"\x92\x01"] + [v2_record(1, 0, {"k": "never", "v": 1})] * 5
+    off = np.zeros(len(rows) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in rows])
+    blob = b"".join(rows)
+    L = g.lib()
+    d_data = L.flbgpu_dev_alloc(len(blob) + 16); d_off = L.flbgpu_dev_alloc(off.nbytes)
+    L.flbgpu_memcpy_h2d(d_data, blob, len(blob)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+    f = g.FilterLogToMetrics("counter", [("label_field", "k")])
+    r, _ = f.filter_dev(g.DevChunk(d_data, d_off, len(rows), len(blob)))
+    assert r == g.NOTOUCH
+    assert [(x["labels"], x["value"]) for x in f.snapshot()] == [((b"a",), 100.0)]
+    f.close()
+    L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+
+
+def test_apache_chain_parser_then_metrics(g):
+    # BASELINE config 4 shape: parsed access log -> counter by (method, code) and histogram of size
+    data, off, ep = synth.apache_records(200000)
+    po = ob.Parser(APACHE2, time_fmt=TF, time_key="time")
+    r, parsed = ob.FilterParser("log", [po]).filter(bytes(data))
+    gp = g.Parser(APACHE2, time_fmt=TF, time_key="time")
+    fp = g.FilterParser("log", [gp])
+    n = len(off) - 1
+    L = g.lib()
+    d_data = L.flbgpu_dev_alloc(int(data.nbytes)); d_off = L.flbgpu_dev_alloc(off.nbytes)
+    L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, int(data.nbytes)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+    r1, o1 = fp.filter_dev(g.DevChunk(d_data, d_off, n, int(data.nbytes)))
+    assert r1 == g.MODIFIED
+    for mode, props, vf in (("counter", [("label_field", "method"), ("label_field", "code")], None),
+                            ("histogram", [("label_field", "code"), ("bucket", "1000"), ("bucket", "100000"), ("bucket", "10")], "size"),
+                            ("counter", [("label_field", "code"), ("regex", "code ^5")], None)):
+        o = ob.L2M(mode, props, value_field=vf)
+        o.filter(parsed)
+        f = g.FilterLogToMetrics(mode, props, value_field=vf)
+        r2, _ = f.filter_dev(o1)
+        assert r2 == g.NOTOUCH
+        a, b = f.snapshot(), o.snapshot()[2]
+        assert [x["labels"] for x in a] == [x["labels"] for x in b]
+        for x, y in zip(a, b):
+            assert x["value"] == y["value"] and x["buckets"] == y["buckets"] and x["count"] == y["count"] and x["sum"] == y["sum"]
+        if mode == "counter" and len(props) == 2:
+            assert sum(x["value"] for x in a) == n
+        f.close()
+    fp.close(); gp.close()
+    L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+
+
+def test_numconv_on_device(g):
+    import ctypes
+    rng = random.Random(2)
+    cases = ["1e", "0x", "0x.", "infinit", "inf", "nan", " 12", "1e400", "4.9e-324", "2.4703282292062327e-324", "2.4703282292062328e-324",
+             "9007199254740993", "1e23", "8.41e21", "0x1.fffffffffffff8p0", "123456789012345678901234567890", "1.7976931348623159e308"]
+    for _ in range(3000):
+        t = rng.randrange(4)
+        if t == 0: cases.append(repr(struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0]))
+        elif t == 1: cases.append("%d.%de%d" % (rng.randrange(10 ** 6), rng.getrandbits(70), rng.randrange(-330, 300)))
+        elif t == 2: cases.append("%.*e" % (rng.randrange(1, 40), rng.uniform(-1, 1) * 10.0 ** rng.randrange(-320, 308)))
+        else: cases.append("".join(rng.choice("0123456789.eE+-xXpinfa ") for _ in range(rng.randrange(1, 10))))
+    blob = b"".join(c.encode() for c in cases)
+    off = np.zeros(len(cases) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(c.encode()) for c in cases])
+    for mode in (0, 1):
+        bits_ = np.zeros(len(cases), dtype=np.uint64); cons = np.zeros(len(cases), dtype=np.int32)
+        assert g.lib().flbgpu_nc_scan_double_dev(blob, off.ctypes.data, len(cases), mode, bits_.ctypes.data, cons.ctypes.data) == 0
+        for i, c in enumerate(cases):
+            out = ctypes.c_double(); cn = ctypes.c_int()
+            st = g.lib().flbgpu_nc_scan_double(c.encode(), len(c.encode()), mode, 1, ctypes.byref(out), ctypes.byref(cn))
+            hb = struct.unpack("<Q", struct.pack("<d", out.value))[0]
+            if st == 1:
+                assert cons[i] == cn.value and (int(bits_[i]) == hb or (math.isnan(out.value))), (c, mode)
+            else:
+                assert cons[i] == -1, (c, mode)
