@@ -178,7 +178,7 @@ def test_histogram_exact_sum(g):
     for i in range(20000):
         k = rng.choice([b"a", b"b", b"c", b"d"])
         t = rng.random()
-        if t < 0.5: v = struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64) & 0xBFFFFFFFFFFFFFFF | (rng.randrange(900, 1150) << 52)))[0]
+        if t < 0.5: v = struct.unpack("<d", struct.pack("<Q", (rng.getrandbits(64) & 0x800FFFFFFFFFFFFF) | (rng.randrange(900, 1150) << 52)))[0]
         elif t < 0.7: v = rng.uniform(-1e6, 1e6)
         elif t < 0.8: v = float(rng.randrange(-10 ** 15, 10 ** 15))
         elif t < 0.9: v = struct.unpack("<d", struct.pack("<Q", rng.getrandbits(52) | (rng.getrandbits(1) << 63)))[0]   # subnormal
@@ -272,7 +272,7 @@ def test_apache_chain_parser_then_metrics(g):
         assert [x["labels"] for x in a] == [x["labels"] for x in b]
         for x, y in zip(a, b):
             assert x["value"] == y["value"] and x["buckets"] == y["buckets"] and x["count"] == y["count"] and x["sum"] == y["sum"]
-        if mode == "counter" and len(props) == 2:
+        if mode == "counter" and props[-1][0] != "regex":
             assert sum(x["value"] for x in a) == n
         f.close()
     fp.close(); gp.close()
