@@ -322,3 +322,317 @@ struct flb_filter_plugin filter_parser_gpu_plugin = {
     .config_map   = parser_config_map,
     .flags        = 0
 };
+
+/* ------------------------------------------------------------------ log_to_metrics */
+/*
+ * The device keeps the series state (flbgpu_filter_l2m_create / flbgpu_filter_run); this shim keeps
+ * what the reference plugin keeps around it (plugins/filter_log_to_metrics/log_to_metrics.c:655-968,
+ * 610-652): the cmetrics context with one counter / gauge / histogram, the hidden emitter input and
+ * the optional flush timer.  Publishing = copy the finalized series into the cmetrics context with
+ * the *_set calls and append it to the emitter.
+ */
+#include <fluent-bit/flb_input.h>
+#include <fluent-bit/flb_input_metric.h>
+#include <fluent-bit/flb_scheduler.h>
+#include <fluent-bit/flb_storage.h>
+#include <fluent-bit/flb_sds.h>
+#include <cmetrics/cmetrics.h>
+#include <cmetrics/cmt_counter.h>
+#include <cmetrics/cmt_gauge.h>
+#include <cmetrics/cmt_histogram.h>
+#include <cfl/cfl_time.h>
+
+struct l2m_gpu_ctx {
+    flbgpu_filter *f;                 /* first member: shared with cb_gpu_filter's view */
+    struct flb_filter_instance *ins;
+    int mode, label_count, nbuckets, row_words;
+    struct cmt *cmt;
+    struct cmt_counter *c;
+    struct cmt_gauge *g;
+    struct cmt_histogram *h;
+    struct flb_input_instance *emitter;
+    struct flb_sched_timer *timer;
+    int timer_mode;
+    int new_data;
+    /* config map targets */
+    flb_sds_t mode_name, value_field, metric_name, metric_namespace, metric_subsystem, metric_description;
+    flb_sds_t tag, emitter_name;
+    size_t emitter_mem_buf_limit;
+    int kubernetes_mode, discard_logs;
+    int flush_interval_sec, flush_interval_nsec;
+};
+
+/* device state -> cmetrics context -> emitter */
+static int l2m_gpu_publish(struct l2m_gpu_ctx *ctx)
+{
+    int64_t n;
+    int64_t s;
+    int i;
+    size_t need = 0;
+    size_t kcap = 1 << 16;
+    uint64_t cap = 1024;
+    uint64_t *rows = NULL;
+    uint64_t *koff = NULL;
+    uint64_t *buckets = NULL;
+    char *keys = NULL;
+    char **labels = NULL;
+    uint64_t ts = cfl_time_now();
+
+    for (;;) {
+        rows = flb_malloc(cap * ctx->row_words * sizeof(uint64_t));
+        koff = flb_malloc((cap + 1) * sizeof(uint64_t));
+        keys = flb_malloc(kcap);
+        if (!rows || !koff || !keys) {
+            flb_errno();
+            flb_free(rows); flb_free(koff); flb_free(keys);
+            return -1;
+        }
+        n = flbgpu_l2m_export(ctx->f, cap, rows, koff, keys, kcap, &need);
+        if (n >= 0) {
+            break;
+        }
+        flb_free(rows); flb_free(koff); flb_free(keys);
+        if (n == -1) {
+            flb_plg_error(ctx->ins, "%s", flbgpu_last_error());
+            return -1;
+        }
+        cap = (uint64_t) (-n - 2) + 16;
+        kcap = need + 16;
+    }
+    labels = flb_calloc(ctx->label_count ? ctx->label_count : 1, sizeof(char *));
+    buckets = flb_calloc(ctx->nbuckets + 1, sizeof(uint64_t));
+    for (s = 0; s < n && labels && buckets; s++) {
+        double value;
+        double sum;
+        uint64_t count;
+        char *p = keys + koff[s];
+
+        for (i = 0; i < ctx->label_count; i++) {      /* NUL-terminated label values back to back */
+            labels[i] = p;
+            p += strlen(p) + 1;
+        }
+        flbgpu_l2m_finalize_row(ctx->mode, ctx->nbuckets, rows + s * ctx->row_words, &value, buckets, &count, &sum);
+        if (ctx->mode == 0) {
+            cmt_counter_set(ctx->c, ts, value, ctx->label_count, labels);
+        }
+        else if (ctx->mode == 1) {
+            cmt_gauge_set(ctx->g, ts, value, ctx->label_count, labels);
+        }
+        else {
+            cmt_histogram_set_default(ctx->h, ts, buckets, sum, count, ctx->label_count, labels);
+        }
+    }
+    flb_free(labels); flb_free(buckets); flb_free(rows); flb_free(koff); flb_free(keys);
+    return flb_input_metrics_append(ctx->emitter, ctx->tag, flb_sds_len(ctx->tag), ctx->cmt);
+}
+
+static void cb_l2m_gpu_timer(struct flb_config *config, void *data)
+{
+    struct l2m_gpu_ctx *ctx = data;
+    (void) config;
+    if (ctx->new_data && l2m_gpu_publish(ctx) == 0) {
+        ctx->new_data = FLB_FALSE;
+    }
+}
+
+static int cb_l2m_gpu_filter(const void *data, size_t bytes, const char *tag, int tag_len,
+                             void **out_buf, size_t *out_size,
+                             struct flb_filter_instance *f_ins, struct flb_input_instance *i_ins,
+                             void *context, struct flb_config *config)
+{
+    struct l2m_gpu_ctx *ctx = context;
+    int ret;
+    (void) tag; (void) tag_len; (void) f_ins; (void) i_ins; (void) config;
+
+    ret = flbgpu_filter_run(ctx->f, data, bytes, out_buf, out_size);
+    if (ctx->timer_mode) {
+        ctx->new_data = FLB_TRUE;
+    }
+    else if (l2m_gpu_publish(ctx) != 0) {
+        flb_plg_error(ctx->ins, "could not append metrics");
+    }
+    return ret;
+}
+
+static int cb_l2m_gpu_exit(void *data, struct flb_config *config)
+{
+    struct l2m_gpu_ctx *ctx = data;
+    (void) config;
+    if (!ctx) {
+        return 0;
+    }
+    if (ctx->timer) {
+        flb_sched_timer_cb_destroy(ctx->timer);
+    }
+    if (ctx->cmt) {
+        cmt_destroy(ctx->cmt);
+    }
+    flbgpu_filter_destroy(ctx->f);
+    flb_free(ctx);
+    return 0;
+}
+
+static int cb_l2m_gpu_init(struct flb_filter_instance *f_ins, struct flb_config *config, void *data)
+{
+    int n = 0;
+    int i = 0;
+    int ms;
+    const char **keys;
+    const char **vals;
+    char **label_keys;
+    double *bounds;
+    const char *alias;
+    char alias_buf[256];
+    struct mk_list *head;
+    struct flb_kv *kv;
+    struct l2m_gpu_ctx *ctx;
+    struct flb_sched *sched;
+    (void) data;
+
+    if (ensure_gpu(f_ins) != 0) {
+        return -1;
+    }
+    ctx = flb_calloc(1, sizeof(struct l2m_gpu_ctx));
+    if (!ctx) {
+        flb_errno();
+        return -1;
+    }
+    ctx->ins = f_ins;
+    if (flb_filter_config_map_set(f_ins, ctx) < 0) {
+        flb_free(ctx);
+        return -1;
+    }
+    if (!ctx->tag || !ctx->metric_name || !ctx->metric_description) {
+        flb_plg_error(f_ins, "tag, metric_name and metric_description must be set");
+        flb_free(ctx);
+        return -1;
+    }
+    /* the multi-valued properties in configuration order (set_rules / set_labels / set_buckets) */
+    mk_list_foreach(head, &f_ins->properties) {
+        n++;
+    }
+    keys = flb_calloc(n ? n : 1, sizeof(char *));
+    vals = flb_calloc(n ? n : 1, sizeof(char *));
+    mk_list_foreach(head, &f_ins->properties) {
+        kv = mk_list_entry(head, struct flb_kv, _head);
+        keys[i] = kv->key;
+        vals[i] = kv->val;
+        i++;
+    }
+    ctx->f = flbgpu_filter_l2m_create(ctx->mode_name, n, keys, vals, ctx->kubernetes_mode, ctx->value_field,
+                                      ctx->discard_logs);
+    flb_free(keys);
+    flb_free(vals);
+    if (!ctx->f) {
+        flb_plg_error(f_ins, "%s", flbgpu_last_error());
+        flb_free(ctx);
+        return -1;
+    }
+    flbgpu_l2m_info(ctx->f, &ctx->mode, &ctx->label_count, &ctx->nbuckets, &ctx->row_words);
+
+    /* cmetrics context (:825-850); an empty subsystem defaults to the mode name (:769-776) */
+    label_keys = flb_calloc(ctx->label_count ? ctx->label_count : 1, sizeof(char *));
+    for (i = 0; i < ctx->label_count; i++) {
+        label_keys[i] = (char *) flbgpu_l2m_label_key(ctx->f, i);
+    }
+    ctx->cmt = cmt_create();
+    if (!ctx->metric_subsystem || flb_sds_len(ctx->metric_subsystem) == 0) {
+        ctx->metric_subsystem = ctx->mode_name;
+    }
+    if (ctx->mode == 0) {
+        ctx->c = cmt_counter_create(ctx->cmt, ctx->metric_namespace, ctx->metric_subsystem, ctx->metric_name,
+                                    ctx->metric_description, ctx->label_count, label_keys);
+    }
+    else if (ctx->mode == 1) {
+        ctx->g = cmt_gauge_create(ctx->cmt, ctx->metric_namespace, ctx->metric_subsystem, ctx->metric_name,
+                                  ctx->metric_description, ctx->label_count, label_keys);
+    }
+    else {
+        bounds = flb_calloc(ctx->nbuckets ? ctx->nbuckets : 1, sizeof(double));
+        flbgpu_l2m_bounds(ctx->f, bounds);
+        ctx->h = cmt_histogram_create(ctx->cmt, ctx->metric_namespace, ctx->metric_subsystem, ctx->metric_name,
+                                      ctx->metric_description,
+                                      cmt_histogram_buckets_create_size(bounds, ctx->nbuckets),
+                                      ctx->label_count, label_keys);
+        flb_free(bounds);
+    }
+    flb_free(label_keys);
+
+    /* hidden emitter input (:852-930) */
+    if (ctx->emitter_name && flb_sds_len(ctx->emitter_name) > 0) {
+        alias = ctx->emitter_name;
+    }
+    else {
+        snprintf(alias_buf, sizeof(alias_buf) - 1, "emitter_for_%s", flb_filter_name(f_ins));
+        alias = alias_buf;
+    }
+    if (flb_input_name_exists(alias, config)) {
+        flb_plg_error(f_ins, "emitter_name '%s' already exists", alias);
+        cb_l2m_gpu_exit(ctx, config);
+        return -1;
+    }
+    ctx->emitter = flb_input_new(config, "emitter", NULL, FLB_FALSE);
+    if (!ctx->emitter ||
+        flb_input_set_property(ctx->emitter, "alias", alias) == -1 ||
+        flb_input_set_property(ctx->emitter, "storage.type", "memory") == -1) {
+        flb_plg_error(f_ins, "cannot create metrics emitter instance");
+        cb_l2m_gpu_exit(ctx, config);
+        return -1;
+    }
+    if (ctx->emitter_mem_buf_limit > 0) {
+        ctx->emitter->mem_buf_limit = ctx->emitter_mem_buf_limit;
+    }
+    if (flb_input_instance_init(ctx->emitter, config) == -1 ||
+        flb_storage_input_create(config->cio, ctx->emitter) == -1) {
+        flb_plg_error(f_ins, "cannot initialize metrics emitter instance");
+        cb_l2m_gpu_exit(ctx, config);
+        return -1;
+    }
+
+    /* flush timer (:933-966): both intervals 0 => publish after every call */
+    ms = ctx->flush_interval_sec * 1000 + ctx->flush_interval_nsec / 1000000;
+    if (ms > 0) {
+        sched = flb_sched_ctx_get();
+        if (!sched || flb_sched_timer_cb_create(sched, FLB_SCHED_TIMER_CB_PERM, ms, cb_l2m_gpu_timer, ctx,
+                                                &ctx->timer) < 0) {
+            flb_plg_error(f_ins, "could not create timer callback");
+            cb_l2m_gpu_exit(ctx, config);
+            return -1;
+        }
+        ctx->timer_mode = FLB_TRUE;
+    }
+    flb_filter_set_context(f_ins, ctx);
+    return 0;
+}
+
+static struct flb_config_map l2m_config_map[] = {
+    { FLB_CONFIG_MAP_STR, "regex", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0, "Optional filter: KEY REGEX must match." },
+    { FLB_CONFIG_MAP_STR, "exclude", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0, "Optional filter: KEY REGEX must not match." },
+    { FLB_CONFIG_MAP_STR, "metric_mode", "counter", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, mode_name), "counter, gauge or histogram." },
+    { FLB_CONFIG_MAP_STR, "value_field", NULL, 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, value_field), "Numeric field for gauge / histogram." },
+    { FLB_CONFIG_MAP_STR, "metric_name", "a", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, metric_name), "Name of the metric." },
+    { FLB_CONFIG_MAP_STR, "metric_namespace", "log_metric", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, metric_namespace), "Namespace of the metric." },
+    { FLB_CONFIG_MAP_STR, "metric_subsystem", NULL, 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, metric_subsystem), "Subsystem of the metric." },
+    { FLB_CONFIG_MAP_STR, "metric_description", NULL, 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, metric_description), "Help text for metric." },
+    { FLB_CONFIG_MAP_BOOL, "kubernetes_mode", "false", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, kubernetes_mode), "Enable kubernetes log metric fields." },
+    { FLB_CONFIG_MAP_STR, "add_label", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0, "Add a label: NAME ACCESSOR." },
+    { FLB_CONFIG_MAP_STR, "label_field", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0, "Message field to include as a label." },
+    { FLB_CONFIG_MAP_STR, "bucket", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0, "Histogram bucket upper bound." },
+    { FLB_CONFIG_MAP_STR, "tag", NULL, 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, tag), "Metric Tag." },
+    { FLB_CONFIG_MAP_STR, "emitter_name", NULL, 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, emitter_name), "Name of the emitter." },
+    { FLB_CONFIG_MAP_SIZE, "emitter_mem_buf_limit", "10M", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, emitter_mem_buf_limit), "Emitter buffer limit." },
+    { FLB_CONFIG_MAP_INT, "flush_interval_sec", "0", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, flush_interval_sec), "Timer interval (s); 0/0 = emit immediately." },
+    { FLB_CONFIG_MAP_INT, "flush_interval_nsec", "0", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, flush_interval_nsec), "Timer interval (ns part)." },
+    { FLB_CONFIG_MAP_BOOL, "discard_logs", "false", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, discard_logs), "Drop the logs after processing." },
+    {0}
+};
+
+struct flb_filter_plugin filter_log_to_metrics_gpu_plugin = {
+    .name         = "log_to_metrics" FLBGPU_PLUGIN_SUFFIX,
+    .description  = "generate log derived metrics (MI355X)",
+    .cb_init      = cb_l2m_gpu_init,
+    .cb_filter    = cb_l2m_gpu_filter,
+    .cb_exit      = cb_l2m_gpu_exit,
+    .config_map   = l2m_config_map,
+    .flags        = 0
+};

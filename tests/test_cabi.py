@@ -82,3 +82,14 @@ def test_index_host(g):
     assert n == 100 and consumed == len(data)
     n, o, consumed = g.index_host(bytes(data[:277]) + b"\xc1" + bytes(data[277:]))
     assert n == 1 and consumed == 277
+
+
+def test_reference_side_binding_type_checks_against_reference_headers():
+    """fluent-bit_amd/plugin/filter_gpu_plugins.c (the struct flb_filter_plugin shim of INTEGRATION.md)
+    against the real fluent-bit headers; only where the reference tree is mounted."""
+    import os, subprocess, pytest
+    if not os.path.isdir("/root/reference/include/fluent-bit"):
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "fluent-bit_amd", "plugin", "check_syntax.sh")], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
