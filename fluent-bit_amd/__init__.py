@@ -73,6 +73,8 @@ def lib():
     L.flbgpu_rx_simulate_match.argtypes = [c_void_p, c_char_p, c_int]
     L.flbgpu_rx_info.argtypes = [c_void_p, POINTER(c_int)]
     L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
+    L.flbgpu_filter_chain_run.argtypes = [POINTER(c_void_p), c_int, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), c_void_p]
+    L.flbgpu_filter_chain_run_dev.argtypes = [POINTER(c_void_p), c_int, POINTER(DevChunk), POINTER(DevChunk), c_void_p]
     L.flbgpu_filter_l2m_create.restype = c_void_p
     L.flbgpu_filter_l2m_create.argtypes = [c_char_p, c_int, POINTER(c_char_p), POINTER(c_char_p), c_int, c_char_p, c_int]
     L.flbgpu_l2m_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
@@ -151,7 +153,8 @@ class _Filter:
         if r != MODIFIED:
             return r, None
         b = ctypes.string_at(out, sz.value) if sz.value else b""
-        _libc.free(out)
+        if out.value:
+            _libc.free(out)
         return r, b
 
     def filter_dev(self, chunk, stream=None):
@@ -202,6 +205,39 @@ class FilterGrep(_Filter):
         self.h = lib().flbgpu_filter_grep_create(n, kinds, vals, _b(logical_op))
         if not self.h:
             raise ValueError("flbgpu_filter_grep_create: " + last_error())
+
+
+class ChainStat(Structure):
+    _fields_ = [("ret", c_int), ("in_records", c_uint64), ("out_records", c_uint64), ("out_bytes", c_uint64)]
+
+
+class FilterChain:
+    """flb_filter_do (src/flb_filter.c:121-325) over GPU filters that match the chunk's tag."""
+
+    def __init__(self, filters):
+        self.filters = list(filters)
+        self.arr = (c_void_p * max(len(self.filters), 1))(*[f.h for f in self.filters])
+        self.stats = (ChainStat * max(len(self.filters), 1))()
+
+    def filter(self, data):
+        """-> (MODIFIED|NOTOUCH, bytes|None); NOTOUCH means the engine keeps `data`"""
+        out = c_void_p(); sz = c_size_t()
+        r = lib().flbgpu_filter_chain_run(self.arr, len(self.filters), data, len(data), byref(out), byref(sz), self.stats)
+        if r != MODIFIED:
+            return r, None
+        b = ctypes.string_at(out, sz.value) if sz.value else b""
+        if out.value:
+            _libc.free(out)
+        return r, b
+
+    def filter_dev(self, chunk):
+        out = DevChunk()
+        r = lib().flbgpu_filter_chain_run_dev(self.arr, len(self.filters), byref(chunk), byref(out), self.stats)
+        return r, out
+
+    def last_stats(self):
+        return [dict(ret=s.ret, in_records=s.in_records, out_records=s.out_records, out_bytes=s.out_bytes)
+                for s in self.stats[: len(self.filters)]]
 
 
 def index_host(data):

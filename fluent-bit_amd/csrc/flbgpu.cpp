@@ -561,17 +561,55 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     return true;
 }
 
-extern "C" int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream) {
-    hipStream_t st = stream ? (hipStream_t) stream : f->stream;
+// one cb_filter call on a device-resident chunk; `garbage` = undecodable bytes follow the rows
+static int run_any_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, bool garbage) {
     int ret = FLBGPU_FILTER_NOTOUCH;
     bool ok;
     if (f->kind == F_L2M) {
         ok = run_l2m_dev(f, in, st, &ret);
         if (ok && ret == FLBGPU_FILTER_MODIFIED && out) memset(out, 0, sizeof(*out));   // discard_logs: every record dropped
     }
-    else ok = f->kind == F_PARSER ? run_parser_dev(f, in, out, st, &ret) : run_grep_dev(f, in, out, st, &ret, false);
+    else ok = f->kind == F_PARSER ? run_parser_dev(f, in, out, st, &ret) : run_grep_dev(f, in, out, st, &ret, garbage);
     if (!ok) return FLBGPU_FILTER_NOTOUCH;      // errors degrade to NOTOUCH (SURVEY 8b "Errors")
     return ret;
+}
+
+extern "C" int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream) {
+    return run_any_dev(f, in, out, stream ? (hipStream_t) stream : f->stream, false);
+}
+
+// flb_filter_do (src/flb_filter.c:121-325) over device-resident chunks: every MODIFIED output
+// becomes the next filter's input, an empty MODIFIED output ends the chain (:247-269), a NOTOUCH
+// filter leaves the working chunk alone.
+static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, bool garbage,
+                     flbgpu_chain_stat *stats) {
+    flbgpu_dev_chunk cur = *in;
+    bool modified = false;
+    for (int i = 0; i < n; i++) {
+        flbgpu_dev_chunk o;
+        memset(&o, 0, sizeof(o));
+        int ret = run_any_dev(filters[i], &cur, &o, filters[i]->stream, garbage && !modified);
+        if (stats) {
+            stats[i].ret = ret;
+            stats[i].in_records = filters[i]->last_in;
+            stats[i].out_records = ret == FLBGPU_FILTER_MODIFIED ? filters[i]->last_out : filters[i]->last_in;
+            stats[i].out_bytes = ret == FLBGPU_FILTER_MODIFIED ? o.bytes : cur.bytes;
+        }
+        if (ret != FLBGPU_FILTER_MODIFIED) continue;
+        modified = true;
+        cur = o;
+        if (o.bytes == 0) {                     // all records removed, no data to continue processing
+            if (stats) for (int j = i + 1; j < n; j++) { memset(&stats[j], 0, sizeof(stats[j])); }
+            break;
+        }
+    }
+    *out = cur;
+    return modified ? FLBGPU_FILTER_MODIFIED : FLBGPU_FILTER_NOTOUCH;
+}
+
+extern "C" int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nfilters, const flbgpu_dev_chunk *in,
+                                           flbgpu_dev_chunk *out, flbgpu_chain_stat *stats) {
+    return chain_dev(filters, nfilters, in, out, false, stats);
 }
 
 // ------------------------------------------------------------------------------------------ host indexer
@@ -655,40 +693,42 @@ extern "C" int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *r
 }
 
 // ------------------------------------------------------------------------------------------ run (host level)
-extern "C" int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **out_buf, size_t *out_size) {
-    if (bytes == 0) return FLBGPU_FILTER_NOTOUCH;
+extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilters, const void *data, size_t bytes,
+                                       void **out_buf, size_t *out_size, flbgpu_chain_stat *stats) {
+    if (stats) memset(stats, 0, sizeof(*stats) * (size_t) (nfilters > 0 ? nfilters : 0));
+    if (bytes == 0 || nfilters <= 0) return FLBGPU_FILTER_NOTOUCH;
+    flbgpu_filter *f = filters[0];
     // record boundaries: worst case one record per 3 bytes
     std::vector<uint64_t> off(bytes / 3 + 2);
     size_t consumed = 0;
     int64_t n = flbgpu_index_host(data, bytes, off.data(), off.size(), &consumed);
     bool garbage = consumed != bytes;
-    if (n == 0) return FLBGPU_FILTER_NOTOUCH;
+    if (n == 0) {
+        // nothing decodes: every callback's loop ends at once; log_to_metrics still answers
+        // MODIFIED/empty when discard_logs is set (log_to_metrics.c:1141-1145)
+        if (nfilters == 1 && f->kind == F_L2M) {
+            flbgpu_dev_chunk in0, o0;
+            memset(&in0, 0, sizeof(in0));
+            if (run_any_dev(f, &in0, &o0, f->stream, garbage) == FLBGPU_FILTER_MODIFIED) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
+        }
+        return FLBGPU_FILTER_NOTOUCH;
+    }
     hipStream_t st = f->stream;
     if (!f->h_in_data.ensure(consumed + 16) || !f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return FLBGPU_FILTER_NOTOUCH;
     if (hipMemcpyAsync(f->h_in_data.p, data, consumed, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(f->h_in_off.p, off.data(), (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
+        hipMemcpyAsync(f->h_in_off.p, off.data(), (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
         set_err("host to device copy failed");
         return FLBGPU_FILTER_NOTOUCH;
     }
     flbgpu_dev_chunk in, out;
     in.data = f->h_in_data.p; in.row_off = f->h_in_off.as<uint64_t>(); in.n = (uint64_t) n; in.bytes = consumed;
     memset(&out, 0, sizeof(out));
-    int ret = FLBGPU_FILTER_NOTOUCH;
-    bool ok;
-    if (f->kind == F_L2M) {
-        // cb_log_to_metrics_filter: *out_buf = NULL, *out_size = 0 with MODIFIED when discard_logs
-        // (plugins/filter_log_to_metrics/log_to_metrics.c:1141-1145)
-        ok = run_l2m_dev(f, &in, st, &ret);
-        if (!ok || ret != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
-        *out_buf = NULL;
-        *out_size = 0;
-        return FLBGPU_FILTER_MODIFIED;
-    }
-    ok = f->kind == F_PARSER ? run_parser_dev(f, &in, &out, st, &ret) : run_grep_dev(f, &in, &out, st, &ret, garbage);
-    if (!ok || ret != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
-    void *hb = malloc(out.bytes ? out.bytes : 1);
+    if (chain_dev(filters, nfilters, &in, &out, garbage, stats) != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
+    if (out.bytes == 0) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
+    void *hb = malloc(out.bytes);
     if (!hb) return FLBGPU_FILTER_NOTOUCH;
-    if (out.bytes && hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
         free(hb);
         set_err("device to host copy failed");
         return FLBGPU_FILTER_NOTOUCH;
@@ -696,6 +736,11 @@ extern "C" int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t byte
     *out_buf = hb;
     *out_size = out.bytes;
     return FLBGPU_FILTER_MODIFIED;
+}
+
+extern "C" int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **out_buf, size_t *out_size) {
+    flbgpu_filter *one[1] = {f};
+    return flbgpu_filter_chain_run(one, 1, data, bytes, out_buf, out_size, nullptr);
 }
 
 // flb_parser_do on a batch of one: wraps the value as {"k": value} and runs filter_parser with

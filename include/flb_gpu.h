@@ -126,6 +126,25 @@ int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **o
  * enqueued has completed (sizes are needed on the host to size the output). */
 int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream);
 
+/* ---- flb_filter_do: replaces the filter loop of src/flb_filter.c:121-325 for GPU filters -------------
+ * Runs filters[0..n) in order on one chunk: a MODIFIED output becomes the next filter's input
+ * (:235-245), an empty MODIFIED output ends the chain (:247-269), NOTOUCH leaves the working chunk
+ * alone.  The chunk crosses PCIe once in each direction; intermediate chunks stay in HBM.  Tag
+ * routing (flb_router_match, :179-186) stays with the engine: pass the filters that match.
+ * Returns MODIFIED (*out_buf malloc()'d, or NULL with *out_size 0 when every record was dropped) or
+ * NOTOUCH (*out_buf / *out_size untouched: the engine keeps `data`).  stats[i] (optional, n entries)
+ * is what flb_filter_do feeds its per-filter counters with (:213-222,272-312). */
+typedef struct flbgpu_chain_stat {
+    int ret;                 /* MODIFIED / NOTOUCH; 0 = not reached */
+    uint64_t in_records;
+    uint64_t out_records;    /* flb_mp_count_log_records of the output (src/flb_filter.c:272) */
+    uint64_t out_bytes;
+} flbgpu_chain_stat;
+int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilters, const void *data, size_t bytes,
+                            void **out_buf, size_t *out_size, flbgpu_chain_stat *stats);
+int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nfilters, const flbgpu_dev_chunk *in,
+                                flbgpu_dev_chunk *out, flbgpu_chain_stat *stats);
+
 /* Record accounting of the last run (what flb_filter_do derives with flb_mp_count_log_records,
  * src/flb_filter.c:272): records decoded from the input / records in the output. */
 void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t *out_records);

@@ -195,3 +195,58 @@ def test_device_level_chain_matches_host_level(g):
     assert bytes(out) == want2
     assert fg.counts() == (5000, ob.count_records(want2))
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+
+
+def oracle_chain(filters, data):
+    """flb_filter_do (src/flb_filter.c:121-325) with oracle filters"""
+    work, modified = data, False
+    for f in filters:
+        r = f.filter(work)
+        if isinstance(r, tuple):
+            r, out = r
+        else:
+            out = b""                      # log_to_metrics: MODIFIED only with discard_logs (empty output)
+        if r != ob.MODIFIED:
+            continue
+        work, modified = out, True
+        if len(out) == 0:
+            break
+    return (ob.MODIFIED, work) if modified else (ob.NOTOUCH, None)
+
+
+def test_filter_chain_matches_flb_filter_do(g):
+    data, off, ep = synth.apache_records(30000)
+    data = bytes(data)
+    pa = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    cases = [
+        [("parser", "log"), ("grep", [("regex", r"code ^5\d\d$")])],
+        [("grep", [("regex", "log HTTP")]), ("parser", "log"), ("grep", [("exclude", "method GET")])],   # first filter keeps everything: NOTOUCH
+        [("parser", "log"), ("grep", [("regex", "code ^9")]), ("grep", [("regex", "code .")])],          # everything dropped: chain stops
+        [("parser", "log"), ("l2m", dict(metric_mode="counter", props=[("label_field", "code")])), ("grep", [("regex", "code ^2")])],
+        [("parser", "log"), ("l2m", dict(metric_mode="counter", props=[("label_field", "code")], discard_logs=True)), ("grep", [("regex", "code ^2")])],
+        [("grep", [("regex", "nokey x")])],
+    ]
+    for spec in cases:
+        of, gf, keep = [], [], []
+        for kind, arg in spec:
+            if kind == "parser":
+                op, gp = ob.Parser(**pa), g.Parser(**pa)
+                keep.append(gp)
+                of.append(ob.FilterParser(arg, [op])); gf.append(g.FilterParser(arg, [gp]))
+            elif kind == "grep":
+                of.append(ob.Grep(arg)); gf.append(g.FilterGrep(arg))
+            else:
+                of.append(ob.L2M(**arg)); gf.append(g.FilterLogToMetrics(**arg))
+        for payload in (data, data + b"\xc1trailing"):
+            want = oracle_chain(of, payload)
+            ch = g.FilterChain(gf)
+            got = ch.filter(payload)
+            assert got[0] == want[0], (spec, ch.last_stats())
+            assert got[1] == want[1], (spec, first_diff(want[1], got[1]))
+        for o_, g_ in zip(of, gf):
+            if isinstance(o_, ob.L2M):
+                assert [(x["labels"], x["value"]) for x in g_.snapshot()] == [(x["labels"], x["value"]) for x in o_.snapshot()[2]]
+        for f in gf:
+            f.close()
+        for p in keep:
+            p.close()
