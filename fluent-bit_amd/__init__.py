@@ -75,6 +75,15 @@ def lib():
     L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
     L.flbgpu_filter_chain_run.argtypes = [POINTER(c_void_p), c_int, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), c_void_p]
     L.flbgpu_filter_chain_run_dev.argtypes = [POINTER(c_void_p), c_int, POINTER(DevChunk), POINTER(DevChunk), c_void_p]
+    L.flbgpu_pack_json_recs.argtypes = [c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]
+    L.flbgpu_pack_json.argtypes = [c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int), POINTER(c_size_t)]
+    L.flbgpu_json_create.restype = c_void_p
+    L.flbgpu_json_destroy.argtypes = [c_void_p]
+    L.flbgpu_json_run_dev.argtypes = [c_void_p, POINTER(DevChunk), c_int, c_uint, c_uint, POINTER(DevChunk)]
+    L.flbgpu_json_row_info.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.flbgpu_json_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+    L.flbgpu_split_lines_host.restype = c_int64
+    L.flbgpu_split_lines_host.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t]
     L.flbgpu_filter_l2m_create.restype = c_void_p
     L.flbgpu_filter_l2m_create.argtypes = [c_char_p, c_int, POINTER(c_char_p), POINTER(c_char_p), c_int, c_char_p, c_int]
     L.flbgpu_l2m_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]
@@ -371,3 +380,80 @@ def l2m_merge(keys, rows, W, dist, device=None):
     order = np.argsort(~merged[:, 0], kind="stable")
     inv = sorted(index, key=index.get)
     return [inv[i] for i in order], merged[order]
+
+
+# ---- JSON -> msgpack -----------------------------------------------------------------------------
+def pack_json(js):
+    """flb_pack_json_recs (src/flb_pack.c:683-688): -> (ret, msgpack bytes | None, root_type, records, consumed)"""
+    out = c_void_p(); sz = c_size_t(); rt = c_int(0); rec = c_int(0); cons = c_size_t(0)
+    r = lib().flbgpu_pack_json_recs(js, len(js), byref(out), byref(sz), byref(rt), byref(rec), byref(cons))
+    if r != 0:
+        return (r, None, 0, 0, 0)
+    data = ctypes.string_at(out, sz.value) if out.value else b""
+    if out.value:
+        _libc.free(out)
+    return (0, data, rt.value, rec.value, cons.value)
+
+
+def split_lines(data):
+    """row offsets (np.uint64[n+1]) of an NDJSON buffer, one row per line"""
+    import numpy as np
+    off = np.zeros(data.count(b"\n") + 3, dtype=np.uint64)
+    n = lib().flbgpu_split_lines_host(data, len(data), off.ctypes.data, off.size)
+    assert n >= 0
+    return off[: n + 1]
+
+
+class JsonPacker:
+    """batched flb_pack_json: rows of JSON text in HBM -> rows of msgpack (or V2 log events) in HBM"""
+
+    def __init__(self):
+        self.h = lib().flbgpu_json_create()
+        if not self.h:
+            raise RuntimeError("flbgpu_json_create: " + last_error())
+
+    def run_dev(self, chunk, events=False, ts=(0, 0)):
+        out = DevChunk()
+        if lib().flbgpu_json_run_dev(self.h, byref(chunk), int(events), ts[0], ts[1], byref(out)) != 0:
+            raise RuntimeError("flbgpu_json_run_dev: " + last_error())
+        return out
+
+    def row_info(self, n):
+        import numpy as np
+        rec = np.zeros(n, dtype=np.uint32); cons = np.zeros(n, dtype=np.uint32)
+        rt = np.zeros(n, dtype=np.uint8); st = np.zeros(n, dtype=np.uint8)
+        if n and lib().flbgpu_json_row_info(self.h, 0, n, rec.ctypes.data, cons.ctypes.data, rt.ctypes.data, st.ctypes.data) != 0:
+            raise RuntimeError(last_error())
+        return rec, cons, rt, st
+
+    def stats(self):
+        o = (c_uint64 * 3)()
+        lib().flbgpu_json_stats(self.h, o)
+        return dict(generic_rows=o[0], values=o[1], error_rows=o[2])
+
+    def run_host(self, rows, events=False, ts=(0, 0)):
+        """rows: list of bytes -> (list of output rows, records, consumed, root_type, status)"""
+        import numpy as np
+        blob = b"".join(rows)
+        off = np.zeros(len(rows) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in rows])
+        L = lib()
+        d_data = L.flbgpu_dev_alloc(len(blob) + 16); d_off = L.flbgpu_dev_alloc(off.nbytes)
+        L.flbgpu_memcpy_h2d(d_data, blob, len(blob)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+        try:
+            out = self.run_dev(DevChunk(d_data, d_off, len(rows), len(blob)), events, ts)
+            ooff = np.zeros(len(rows) + 1, dtype=np.uint64)
+            L.flbgpu_memcpy_d2h(ooff.ctypes.data, out.row_off, ooff.nbytes)
+            buf = ctypes.create_string_buffer(int(out.bytes) + 1)
+            if out.bytes:
+                L.flbgpu_memcpy_d2h(buf, out.data, int(out.bytes))
+            raw = buf.raw
+            outs = [raw[int(ooff[i]): int(ooff[i + 1])] for i in range(len(rows))]
+            return (outs,) + self.row_info(len(rows))
+        finally:
+            L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_json_destroy(self.h)
+            self.h = None

@@ -257,6 +257,24 @@ struct L2mAggArgs {
     const unsigned int *n_series;
 };
 
+// ---- JSON text -> msgpack (src/flb_pack.c:389-508)
+struct JsonArgs {
+    const uint8_t *text;
+    const uint64_t *row_off;
+    uint64_t n;
+    uint32_t *out_len;          // [n] msgpack bytes of the row (events mode: event bytes, 0 when not one object)
+    uint32_t *records;          // [n] values parsed (0 => flb_pack_json returns -1 unless the row was blank)
+    uint32_t *consumed;         // [n]
+    uint8_t *root_type;         // [n] jsmn type of the first value: 1 object 2 array 3 string 4 primitive
+    uint8_t *status;            // [n] 0 ok, 1 error (no value parsed), 2 deferred to the generic kernels
+    const uint64_t *out_off;    // [n + 1] (emit)
+    uint8_t *out;
+    int events;                 // wrap single-object rows as V2 log events with the timestamp below
+    uint32_t ts_sec, ts_nsec;
+    unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error
+};
+
+
 struct GatherArgs {
     const uint8_t *data;
     const uint64_t *row_off;
@@ -290,6 +308,9 @@ void launch_l2m_stale(uint32_t *sid_col, uint64_t *val_col, uint64_t n, const un
 size_t l2m_stale_tmp_elems(uint64_t n);
 void launch_l2m_aggregate(const L2mAggArgs &a, int cus, hipStream_t st);
 void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
+void launch_json_size(const JsonArgs &a, int cus, hipStream_t st);
+void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);
+void launch_json_generic(const JsonArgs &a, bool emit, hipStream_t st);
 bool l2m_test_numconv(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *status);
 
 }  // namespace flbgpu

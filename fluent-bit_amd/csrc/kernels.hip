@@ -284,6 +284,9 @@ struct Event {
 DEV Event decode_event(const uint8_t *rec, const uint8_t *end) {
     Event ev;
     ev.flags = RF_BAD; ev.sec = 0; ev.nsec = 0; ev.meta = nullptr; ev.meta_end = nullptr; ev.body = nullptr; ev.body_end = nullptr;
+    // an empty row is a record an earlier filter dropped (device chunks keep one row per input
+    // record): there are no bytes, so there is nothing to decode -- invisible like a group marker
+    if (rec == end) { ev.flags = RF_VALID | RF_SKIP; return ev; }
     Tok root = mp_tok(rec, end);
     if (root.type != T_ARRAY || root.len != 2) return ev;
     const uint8_t *p = root.next;
@@ -2024,5 +2027,6 @@ void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long 
 }
 
 #include "l2m_kernels.inc"
+#include "json_kernels.inc"
 
 }  // namespace flbgpu

@@ -154,6 +154,33 @@ void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t 
 void flbgpu_filter_profile(flbgpu_filter *f, int enable);
 int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char **names, double *ms, uint64_t *launches);
 
+/* ---- JSON -> msgpack: replaces flb_pack_json / flb_pack_json_recs --------------------------------
+ * src/flb_pack.c:670-688 -> :389-508 (default backend: the yyjson reader with STOP_WHEN_DONE | INSITU |
+ * ALLOW_INVALID_UNICODE | REPLACE_INVALID_UNICODE, then yyjson_val_to_msgpack :328-387).  Same arguments
+ * and results: 0 / -1, *buffer malloc()'d (NULL with *size 0 for blank input), *root_type one of jsmn's
+ * JSMN_OBJECT 1 / ARRAY 2 / STRING 3 / PRIMITIVE 4, *consumed = offset where the value stream stopped. */
+int flbgpu_pack_json(const char *js, size_t len, char **buffer, size_t *size, int *root_type, size_t *consumed);
+int flbgpu_pack_json_recs(const char *js, size_t len, char **buffer, size_t *size, int *root_type, int *out_records,
+                          size_t *consumed);
+/* Batched sibling: `text_rows` is a device-resident byte column + row offsets, every row an independent
+ * flb_pack_json_recs call (for NDJSON: one line per row).  events == 0: out row i = the msgpack of row
+ * i's values.  events != 0: a row that is exactly one JSON object becomes the V2 log event
+ * [[ts, {}], object] (src/flb_log_event_encoder.c:195-217), any other row is left empty -- the output is
+ * then a chunk for flbgpu_filter_run_dev / flbgpu_filter_chain_run_dev.  Output buffers belong to the
+ * packer and stay valid until its next run. */
+typedef struct flbgpu_json flbgpu_json;
+flbgpu_json *flbgpu_json_create(void);
+void flbgpu_json_destroy(flbgpu_json *j);
+int flbgpu_json_run_dev(flbgpu_json *j, const flbgpu_dev_chunk *text_rows, int events, uint32_t ts_sec, uint32_t ts_nsec,
+                        flbgpu_dev_chunk *out);
+/* per-row results of the last run, rows [first, first + count): values parsed, bytes consumed, root type
+ * of the first value, status (0 ok / blank, 1 error: flb_pack_json would return -1) */
+int flbgpu_json_row_info(flbgpu_json *j, uint64_t first, uint64_t count, uint32_t *records, uint32_t *consumed,
+                         uint8_t *root_type, uint8_t *status);
+void flbgpu_json_stats(flbgpu_json *j, uint64_t *out3);   /* rows sent to the generic kernels, values, error rows */
+/* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
+int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);
+
 /* ---- record boundary discovery (flb_log_event_decoder_next loop, src/flb_log_event_decoder.c:342) --
  * Walks concatenated msgpack objects in host memory; fills row_off[0..n] (capacity cap entries).
  * Returns n; *consumed is the offset where decoding stopped (== bytes for a clean chunk). */
