@@ -31,6 +31,91 @@ GREP_RULE = ("regex", r"code ^5\d\d$")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args):
+    """filter_log_to_metrics on the parsed chunk (BASELINE configs[3] shape: counter + histogram, partial
+    aggregates all-reduced over RCCL when N > 1) and NDJSON -> msgpack events -> 32-rule filter_grep
+    (configs[2] shape).  Reported next to the headline number, never folded into it."""
+    import json as _json
+    import random
+    out = {}
+    steps = 3
+    # -- log_to_metrics
+    for name, mode, props, vf in (("l2m_counter", "counter", [("label_field", "method"), ("label_field", "code")], None),
+                                  ("l2m_histogram", "histogram", [("label_field", "code")], "size")):
+        f = g.FilterLogToMetrics(mode, props, value_field=vf)
+        f.set_index_base(rank << 40)
+        f.filter_dev(parsed_chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            f.filter_dev(parsed_chunk)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        e = {"records_per_s_per_gpu": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
+        if dist is not None:
+            t0 = time.perf_counter()
+            keys, rows = g.l2m_all_reduce(f, dist)
+            e["all_reduce_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            snap = f.snapshot((keys, rows))
+        else:
+            snap = f.snapshot()
+        e["series"] = len(snap)
+        e["observations"] = int(sum(x["value"] for x in snap)) if mode == "counter" else int(sum(x["count"] for x in snap))
+        out[name] = e
+        f.close()
+    # -- NDJSON lines -> events -> grep with 32 rules
+    rng = random.Random(7 + rank)
+    base = []
+    for i in range(4096):
+        d = {"time": "2026-09-21T10:%02d:%02d.%03dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(1000)),
+             "level": rng.choice(["info", "warn", "error", "debug"]),
+             "msg": "request %d finished %s" % (rng.randrange(10 ** 6), rng.choice(["ok", "timeout", "refused"])),
+             "code": rng.randrange(200, 600), "latency": round(rng.random() * 100, 3),
+             "svc": {"name": rng.choice(["api", "db", "cache"]), "pod": "pod-%d" % rng.randrange(1000)},
+             "path": "/v1/items/%d?x=%d" % (rng.randrange(10 ** 5), rng.randrange(100)), "bytes": rng.randrange(10 ** 6)}
+        base.append(_json.dumps(d).encode() + b"\n")
+    nl = min(n, 4_000_000)
+    data = b"".join(base) * ((nl + len(base) - 1) // len(base))
+    off = g.split_lines(data)
+    nl = len(off) - 1
+    L = g.lib()
+    d_data = L.flbgpu_dev_alloc(len(data) + 16); d_off = L.flbgpu_dev_alloc(off.nbytes)
+    L.flbgpu_memcpy_h2d(d_data, data, len(data)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+    chunk = g.DevChunk(d_data, d_off, nl, len(data))
+    pk = g.JsonPacker()
+    rules = [("regex", "level ^(error|warn)$")] + [("exclude", "msg pattern%d" % i) for i in range(31)]
+    fg = g.FilterGrep(rules)
+    ev = pk.run_dev(chunk, events=True, ts=(1, 0))
+    fg.filter_dev(ev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev = pk.run_dev(chunk, events=True, ts=(1, 0))
+    torch.cuda.synchronize()
+    dt_j = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fg.filter_dev(ev)
+    torch.cuda.synchronize()
+    dt_g = (time.perf_counter() - t0) / steps
+    out["ndjson_to_events"] = {"lines_per_s_per_gpu": round(nl / dt_j, 1), "ms_per_step": round(dt_j * 1e3, 3), "lines": nl,
+                               "text_bytes": len(data), "text_GBps": round(len(data) / dt_j / 1e9, 2)}
+    out["grep_32_rules"] = {"records_per_s_per_gpu": round(nl / dt_g, 1), "ms_per_step": round(dt_g * 1e3, 3), "kept": int(fg.counts()[1])}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob
+        import jsonfuzz as jf
+        o = jf.oracle()
+        sample = data[: int(off[200_000])] if nl > 200_000 else data
+        t0 = time.perf_counter()
+        r = o(sample)
+        cdt = time.perf_counter() - t0
+        out["ndjson_to_events"]["cpu_port_lines_per_s"] = round(r[3] / cdt, 1)
+    fg.close(); pk.close()
+    L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,6 +124,7 @@ def main():
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the log_to_metrics / JSON side measurements")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +197,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- side measurements (never part of `value`): the other rows of the hot-path scope table
+    secondary = None
+    if not args.no_secondary:
+        try:
+            secondary = measure_secondary(g, torch, dist, rank, world, o1, n, args)
+        except Exception as e:                      # the headline line must survive a failure here
+            secondary = {"error": repr(e)[:300]}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -165,7 +259,7 @@ def main():
                                "on %d x 256B apache-combined lines per GPU (277B V2 events), chained on device, unfused" % n,
                    "records_per_gpu": n, "in_bytes": in_bytes, "parsed_bytes": parsed_bytes, "kept_records": int(kept_records),
                    "seed": synth.SEED, "parallelism": "shard%d" % world, "gen_seconds": round(gen_s, 1)},
-        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary,
     }
     print(json.dumps(line))
     if dist is not None:
