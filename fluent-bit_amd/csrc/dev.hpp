@@ -64,6 +64,8 @@ struct DevParser {
     char fmt1[MAX_TIMEFMT];              // expanded to primitive directives, NUL terminated
     char fmt2[MAX_TIMEFMT];
     uint8_t slot2cap[2 * MAX_GROUPS];    // capture slot -> index in the caps row (0xFF: not a named field)
+    int time_field;                      // the ONE named field that is the time key, -1 if none or several
+    int plain_types;                     // no Types cast changes a value's encoded size (all string / none)
 };
 
 // ---- record accessor / key
@@ -90,9 +92,10 @@ struct alignas(16) RecInfo {
     uint32_t nkept;                      // fields that will be packed (map count after skips)
     uint32_t drop_mask;                  // bit f: named field f is not packed (empty+skip_empty,
                                          // unparsable time, or time consumed and !time_keep)
-    uint32_t pad_[3];                    // 64 bytes: four 16-byte stores
+    uint32_t meta_canon;                 // size of the canonically re-packed metadata (1 when there is none)
+    uint32_t pad_[2];                    // 64 bytes
 };
-constexpr int REC_NCOLS = 13;
+constexpr int REC_NCOLS = 14;
 // capture spans live in a separate column: caps[rec][2*field + {0,1}] (begin/end relative to the
 // value, 0xFFFFFFFF = group did not participate), field = index in DevParser::field_group
 
@@ -108,6 +111,7 @@ enum {
 };
 
 constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
+constexpr int TBUF_WORDS = 8;
 constexpr int CHK_STEP = 16;             // one reverse-DFA state id is kept every CHK_STEP boundaries
 constexpr uint32_t FT_SPECIAL = 0x80000000u, FT_CAPS = 1, FT_MATCH = 2, FT_LOOK = 3, FT_MULTI = 4, FT_DEAD = 5;
 constexpr uint32_t TG_MATCH = 0xFFFFFFFDu, TG_DEAD = 0xFFFFFFFFu;   // results of the slow-path resolver
@@ -131,6 +135,8 @@ struct ParserMatchArgs {
     uint32_t caps_stride;
     uint64_t *null_mask;        // [n]
     uint32_t *out_len;          // [n]
+    uint32_t *tbuf;             // [TBUF_WORDS][n]: the first 32 bytes of the time field's text, copied by k_parser_rx
+                                // while they are cache-hot so that k_parser_finish never touches the chunk
     uint16_t *chk;              // scratch: reverse-DFA state checkpoints [slots][chk_len][64]
     uint32_t chk_len;           // checkpoints per lane (max value length / CHK_STEP + 2)
     uint32_t lds_bytes;         // dynamic LDS: parser 0's hot ASCII tables are staged when > 0

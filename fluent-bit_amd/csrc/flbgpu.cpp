@@ -243,6 +243,16 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
             for (auto &ty : tys) if (ty.first == p->prog.names[i]) { d.field_type[f] = ty.second; break; }   // first match wins
         }
     }
+    d.time_field = -1;
+    d.plain_types = 1;
+    {
+        int ntime = 0;
+        for (int f = 0; f < d.nfields; f++) {
+            if (d.field_is_time[f]) { ntime++; d.time_field = f; }
+            if (d.field_type[f] != TY_NONE && d.field_type[f] != TY_STRING) d.plain_types = 0;
+        }
+        if (ntime != 1) d.time_field = -1;
+    }
     return p;
 }
 
@@ -468,14 +478,16 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     if (!f->d_rid.ensure((size_t) grid * (rx_threads / 64) * 64 * chk_len * sizeof(uint16_t))) return false;
     if (!f->d_info.ensure(n * REC_NCOLS * sizeof(uint32_t)) || !f->d_caps.ensure(n * f->caps_stride * sizeof(uint32_t)) ||
         !f->d_null.ensure(n * sizeof(uint64_t)) || !f->d_len.ensure(n * sizeof(uint32_t)) ||
-        !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)))
+        !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)) ||
+        !f->d_status.ensure(n * TBUF_WORDS * sizeof(uint32_t)))
         return false;
     ParserMatchArgs ma;
+    ma.tbuf = f->d_status.as<uint32_t>();                    // (the status buffer is grep's; a parser filter uses it for the time text)
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
     ma.info = f->d_info.as<uint32_t>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
-    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
     { ProfScope ps(f, st, "k_parser_rx"); launch_parser_rx(ma, grid, rx_threads, st); }

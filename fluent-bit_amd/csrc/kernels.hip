@@ -785,8 +785,14 @@ struct TStr {
     const uint8_t *s, *e;
     const uint8_t *wb = nullptr;     // window base, nullptr = empty
     v4u32 w;
+    // LDS mode: the text was copied into this lane's private LDS slot (from k_parser_rx's time
+    // column); s is then only a position origin and is never dereferenced.  One ds_read_u8 per
+    // character instead of a window check + select chain: strptime calls at() hundreds of times.
+    LDS_AS const uint8_t *lds = nullptr;
+    bool in_lds = false;             // (LDS offset 0 is a valid slot: the pointer cannot be the flag)
     DEV uint32_t at(const uint8_t *p) {
         if (p >= e) return 0;
+        if (in_lds) return lds[(uint32_t) (p - s)];
         if (wb == nullptr || p < wb || p >= wb + 16) {
             wb = p;
             w = load16(p, 0, (uint32_t) (e - p));
@@ -803,27 +809,27 @@ enum { TF_MDAY = 0, TF_HOUR, TF_MIN, TF_SEC, TF_MON1, TF_YEAR, TF_RELYEAR, TF_CE
        TF_MONNAME, TF_DAYNAME };
 struct DirInfo { uint8_t kind, field, eatspace, pad; uint16_t lo, hi; };
 __constant__ DirInfo c_dir[128] = {};
-__constant__ char c_mon_full[12][10] = { "january", "february", "march", "april", "may", "june", "july",
-                                         "august", "september", "october", "november", "december" };
-__constant__ char c_day_full[7][10] = { "sunday", "monday", "tuesday", "wednesday", "thursday", "friday", "saturday" };
 __constant__ int c_mon_len[2][12] = { { 31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 },
                                       { 31, 29, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31 } };
 
 DEV bool d_isleap(int y) { return (y % 4) == 0 && ((y % 100) != 0 || (y % 400) == 0); }
 
 // days since 1970-01-01 of year/month(1..12)/day
-DEV int64_t days_from_civil(int64_t y, int m, int d) {
+DEV int64_t days_from_civil(int64_t y64, int m, int d) {
+    // the year is a parsed %Y/%C%y (|y| < 2^20): 32-bit divisions, the 64-bit ones are emulated
+    int y = (int) y64;
     y -= m <= 2;
-    int64_t era = (y >= 0 ? y : y - 399) / 400;
-    int64_t yoe = y - era * 400;
-    int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
-    int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-    return era * 146097 + doe - 719468;
+    int era = (y >= 0 ? y : y - 399) / 400;
+    int yoe = y - era * 400;
+    int doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    int doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return (int64_t) era * 146097 + doe - 719468;
 }
 
 // one flb_strptime() call (initialize = 1).  fmt holds only primitive directives (the host
 // expands %T %D %F %R %r %c %x %X).  Returns the new input pointer or nullptr.
-DEV const uint8_t *d_strptime(TStr &in, const uint8_t *bp, const char *fmt, Tm &tm) {
+template <class FP>
+DEV const uint8_t *d_strptime(TStr &in, const uint8_t *bp, FP fmt, Tm &tm) {
     tm.century = 1900; tm.relyear = -1; tm.fields = 0; tm.gmtoff = 0;
     uint32_t c;
     while ((c = (uint8_t) *fmt) != 0) {
@@ -854,14 +860,15 @@ DEV const uint8_t *d_strptime(TStr &in, const uint8_t *bp, const char *fmt, Tm &
         case DK_NUM: {
             if (di.eatspace && d_isspace(cur)) { bp++; cur = in.at(bp); }
             // _conv_num (src/flb_strptime.c:819-840)
-            int result = 0, rulim = di.hi;
+            // rulim /= 10 per digit reaches 0 after as many digits as the upper limit has
+            int result = 0, left = di.hi >= 1000 ? 4 : di.hi >= 100 ? 3 : di.hi >= 10 ? 2 : 1;
             if (cur < '0' || cur > '9') return nullptr;
             for (;;) {
                 result = result * 10 + (int) (cur - '0');
                 bp++;
-                rulim /= 10;
+                left--;
                 cur = in.at(bp);
-                if (!((result * 10 <= (int) di.hi) && rulim && cur >= '0' && cur <= '9')) break;
+                if (!((result * 10 <= (int) di.hi) && left && cur >= '0' && cur <= '9')) break;
             }
             if (result < (int) di.lo || result > (int) di.hi) return nullptr;
             switch (di.field) {
@@ -884,14 +891,51 @@ DEV const uint8_t *d_strptime(TStr &in, const uint8_t *bp, const char *fmt, Tm &
             // full name first, then the 3-letter abbreviation, case-insensitively (:381-419)
             const int count = di.field == TF_MONNAME ? 12 : 7;
             int i, len = 0;
-            for (i = 0; i < count; i++) {
-                const char *w = di.field == TF_MONNAME ? c_mon_full[i] : c_day_full[i];
-                int wl = 0;
-                while (w[wl]) wl++;
+            // The three-letter abbreviation is a prefix of the full name and unique, so the index is
+            // found by comparing the first three characters (lower-cased, packed) against immediates;
+            // the rest of the full name decides between len = full and len = 3.
+            const uint32_t key = d_lower(in.at(bp)) | (d_lower(in.at(bp + 1)) << 8) | (d_lower(in.at(bp + 2)) << 16);
+            #define P3(a, b, c) ((uint32_t) (a) | ((uint32_t) (b) << 8) | ((uint32_t) (c) << 16))
+            #define P8(str) (uint64_t) ((uint64_t) (uint8_t) (str)[0] | ((uint64_t) (uint8_t) (str)[1] << 8) | ((uint64_t) (uint8_t) (str)[2] << 16) | \
+                             ((uint64_t) (uint8_t) (str)[3] << 24) | ((uint64_t) (uint8_t) (str)[4] << 32) | ((uint64_t) (uint8_t) (str)[5] << 40))
+            uint64_t rest = 0;            // the characters of the full name after the abbreviation, NUL padded
+            i = count;
+            if (di.field == TF_MONNAME) {
+                switch (key) {
+                case P3('j', 'a', 'n'): i = 0; rest = P8("uary\0\0"); break;
+                case P3('f', 'e', 'b'): i = 1; rest = P8("ruary\0"); break;
+                case P3('m', 'a', 'r'): i = 2; rest = P8("ch\0\0\0\0"); break;
+                case P3('a', 'p', 'r'): i = 3; rest = P8("il\0\0\0\0"); break;
+                case P3('m', 'a', 'y'): i = 4; rest = 0; break;
+                case P3('j', 'u', 'n'): i = 5; rest = P8("e\0\0\0\0\0"); break;
+                case P3('j', 'u', 'l'): i = 6; rest = P8("y\0\0\0\0\0"); break;
+                case P3('a', 'u', 'g'): i = 7; rest = P8("ust\0\0\0"); break;
+                case P3('s', 'e', 'p'): i = 8; rest = P8("tember"); break;
+                case P3('o', 'c', 't'): i = 9; rest = P8("ober\0\0"); break;
+                case P3('n', 'o', 'v'): i = 10; rest = P8("ember\0"); break;
+                case P3('d', 'e', 'c'): i = 11; rest = P8("ember\0"); break;
+                default: break;
+                }
+            }
+            else {
+                switch (key) {
+                case P3('s', 'u', 'n'): i = 0; rest = P8("day\0\0\0"); break;
+                case P3('m', 'o', 'n'): i = 1; rest = P8("day\0\0\0"); break;
+                case P3('t', 'u', 'e'): i = 2; rest = P8("sday\0\0"); break;
+                case P3('w', 'e', 'd'): i = 3; rest = P8("nesday"); break;
+                case P3('t', 'h', 'u'): i = 4; rest = P8("rsday\0"); break;
+                case P3('f', 'r', 'i'): i = 5; rest = P8("day\0\0\0"); break;
+                case P3('s', 'a', 't'): i = 6; rest = P8("urday\0"); break;
+                default: break;
+                }
+            }
+            #undef P3
+            #undef P8
+            if (i < count) {
+                len = 3;
                 int q = 0;
-                while (q < wl && d_lower(in.at(bp + q)) == (uint32_t) w[q]) q++;
-                if (q == wl) { len = wl; break; }
-                if (q >= 3) { len = 3; break; }
+                while (q < 6 && ((rest >> (8 * q)) & 0xff) != 0 && d_lower(in.at(bp + 3 + q)) == (uint32_t) ((rest >> (8 * q)) & 0xff)) q++;
+                if (q == 6 || ((rest >> (8 * q)) & 0xff) == 0) len = 3 + q;       // the whole name was there
             }
             if (i == count) return nullptr;
             if (di.field == TF_MONNAME) { tm.mon = i; tm.fields |= F_MON; }
@@ -1015,14 +1059,15 @@ DEV int64_t tm2time(const Tm &tm) {
 
 // flb_parser_time_lookup + tm2time for formats that carry the year.  Returns -1 (field is
 // dropped, time stays 0), or 0 with *sec / *frac set.
-DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_t *sec, double *frac) {
+// fmt1 / fmt2: the parser's two format halves, through whatever pointer type the caller staged them in
+template <class FP>
+DEV int time_lookup_in(const DevParser &ps, TStr &in, const uint8_t *v, uint32_t vlen, int64_t *sec, double *frac, FP fmt1, FP fmt2) {
     Tm tm;
     tm.year = tm.mon = tm.mday = tm.hour = tm.min = tm.sec = tm.yday = tm.wday = 0;
     tm.gmtoff = 0; tm.have_epoch = 0; tm.epoch = 0;
     *frac = 0;
     // the reference copies the text into a NUL-terminated buffer and works on strlen() of it:
     // an embedded NUL ends the string
-    TStr in;
     in.s = v; in.e = v + vlen;
     uint32_t n = 0;
     while (n < vlen && in.at(v + n) != 0) n++;
@@ -1061,7 +1106,7 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
             p += consumed;
         }
         // (the second call re-initialises gmtoff/century/relyear/fields but keeps the tm fields)
-        const uint8_t *p2 = d_strptime(in, p, pass == 0 ? ps.fmt1 : ps.fmt2, tm);
+        const uint8_t *p2 = d_strptime(in, p, pass == 0 ? fmt1 : fmt2, tm);
         if (!p2) ok = false;
         else p = p2;
     }
@@ -1075,6 +1120,10 @@ DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_
     if (!ps.time_with_tz) tm.gmtoff = ps.time_offset;
     *sec = tm2time(tm);
     return 0;
+}
+DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_t *sec, double *frac) {
+    TStr in;
+    return time_lookup_in(ps, in, v, vlen, sec, frac, (const char *) ps.fmt1, (const char *) ps.fmt2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1127,15 +1176,15 @@ DEV void rec_store(uint32_t *cols, uint64_t n, uint64_t r, const RecInfo &ri) {
     cols[0 * n + r] = ri.flags; cols[1 * n + r] = ri.val_off; cols[2 * n + r] = ri.val_len; cols[3 * n + r] = ri.key_index;
     cols[4 * n + r] = ri.ts_sec; cols[5 * n + r] = ri.ts_nsec; cols[6 * n + r] = ri.body_off; cols[7 * n + r] = ri.body_len;
     cols[8 * n + r] = ri.meta_off; cols[9 * n + r] = ri.meta_len; cols[10 * n + r] = (uint32_t) ri.parser_idx;
-    cols[11 * n + r] = ri.nkept; cols[12 * n + r] = ri.drop_mask;
+    cols[11 * n + r] = ri.nkept; cols[12 * n + r] = ri.drop_mask; cols[13 * n + r] = ri.meta_canon;
 }
 DEV RecInfo rec_load(const uint32_t *cols, uint64_t n, uint64_t r) {
     RecInfo ri;
     ri.flags = cols[0 * n + r]; ri.val_off = cols[1 * n + r]; ri.val_len = cols[2 * n + r]; ri.key_index = cols[3 * n + r];
     ri.ts_sec = cols[4 * n + r]; ri.ts_nsec = cols[5 * n + r]; ri.body_off = cols[6 * n + r]; ri.body_len = cols[7 * n + r];
     ri.meta_off = cols[8 * n + r]; ri.meta_len = cols[9 * n + r]; ri.parser_idx = (int32_t) cols[10 * n + r];
-    ri.nkept = cols[11 * n + r]; ri.drop_mask = cols[12 * n + r];
-    ri.pad_[0] = ri.pad_[1] = ri.pad_[2] = 0;
+    ri.nkept = cols[11 * n + r]; ri.drop_mask = cols[12 * n + r]; ri.meta_canon = cols[13 * n + r];
+    ri.pad_[0] = ri.pad_[1] = 0;
     return ri;
 }
 // one record's capture spans inside the [span][n] column block
@@ -1293,7 +1342,7 @@ constexpr int LOC_TILE = 18432;             // LDS bytes per wave (64 records of
 DEV void recinfo_init(RecInfo &ri) {
     ri.flags = 0; ri.val_off = 0; ri.val_len = 0; ri.key_index = 0; ri.ts_sec = 0; ri.ts_nsec = 0;
     ri.body_off = 0; ri.body_len = 0; ri.meta_off = 0; ri.meta_len = 0; ri.parser_idx = -1; ri.nkept = 0; ri.drop_mask = 0;
-    ri.pad_[0] = ri.pad_[1] = ri.pad_[2] = 0;
+    ri.meta_canon = 1; ri.pad_[0] = ri.pad_[1] = 0;
 }
 
 // per-record part of k_parser_locate; rec may point into LDS (generic pointer)
@@ -1346,6 +1395,7 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         CountSink cs;
         cs.n = 12;
         if (ev.meta) mp_canon(ev.meta, ev.meta_end, cs); else cs.n += 1;
+        ri.meta_canon = (uint32_t) cs.n - 12;
         mp_canon(ev.body, ev.body_end, cs);
         out_len = (uint32_t) cs.n;
     }
@@ -1447,6 +1497,16 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
             // publish the spans: [span][record] columns, a wave stores 64 consecutive words
             for (int c = 0; c < ncap; c++) a.caps[(uint64_t) c * a.n + r] = capl.get((uint32_t) c);
             a.info[r] = flags | RF_RXOK;
+            if (ps.time_field >= 0) {
+                // the time text (cache-hot here) goes to its own coalesced column
+                const uint32_t tb = capl.get((uint32_t) (2 * ps.time_field)), te = capl.get((uint32_t) (2 * ps.time_field + 1));
+                if (tb != CAP_UNSET && te != CAP_UNSET && te - tb <= 4 * TBUF_WORDS) {
+                    const uint32_t tl = te - tb;
+                    v4u32 w0 = load16(val + tb, 0, tl), w1 = load16(val + tb + 16, 0, tl > 16 ? tl - 16 : 0);
+                    a.tbuf[0 * a.n + r] = w0.x; a.tbuf[1 * a.n + r] = w0.y; a.tbuf[2 * a.n + r] = w0.z; a.tbuf[3 * a.n + r] = w0.w;
+                    a.tbuf[4 * a.n + r] = w1.x; a.tbuf[5 * a.n + r] = w1.y; a.tbuf[6 * a.n + r] = w1.z; a.tbuf[7 * a.n + r] = w1.w;
+                }
+            }
         }
         else if (best == -2 || a.cfg.nparsers > 1) {
             // a byte >= 0x80 (UTF-8 tables) or more parsers to try: the generic kernel takes over
@@ -1459,20 +1519,30 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
 }
 
 // named fields, time lookup and size of the records parser 0 matched
+constexpr int FIN_SLOT = 4 * TBUF_WORDS + 4;      // per-lane LDS slot for the time text (+4: spreads the banks)
 __global__ void __launch_bounds__(256) k_parser_finish(ParserMatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t tls_mem[256 * FIN_SLOT];
+    __shared__ char fmt_mem[2 * MAX_TIMEFMT];
+    LDS_AS uint8_t *tls = (LDS_AS uint8_t *) tls_mem;
     const DevParser &ps = a.parsers[0];
+    // the format strings are walked character by character for every record: from LDS, not through
+    // a chain of dependent global loads
+    for (uint32_t i = threadIdx.x; i < 2 * MAX_TIMEFMT; i += blockDim.x) fmt_mem[i] = i < MAX_TIMEFMT ? ps.fmt1[i] : ps.fmt2[i - MAX_TIMEFMT];
+    __syncthreads();
+    LDS_AS const char *lfmt1 = (LDS_AS const char *) fmt_mem, *lfmt2 = lfmt1 + MAX_TIMEFMT;
     uint32_t n_gen = 0;
-    for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * blockDim.x) {
+    // When the record's size does not depend on bytes of the chunk (no reserved / preserved kvs, no
+    // Types cast) and the time text sits in the tbuf column, this kernel reads and writes nothing
+    // but coalesced columns.
+    const bool size_from_columns = !a.cfg.reserve_data && !(a.cfg.preserve_key && !a.cfg.key.is_ra) && ps.plain_types;
+    const uint64_t n = a.n;
+    for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t fl0 = a.info[r];
         if (!(fl0 & RF_RXOK) || (fl0 & RF_GENERIC)) { if (!(fl0 & RF_GENERIC)) a.null_mask[r] = 0; continue; }
-        RecInfo ri = rec_load(a.info, a.n, r);
-        const uint8_t *rec = a.data + a.row_off[r];
-        const uint8_t *rec_end = a.data + a.row_off[r + 1];
-        const uint8_t *val = rec + ri.val_off;
         CapsView caps;
-        caps.base = a.caps; caps.n = a.n; caps.r = r;
+        caps.base = a.caps; caps.n = n; caps.r = r;
         bool any = false;
-        uint32_t kept = 0, drop = 0;
+        uint32_t kept = 0, drop = 0, body_bytes = 0;
         int64_t sec = 0; double frac = 0;
         for (int f = 0; f < ps.nfields; f++) {
             uint32_t b = caps[2 * f], e = caps[2 * f + 1];
@@ -1482,39 +1552,65 @@ __global__ void __launch_bounds__(256) k_parser_finish(ParserMatchArgs a) {
             if (fl == 0 && ps.skip_empty) { drop |= 1u << f; continue; }
             if (ps.field_is_time[f]) {
                 int64_t s2; double f2;
-                if (time_lookup(ps, set ? val + b : val, fl, &s2, &f2) == -1) { drop |= 1u << f; continue; }
+                TStr in;
+                const uint8_t *tv;
+                if (f == ps.time_field && fl <= 4 * TBUF_WORDS) {
+                    LDS_AS uint32_t *slot = (LDS_AS uint32_t *) (tls + threadIdx.x * FIN_SLOT);
+                    #pragma unroll
+                    for (int k = 0; k < TBUF_WORDS; k++) slot[k] = fl > (uint32_t) (4 * k) ? a.tbuf[(uint64_t) k * n + r] : 0;
+                    in.lds = (LDS_AS const uint8_t *) slot; in.in_lds = true;
+                    tv = (const uint8_t *) 4096;               // position origin only, never dereferenced
+                }
+                else {
+                    const uint8_t *val = a.data + a.row_off[r] + a.info[1 * n + r];
+                    tv = set ? val + b : val;
+                }
+                if (time_lookup_in(ps, in, tv, fl, &s2, &f2, lfmt1, lfmt2) == -1) { drop |= 1u << f; continue; }
                 sec = s2; frac = f2;
                 if (!ps.time_keep) { drop |= 1u << f; continue; }
             }
             kept++;
+            const uint32_t nl = (uint32_t) ps.field_name_len[f];
+            body_bytes += (nl < 32 ? 1 : nl < 256 ? 2 : nl < 65536 ? 3 : 5) + nl + (fl < 32 ? 1 : fl < 256 ? 2 : fl < 65536 ? 3 : 5) + fl;
         }
         if (!any) {
             // flb_regex_parse found no participating named group: the parser fails
-            if (a.cfg.nparsers > 1) { a.info[r] = ri.flags | RF_GENERIC; n_gen++; }
+            if (a.cfg.nparsers > 1) { a.info[r] = fl0 | RF_GENERIC; n_gen++; }
             else a.null_mask[r] = 0;
             continue;
         }
-        ri.flags |= RF_PARSED;
-        ri.flags &= ~(uint32_t) RF_BADTS;
-        ri.parser_idx = 0; ri.nkept = kept; ri.drop_mask = drop;
-        uint64_t null_mask = (!a.cfg.key.is_ra && ri.key_index < 64) ? 1ull << ri.key_index : 0;
-        int64_t tsec = ri.ts_sec, tnsec = ri.ts_nsec;
+        uint32_t flags = (fl0 | RF_PARSED) & ~(uint32_t) RF_BADTS;
+        const uint32_t key_index = a.info[3 * n + r];
+        uint64_t null_mask = (!a.cfg.key.is_ra && key_index < 64) ? 1ull << key_index : 0;
+        int64_t tsec = a.info[4 * n + r], tnsec = a.info[5 * n + r];
         if (fl0 & RF_BADTS) { tsec = -1; tnsec = 0; }                        // the event time was out of range
         int64_t psec = sec, pnsec = (int64_t) (frac * 1000000000);
         bool have_parsed_time = ((uint64_t) psec * 1000000000ull + (uint64_t) pnsec) != 0;
         if (have_parsed_time) { tsec = psec; tnsec = pnsec; }
         a.null_mask[r] = null_mask;
+        a.info[10 * n + r] = 0;                                // parser_idx
+        a.info[11 * n + r] = kept;
+        a.info[12 * n + r] = drop;
         // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
         if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
-            ri.flags |= RF_BADTS;
-            rec_store(a.info, a.n, r, ri); a.out_len[r] = 0;
+            a.info[r] = flags | RF_BADTS;
+            a.out_len[r] = 0;
             continue;
         }
-        ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
-        CountSink cs;
-        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
-        rec_store(a.info, a.n, r, ri);
-        a.out_len[r] = (uint32_t) cs.n;
+        a.info[r] = flags;
+        a.info[4 * n + r] = (uint32_t) tsec; a.info[5 * n + r] = (uint32_t) tnsec;
+        if (size_from_columns) {
+            // 92 92 d7 00 ts(8) + metadata + map header (width of the ORIGINAL count) + fields
+            const uint32_t n0 = (uint32_t) ps.nregs_minus1;
+            a.out_len[r] = 12 + a.info[13 * n + r] + (n0 < 16 ? 1 : n0 < 65536 ? 3 : 5) + body_bytes;
+        }
+        else {
+            RecInfo ri = rec_load(a.info, n, r);
+            const uint8_t *rec = a.data + a.row_off[r];
+            CountSink cs;
+            write_record(cs, a.cfg, a.parsers, rec, a.data + a.row_off[r + 1], ri, caps, null_mask);
+            a.out_len[r] = (uint32_t) cs.n;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) n_gen += __shfl_down(n_gen, o, 64);
     if ((threadIdx.x & 63) == 0 && n_gen) atomicAdd(&a.counts[2], (unsigned long long) n_gen);
@@ -1592,7 +1688,9 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
         CountSink cs;
+        if (a.debug_skip & 2) cs.n = 270; else
         write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        if (!(a.debug_skip & 4))
         rec_store(a.info, a.n, r, ri);
         a.null_mask[r] = null_mask;
         a.out_len[r] = (uint32_t) cs.n;
