@@ -64,6 +64,9 @@ struct DevParser {
     char fmt1[MAX_TIMEFMT];              // expanded to primitive directives, NUL terminated
     char fmt2[MAX_TIMEFMT];
     uint8_t slot2cap[2 * MAX_GROUPS];    // capture slot -> index in the caps row (0xFF: not a named field)
+    uint32_t keywords[MAX_NAMES + 1024 / 4 + MAX_NAMES];   // per field: msgpack str header + name, zero padded to a dword multiple
+    int kw_off[MAX_NAMES];               // first dword of field f in keywords[]
+    int kw_bytes[MAX_NAMES];             // header + name bytes
     int time_field;                      // the ONE named field that is the time key, -1 if none or several
     int plain_types;                     // no Types cast changes a value's encoded size (all string / none)
 };
@@ -163,6 +166,7 @@ struct ParserEmitArgs {
     const uint32_t *out_len;
     const uint64_t *out_off;    // exclusive scan of out_len, [n+1]
     uint8_t *out;
+    uint64_t bytes;             // chunk size (bounds the wide tail loads)
 };
 
 // ---- filter_grep (plugins/filter_grep/grep.c)

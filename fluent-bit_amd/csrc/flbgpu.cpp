@@ -243,6 +243,26 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
             for (auto &ty : tys) if (ty.first == p->prog.names[i]) { d.field_type[f] = ty.second; break; }   // first match wins
         }
     }
+    {
+        // packed "str header + name" per field: the emit kernel stores them a dword at a time
+        size_t w = 0;
+        memset(d.keywords, 0, sizeof(d.keywords));
+        for (int f = 0; f < d.nfields; f++) {
+            uint8_t tmp[8 + 1024];
+            size_t nb = 0;
+            const uint32_t nl = (uint32_t) d.field_name_len[f];
+            if (nl < 32) tmp[nb++] = (uint8_t) (0xa0 | nl);
+            else if (nl < 256) { tmp[nb++] = 0xd9; tmp[nb++] = (uint8_t) nl; }
+            else { tmp[nb++] = 0xda; tmp[nb++] = (uint8_t) (nl >> 8); tmp[nb++] = (uint8_t) nl; }
+            memcpy(tmp + nb, d.names + d.field_name_off[f], nl);
+            nb += nl;
+            d.kw_off[f] = (int) w;
+            d.kw_bytes[f] = (int) nb;
+            if (w + (nb + 3) / 4 > sizeof(d.keywords) / 4) { set_err("parser '%s': field names too long", p->name.c_str()); delete p; return nullptr; }
+            memcpy((uint8_t *) (d.keywords + w), tmp, nb);
+            w += (nb + 3) / 4;
+        }
+    }
     d.time_field = -1;
     d.plain_types = 1;
     {
@@ -519,7 +539,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ea.data = data; ea.row_off = row_off; ea.n = n; ea.cfg = f->pcfg; ea.parsers = f->d_parsers.as<DevParser>();
     ea.n_cols = in->n; ea.info = f->d_info.as<uint32_t>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
-    ea.out = f->d_out.as<uint8_t>();
+    ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes;
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
     HIPOK(hipStreamSynchronize(st));
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;

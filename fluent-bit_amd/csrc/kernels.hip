@@ -60,6 +60,8 @@ struct CountSink {
     uint64_t n = 0;
     DEV void put(uint32_t) { n++; }
     DEV void copy(const uint8_t *, uint32_t len) { n += len; }
+    DEV void words(const uint32_t *, uint32_t nbytes) { n += nbytes; }
+    DEV void put32(uint32_t) { n += 4; }
     DEV void finish() {}
 };
 
@@ -68,31 +70,59 @@ struct ByteSink {
     DEV explicit ByteSink(uint8_t *dst) : p(dst) {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = (uint8_t) ld8(src + i); }
+    DEV void words(const uint32_t *w, uint32_t nbytes) { for (uint32_t i = 0; i < nbytes; i++) *p++ = (uint8_t) (w[i >> 2] >> (8 * (i & 3))); }
+    DEV void put32(uint32_t v) { for (int i = 0; i < 4; i++) *p++ = (uint8_t) (v >> (8 * i)); }
     DEV void finish() {}
 };
 
 // stages a record into LDS; source bytes are pulled through a one-dword cache
 struct LdsSink {
     __attribute__((address_space(3))) uint8_t *p;
+    const uint8_t *src_end = nullptr;   // end of the readable source buffer: a 16-byte load may run past a
+                                        // field but never past this (nullptr: no over-read at all)
+    __attribute__((address_space(3))) uint8_t *limit = nullptr;   // end of this record's staging region: the
+                                        // neighbouring lane owns what follows, nothing may be written there
     DEV explicit LdsSink(__attribute__((address_space(3))) uint8_t *dst) : p(dst) {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) {
-        // gfx950 accepts unaligned dword accesses to LDS and to global memory alike
+        // gfx950 accepts unaligned dword accesses to LDS and to global memory alike.  The tail of a
+        // field is copied with ONE more 16-byte load + four dword stores: the bytes written past
+        // `len` are scratch that the next put()/copy() of the same record overwrites, which
+        // replaces up to six dependent dword/byte loads per field.
         typedef uint32_t u32u __attribute__((aligned(1)));
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         typedef v4 v4u __attribute__((aligned(1)));
         uint32_t i = 0;
         for (; i + 16 <= len; i += 16) {
             v4 w = *(const v4u *) (src + i);
-            *(LDS_AS u32u *) (p) = w.x; *(LDS_AS u32u *) (p + 4) = w.y;
-            *(LDS_AS u32u *) (p + 8) = w.z; *(LDS_AS u32u *) (p + 12) = w.w;
-            p += 16;
+            *(LDS_AS u32u *) (p + i) = w.x; *(LDS_AS u32u *) (p + i + 4) = w.y;
+            *(LDS_AS u32u *) (p + i + 8) = w.z; *(LDS_AS u32u *) (p + i + 12) = w.w;
         }
-        for (; i + 4 <= len; i += 4) {
-            *(LDS_AS u32u *) p = *(const u32u *) (src + i);
-            p += 4;
+        if (i < len) {
+            if (src + i + 16 <= src_end && p + i + 16 <= limit) {
+                v4 w = *(const v4u *) (src + i);
+                *(LDS_AS u32u *) (p + i) = w.x; *(LDS_AS u32u *) (p + i + 4) = w.y;
+                *(LDS_AS u32u *) (p + i + 8) = w.z; *(LDS_AS u32u *) (p + i + 12) = w.w;
+            }
+            else {
+                for (; i + 4 <= len; i += 4) *(LDS_AS u32u *) (p + i) = *(const u32u *) (src + i);
+                for (; i < len; i++) p[i] = (uint8_t) ld8(src + i);
+            }
         }
-        for (; i < len; i++) *p++ = (uint8_t) ld8(src + i);
+        p += len;
+    }
+    // `nbytes` bytes held little-endian in dwords at a wave-uniform address (scalar loads)
+    DEV void words(const uint32_t *w, uint32_t nbytes) {
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        const uint32_t nw = (nbytes + 3) / 4;
+        if (p + 4 * nw <= limit) for (uint32_t i = 0; i < nw; i++) *(LDS_AS u32u *) (p + 4 * i) = w[i];
+        else for (uint32_t i = 0; i < nbytes; i++) p[i] = (uint8_t) (w[i >> 2] >> (8 * (i & 3)));
+        p += nbytes;
+    }
+    DEV void put32(uint32_t v) {
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        *(LDS_AS u32u *) p = v;
+        p += 4;
     }
     DEV void finish() {}
 };
@@ -1218,8 +1248,7 @@ template <class S>
 DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
                       const RecInfo &ri, const CapsView &caps, uint64_t null_mask) {
     // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
-    s.put(0x92); s.put(0x92); s.put(0xd7); s.put(0x00);
-    pk_be(s, ri.ts_sec, 4); pk_be(s, ri.ts_nsec, 4);
+    s.put32(0x00d79292u); s.put32(__builtin_bswap32(ri.ts_sec)); s.put32(__builtin_bswap32(ri.ts_nsec));
     if (ri.meta_len) mp_canon(rec + ri.meta_off, rec + ri.meta_off + ri.meta_len, s);
     else s.put(0x80);
     const uint8_t *body = rec + ri.body_off, *body_end = body + ri.body_len;
@@ -1253,8 +1282,7 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
         uint32_t b = caps[2 * f], e = caps[2 * f + 1];
         uint32_t vlen = (b == CAP_UNSET || e == CAP_UNSET) ? 0 : e - b;
         const uint8_t *v = (b == CAP_UNSET || e == CAP_UNSET) ? val : val + b;
-        pk_str_hdr(s, (uint32_t) ps.field_name_len[f]);
-        for (int q = 0; q < ps.field_name_len[f]; q++) s.put((uint8_t) ps.names[ps.field_name_off[f] + q]);
+        s.words(ps.keywords + ps.kw_off[f], (uint32_t) ps.kw_bytes[f]);
         write_field_value(s, ps.field_type[f], v, vlen);
     }
     if (nappend > 0) {
@@ -1743,6 +1771,8 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
             }
             if (lane >= lo && lane < lo + m && o1 > o0) {
                 LdsSink s(stg + align + (uint32_t) (o0 - batch_base));
+                s.src_end = a.data + a.bytes;
+                s.limit = s.p + (uint32_t) (o1 - o0);
                 CapsView cv;
                 cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
                 write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r),
