@@ -274,6 +274,15 @@ DEV const uint8_t *mp_skip(const uint8_t *p, const uint8_t *end) {
     return p;
 }
 
+// end of the object whose header token `t` was read at `p`: scalars and str/bin/ext need no second
+// decode, only containers are walked
+DEV const uint8_t *mp_end_of(const Tok &t, const uint8_t *p, const uint8_t *end) {
+    if (t.type == T_BAD) return nullptr;
+    if (t.type == T_ARRAY || t.type == T_MAP) return t.len == 0 ? t.next : mp_skip(p, end);
+    if (t.type == T_STR || t.type == T_BIN || t.type == T_EXT) return t.next + t.len;
+    return t.next;
+}
+
 // canonical re-pack of one object (msgpack_pack_object, lib/msgpack-c/src/objectc.c:39-126)
 template <class S> DEV const uint8_t *mp_canon(const uint8_t *p, const uint8_t *end, S &s) {
     uint64_t remaining = 1;
@@ -395,11 +404,11 @@ DEV const uint8_t *map_find_last(const uint8_t *map, const uint8_t *end, const c
     const uint8_t *p = m.next, *found = nullptr;
     for (uint32_t i = 0; i < m.len; i++) {
         Tok k = mp_tok(p, end);
-        if (k.type == T_BAD) return nullptr;
-        const uint8_t *kend = mp_skip(p, end);
+        const uint8_t *kend = mp_end_of(k, p, end);
         if (!kend) return nullptr;
         if (k.type == T_STR && k.len == klen && bytes_eq(k.next, key, klen)) found = kend;
-        p = mp_skip(kend, end);
+        Tok v = mp_tok(kend, end);
+        p = mp_end_of(v, kend, end);
         if (!p) return nullptr;
     }
     return found;
@@ -1402,9 +1411,9 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         const uint8_t *p = bm.next;
         for (uint32_t i = 0; i < bm.len; i++) {
             Tok kt = mp_tok(p, ev.body_end);
-            const uint8_t *kend = mp_skip(p, ev.body_end);
+            const uint8_t *kend = mp_end_of(kt, p, ev.body_end);
             Tok vt = mp_tok(kend, ev.body_end);
-            p = mp_skip(kend, ev.body_end);
+            p = mp_end_of(vt, kend, ev.body_end);
             if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
                 bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) {
                 if (ncand == 0) { ri.val_off = (uint32_t) (vt.next - rec); ri.val_len = vt.len; ri.key_index = i; }
