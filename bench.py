@@ -31,6 +31,26 @@ GREP_RULE = ("regex", r"code ^5\d\d$")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def recorded_traffic(kernel, n):
+    """HBM bytes per launch of `kernel` from the committed PMC pass of this same command (rocprofv3 cannot
+    run inside the timed process): FETCH_SIZE + WRITE_SIZE (KiB), FETCH doubled for the kernels whose reads
+    are wide coalesced streams as the microarchitecture guide prescribes for gfx950.  None when the
+    workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r1_final_pmc_hbm_bench_10M.json")
+    if n != 10_000_000 or not os.path.exists(path):
+        return None, None
+    try:
+        ks = json.load(open(path))["kernels"]
+        hit = [v for k, v in ks.items() if k.split("::")[-1].split("<")[0] == kernel]
+        if not hit:
+            return None, None
+        coalesced = kernel in ("k_parser_locate", "k_grep_match", "k_gather")
+        b = hit[0].get("FETCH_SIZE", 0) * 1024 * (2 if coalesced else 1) + hit[0].get("WRITE_SIZE", 0) * 1024
+        return int(b), "profiles/r1_final_pmc_hbm_bench_10M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except Exception:
+        return None, None
+
+
 def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args):
     """filter_log_to_metrics on the parsed chunk (BASELINE configs[3] shape: counter + histogram, partial
     aggregates all-reduced over RCCL when N > 1) and NDJSON -> msgpack events -> 32-rule filter_grep
@@ -228,8 +248,9 @@ def main():
         ms, launches = prof[dom]
         avg_s = ms / 1e3 / max(launches, 1)
         ach = alg_bytes_per_launch.get(dom, in_bytes) / avg_s / 1e9
+        traffic, traffic_src = recorded_traffic(dom, n)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg_bytes_per_launch.get(dom, in_bytes))}
     kernels = {k: {"total_ms": round(v[0], 3), "launches": int(v[1])} for k, v in prof.items()}
