@@ -111,6 +111,7 @@ enum {
     RF_CAND = 32,          // exactly one candidate value located (fast phases)
     RF_RXOK = 64,          // parser 0's regex matched, spans published
     RF_GENERIC = 128,      // needs k_parser_generic
+    RF_EXACT = 256,        // a Types float value needs the exact decimal conversion: k_parser_emit_exact rewrites the record
 };
 
 constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
@@ -148,7 +149,8 @@ struct ParserMatchArgs {
     uint32_t lds_total;         // dynamic LDS bytes to request (tables + capture columns)
     uint32_t debug_skip;        // timing experiments only (FLBGPU_DEBUG_SKIP): results are wrong when != 0
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
-    unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel
+    unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel,
+                                     // [3] records for k_parser_emit_exact
     uint64_t bytes;                  // chunk size (bounds the coalesced tile loads)
 };
 
@@ -307,6 +309,7 @@ void launch_parser_generic(const ParserMatchArgs &a, int grid, hipStream_t st);
 void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out, hipStream_t st);
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
+void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);

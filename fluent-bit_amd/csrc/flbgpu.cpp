@@ -216,11 +216,6 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
                 else if (!strcasecmp(ty.c_str(), "bool")) t = TY_BOOL;
                 else if (!strcasecmp(ty.c_str(), "float")) t = TY_FLOAT;
                 else if (!strcasecmp(ty.c_str(), "hex")) t = TY_HEX;
-                if (t == TY_FLOAT) {
-                    set_err("parser '%s': Types float (libc atof) is not implemented on the GPU path yet", p->name.c_str());
-                    delete p;
-                    return nullptr;
-                }
                 tys.emplace_back(key, t);
             }
             q = *sp ? sp + 1 : sp;
@@ -456,7 +451,7 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[3]; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[4]; };
 
 static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
     uint64_t n = in->n;
@@ -541,6 +536,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
     ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes;
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
+    if (hm.counts[3] > 0) { ProfScope ps(f, st, "k_parser_emit_exact"); launch_parser_emit_exact(ea, st); }
     HIPOK(hipStreamSynchronize(st));
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     f->last_out = hm.counts[1];   // rows with length 0 (dropped/skipped) remain as empty rows

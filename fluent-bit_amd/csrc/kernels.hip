@@ -58,6 +58,8 @@ DEV uint32_t ldbe16(const uint8_t *p) { return (ld8(p) << 8) | ld8(p + 1); }
 // ------------------------------------------------------------------------------------------
 struct CountSink {
     uint64_t n = 0;
+    bool need_exact = false;          // set by the size pass when a Types float literal is a hard rounding case
+    DEV void note_exact() { need_exact = true; }
     DEV void put(uint32_t) { n++; }
     DEV void copy(const uint8_t *, uint32_t len) { n += len; }
     DEV void words(const uint32_t *, uint32_t nbytes) { n += nbytes; }
@@ -67,6 +69,7 @@ struct CountSink {
 
 struct ByteSink {
     uint8_t *p;
+    DEV void note_exact() {}
     DEV explicit ByteSink(uint8_t *dst) : p(dst) {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = (uint8_t) ld8(src + i); }
@@ -83,6 +86,7 @@ struct LdsSink {
     __attribute__((address_space(3))) uint8_t *limit = nullptr;   // end of this record's staging region: the
                                         // neighbouring lane owns what follows, nothing may be written there
     DEV explicit LdsSink(__attribute__((address_space(3))) uint8_t *dst) : p(dst) {}
+    DEV void note_exact() {}
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) {
         // gfx950 accepts unaligned dword accesses to LDS and to global memory alike.  The tail of a
@@ -1236,9 +1240,23 @@ struct CapsView {
 // ------------------------------------------------------------------------------------------
 // parsed-record body writer shared by the size pass and the emit pass
 // ------------------------------------------------------------------------------------------
-template <class S>
+struct FieldSrc {
+    const uint8_t *p;
+    DEV uint32_t operator[](uint32_t i) const { return ld8(p + i); }
+};
+
+template <bool EXACT, class S>
 DEV void write_field_value(S &s, int type, const uint8_t *v, uint32_t vlen) {
     switch (type) {
+    case TY_FLOAT: {
+        // atof(strndup(val)) (src/flb_parser.c:2111-2118): strtod, 0.0 when nothing converts
+        FieldSrc src{v};
+        nc::ScanResult r = nc::scan_double<EXACT>(src, vlen, nc::MODE_STRTOD);
+        if (r.status == nc::NC_NEED_EXACT) s.note_exact();      // k_parser_emit_exact rewrites this record
+        s.put(0xcb);
+        pk_be(s, r.status == nc::NC_OK ? r.bits : 0ull, 8);
+        break;
+    }
     case TY_INT: pk_int(s, d_atoll(v, vlen)); break;
     case TY_HEX: pk_uint(s, d_strtoull16(v, vlen)); break;
     case TY_BOOL:
@@ -1253,7 +1271,7 @@ DEV void write_field_value(S &s, int type, const uint8_t *v, uint32_t vlen) {
 
 
 // Writes (or sizes) the complete output record for `rec`.
-template <class S>
+template <bool EXACT = false, class S>
 DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
                       const RecInfo &ri, const CapsView &caps, uint64_t null_mask) {
     // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
@@ -1292,7 +1310,7 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
         uint32_t vlen = (b == CAP_UNSET || e == CAP_UNSET) ? 0 : e - b;
         const uint8_t *v = (b == CAP_UNSET || e == CAP_UNSET) ? val : val + b;
         s.words(ps.keywords + ps.kw_off[f], (uint32_t) ps.kw_bytes[f]);
-        write_field_value(s, ps.field_type[f], v, vlen);
+        write_field_value<EXACT>(s, ps.field_type[f], v, vlen);
     }
     if (nappend > 0) {
         const uint8_t *p = bm.next;
@@ -1647,6 +1665,7 @@ __global__ void __launch_bounds__(256) k_parser_finish(ParserMatchArgs a) {
             CountSink cs;
             write_record(cs, a.cfg, a.parsers, rec, a.data + a.row_off[r + 1], ri, caps, null_mask);
             a.out_len[r] = (uint32_t) cs.n;
+            if (cs.need_exact) { a.info[r] = flags | RF_EXACT; atomicAdd(&a.counts[3], 1ull); }
         }
     }
     for (int o = 32; o > 0; o >>= 1) n_gen += __shfl_down(n_gen, o, 64);
@@ -1725,9 +1744,8 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
         CountSink cs;
-        if (a.debug_skip & 2) cs.n = 270; else
         write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
-        if (!(a.debug_skip & 4))
+        if (cs.need_exact) { ri.flags |= RF_EXACT; atomicAdd(&a.counts[3], 1ull); }
         rec_store(a.info, a.n, r, ri);
         a.null_mask[r] = null_mask;
         a.out_len[r] = (uint32_t) cs.n;
@@ -1804,6 +1822,19 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // staging area reusable
             lo += m;
         }
+    }
+}
+
+// records whose Types float literal is a hard rounding case (RF_EXACT): rewritten in place with the
+// big-integer conversion, one record per lane straight to global memory (rare)
+__global__ void __launch_bounds__(64) k_parser_emit_exact(ParserEmitArgs a) {
+    for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * blockDim.x) {
+        if (!(a.info[r] & RF_EXACT) || a.out_off[r + 1] == a.out_off[r]) continue;
+        ByteSink s(a.out + a.out_off[r]);
+        CapsView cv;
+        cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
+        write_record<true>(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r), cv,
+                           a.null_mask[r]);
     }
 }
 
@@ -2139,6 +2170,11 @@ void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st) {
     uint64_t cap = (uint64_t) cus * 2 * 4;                 // 2 resident workgroups per CU, a few rounds each
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_grep_match, dim3((unsigned) blocks), dim3(GREP_BLOCK), lds, st, a);
+}
+void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st) {
+    uint64_t grid = (a.n + 63) / 64;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_parser_emit_exact, dim3((unsigned) grid), dim3(64), 0, st, a);
 }
 void launch_gather(const GatherArgs &a, hipStream_t st) {
     if (a.n == 0) return;

@@ -250,3 +250,26 @@ def test_filter_chain_matches_flb_filter_do(g):
             f.close()
         for p in keep:
             p.close()
+
+
+def test_types_float_and_friends(g):
+    # flb_parser_typecast (src/flb_parser.c:2067-2164): atof on the field text -- incl. literals whose
+    # rounding needs the exact path (rewritten by k_parser_emit_exact), junk, hex floats, inf/nan
+    rx = r"^(?<i>[^ ]*) (?<f>[^ ]*) (?<b>[^ ]*) (?<h>[^ ]*) (?<s>.*)$"
+    types = "i:integer f:float b:bool h:hex s:string"
+    floats = ["1.5", "0.1", "-2.5e3", "abc", "", "1e400", "-1e-400", "0x1.8p1", "inf", "nan", "9007199254740993",
+              "2.4703282292062328e-324", "1.7976931348623157e308", "123456789012345678901234567890.5", "  7", "1,5", "12abc",
+              "0.30000000000000004", "8.41e21", "1e23", "3.141592653589793238462643383279502884197", "+.5", ".", "-"]
+    rng = random.Random(12)
+    recs = []
+    for i in range(3000):
+        f = rng.choice(floats) if rng.random() < 0.7 else repr(rng.uniform(-1, 1) * 10.0 ** rng.randrange(-30, 30))
+        if rng.random() < 0.1: f = "%d.%d" % (rng.randrange(10), rng.getrandbits(90))
+        line = "%s %s %s %s tail %d" % (rng.choice(["12", "-7", "x", "99999999999"]), f, rng.choice(["true", "FALSE", "maybe"]),
+                                        rng.choice(["ff", "0x10", "zz"]), i)
+        recs.append(synth.v2_record(1700000000 + i, 0, {"log": line, "other": i}))
+    data = b"".join(recs)
+    for reserve, preserve in ((False, False), (True, True)):
+        o, q = both_parser(g, data, "log", [dict(regex=rx, types=types, skip_empty=False)], reserve, preserve)
+        assert o[0] == q[0] == ob.MODIFIED
+        assert o[1] == q[1], first_diff(o[1], q[1])
