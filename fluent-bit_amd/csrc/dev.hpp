@@ -67,6 +67,8 @@ struct DevParser {
     uint32_t keywords[MAX_NAMES + 1024 / 4 + MAX_NAMES];   // per field: msgpack str header + name, zero padded to a dword multiple
     int kw_off[MAX_NAMES];               // first dword of field f in keywords[]
     int kw_bytes[MAX_NAMES];             // header + name bytes
+    int fwd_first;                       // the pattern is anchored at the start: try the forward walk from boundary 0 before
+                                         // paying for the reverse pass (any match that starts at 0 is the leftmost one)
     int time_field;                      // the ONE named field that is the time key, -1 if none or several
     int plain_types;                     // no Types cast changes a value's encoded size (all string / none)
 };

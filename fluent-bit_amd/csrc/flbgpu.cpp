@@ -258,6 +258,8 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
             w += (nb + 3) / 4;
         }
     }
+    d.fwd_first = (regex[0] == '^' || (regex[0] == '\\' && regex[1] == 'A') || (regex[0] == '/' && (regex[1] == '^' || (regex[1] == '\\' && regex[2] == 'A')))) ? 1 : 0;
+    if (getenv("FLBGPU_NO_FWD_FIRST")) d.fwd_first = 0;
     d.time_field = -1;
     d.plain_types = 1;
     {

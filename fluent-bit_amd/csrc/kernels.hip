@@ -724,12 +724,48 @@ DEV uint32_t pack_col(const HotTabs<LDS> &t, uint32_t w, uint32_t pos, uint32_t 
     return v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
 }
 
-// Pass 2: deterministic leftmost-first walk from boundary `start`.  Value bytes are fetched four
-// at a time (unaligned dword, issued two groups ahead) and turned into a packed queue of column
-// codes one group ahead, so that a plain step is: index = row << wsh | column, ONE dependent LDS
-// read, and the entry IS the next row.  Everything else (capture writes, MATCH, lookahead, the
-// rare multi-candidate resolution) sits behind one "special" bit test.  Returns the end boundary of
-// the match (>= 0) or -1 on a table inconsistency.
+// the rare entries of the forward walk: one-byte lookahead, MATCH, the multi-candidate resolution
+// and dead ends.  Returns the plain entry to continue with; after a MATCH / dead end that is the
+// absorbing row (no capture writes, every column maps to itself), so the caller's loop needs no
+// early exit -- a lane that is done idles there until the wave's last position.
+template <bool LDS, class CAP>
+DEV uint32_t rx_forward_special(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, uint32_t j, uint32_t S,
+                                uint32_t colc, uint32_t next_code, uint32_t e, const uint16_t *chk, const uint8_t *slot2cap,
+                                CAP &caps, int &endpos, bool &fail) {
+    const uint32_t fsh = (uint32_t) t.fc_shift;
+    const uint32_t absorb = (uint32_t) t.nX * (uint32_t) t.NKp;
+    uint32_t ty = (e >> 28) & 7;
+    if (ty == FT_LOOK) {
+        const uint32_t cn = next_code & ((1u << fsh) - 1);           // class of the next byte / EOT
+        e = t.ft2[((e & 0xFFFFFF) << fsh) + cn];
+        if (!(e & FT_SPECIAL)) return e;
+        ty = (e >> 28) & 7;
+    }
+    if (ty == FT_MATCH) {
+        caps.set_raw((e >> 12) & 63, j);
+        caps.set_raw((e >> 18) & 63, j);
+        if (endpos < 0) endpos = (int) j;
+        return absorb;
+    }
+    if (ty == FT_MULTI && chk) {
+        const uint32_t x = S / (uint32_t) t.NKp, pkk = S % (uint32_t) t.NKp, nk = colc >> fsh;
+        const uint32_t li = (x * (uint32_t) t.NK + pkk) * (uint32_t) t.NK + nk;
+        const uint32_t tg = rx_resolve_multi(d, t, s, len, j, li, chk, slot2cap, caps);
+        if (tg == TG_MATCH) { if (endpos < 0) endpos = (int) j; return absorb; }
+        if (tg != TG_DEAD) return tg * (uint32_t) t.NKp + nk;         // plain entry without capture writes
+    }
+    // dead end, or a multi-candidate cell during the forward-first attempt (no reverse states yet)
+    fail = true;
+    return absorb;
+}
+
+// Pass 2: deterministic leftmost-first walk from boundary `start`.  Value bytes are fetched through
+// 64-byte windows (four unaligned dwordx4 loads issued together, a window ahead of use) and turned
+// into packed queues of 4 column codes one group ahead, so that a plain step is: index = row << wsh
+// | column, ONE dependent LDS read, and the entry IS the next row, plus two unconditional capture
+// writes (slot 0 is a dummy column).  Four steps are unrolled per trip; everything rare sits behind
+// one "special" bit test per step and never leaves the loop (rx_forward_special).  The loop runs to
+// the end-of-text column for every lane.  Returns the end boundary of the match (>= 0) or -1.
 template <bool LDS, class CAP>
 DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, int start, const uint16_t *chk,
                    const uint8_t *slot2cap, CAP &caps) {
@@ -737,68 +773,45 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
     const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
     uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : (uint32_t) (t.col[ld8(s + j - 1)] >> fsh);
     uint32_t S = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + pk;
-    // 64-byte windows of the value: four unaligned dwordx4 loads issued together (one L1 line
-    // fill), a window ahead of use; every 4 steps the next dword of the window becomes a packed
-    // queue of 4 column codes
     uint32_t gb = j;                                            // position of the current 4-byte group
     v4u32 c0 = load16(s, gb, len), c1 = load16(s, gb + 16, len), c2 = load16(s, gb + 32, len), c3 = load16(s, gb + 48, len);
     v4u32 x0 = load16(s, gb + 64, len), x1 = load16(s, gb + 80, len), x2 = load16(s, gb + 96, len), x3 = load16(s, gb + 112, len);
     uint32_t vq = pack_col(t, c0.x, gb, len);                   // codes of positions gb..gb+3
     uint32_t vqn = pack_col(t, c0.y, gb + 4, len);
     uint32_t sub = 2;                                           // dword of the window feeding the NEXT refill
-    uint32_t k = 0;
+    int endpos = -1;
+    bool fail = false;
     for (;;) {
-        const uint32_t colc = vq & 255;
-        uint32_t e = t.ft[(S << wsh) + colc];
-        if (e & FT_SPECIAL) {
-            uint32_t ty = (e >> 28) & 7;
-            if (ty == FT_LOOK) {
-                uint32_t cn = (k < 3 ? (vq >> 8) : vqn) & ((1u << fsh) - 1);   // class of the next byte / EOT
-                e = t.ft2[((e & 0xFFFFFF) << fsh) + cn];
-                ty = (e & FT_SPECIAL) ? (e >> 28) & 7 : 0;
-            }
-            if (ty == FT_MATCH) {
-                caps.set_raw((e >> 12) & 63, j);
-                caps.set_raw((e >> 18) & 63, j);
-                return (int) j;
-            }
-            if (ty == FT_MULTI) {
-                uint32_t x = S / (uint32_t) t.NKp, pkk = S % (uint32_t) t.NKp, nk = colc >> fsh;
-                uint32_t li = (x * (uint32_t) t.NK + pkk) * (uint32_t) t.NK + nk;
-                uint32_t tg = rx_resolve_multi(d, t, s, len, j, li, chk, slot2cap, caps);
-                if (tg == TG_DEAD) return -1;
-                if (tg == TG_MATCH) return (int) j;
-                e = tg * (uint32_t) t.NKp + nk;          // plain entry without capture writes
-            }
-            else if (ty != 0) return -1;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t colc = (vq >> (8 * k)) & 255;
+            uint32_t e = t.ft[(S << wsh) + colc];
+            if (e & FT_SPECIAL)
+                e = rx_forward_special(d, t, s, len, j, S, colc, k < 3 ? (vq >> (8 * (k + 1))) & 255 : vqn & 255, e, chk, slot2cap, caps,
+                                       endpos, fail);
+            caps.set_raw((e >> 12) & 63, j);
+            caps.set_raw((e >> 18) & 63, j);
+            S = e & 0xFFF;
+            j++;
         }
-        // plain step: capture writes are unconditional (column 0 is a dummy), so group boundaries
-        // cost no divergent branch
-        caps.set_raw((e >> 12) & 63, j);
-        caps.set_raw((e >> 18) & 63, j);
-        S = e & 0xFFF;
-        j++;
-        vq >>= 8;
-        if (++k == 4) {
-            if (j > len) return -1;
-            k = 0;
-            gb += 4;
-            vq = vqn;
-            // codes of positions gb+4..gb+7: dword `sub` of the current window, or the first dword
-            // of the next window once the current one is used up
-            if (sub == 16) {
-                c0 = x0; c1 = x1; c2 = x2; c3 = x3;
-                const uint32_t nb = gb + 4 + 64;
-                x0 = load16(s, nb, len); x1 = load16(s, nb + 16, len); x2 = load16(s, nb + 32, len); x3 = load16(s, nb + 48, len);
-                sub = 0;
-            }
-            const uint32_t q4 = sub >> 2, q1 = sub & 3;
-            const v4u32 cv = q4 == 0 ? c0 : q4 == 1 ? c1 : q4 == 2 ? c2 : c3;
-            const uint32_t w = q1 == 0 ? cv.x : q1 == 1 ? cv.y : q1 == 2 ? cv.z : cv.w;
-            vqn = pack_col(t, w, gb + 4, len);
-            sub++;
+        if (j > len) break;                                      // the end-of-text column has been consumed
+        gb += 4;
+        vq = vqn;
+        // codes of positions gb+4..gb+7: dword `sub` of the current window, or the first dword of the
+        // next window once the current one is used up
+        if (sub == 16) {
+            c0 = x0; c1 = x1; c2 = x2; c3 = x3;
+            const uint32_t nb = gb + 4 + 64;
+            x0 = load16(s, nb, len); x1 = load16(s, nb + 16, len); x2 = load16(s, nb + 32, len); x3 = load16(s, nb + 48, len);
+            sub = 0;
         }
+        const uint32_t q4 = sub >> 2, q1 = sub & 3;
+        const v4u32 cv = q4 == 0 ? c0 : q4 == 1 ? c1 : q4 == 2 ? c2 : c3;
+        const uint32_t w = q1 == 0 ? cv.x : q1 == 1 ? cv.y : q1 == 2 ? cv.z : cv.w;
+        vqn = pack_col(t, w, gb + 4, len);
+        sub++;
     }
+    return fail ? -1 : endpos;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1542,11 +1555,22 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
         if (!(flags & RF_CAND)) continue;
         const uint32_t vlen = a.info[2 * a.n + r];
         const uint8_t *val = a.data + a.row_off[r] + a.info[1 * a.n + r];
-        int best = rx_reverse(hot0, ps.ascii.r_info, val, vlen, chk);
-        int endb = -1;
-        if (best >= 0 && ps.nregs_minus1 > 0) {
+        // phase 0: forward walk from boundary 0 with no reverse pass (start-anchored patterns: a match
+        // that starts at 0 is the leftmost one, and every choice the walk makes is forced by the
+        // byte / the next byte whenever a match exists); phase 1: reverse pass; phase 2: forward
+        // walk from the leftmost viable start.  One call site each keeps the kernel small.
+        int phase = (ps.fwd_first && ps.nregs_minus1 > 0) ? 0 : 1;
+        int best = 0, endb = -1;
+        for (;;) {
+            if (phase == 1) {
+                best = rx_reverse(hot0, ps.ascii.r_info, val, vlen, chk);
+                if (best < 0 || ps.nregs_minus1 <= 0) break;
+                phase = 2;
+            }
             for (int c = 0; c < ncap; c++) capl.set((uint32_t) c, CAP_UNSET);
-            endb = rx_forward(ps.ascii, hot0, val, vlen, best, chk, ps.slot2cap, capl);
+            endb = rx_forward(ps.ascii, hot0, val, vlen, phase == 0 ? 0 : best, phase == 0 ? (const uint16_t *) nullptr : chk, ps.slot2cap, capl);
+            if (endb >= 0 || phase == 2) break;
+            phase = 1;
         }
         if (endb >= 0) {
             // publish the spans: [span][record] columns, a wave stores 64 consecutive words

@@ -1168,7 +1168,10 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
             // a plain step: next row | capture writes (slot 0 = the dummy "no write" column)
             return (tg * (uint32_t) out.NKp + (uint32_t) nk) | caps;
         };
-        out.ft.assign((size_t) X * out.NKp * W, FT_SPECIAL | (FT_DEAD << 28));
+        // one more row than there are (core, previous kind) pairs: the absorbing row the forward walk
+        // parks in after MATCH / a dead end (every column -> itself, no capture writes)
+        out.ft.assign(((size_t) X * out.NKp + 1) * W, FT_SPECIAL | (FT_DEAD << 28));
+        for (size_t c = 0; c < W; c++) out.ft[(size_t) X * out.NKp * W + c] = (uint32_t) X * (uint32_t) out.NKp;
         out.ft2.assign(out.fast2.size(), FT_SPECIAL | (FT_DEAD << 28));
         for (int x = 0; x < X; x++)
             for (int pk = 0; pk < out.NK; pk++)
