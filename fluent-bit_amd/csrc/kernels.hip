@@ -324,12 +324,37 @@ struct Event {
     const uint8_t *body_end;
 };
 
-DEV Event decode_event(const uint8_t *rec, const uint8_t *end) {
+// lazy_body: the body map is NOT walked here; ev.body_end is the end of the row and the caller's
+// own walk over the map (a key lookup) has to end exactly there, which is the same validation at
+// no extra cost (map_find_last's `whole` flag).
+DEV Event decode_event(const uint8_t *rec, const uint8_t *end, bool lazy_body = false) {
     Event ev;
     ev.flags = RF_BAD; ev.sec = 0; ev.nsec = 0; ev.meta = nullptr; ev.meta_end = nullptr; ev.body = nullptr; ev.body_end = nullptr;
     // an empty row is a record an earlier filter dropped (device chunks keep one row per input
     // record): there are no bytes, so there is nothing to decode -- invisible like a group marker
     if (rec == end) { ev.flags = RF_VALID | RF_SKIP; return ev; }
+    // the encoder's own layout first: 92 92 d7 00 <sec32> <nsec32> 80 <body map>  (one compare
+    // instead of five token decodes)
+    if ((uint64_t) (end - rec) >= 14 && ldu32(rec) == 0x00d79292u && ld8(rec + 12) == 0x80) {
+        const uint32_t s0 = ldbe32(rec + 4), ns0 = ldbe32(rec + 8);
+        Tok b0 = mp_tok(rec + 13, end);
+        if (b0.type != T_MAP) return ev;
+        if (s0 == 0xffffffffu || s0 == 0xfffffffeu) {
+            if (ns0 != 0) return ev;
+            ev.sec = s0 == 0xffffffffu ? -1 : -2;
+        }
+        else {
+            if (ns0 >= 1000000000u) return ev;
+            ev.sec = s0; ev.nsec = ns0;
+        }
+        ev.meta = rec + 12; ev.meta_end = rec + 13;
+        ev.body = rec + 13;
+        ev.body_end = lazy_body ? end : mp_skip(rec + 13, end);
+        if (!ev.body_end) return ev;
+        ev.flags = RF_VALID;
+        if (ev.sec < 0) ev.flags |= RF_SKIP;
+        return ev;
+    }
     Tok root = mp_tok(rec, end);
     if (root.type != T_ARRAY || root.len != 2) return ev;
     const uint8_t *p = root.next;
@@ -360,7 +385,7 @@ DEV Event decode_event(const uint8_t *rec, const uint8_t *end) {
     Tok b = mp_tok(after_header, end);
     if (b.type != T_MAP) return ev;
     ev.body = after_header;
-    ev.body_end = mp_skip(after_header, end);
+    ev.body_end = lazy_body ? end : mp_skip(after_header, end);
     if (!ev.body_end) return ev;
     // timestamp value (flb_log_event_decoder_decode_timestamp)
     if (ts.type == T_UINT) { ev.sec = (int64_t) ts.u; ev.nsec = 0; }
@@ -402,7 +427,9 @@ DEV bool bytes_eq(const uint8_t *a, const char *b, uint32_t n) {
 }
 
 // src/flb_ra_key.c:108-135: LAST entry whose key is a STR equal to `key`; returns the value ptr
-DEV const uint8_t *map_find_last(const uint8_t *map, const uint8_t *end, const char *key, uint32_t klen) {
+// *whole (optional) is set when the walk decoded every key and value of the map and ended exactly
+// at `end`: the map is then a well-formed object that fills [map, end)
+DEV const uint8_t *map_find_last(const uint8_t *map, const uint8_t *end, const char *key, uint32_t klen, bool *whole = nullptr) {
     Tok m = mp_tok(map, end);
     if (m.type != T_MAP) return nullptr;
     const uint8_t *p = m.next, *found = nullptr;
@@ -415,13 +442,14 @@ DEV const uint8_t *map_find_last(const uint8_t *map, const uint8_t *end, const c
         p = mp_end_of(v, kend, end);
         if (!p) return nullptr;
     }
+    if (whole) *whole = (p == end);
     return found;
 }
 
 // src/flb_ra_key.c:151-236 + :374-434: resolves `$key['a'][1]`; returns pointer to the value
 // object or nullptr.  *plain is set when the top-level value was used as is.
-DEV const uint8_t *ra_resolve(const DevKey &k, const uint8_t *body, const uint8_t *end) {
-    const uint8_t *val = map_find_last(body, end, k.key, (uint32_t) k.key_len);
+DEV const uint8_t *ra_resolve(const DevKey &k, const uint8_t *body, const uint8_t *end, bool *whole = nullptr) {
+    const uint8_t *val = map_find_last(body, end, k.key, (uint32_t) k.key_len, whole);
     if (!val) return nullptr;
     Tok t = mp_tok(val, end);
     if ((t.type == T_MAP || t.type == T_ARRAY) && k.nsub > 0) {
@@ -1417,21 +1445,30 @@ DEV void recinfo_init(RecInfo &ri) {
 DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec, const uint8_t *rec_end, uint32_t &n_dec) {
     RecInfo ri;
     recinfo_init(ri);
-    Event ev = decode_event(rec, rec_end);
+    // the body map is validated by the candidate search below (it walks every key and value)
+    Event ev = decode_event(rec, rec_end, true);
     ri.flags = ev.flags;
     if (ev.flags & RF_BAD) {
         atomicMin(a.first_bad, (unsigned long long) r);
         rec_store(a.info, a.n, r, ri);
         return 0;
     }
-    if (ev.flags & RF_SKIP) { rec_store(a.info, a.n, r, ri); return 0; }
+    if (ev.flags & RF_SKIP) {
+        if (rec != rec_end && mp_skip(ev.body, rec_end) != rec_end) {        // a marker with a broken body is a decoder error too
+            ri.flags = RF_BAD;
+            atomicMin(a.first_bad, (unsigned long long) r);
+        }
+        rec_store(a.info, a.n, r, ri);
+        return 0;
+    }
     n_dec++;
     ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
     if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
     // candidate values (plugins/filter_parser/filter_parser.c:259-323)
     uint32_t ncand = 0;
+    bool whole = false;
     if (a.cfg.key.is_ra) {
-        const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end);
+        const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end, &whole);
         if (v) {
             Tok t = mp_tok(v, ev.body_end);
             if (t.type == T_STR || t.type == T_BIN) { ri.val_off = (uint32_t) (t.next - rec); ri.val_len = t.len; ncand = 1; }
@@ -1443,14 +1480,26 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         for (uint32_t i = 0; i < bm.len; i++) {
             Tok kt = mp_tok(p, ev.body_end);
             const uint8_t *kend = mp_end_of(kt, p, ev.body_end);
+            if (!kend) { p = nullptr; break; }
             Tok vt = mp_tok(kend, ev.body_end);
             p = mp_end_of(vt, kend, ev.body_end);
+            if (!p) break;
             if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
                 bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) {
                 if (ncand == 0) { ri.val_off = (uint32_t) (vt.next - rec); ri.val_len = vt.len; ri.key_index = i; }
                 ncand++;
             }
         }
+        whole = (p == ev.body_end);
+    }
+    if (!whole) {
+        // the body does not decode to exactly the rest of the row: decoder error, the loop stops here
+        n_dec--;
+        recinfo_init(ri);
+        ri.flags = RF_BAD;
+        atomicMin(a.first_bad, (unsigned long long) r);
+        rec_store(a.info, a.n, r, ri);
+        return 0;
     }
     if (ncand == 1 && a.caps_in_lds && ri.val_len < 0xFFFF && (ri.val_len / CHK_STEP + 2) <= a.chk_len) ri.flags |= RF_CAND;
     else if (ncand >= 1) { ri.flags |= RF_GENERIC; atomicAdd(&a.counts[2], 1ull); }
@@ -1867,8 +1916,8 @@ __global__ void __launch_bounds__(64) k_parser_emit_exact(ParserEmitArgs a) {
 // ------------------------------------------------------------------------------------------
 
 // flb_ra_regex_match (src/flb_record_accessor.c:753-765): > 0 match, <= 0 no match
-DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_end) {
-    const uint8_t *v = ra_resolve(ru.key, body, body_end);
+DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_end, bool *whole = nullptr) {
+    const uint8_t *v = ra_resolve(ru.key, body, body_end, whole);
     if (!v) return -1;
     Tok t = mp_tok(v, body_end);
     if (t.type != T_STR) return -1;
@@ -1882,13 +1931,15 @@ DEV int rule_match(const GrepRule &ru, const uint8_t *body, const uint8_t *body_
 }
 
 // rule evaluation for one decoded event
-DEV bool grep_decide(const GrepArgs &a, const Event &ev) {
+// *valid: the first rule's key lookup walks the whole body map -- that walk doubles as the
+// decoder's validation of the body (decode_event(lazy_body))
+DEV bool grep_decide(const GrepArgs &a, const Event &ev, bool *valid) {
     bool keep = true;
     if (a.logical_op == OP_LEGACY) {
         // plugins/filter_grep/grep.c:167-194
         for (int i = 0; i < a.nrules; i++) {
             const GrepRule &ru = a.rules[i];
-            int ret = rule_match(ru, ev.body, ev.body_end);
+            int ret = rule_match(ru, ev.body, ev.body_end, i == 0 ? valid : nullptr);
             if (ret <= 0) { if (ru.type == GREP_REGEX) { keep = false; break; } }
             else { keep = (ru.type != GREP_EXCLUDE); break; }
         }
@@ -1899,7 +1950,7 @@ DEV bool grep_decide(const GrepArgs &a, const Event &ev) {
         int last = 0;
         for (int i = 0; i < a.nrules; i++) {
             last = i;
-            found = rule_match(a.rules[i], ev.body, ev.body_end) > 0;
+            found = rule_match(a.rules[i], ev.body, ev.body_end, i == 0 ? valid : nullptr) > 0;
             if (a.logical_op == OP_OR && found) break;
             if (a.logical_op == OP_AND && !found) break;
         }
@@ -1965,12 +2016,19 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
                     rec = (const uint8_t *) (tile + align + (uint32_t) (o0 - g0));
                     rec_end = rec + (o1 - o0);
                 }
-                Event ev = decode_event(rec, rec_end);
+                Event ev = decode_event(rec, rec_end, true);
+                bool keep = false;
+                if (!(ev.flags & (RF_BAD | RF_SKIP))) {
+                    bool valid = false;
+                    keep = grep_decide(a, ev, &valid);
+                    if (!valid) valid = mp_skip(ev.body, rec_end) == rec_end;     // no rule walked the map
+                    if (!valid) ev.flags = RF_BAD;
+                }
+                else if ((ev.flags & RF_SKIP) && rec != rec_end && mp_skip(ev.body, rec_end) != rec_end) ev.flags = RF_BAD;
                 a.status[r] = ev.flags;
                 if (ev.flags & RF_BAD) { atomicMin(a.first_bad, (unsigned long long) r); a.keep_len[r] = 0; }
                 else if (ev.flags & RF_SKIP) a.keep_len[r] = 0;
                 else {
-                    bool keep = grep_decide(a, ev);
                     a.keep_len[r] = keep ? (uint32_t) (o1 - o0) : 0;
                     n_dec++;
                     if (keep) n_keep++;
