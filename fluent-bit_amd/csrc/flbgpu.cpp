@@ -331,9 +331,24 @@ bool filter_common_init(flbgpu_filter *f) {
     return true;
 }
 
-extern "C" void flbgpu_filter_profile(flbgpu_filter *f, int enable) { f->prof = enable != 0; f->kp.clear(); }
+void prof_resolve(flbgpu_filter *f) {
+    for (auto &p : f->pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            bool hit = false;
+            for (auto &k : f->kp) if (!strcmp(k.name, p.name)) { k.ms += ms; k.launches++; hit = true; break; }
+            if (!hit) { KernelProf k; k.name = p.name; k.ms = ms; k.launches = 1; f->kp.push_back(k); }
+        }
+        (void) hipEventDestroy(p.e0);
+        (void) hipEventDestroy(p.e1);
+    }
+    f->pending.clear();
+}
+
+extern "C" void flbgpu_filter_profile(flbgpu_filter *f, int enable) { prof_resolve(f); f->prof = enable != 0; f->kp.clear(); }
 
 extern "C" int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char **names, double *ms, uint64_t *launches) {
+    prof_resolve(f);
     int n = 0;
     for (auto &k : f->kp) {
         if (n >= max) break;

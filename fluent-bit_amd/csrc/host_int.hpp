@@ -62,6 +62,7 @@ struct L2mState;
 void l2m_state_destroy(L2mState *);
 
 struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
+struct ProfPending { const char *name; hipEvent_t e0, e1; };
 
 enum { F_PARSER = 1, F_GREP = 2, F_L2M = 3 };
 
@@ -87,8 +88,10 @@ struct flbgpu_filter {
     // profiling
     bool prof = false;
     std::vector<KernelProf> kp;
+    std::vector<ProfPending> pending;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~flbgpu_filter() {
+        for (auto &p : pending) { (void) hipEventDestroy(p.e0); (void) hipEventDestroy(p.e1); }
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
@@ -102,22 +105,23 @@ struct flbgpu_filter {
 
 bool filter_common_init(flbgpu_filter *f);
 
+// Kernel timing: an event pair per launch, recorded on the stream the kernel runs on and resolved
+// only when the totals are read (no host synchronisation inside the timed region).
 struct ProfScope {
     flbgpu_filter *f; hipStream_t st; const char *name; bool on;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(flbgpu_filter *f_, hipStream_t st_, const char *n) : f(f_), st(st_), name(n), on(f_->prof) {
-        if (on) (void) hipEventRecord(f->ev0, st);
+        if (!on) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        (void) hipEventRecord(e0, st);
     }
     ~ProfScope() {
         if (!on) return;
-        (void) hipEventRecord(f->ev1, st);
-        (void) hipEventSynchronize(f->ev1);
-        float ms = 0;
-        (void) hipEventElapsedTime(&ms, f->ev0, f->ev1);
-        for (auto &k : f->kp) if (!strcmp(k.name, name)) { k.ms += ms; k.launches++; return; }
-        KernelProf k; k.name = name; k.ms = ms; k.launches = 1;
-        f->kp.push_back(k);
+        (void) hipEventRecord(e1, st);
+        f->pending.push_back(ProfPending{name, e0, e1});
     }
 };
+void prof_resolve(flbgpu_filter *f);
 
 // filter_log_to_metrics entry used by flbgpu_filter_run / flbgpu_filter_run_dev
 bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, int *ret);

@@ -1317,8 +1317,8 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
                       const RecInfo &ri, const CapsView &caps, uint64_t null_mask) {
     // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
     s.put32(0x00d79292u); s.put32(__builtin_bswap32(ri.ts_sec)); s.put32(__builtin_bswap32(ri.ts_nsec));
-    if (ri.meta_len) mp_canon(rec + ri.meta_off, rec + ri.meta_off + ri.meta_len, s);
-    else s.put(0x80);
+    if (ri.meta_len > 1) mp_canon(rec + ri.meta_off, rec + ri.meta_off + ri.meta_len, s);
+    else s.put(0x80);                                        // no metadata, or the one-byte empty map
     const uint8_t *body = rec + ri.body_off, *body_end = body + ri.body_len;
     if (!(ri.flags & RF_PARSED)) {
         mp_canon(body, body_end, s);
@@ -1326,9 +1326,11 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
     }
     const DevParser &ps = parsers[ri.parser_idx];
     // kvs to append after the parsed ones (filter_parser.c:343-395)
-    Tok bm = mp_tok(body, body_end);
+    Tok bm;
+    bm.type = T_MAP; bm.len = 0; bm.u = 0; bm.next = body;
     uint32_t nappend = 0;
     bool plain_key = !cfg.key.is_ra;
+    if (cfg.reserve_data || cfg.preserve_key) bm = mp_tok(body, body_end);
     if (cfg.reserve_data) {
         nappend = bm.len;
         if (plain_key && !cfg.preserve_key) {
