@@ -1650,7 +1650,7 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
 
 // named fields, time lookup and size of the records parser 0 matched
 constexpr int FIN_SLOT = 4 * TBUF_WORDS + 4;      // per-lane LDS slot for the time text (+4: spreads the banks)
-__global__ void __launch_bounds__(256) k_parser_finish(ParserMatchArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_parser_finish(ParserMatchArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t tls_mem[256 * FIN_SLOT];
     __shared__ char fmt_mem[2 * MAX_TIMEFMT];
     LDS_AS uint8_t *tls = (LDS_AS uint8_t *) tls_mem;
