@@ -58,7 +58,18 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint8_t> b;
     std::vector<uint8_t> cls(t.cls, t.cls + 256);
     // hot block first (staged into LDS as one piece): rdelta | ft | ft2 | cls | col
-    size_t o_rd = put(b, t.rdelta_p), o_ft = put(b, t.ft), o_f2 = put(b, t.ft2), o_cls = put(b, cls), o_col = put(b, t.col);
+    // device encoding of the forward tables: a plain entry carries the dword index of the next
+    // ROW (row << wsh, 19 bits: rx.cpp caps the table at 2 MiB) so that a step's address is one add
+    // and one shift-add; the two capture actions move up to bits 19 / 25.  Special entries keep
+    // the layout of rx.hpp (the rare path decodes them).
+    auto dev_entry = [&](uint32_t e) -> uint32_t {
+        if (e & FT_SPECIAL) return e;
+        return ((e & 0xFFF) << t.wsh) | (((e >> 12) & 63) << 19) | (((e >> 18) & 63) << 25);
+    };
+    std::vector<uint32_t> ftd(t.ft.size()), ft2d(t.ft2.size());
+    for (size_t i = 0; i < t.ft.size(); i++) ftd[i] = dev_entry(t.ft[i]);
+    for (size_t i = 0; i < t.ft2.size(); i++) ft2d[i] = dev_entry(t.ft2[i]);
+    size_t o_rd = put(b, t.rdelta_p), o_ft = put(b, ftd), o_f2 = put(b, ft2d), o_cls = put(b, cls), o_col = put(b, t.col);
     size_t hot_end = (b.size() + 15) & ~(size_t) 15;
     b.resize(hot_end);
     size_t o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);

@@ -699,11 +699,12 @@ DEV int rx_reverse(const HotTabs<LDS> &t, const uint8_t *r_info, const uint8_t *
 // ([slot][thread] layout, conflict-free) -- no divergent global stores in the walk; CapGlobal
 // writes the u32 row in global memory directly (values of 65535 bytes or more).
 struct CapLds {
-    LDS_AS uint16_t *base;      // this thread's column; slot 0 is a dummy, span index ci lives in slot ci+1
-    uint32_t stride;            // threads per workgroup
-    DEV void set_raw(uint32_t slot, uint32_t j) { base[slot * stride] = (uint16_t) j; }
-    DEV void set(uint32_t ci, uint32_t j) { base[(ci + 1) * stride] = (uint16_t) j; }
-    DEV uint32_t get(uint32_t ci) const { uint32_t v = base[(ci + 1) * stride]; return v == 0xFFFF ? CAP_UNSET : v; }
+    LDS_AS uint8_t *base;       // this thread's column; slot 0 is a dummy, span index ci lives in slot ci+1
+    uint32_t stride_b;          // BYTES between slots (2 * threads per workgroup): address = one 24-bit mad
+    DEV LDS_AS uint16_t *at(uint32_t slot) const { return (LDS_AS uint16_t *) (base + __umul24(slot, stride_b)); }
+    DEV void set_raw(uint32_t slot, uint32_t j) { *at(slot) = (uint16_t) j; }
+    DEV void set(uint32_t ci, uint32_t j) { *at(ci + 1) = (uint16_t) j; }
+    DEV uint32_t get(uint32_t ci) const { uint32_t v = *at(ci + 1); return v == 0xFFFF ? CAP_UNSET : v; }
 };
 struct CapGlobal {
     uint32_t *base;             // [span][n] column block
@@ -757,11 +758,12 @@ DEV uint32_t pack_col(const HotTabs<LDS> &t, uint32_t w, uint32_t pos, uint32_t 
 // absorbing row (no capture writes, every column maps to itself), so the caller's loop needs no
 // early exit -- a lane that is done idles there until the wave's last position.
 template <bool LDS, class CAP>
-DEV uint32_t rx_forward_special(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, uint32_t j, uint32_t S,
+DEV uint32_t rx_forward_special(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uint32_t len, uint32_t j, uint32_t Sidx,
                                 uint32_t colc, uint32_t next_code, uint32_t e, const uint16_t *chk, const uint8_t *slot2cap,
                                 CAP &caps, int &endpos, bool &fail) {
-    const uint32_t fsh = (uint32_t) t.fc_shift;
-    const uint32_t absorb = (uint32_t) t.nX * (uint32_t) t.NKp;
+    const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
+    const uint32_t absorb = ((uint32_t) t.nX * (uint32_t) t.NKp) << wsh;       // plain entries carry row << wsh
+    const uint32_t S = Sidx >> wsh;
     uint32_t ty = (e >> 28) & 7;
     if (ty == FT_LOOK) {
         const uint32_t cn = next_code & ((1u << fsh) - 1);           // class of the next byte / EOT
@@ -780,7 +782,7 @@ DEV uint32_t rx_forward_special(const DevCap &d, const HotTabs<LDS> &t, const ui
         const uint32_t li = (x * (uint32_t) t.NK + pkk) * (uint32_t) t.NK + nk;
         const uint32_t tg = rx_resolve_multi(d, t, s, len, j, li, chk, slot2cap, caps);
         if (tg == TG_MATCH) { if (endpos < 0) endpos = (int) j; return absorb; }
-        if (tg != TG_DEAD) return tg * (uint32_t) t.NKp + nk;         // plain entry without capture writes
+        if (tg != TG_DEAD) return (tg * (uint32_t) t.NKp + nk) << wsh;  // plain entry without capture writes
     }
     // dead end, or a multi-candidate cell during the forward-first attempt (no reverse states yet)
     fail = true;
@@ -800,7 +802,7 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
     uint32_t j = (uint32_t) start;
     const uint32_t fsh = (uint32_t) t.fc_shift, wsh = (uint32_t) t.wsh;
     uint32_t pk = j == 0 ? (uint32_t) t.kind_edge : (uint32_t) (t.col[ld8(s + j - 1)] >> fsh);
-    uint32_t S = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + pk;
+    uint32_t S = (((uint32_t) t.nX - 1) * (uint32_t) t.NKp + pk) << wsh;   // dword index of the current row
     uint32_t gb = j;                                            // position of the current 4-byte group
     v4u32 c0 = load16(s, gb, len), c1 = load16(s, gb + 16, len), c2 = load16(s, gb + 32, len), c3 = load16(s, gb + 48, len);
     v4u32 x0 = load16(s, gb + 64, len), x1 = load16(s, gb + 80, len), x2 = load16(s, gb + 96, len), x3 = load16(s, gb + 112, len);
@@ -813,13 +815,13 @@ DEV int rx_forward(const DevCap &d, const HotTabs<LDS> &t, const uint8_t *s, uin
         #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t colc = (vq >> (8 * k)) & 255;
-            uint32_t e = t.ft[(S << wsh) + colc];
+            uint32_t e = t.ft[S + colc];
             if (e & FT_SPECIAL)
                 e = rx_forward_special(d, t, s, len, j, S, colc, k < 3 ? (vq >> (8 * (k + 1))) & 255 : vqn & 255, e, chk, slot2cap, caps,
                                        endpos, fail);
-            caps.set_raw((e >> 12) & 63, j);
-            caps.set_raw((e >> 18) & 63, j);
-            S = e & 0xFFF;
+            caps.set_raw((e >> 19) & 63, j);
+            caps.set_raw((e >> 25) & 63, j);
+            S = e & 0x7FFFF;
             j++;
         }
         if (j > len) break;                                      // the end-of-text column has been consumed
@@ -1595,8 +1597,8 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
     }
     else hot0 = hot_global(ps.ascii);
     CapLds capl;
-    capl.base = (LDS_AS uint16_t *) (g_lds + a.caps_lds_off) + threadIdx.x;
-    capl.stride = blockDim.x;
+    capl.base = (LDS_AS uint8_t *) (g_lds + a.caps_lds_off) + 2 * threadIdx.x;
+    capl.stride_b = 2 * blockDim.x;
     const int ncap = 2 * ps.nfields;
     uint32_t n_gen = 0;
     for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {

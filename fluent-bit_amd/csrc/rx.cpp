@@ -1156,6 +1156,7 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
         out.wsh = out.fc_shift + (out.NKp == 1 ? 0 : out.NKp == 2 ? 1 : 2);
         const size_t W = (size_t) 1 << out.wsh;
         if ((size_t) X * out.NKp >= 4096 || out.NKp * ncols > 256) { err = "pattern too large for the GPU fast tables"; return false; }
+        if ((((size_t) X * out.NKp + 1) << out.wsh) > (1u << 19)) { err = "pattern too large for the GPU fast tables (forward table over 2 MiB)"; return false; }
         out.col.resize(256);
         for (int b = 0; b < 256; b++) out.col[b] = (uint8_t) ((out.kind_of_cls[out.cls[b]] << out.fc_shift) | out.cls[b]);
         out.col_eot = (out.kind_edge << out.fc_shift) | out.ncls;
