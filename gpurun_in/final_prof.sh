@@ -2,8 +2,8 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
+python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 CMD="python $R/bench.py --no-cpu --steps 5 --warmup 1"
-$CMD > $O/bench_nocpu.json 2> $O/bench_nocpu.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats_run.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $CMD > /dev/null 2>&1
@@ -19,7 +19,7 @@ for d in ("pmc_fetch", "pmc_write"):
 out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}
 json.dump(out, open(os.path.join(O, "pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
-    if "flbgpu" in k: print(k, {c: round(x / 1e6, 3) for c, x in v.items()})
+    if "parser" in k or "grep" in k: print(k, {c: round(x / 1e6, 3) for c, x in v.items()})
 PY
-head -30 $O/kernel_stats.csv
-tail -c 1500 $O/bench_nocpu.json
+head -12 $O/kernel_stats.csv | cut -c1-160
+cat $O/bench_default.json | cut -c1-2600
