@@ -273,3 +273,60 @@ def test_types_float_and_friends(g):
         o, q = both_parser(g, data, "log", [dict(regex=rx, types=types, skip_empty=False)], reserve, preserve)
         assert o[0] == q[0] == ob.MODIFIED
         assert o[1] == q[1], first_diff(o[1], q[1])
+
+
+def _rand_obj(rng, depth=0):
+    t = rng.randrange(12 if depth < 3 else 8)
+    if t == 0: return None
+    if t == 1: return rng.choice([True, False])
+    if t == 2: return rng.choice([0, 1, 127, 128, 255, 256, 65535, 65536, 2 ** 32, 2 ** 63, -1, -32, -33, -128, -129, -32769, -2 ** 31 - 1])
+    if t == 3: return rng.choice([0.5, -1e10, 3.14])
+    if t == 4: return synth.Raw(b"\xca" + struct.pack(">f", rng.random()))
+    if t == 5: return synth.Raw(b"\xc4\x03abc")                                  # bin
+    if t == 6: return synth.Raw(b"\xc7\x02\x05xy")                               # ext
+    if t < 9: return rng.choice(["", "x", "GET /a HTTP/1.1", "500", "é", "y" * rng.choice([31, 32, 255, 256, 70000])])
+    if t == 9: return [_rand_obj(rng, depth + 1) for _ in range(rng.randrange(0, 18))]
+    return synth.KV([(rng.choice(["a", "b", "log", "code", 7, None, "k%d" % rng.randrange(20)]), _rand_obj(rng, depth + 1)) for _ in range(rng.randrange(0, 18))])
+
+
+def test_structural_fuzz_all_filters(g):
+    """random record shapes (every msgpack family, nested containers, non-string keys, duplicate keys,
+    legacy / V2 / float / integer timestamps, metadata, group markers) and byte-level corruptions,
+    through filter_parser, filter_grep and filter_log_to_metrics against the oracle"""
+    rng = random.Random(2026)
+    pa = dict(regex=r"^(?<method>[A-Z]+) (?<path>[^ ]*)(?: (?<proto>.*))?$")
+    for trial in range(12):
+        recs = []
+        for i in range(400):
+            body = synth.KV([(rng.choice(["log", "code", "a", "b", "nest", 5, "log"]), _rand_obj(rng)) for _ in range(rng.randrange(0, 7))])
+            r = rng.random()
+            if r < 0.55: rec = synth.v2_record(rng.randrange(2 ** 32), rng.randrange(10 ** 9), body, rng.choice([None, {}, {"m": [1, {"x": "y"}]}]))
+            elif r < 0.7: rec = synth.legacy_record(rng.choice([5, 2 ** 31, 1.5, 1e9 + 0.25]), body)
+            elif r < 0.75: rec = synth.mp([[synth.ext_ts(rng.choice([0xffffffff, 0xfffffffe]), 0), {}], body])
+            elif r < 0.8: rec = synth.mp([[rng.randrange(10 ** 6), {}], body])
+            elif r < 0.85: rec = synth.mp([[synth.ext_ts(7, 10 ** 9 + 5), {}], body])              # invalid nsec
+            else: rec = synth.v2_record(1, 2, body)
+            recs.append(rec)
+        data = b"".join(recs)
+        if trial % 3 == 1:
+            # corrupt one byte / truncate / splice junk somewhere: everything before it must still agree
+            k = rng.randrange(len(data))
+            data = rng.choice([data[:k] + bytes([rng.randrange(256)]) + data[k + 1:], data[:k], data[:k] + b"\xc1" + data[k:]])
+        for reserve, preserve in ((False, False), (True, True)):
+            o, q = both_parser(g, data, "log", [pa], reserve, preserve)
+            assert o == q, (trial, first_diff(o[1], q[1]))
+        for rules, op in (([("regex", "log ^GET"), ("exclude", "code ^5")], None), ([("regex", "a x"), ("regex", "$nest['a'] y")], "OR"),
+                          ([("exclude", "log HTTP"), ("exclude", "b ^$")], "AND")):
+            a, b = both_grep(g, data, rules, op)
+            assert a == b, (trial, rules, first_diff(a[1], b[1]))
+        props = [("label_field", "code"), ("add_label", "n $nest['a']"), ("exclude", "log ^POST")]
+        for mode, vf in (("counter", None), ("histogram", "a"), ("gauge", "b")):
+            om = ob.L2M(mode, props, value_field=vf); gm = g.FilterLogToMetrics(mode, props, value_field=vf)
+            assert om.filter(data) == gm.filter(data)[0]
+            want, got = om.snapshot()[2], gm.snapshot()
+            assert [x["labels"] for x in got] == [x["labels"] for x in want], (trial, mode)
+            for x, y in zip(got, want):
+                assert x["buckets"] == y["buckets"] and x["count"] == y["count"], (trial, mode)
+                assert struct.pack("<d", x["value"]) == struct.pack("<d", y["value"]) or (x["value"] != x["value"] and y["value"] != y["value"])
+                assert x["sum"] == y["sum"] or (x["sum"] != x["sum"] and y["sum"] != y["sum"]) or abs(x["sum"] - y["sum"]) <= 1e-9 * abs(y["sum"])
+            gm.close()
