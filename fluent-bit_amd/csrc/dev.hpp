@@ -283,6 +283,7 @@ struct JsonArgs {
     uint8_t *status;            // [n] 0 ok, 1 error (no value parsed), 2 deferred to the generic kernels
     const uint64_t *out_off;    // [n + 1] (emit)
     uint8_t *out;
+    uint32_t *cnt;              // [8][n] element counts of each row's first containers (size pass -> emit pass)
     int events;                 // wrap single-object rows as V2 log events with the timestamp below
     uint32_t ts_sec, ts_nsec;
     unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error

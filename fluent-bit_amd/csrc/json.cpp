@@ -13,11 +13,11 @@ struct JsonMisc { unsigned long long counts[3]; };
 
 struct flbgpu_json {
     hipStream_t stream = nullptr;
-    DevBuf d_len, d_rec, d_cons, d_rt, d_st, d_off, d_tmp, d_out, d_misc, h_text, h_off;
+    DevBuf d_len, d_rec, d_cons, d_rt, d_st, d_off, d_tmp, d_out, d_misc, d_cnt, h_text, h_off;
     uint64_t n = 0;
     uint64_t stats[3] = {0, 0, 0};
     ~flbgpu_json() {
-        DevBuf *all[] = {&d_len, &d_rec, &d_cons, &d_rt, &d_st, &d_off, &d_tmp, &d_out, &d_misc, &h_text, &h_off};
+        DevBuf *all[] = {&d_len, &d_rec, &d_cons, &d_rt, &d_st, &d_off, &d_tmp, &d_out, &d_misc, &d_cnt, &h_text, &h_off};
         for (auto *b : all) b->release();
         if (stream) (void) hipStreamDestroy(stream);
     }
@@ -38,13 +38,14 @@ static bool json_run(flbgpu_json *j, const flbgpu_dev_chunk *in, int events, uin
     j->stats[0] = j->stats[1] = j->stats[2] = 0;
     if (n == 0) return true;
     if (!j->d_len.ensure(n * 4) || !j->d_rec.ensure(n * 4) || !j->d_cons.ensure(n * 4) || !j->d_rt.ensure(n) || !j->d_st.ensure(n) ||
-        !j->d_off.ensure((n + 1) * 8) || !j->d_tmp.ensure(scan_tmp_elems(n) * 8) || !j->d_misc.ensure(sizeof(JsonMisc))) return false;
+        !j->d_off.ensure((n + 1) * 8) || !j->d_tmp.ensure(scan_tmp_elems(n) * 8) || !j->d_misc.ensure(sizeof(JsonMisc)) ||
+        !j->d_cnt.ensure(n * 8 * 4)) return false;
     HIPOK(hipMemsetAsync(j->d_misc.p, 0, sizeof(JsonMisc), st));
     JsonArgs a;
     memset(&a, 0, sizeof(a));
     a.text = (const uint8_t *) in->data; a.row_off = in->row_off; a.n = n;
     a.out_len = j->d_len.as<uint32_t>(); a.records = j->d_rec.as<uint32_t>(); a.consumed = j->d_cons.as<uint32_t>();
-    a.root_type = j->d_rt.as<uint8_t>(); a.status = j->d_st.as<uint8_t>();
+    a.root_type = j->d_rt.as<uint8_t>(); a.status = j->d_st.as<uint8_t>(); a.cnt = j->d_cnt.as<uint32_t>();
     a.events = events; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
     a.counts = j->d_misc.as<JsonMisc>()->counts;
     const int cus = device_cus() > 0 ? device_cus() : 256;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
 
@@ -74,7 +75,11 @@ struct ByteSink {
     DEV void put(uint32_t b) { *p++ = (uint8_t) b; }
     DEV void copy(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) *p++ = (uint8_t) ld8(src + i); }
     DEV void words(const uint32_t *w, uint32_t nbytes) { for (uint32_t i = 0; i < nbytes; i++) *p++ = (uint8_t) (w[i >> 2] >> (8 * (i & 3))); }
-    DEV void put32(uint32_t v) { for (int i = 0; i < 4; i++) *p++ = (uint8_t) (v >> (8 * i)); }
+    DEV void put32(uint32_t v) {
+        typedef uint32_t u32u __attribute__((aligned(1)));
+        *(u32u *) p = v;                  // gfx950 global stores accept any byte address
+        p += 4;
+    }
     DEV void finish() {}
 };
 
