@@ -316,7 +316,8 @@ void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);
-void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st);
+// exclusive scan u32 -> u64 (out[n] = total); nonzero (optional) receives the number of non-zero inputs
+void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st, unsigned long long *nonzero = nullptr);
 void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st);
 void launch_l2m_extract(const L2mArgs &a, int cus, hipStream_t st);
 void launch_l2m_generic(const L2mArgs &a, hipStream_t st);

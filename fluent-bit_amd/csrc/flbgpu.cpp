@@ -495,11 +495,10 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     memset(&hm, 0, sizeof(hm));
     hm.first_bad = ~0ull;
     HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
-    launch_max_row_len(row_off, n, &dm->max_row, st);
-    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
-    HIPOK(hipStreamSynchronize(st));
-    // scratch: one reverse-DFA state checkpoint per CHK_STEP bytes of the longest record, per lane
-    uint32_t chk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
+    // scratch of the fast path: one reverse-DFA state checkpoint per CHK_STEP bytes, per lane, for
+    // values up to 4 KiB (longer ones go to the generic kernel, whose scratch is sized from the
+    // longest row -- measured only when that kernel is needed)
+    uint32_t chk_len = 4096 / CHK_STEP + 3;
     int cus = g_cus > 0 ? g_cus : 256;
     // one 1024-thread workgroup (16 waves) per CU shares one LDS copy of parser 0's hot ASCII
     // tables (160 KiB of LDS per CU); bigger tables are read through L2 instead
@@ -539,21 +538,25 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     HIPOK(hipStreamSynchronize(st));
     if (hm.counts[2] > 0) {
         // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...)
+        launch_max_row_len(row_off, n, &dm->max_row, st);
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
         int ggrid = cus * 8;
-        while (ggrid > 1 && (size_t) ggrid * 4 * 64 * chk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
-        if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * chk_len * sizeof(uint16_t))) return false;
+        while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
+        if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
         ParserMatchArgs mg = ma;
         mg.chk = f->d_rid2.as<uint16_t>();
+        mg.chk_len = gchk_len;
         { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
     }
-    launch_count_nonzero(f->d_len.as<uint32_t>(), hm.first_bad < n ? hm.first_bad : n, &dm->counts[1], st);
-    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
-    HIPOK(hipStreamSynchronize(st));
     if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
     if (n == 0) return true;
-    { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
+    // write offsets + the number of emitted records (what flb_mp_count_log_records would report) in one pass
+    { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st, &dm->counts[1]); }
     uint64_t total = 0;
     HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
     f->last_in = hm.counts[0];
     if (total == 0) return true;                            // encoder produced nothing: NOTOUCH (+ error log)

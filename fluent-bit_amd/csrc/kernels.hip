@@ -292,6 +292,23 @@ DEV const uint8_t *mp_end_of(const Tok &t, const uint8_t *p, const uint8_t *end)
     return t.next;
 }
 
+// size of the canonical re-pack of a non-container token (msgpack_pack_object, smallest encodings)
+DEV uint32_t mp_canon_size_scalar(const Tok &t) {
+    CountSink cs;
+    switch (t.type) {
+    case T_NIL: case T_BOOL: return 1;
+    case T_UINT: pk_uint(cs, t.u); break;
+    case T_NINT: pk_int(cs, (int64_t) t.u); break;
+    case T_F32: return 5;
+    case T_F64: return 9;
+    case T_STR: pk_str_hdr(cs, t.len); cs.n += t.len; break;
+    case T_BIN: pk_bin_hdr(cs, t.len); cs.n += t.len; break;
+    case T_EXT: pk_ext_hdr(cs, t.len, (uint32_t) t.u); cs.n += t.len; break;
+    default: break;
+    }
+    return (uint32_t) cs.n;
+}
+
 // canonical re-pack of one object (msgpack_pack_object, lib/msgpack-c/src/objectc.c:39-126)
 template <class S> DEV const uint8_t *mp_canon(const uint8_t *p, const uint8_t *end, S &s) {
     uint64_t remaining = 1;
@@ -1475,7 +1492,8 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
     if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
     // candidate values (plugins/filter_parser/filter_parser.c:259-323)
     uint32_t ncand = 0;
-    bool whole = false;
+    bool whole = false, have_canon = false;
+    CountSink canon;                       // canonical size of the body (the record if no parser matches)
     if (a.cfg.key.is_ra) {
         const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end, &whole);
         if (v) {
@@ -1484,14 +1502,20 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         }
     }
     else {
+        // the same walk validates the body, finds the candidates and sizes the canonical re-pack
         Tok bm = mp_tok(ev.body, ev.body_end);
         const uint8_t *p = bm.next;
+        pk_map_hdr(canon, bm.len);
+        have_canon = true;
         for (uint32_t i = 0; i < bm.len; i++) {
             Tok kt = mp_tok(p, ev.body_end);
-            const uint8_t *kend = mp_end_of(kt, p, ev.body_end);
+            const uint8_t *kend;
+            if (kt.type == T_ARRAY || kt.type == T_MAP) kend = mp_canon(p, ev.body_end, canon);
+            else { kend = mp_end_of(kt, p, ev.body_end); canon.n += mp_canon_size_scalar(kt); }
             if (!kend) { p = nullptr; break; }
             Tok vt = mp_tok(kend, ev.body_end);
-            p = mp_end_of(vt, kend, ev.body_end);
+            if (vt.type == T_ARRAY || vt.type == T_MAP) p = mp_canon(kend, ev.body_end, canon);
+            else { p = mp_end_of(vt, kend, ev.body_end); canon.n += mp_canon_size_scalar(vt); }
             if (!p) break;
             if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
                 bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) {
@@ -1522,7 +1546,7 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         cs.n = 12;
         if (ev.meta) mp_canon(ev.meta, ev.meta_end, cs); else cs.n += 1;
         ri.meta_canon = (uint32_t) cs.n - 12;
-        mp_canon(ev.body, ev.body_end, cs);
+        if (have_canon) cs.n += canon.n; else mp_canon(ev.body, ev.body_end, cs);
         out_len = (uint32_t) cs.n;
     }
     rec_store(a.info, a.n, r, ri);
@@ -2093,13 +2117,20 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;            // per thread
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *tile_sums) {
+// tile_sums[b] = sum of tile b; tile_cnt (optional) [b] = its number of non-zero inputs
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *tile_sums, uint32_t *tile_cnt) {
     __shared__ uint64_t sh[SCAN_BLOCK / 64];
     uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
     uint64_t s = 0;
+    uint32_t nz = 0;
     for (int k = 0; k < SCAN_ITEMS; k++) {
         uint64_t i = base + (uint64_t) k * SCAN_BLOCK + threadIdx.x;
-        if (i < n) s += in[i];
+        if (i < n) { const uint32_t v = in[i]; s += v; nz += v != 0; }
+    }
+    if (tile_cnt) {
+        uint32_t t = nz;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&tile_cnt[blockIdx.x], t);
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -2112,11 +2143,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *i
 }
 
 // single block: exclusive scan of the tile sums in place; total written to tile_sums[ntiles]
-__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *tile_sums, uint64_t ntiles) {
+__global__ void __launch_bounds__(1024) k_scan_spine(uint64_t *tile_sums, uint64_t ntiles, const uint32_t *tile_cnt, unsigned long long *nonzero) {
     __shared__ uint64_t sh[1024];
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
+    if (tile_cnt) {
+        unsigned long long c = 0;
+        for (uint64_t i = threadIdx.x; i < ntiles; i += 1024) c += tile_cnt[i];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(nonzero, c);
+    }
     for (uint64_t base = 0; base < ntiles; base += 1024) {
         uint64_t i = base + threadIdx.x;
         uint64_t v = i < ntiles ? tile_sums[i] : 0;
@@ -2274,12 +2311,18 @@ void launch_gather(const GatherArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(k_gather, dim3((unsigned) blocks), dim3(256), 0, st, a);
 }
 // exclusive scan: out[0..n] (n+1 entries); tmp must hold ntiles+1 u64
-size_t scan_tmp_elems(uint64_t n) { return (size_t) ((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
-void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st) {
+// tmp: ntiles + 1 tile sums, then (u32) ntiles tile counts
+size_t scan_tmp_elems(uint64_t n) { const size_t t = (size_t) ((n + SCAN_TILE - 1) / SCAN_TILE); return t + 2 + (t + 1) / 2 + 1; }
+void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st, unsigned long long *nonzero) {
     uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (ntiles == 0) { (void) hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, ntiles);
+    uint32_t *tile_cnt = nullptr;
+    if (nonzero) {
+        tile_cnt = (uint32_t *) (tmp + ntiles + 2);
+        (void) hipMemsetAsync(tile_cnt, 0, ntiles * sizeof(uint32_t), st);
+    }
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp, tile_cnt);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, ntiles, (const uint32_t *) tile_cnt, nonzero);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp, out);
 }
 void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st) {
