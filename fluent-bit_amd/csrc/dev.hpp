@@ -149,7 +149,7 @@ struct ParserMatchArgs {
     uint32_t caps_lds_off;      // byte offset of the per-thread capture columns inside the dynamic LDS
     uint32_t caps_in_lds;       // 0: spans are written straight to the global row
     uint32_t lds_total;         // dynamic LDS bytes to request (tables + capture columns)
-    uint32_t debug_skip;        // timing experiments only (FLBGPU_DEBUG_SKIP): results are wrong when != 0
+    uint32_t debug_skip;        // reserved (0)
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
     unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel,
                                      // [3] records for k_parser_emit_exact

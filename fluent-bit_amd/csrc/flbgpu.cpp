@@ -529,7 +529,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ma.info = f->d_info.as<uint32_t>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
-    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
     { ProfScope ps(f, st, "k_parser_rx"); launch_parser_rx(ma, grid, rx_threads, st); }

@@ -1,6 +1,9 @@
+# tools/profile_bench.sh -- on the GPU box: the default bench line, rocprofv3 kernel stats and the FETCH/WRITE PMC
+# passes of the same command (separate passes, kernel-trace only); summaries land in gpurun_out/profile/ and are
+# copied to profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-O=$R/gpurun_out/final
+O=$R/gpurun_out/profile
 rm -rf $O; mkdir -p $O
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 CMD="python $R/bench.py --no-cpu --steps 5 --warmup 1"
