@@ -841,7 +841,19 @@ extern "C" int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length
     memcpy(m, o + body, ms);
     free(ob);
     *out_buf = m; *out_size = ms;
-    return (int) length;     // NOTE: the reference returns the end of the last named group
+    // return value of flb_parser_do: the end of the last named group that took part in the match, in
+    // name-iteration order (cb_results / last_pos, src/flb_regex.c:52-54, src/flb_parser_regex.c:44-112).
+    // The capture spans of the record are still in the filter's columns ([span][n] with n == 1).
+    const int nf = p->dev.nfields;
+    std::vector<uint32_t> caps((size_t) 2 * nf + 2, CAP_UNSET);
+    if (nf > 0 && hipMemcpy(caps.data(), p->self_filter->d_caps.p, (size_t) 2 * nf * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_err("device read failed");
+        return (int) length;
+    }
+    int last_pos = -1;
+    for (int f = 0; f < nf; f++)
+        if (caps[2 * f] != CAP_UNSET && caps[2 * f + 1] != CAP_UNSET) last_pos = (int) caps[2 * f + 1];
+    return last_pos >= 0 ? last_pos : (int) length;
 }
 
 // ------------------------------------------------------------------------------------------ device helpers

@@ -59,7 +59,8 @@ flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int ski
                                     int time_keep, int time_strict, const char *types);
 void flbgpu_parser_destroy(flbgpu_parser *p);
 /* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
- * consumed (>= 0) or -1.  Runs the same kernels on a batch of one. */
+ * consumed (>= 0: the end of the last named group that took part in the match, src/flb_regex.c:52-54)
+ * or -1.  Runs the same kernels on a batch of one. */
 int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length, void **out_buf, size_t *out_size,
                      int64_t *out_sec, int64_t *out_nsec);
 

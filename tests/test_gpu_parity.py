@@ -330,3 +330,20 @@ def test_structural_fuzz_all_filters(g):
                 assert struct.pack("<d", x["value"]) == struct.pack("<d", y["value"]) or (x["value"] != x["value"] and y["value"] != y["value"])
                 assert x["sum"] == y["sum"] or (x["sum"] != x["sum"] and y["sum"] != y["sum"]) or abs(x["sum"] - y["sum"]) <= 1e-9 * abs(y["sum"])
             gm.close()
+
+
+def test_parser_do_scalar_entry_point(g):
+    # flb_parser_do (src/flb_parser.c:1784-1806): msgpack map, parsed time and the "last byte consumed"
+    # return value (end of the last named group that took part) -- tests/internal/parser_regex.c style
+    cases = [
+        (dict(regex=r"^(?<a>\d+) (?<b>[a-z]+)(?: (?<c>.+))?$"), [b"12 abc", b"12 abc tail here", b"x", b"7 z "]),
+        (dict(regex=APACHE2, time_fmt=TF, time_key="time"),
+         [b'10.0.0.1 - bob [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326 "http://r" "agent x"', b"garbage"]),
+        (dict(regex=r"(?<k>[a-z]+)=(?<v>\d+)", types="v:integer"), [b"..foo=42;;", b"nothing here"]),
+    ]
+    for pargs, inputs in cases:
+        po, pg = ob.Parser(**pargs), g.Parser(**pargs)
+        for s in inputs:
+            want, got = po.do(s), pg.do(s)
+            assert got == want, (pargs["regex"][:30], s, got, want)
+        pg.close()
