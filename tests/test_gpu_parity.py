@@ -347,3 +347,68 @@ def test_parser_do_scalar_entry_point(g):
             want, got = po.do(s), pg.do(s)
             assert got == want, (pargs["regex"][:30], s, got, want)
         pg.close()
+
+
+def test_full_size_properties_10M(g):
+    """BASELINE configs[1] at full size (10 M records, 2.77 GB): properties that do not need a 10 M-record
+    oracle run -- (a) filtering is linear over concatenation: the two halves filtered separately give
+    the bytes of the whole; (b) a random sample of output rows equals the oracle's output for the same
+    input rows, byte for byte; (c) three independent kernels agree on the 5xx count (grep's kept
+    records, log_to_metrics' counter by code, the sample)."""
+    import hashlib
+    n = 10_000_000
+    data, off, ep = synth.apache_records(n)
+    L = g.lib()
+    nbytes = int(data.nbytes)
+    d_data = L.flbgpu_dev_alloc(nbytes); d_off = L.flbgpu_dev_alloc(off.nbytes)
+    assert d_data and d_off
+    L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, nbytes); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+    p = g.Parser(APACHE2, time_fmt=TF, time_key="time")
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep([("regex", r"code ^5\d\d$")])
+
+    def run(chunk):
+        r1, o1 = fp.filter_dev(chunk)
+        assert r1 == g.MODIFIED
+        parsed = np.empty(int(o1.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(parsed.ctypes.data, o1.data, int(o1.bytes))
+        poff = np.empty(int(o1.n) + 1, dtype=np.uint64)
+        L.flbgpu_memcpy_d2h(poff.ctypes.data, o1.row_off, poff.nbytes)
+        r2, o2 = fg.filter_dev(o1)
+        assert r2 == g.MODIFIED
+        kept = np.empty(int(o2.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(kept.ctypes.data, o2.data, int(o2.bytes))
+        return parsed, poff, kept, fg.counts()[1]
+
+    parsed, poff, kept, nkept = run(g.DevChunk(d_data, d_off, n, nbytes))
+    assert len(poff) == n + 1 and int(poff[-1]) == len(parsed)
+    # (a) halves: row offsets of the second half are rebased on the device copy of the same bytes
+    h = n // 2
+    off2 = (off[h:] - off[h]).astype(np.uint64)
+    d_off2 = L.flbgpu_dev_alloc(off2.nbytes)
+    L.flbgpu_memcpy_h2d(d_off2, off2.ctypes.data, off2.nbytes)
+    pa, _, ka, na = run(g.DevChunk(d_data, d_off, h, int(off[h])))
+    pb, _, kb, nb = run(g.DevChunk(d_data + int(off[h]), d_off2, n - h, nbytes - int(off[h])))
+    sha = lambda *arrs: hashlib.sha256(b"".join(memoryview(a) for a in arrs)).hexdigest()
+    assert sha(pa, pb) == sha(parsed) and sha(ka, kb) == sha(kept) and na + nb == nkept
+    # (b) sample against the oracle
+    rng = random.Random(5)
+    idx = sorted(rng.sample(range(n), 4000))
+    sample_in = b"".join(bytes(data[int(off[i]):int(off[i + 1])]) for i in idx)
+    po = ob.Parser(APACHE2, time_fmt=TF, time_key="time")
+    _, want = ob.FilterParser("log", [po]).filter(sample_in)
+    got = b"".join(bytes(parsed[int(poff[i]):int(poff[i + 1])]) for i in idx)
+    assert got == want, first_diff(want, got)
+    _, want_kept = ob.Grep([("regex", r"code ^5\d\d$")]).filter(want)
+    # (c) 5xx counts: grep vs log_to_metrics vs the sample's proportion
+    fm = g.FilterLogToMetrics("counter", [("label_field", "code")])
+    r, o1 = fp.filter_dev(g.DevChunk(d_data, d_off, n, nbytes))
+    fm.filter_dev(o1)
+    snap = fm.snapshot()
+    assert sum(x["value"] for x in snap) == n
+    assert sum(x["value"] for x in snap if x["labels"][0].startswith(b"5")) == nkept
+    assert abs(ob.count_records(want_kept) / 4000 - nkept / n) < 0.02
+    for f in (fp, fg, fm):
+        f.close()
+    p.close()
+    for d in (d_data, d_off, d_off2):
+        L.flbgpu_dev_free(d)
