@@ -90,6 +90,7 @@ enum { T_INT = 1, T_FLOAT, T_BOOL, T_STRING, T_HEX };
 struct ptype { char *key; int key_len; int type; };
 
 typedef struct oflb_parser {
+    int is_json;             /* Format json (src/flb_parser_json.c) instead of Format regex */
     oflb_regex *regex;
     int skip_empty;
     char *time_fmt;          /* cut at %L */
@@ -167,8 +168,11 @@ oflb_parser *oflb_parser_create(const char *regex, int skip_empty, const char *t
                                 int time_strict, const char *types_str)
 {
     oflb_parser *p = calloc(1, sizeof(*p));
-    p->regex = oflb_regex_create(regex);
-    if (!p->regex) { free(p); return NULL; }
+    if (regex == NULL) p->is_json = 1;                   /* Format json: no regex */
+    else {
+        p->regex = oflb_regex_create(regex);
+        if (!p->regex) { free(p); return NULL; }
+    }
     p->skip_empty = skip_empty;
     if (time_fmt && time_fmt[0]) {
         int is_epoch = 0;
@@ -349,16 +353,87 @@ static void typecast(oflb_parser *parser, const char *key, int key_len, const ch
  * iteration of src/flb_regex.c:28-58,182-231,294-313).  Returns last byte consumed or -1.
  * *out is malloc'd.
  */
+int ojson_pack(const char *js, size_t len, char **buffer, size_t *size, int *root_type, int *records, size_t *consumed);
+
+/*
+ * flb_parser_json_do: src/flb_parser_json.c:28-247.  JSON text -> msgpack (exactly one value, a map),
+ * then the time key: the FIRST key equal to time_key (default "time") whose value is a string goes
+ * through the time lookup; on success the pair is dropped unless time_keep, on failure the map is
+ * left whole and the time is 0 (+ whatever fraction was parsed).  Decoders are not restated.
+ * Returns the bytes consumed or -1.
+ */
+static int oflb_parser_json_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
+                               int64_t *out_sec, int64_t *out_nsec)
+{
+    char *mp = NULL;
+    size_t mp_size = 0, consumed = 0, off = 0;
+    int root_type = 0, records = 0, i, skip, map_size;
+    omp_arena arena;
+    omp_obj map;
+    const char *time_key = parser->time_key ? parser->time_key : "time";
+    int slen = (int) strlen(time_key);
+    const omp_obj *k = NULL, *v = NULL;
+    double tmfrac = 0;
+    struct otm tm;
+    time_t time_lookup_v;
+    omp_buf nb;
+
+    *out_sec = 0; *out_nsec = 0;
+    if (ojson_pack(buf, length, &mp, &mp_size, &root_type, &records, &consumed) != 0) return -1;
+    if (records != 1) { free(mp); return -1; }
+    omp_arena_init(&arena);
+    if (omp_unpack_next(&arena, &map, mp, mp_size, &off) != OMP_UNPACK_SUCCESS || map.type != OMP_MAP) {
+        free(mp); omp_arena_free(&arena);
+        return -1;
+    }
+    *out = mp; *out_size = mp_size;
+    if (!parser->time_fmt) { omp_arena_free(&arena); return (int) consumed; }
+    map_size = (int) map.via.map.size;
+    skip = map_size;
+    for (i = 0; i < map_size; i++) {
+        k = &map.via.map.ptr[i].key;
+        v = &map.via.map.ptr[i].val;
+        if ((int) k->via.str.size != slen) { k = NULL; v = NULL; continue; }
+        if (strncmp(k->via.str.ptr, time_key, k->via.str.size) == 0) {
+            skip = parser->time_keep ? -1 : i;
+            break;
+        }
+        k = NULL; v = NULL;
+    }
+    if (i >= map_size || !k || !v || v->type != OMP_STR) { omp_arena_free(&arena); return (int) consumed; }
+    memset(&tm, 0, sizeof(tm));
+    if (time_lookup(v->via.str.ptr, v->via.str.size, 0, parser, &tm, &tmfrac) == -1) {
+        time_lookup_v = 0;
+        skip = map_size;
+    }
+    else time_lookup_v = tm2time(&tm);
+    omp_buf_init(&nb);
+    omp_pack_map(&nb, (!parser->time_keep && skip < map_size) ? map_size - 1 : map_size);
+    for (i = 0; i < map_size; i++) {
+        if (i == skip) continue;
+        omp_pack_object(&nb, &map.via.map.ptr[i].key);
+        omp_pack_object(&nb, &map.via.map.ptr[i].val);
+    }
+    free(mp);
+    omp_arena_free(&arena);
+    *out = nb.data; *out_size = nb.size;
+    *out_sec = (int64_t) time_lookup_v;
+    *out_nsec = (int64_t) (long) (tmfrac * 1000000000);
+    return (int) consumed;
+}
+
 int oflb_parser_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
                    int64_t *out_sec, int64_t *out_nsec)
 {
+    if (parser->is_json) return oflb_parser_json_do(parser, buf, length, out, out_size, out_sec, out_nsec);
     int beg[ORX_MAX_GROUPS], end[ORX_MAX_GROUPS];
     int nregs, n, i, k, last_pos = -1, num_skipped = 0;
     time_t time_lookup_v = 0;
     double time_frac = 0;
     omp_buf pck;
-    orx_t *rx = parser->regex->rx;
+    orx_t *rx;
 
+    rx = parser->regex->rx;
     nregs = orx_search(rx, buf, (int) length, beg, end, ORX_MAX_GROUPS);
     if (nregs < 0) return -1;
     n = nregs - 1;                           /* flb_regex_do returns num_regs - 1 */

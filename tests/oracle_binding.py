@@ -59,9 +59,11 @@ class Parser:
     """mirrors flb_parser_create(name, "regex", regex, skip_empty, time_fmt, time_key, time_offset,
     time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.
     Defaults are the conf-file defaults (src/flb_parser.c:1277-1304)."""
-    def __init__(self, regex, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None):
+    def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
+                 time_strict=True, skip_empty=True, types=None, format="regex"):
         e = lambda s: s.encode() if isinstance(s, str) else s
+        if format == "json":
+            regex = None                      # Format json (src/flb_parser_json.c)
         self.h = lib().oflb_parser_create(e(regex), int(skip_empty), e(time_fmt), e(time_key), e(time_offset),
                                           int(time_keep), int(time_strict), e(types))
         if not self.h:
