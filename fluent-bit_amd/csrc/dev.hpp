@@ -67,6 +67,9 @@ struct DevParser {
     uint32_t keywords[MAX_NAMES + 1024 / 4 + MAX_NAMES];   // per field: msgpack str header + name, zero padded to a dword multiple
     int kw_off[MAX_NAMES];               // first dword of field f in keywords[]
     int kw_bytes[MAX_NAMES];             // header + name bytes
+    int is_json;                         // Format json (src/flb_parser_json.c): no regex, the value is a JSON object
+    int tkey_len;                        // time key of a json parser (default "time")
+    char tkey[64];
     int fwd_first;                       // the pattern is anchored at the start: try the forward walk from boundary 0 before
                                          // paying for the reverse pass (any match that starts at 0 is the leftmost one)
     int time_field;                      // the ONE named field that is the time key, -1 if none or several
@@ -313,6 +316,8 @@ void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *o
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
+void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
+void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);

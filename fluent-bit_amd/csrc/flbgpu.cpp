@@ -155,24 +155,29 @@ static bool expand_time_fmt(const char *fmt, std::string &out, std::string &why)
     return true;
 }
 
-extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int skip_empty,
-                                               const char *time_fmt, const char *time_key, const char *time_offset,
-                                               int time_keep, int time_strict, const char *types) {
-    if (!regex) { set_err("parser '%s': missing regex", name ? name : ""); return nullptr; }
+// Format regex (regex != NULL) or Format json (is_json)
+static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const char *regex, int skip_empty,
+                                         const char *time_fmt, const char *time_key, const char *time_offset,
+                                         int time_keep, int time_strict, const char *types) {
+    if (!is_json && !regex) { set_err("parser '%s': missing regex", name ? name : ""); return nullptr; }
+    if (is_json) regex = "";
     auto *p = new flbgpu_parser();
     p->name = name ? name : "";
-    const char *s, *e;
-    unsigned opts;
-    rx::split_flb_pattern(regex, &s, &e, &opts);
-    std::string err;
-    if (!rx::compile(s, (size_t) (e - s), opts, true, p->prog, err)) {
-        set_err("parser '%s': cannot compile regex for the GPU path: %s", p->name.c_str(), err.c_str());
-        delete p;
-        return nullptr;
-    }
     DevParser &d = p->dev;
     memset(&d, 0, sizeof(d));
-    if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_cap(p->prog.utf8, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
+    if (!is_json) {
+        const char *s, *e;
+        unsigned opts;
+        rx::split_flb_pattern(regex, &s, &e, &opts);
+        std::string err;
+        if (!rx::compile(s, (size_t) (e - s), opts, true, p->prog, err)) {
+            set_err("parser '%s': cannot compile regex for the GPU path: %s", p->name.c_str(), err.c_str());
+            delete p;
+            return nullptr;
+        }
+        if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_cap(p->prog.utf8, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
+    }
+    d.is_json = is_json ? 1 : 0;
     d.ngroups = p->prog.ngroups;
     d.nregs_minus1 = p->prog.ngroups;
     d.skip_empty = skip_empty;
@@ -234,6 +239,9 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
     }
     // named fields in onig_foreach_name order
     const char *tkey = (time_key && time_key[0]) ? time_key : "time";
+    if (strlen(tkey) >= sizeof(d.tkey)) { set_err("parser '%s': Time_Key too long", p->name.c_str()); delete p; return nullptr; }
+    d.tkey_len = (int) strlen(tkey);
+    memcpy(d.tkey, tkey, (size_t) d.tkey_len);
     size_t noff = 0;
     for (size_t i = 0; i < p->prog.names.size(); i++) {
         for (int g : p->prog.name_groups[i]) {
@@ -282,6 +290,19 @@ extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *reg
         if (ntime != 1) d.time_field = -1;
     }
     return p;
+}
+
+extern "C" flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int skip_empty,
+                                               const char *time_fmt, const char *time_key, const char *time_offset,
+                                               int time_keep, int time_strict, const char *types) {
+    return parser_create_impl(false, name, regex, skip_empty, time_fmt, time_key, time_offset, time_keep, time_strict, types);
+}
+
+extern "C" flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt, const char *time_key,
+                                                    const char *time_offset, int time_keep, int time_strict) {
+    // Types are ignored by the json format (tests/internal/parser_json.c: test_types_is_not_supported);
+    // Decode_Field has no place in this ABI
+    return parser_create_impl(true, name, nullptr, 1, time_fmt, time_key, time_offset, time_keep, time_strict, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ keys
@@ -393,6 +414,12 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         memcpy(f->pcfg.key.key, key_name, n);
         f->pcfg.key.key_len = (int) n;
     }
+    for (int i = 0; i < nparsers; i++)
+        if (parsers[i]->dev.is_json && nparsers > 1) {
+            set_err("filter_parser: a json parser in a list of several parsers is not on the GPU path yet");
+            delete f;
+            return nullptr;
+        }
     std::vector<DevParser> dp;
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
@@ -400,6 +427,7 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
     }
     if (f->caps_stride == 0) f->caps_stride = 2;
+    if (parsers[0]->dev.is_json) f->caps_stride = 8;         // the span columns hold the JSON container counts
     f->caps_stride = (f->caps_stride + 3) & ~3u;             // 16-byte rows
     if (!filter_common_init(f) || !f->d_parsers.ensure(dp.size() * sizeof(DevParser))) { delete f; return nullptr; }
     if (hipMemcpy(f->d_parsers.p, dp.data(), dp.size() * sizeof(DevParser), hipMemcpyHostToDevice) != hipSuccess) { set_err("upload failed"); delete f; return nullptr; }
@@ -531,24 +559,33 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
-    { ProfScope ps(f, st, "k_parser_rx"); launch_parser_rx(ma, grid, rx_threads, st); }
-    { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
-    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
-    HIPOK(hipStreamSynchronize(st));
-    if (hm.counts[2] > 0) {
-        // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...)
-        launch_max_row_len(row_off, n, &dm->max_row, st);
+    if (f->parsers[0]->dev.is_json) {
+        // Format json: one size kernel replaces locate / rx / finish
+        { ProfScope ps(f, st, "k_pjson_size"); launch_pjson_size(ma, cus, st); }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
-        const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
-        int ggrid = cus * 8;
-        while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
-        if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
-        ParserMatchArgs mg = ma;
-        mg.chk = f->d_rid2.as<uint16_t>();
-        mg.chk_len = gchk_len;
-        { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
+        if (hm.counts[2] > 0) { ProfScope ps(f, st, "k_pjson_size_generic"); launch_pjson_size_generic(ma, st); }
+    }
+    else {
+        { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
+        { ProfScope ps(f, st, "k_parser_rx"); launch_parser_rx(ma, grid, rx_threads, st); }
+        { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        if (hm.counts[2] > 0) {
+            // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...)
+            launch_max_row_len(row_off, n, &dm->max_row, st);
+            HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
+            int ggrid = cus * 8;
+            while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
+            if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
+            ParserMatchArgs mg = ma;
+            mg.chk = f->d_rid2.as<uint16_t>();
+            mg.chk_len = gchk_len;
+            { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
+        }
     }
     if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
     if (n == 0) return true;

@@ -1302,6 +1302,9 @@ struct CapsView {
     DEV uint32_t operator[](uint32_t i) const { return base[(uint64_t) i * n + r]; }
 };
 
+#include "json_kernels.inc"
+#include "pjson_dev.inc"
+
 // ------------------------------------------------------------------------------------------
 // parsed-record body writer shared by the size pass and the emit pass
 // ------------------------------------------------------------------------------------------
@@ -1336,7 +1339,7 @@ DEV void write_field_value(S &s, int type, const uint8_t *v, uint32_t vlen) {
 
 
 // Writes (or sizes) the complete output record for `rec`.
-template <bool EXACT = false, class S>
+template <bool EXACT = false, int NW = 1, class S>
 DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
                       const RecInfo &ri, const CapsView &caps, uint64_t null_mask) {
     // 92 92 d7 00 <sec> <nsec>   (src/flb_log_event_encoder.c:195-217)
@@ -1362,7 +1365,7 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
         }
     }
     else if (cfg.preserve_key && plain_key) nappend = 1;
-    if (nappend > 0) pk_map_hdr(s, ri.nkept + nappend);      // flb_msgpack_expand_map repacks
+    if (nappend > 0 || ps.is_json) pk_map_hdr(s, ri.nkept + nappend);   // flb_msgpack_expand_map / flb_parser_json_do repack
     else {
         // header patched in place: width of the ORIGINAL count is kept (flb_parser_regex.c:182-199)
         uint32_t n0 = (uint32_t) ps.nregs_minus1;
@@ -1371,6 +1374,14 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
         else { s.put(0xdf); pk_be(s, ri.nkept, 4); }
     }
     const uint8_t *val = rec + ri.val_off;
+    if (ps.is_json) {
+        // the kept pairs of the JSON object (drop_mask holds the index of the time pair that goes away);
+        // the first capture columns of a json parser hold the record's container counts
+        JsonCounts cc;
+        cc.col = const_cast<uint32_t *>(caps.base); cc.n = caps.n; cc.r = caps.r; cc.store = false;
+        pjson_emit_pairs<EXACT, NW>(val, ri.val_len, ri.drop_mask, s, cc);
+    }
+    else
     for (int f = 0; f < ps.nfields; f++) {
         if ((ri.drop_mask >> f) & 1) continue;
         uint32_t b = caps[2 * f], e = caps[2 * f + 1];
@@ -1939,7 +1950,7 @@ __global__ void __launch_bounds__(64) k_parser_emit_exact(ParserEmitArgs a) {
         ByteSink s(a.out + a.out_off[r]);
         CapsView cv;
         cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
-        write_record<true>(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r), cv,
+        write_record<true, JSON_GENERIC_WORDS>(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r), cv,
                            a.null_mask[r]);
     }
 }
@@ -2334,6 +2345,6 @@ void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long 
 }
 
 #include "l2m_kernels.inc"
-#include "json_kernels.inc"
+#include "pjson_kernels.inc"
 
 }  // namespace flbgpu

@@ -57,6 +57,10 @@ int flbgpu_device_cus(void);
 flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int skip_empty,
                                     const char *time_fmt, const char *time_key, const char *time_offset,
                                     int time_keep, int time_strict, const char *types);
+/* Format json (src/flb_parser_json.c:28-247): the value is one JSON object; Time_Key (default "time") /
+ * Time_Format / Time_Keep as in the parsers file.  Types and Decode_Field do not apply. */
+flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt, const char *time_key,
+                                         const char *time_offset, int time_keep, int time_strict);
 void flbgpu_parser_destroy(flbgpu_parser *p);
 /* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
  * consumed (>= 0: the end of the last named group that took part in the match, src/flb_regex.c:52-54)

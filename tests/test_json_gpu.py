@@ -110,3 +110,68 @@ def test_ndjson_lines_to_events_then_grep(g):
     assert kb.tobytes() == wo
     fg.close(); p.close()
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+
+
+def both_jparser(g, data, key, pargs, reserve=False, preserve=False):
+    op = ob.Parser(format="json", **pargs); gp = g.Parser(format="json", **pargs)
+    want = ob.FilterParser(key, [op], reserve, preserve).filter(data)
+    f = g.FilterParser(key, [gp], reserve, preserve)
+    got = f.filter(data)
+    f.close(); gp.close()
+    return want, got
+
+
+def test_filter_parser_with_json_parser(g):
+    """Format json inside filter_parser (src/flb_parser_json.c + plugins/filter_parser/filter_parser.c):
+    the reference's parser_json KATs, then random documents -- time keys of every kind, Time_Keep,
+    Reserve_Data / Preserve_Key, duplicate Key_Name entries, values that are not one JSON object,
+    deep nesting and hard decimals (generic kernels)."""
+    from synth import v2_record, KV
+    tf = "%Y-%m-%dT%H:%M:%S.%L"
+    kat = [b'{"str":"text", "int":100, "double":1.23, "bool":true, "time":"2022-10-31T12:00:01.123"}',
+           b'{"str":"text", "time":"nonsense"}', b'{"str":"text", "int":100, "double":1.23, "bool":true}',
+           b'{"a":1}{"b":2}', b'[1]', b'"x"', b'', b'{"a":1} junk', b'{"time":5,"time":"2022-10-31T12:00:01.123"}',
+           b'{"time":"2022-10-31T12:00:01.123","time":"2001-01-01T00:00:00.5"}', b'  {"k":"v"}\n', b'{"t\\u0069me":"2022-10-31T12:00:01.123","x":1}',
+           b'{"time":"2022-10-31T12:\\u0030\\u0030:01.123"}', b'{"time":"2022-10-31T12:00:01.123 trailing"}', b'{"time":""}', b'{}',
+           b'{"a":' + b'[' * 100 + b']' * 100 + b',"time":"2022-10-31T12:00:01.123"}', b'{"v":0.30000000000000004,"w":1.7976931348623157e308,"x":123456789012345678901234567890.5}']
+    data = b"".join(v2_record(1700000000 + i, 7, {"log": k, "other": i}) for i, k in enumerate(kat))
+    for pargs in (dict(time_fmt=tf, time_key="time"), dict(time_fmt=tf, time_key="time", time_keep=True), dict(), dict(time_fmt=tf)):
+        for reserve, preserve in ((False, False), (True, False), (True, True), (False, True)):
+            want, got = both_jparser(g, data, "log", pargs, reserve, preserve)
+            assert got == want, (pargs, reserve, preserve, first_diff(want[1], got[1]))
+    # random documents
+    rng = random.Random(77)
+    recs = []
+    for i in range(6000):
+        doc = jf.rand_value(rng, 3) if rng.random() < 0.1 else None
+        if doc is None:
+            items = []
+            for _ in range(rng.randrange(0, 7)):
+                k = rng.choice(["a", "b", "time", "ts", "msg", "t\\u0069me", "nested"])
+                v = rng.choice(['"2022-10-31T12:00:01.123"', '"2023-01-02T03:04:05"', '"2024-02-29T23:59:59.999999999"', '"nonsense"', "5", "null",
+                                '"2022-10-31T12:00:0\\u0031.5"']) if k in ("time", "ts", "t\\u0069me") and rng.random() < 0.8 else jf.rand_value(rng, 4)
+                items.append('"%s":%s' % (k, v))
+            doc = "{" + ",".join(items) + "}"
+            if rng.random() < 0.05: doc += rng.choice([" ", "\n", " junk", '{"second":1}', " 5"])
+            if rng.random() < 0.03: doc = doc[:-1]
+        body = [("log", doc.encode("utf-8", "surrogatepass")), ("n", i)]
+        if rng.random() < 0.1: body.append(("log", rng.choice([b'{"dup":1}', b"not json", b'{"time":"2022-10-31T12:00:01.123"}'])))
+        if rng.random() < 0.05: body[0] = ("log", 5)
+        recs.append(v2_record(1700000000 + i, 1, KV(body), rng.choice([None, {"m": 1}])))
+    data = b"".join(recs)
+    for pargs in (dict(time_fmt=tf, time_key="time"), dict(time_fmt="%Y-%m-%dT%H:%M:%S", time_key="ts", time_keep=True), dict()):
+        for reserve, preserve in ((False, False), (True, False), (True, True)):
+            want, got = both_jparser(g, data, "log", pargs, reserve, preserve)
+            assert got == want, (pargs, reserve, preserve, first_diff(want[1], got[1]))
+    want, got = both_jparser(g, data, "$log", dict(time_fmt=tf, time_key="time"), True, False)
+    assert got == want, first_diff(want[1], got[1])
+
+
+def first_diff(a, b):
+    if a is None or b is None:
+        return "one side None (%r / %r)" % (a is None, b is None)
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return "byte %d: oracle %r gpu %r (len %d vs %d)" % (i, a[max(0, i - 30):i + 30], b[max(0, i - 30):i + 30], len(a), len(b))
+    return "length %d vs %d" % (len(a), len(b))
