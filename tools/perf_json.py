@@ -36,3 +36,24 @@ for _ in range(3):
     r, kept = fg.filter_dev(ev)
 dt2 = (time.perf_counter() - t0) / 3
 print("grep 32 rules %.2f ms %.1f M rec/s kept" % (dt2 * 1e3, n / dt2 / 1e6), fg.counts())
+
+# filter_parser with a Format json parser on {"log": "<json line>"} records
+import synth
+recs = [synth.v2_record(1700000000 + i, 0, {"log": base[i % len(base)].rstrip(b"\n")}) for i in range(len(base))]
+blob = b"".join(recs) * reps
+roff = np.zeros(len(recs) * reps + 1, dtype=np.uint64)
+roff[1:] = np.cumsum(np.tile(np.array([len(r) for r in recs], dtype=np.uint64), reps))
+nr = len(roff) - 1
+d_b = L.flbgpu_dev_alloc(len(blob) + 16); d_o = L.flbgpu_dev_alloc(roff.nbytes)
+L.flbgpu_memcpy_h2d(d_b, blob, len(blob)); L.flbgpu_memcpy_h2d(d_o, roff.ctypes.data, roff.nbytes)
+pj = g.Parser(format="json", time_fmt="%Y-%m-%dT%H:%M:%S.%LZ", time_key="time")
+fpj = g.FilterParser("log", [pj])
+ck = g.DevChunk(d_b, d_o, nr, len(blob))
+fpj.filter_dev(ck)
+fpj.profile(True)
+t0 = time.perf_counter()
+for _ in range(3):
+    r, o = fpj.filter_dev(ck)
+dt3 = (time.perf_counter() - t0) / 3
+print("filter_parser(json) %.2f ms  %.1f M rec/s  in %d B out %d B" % (dt3 * 1e3, nr / dt3 / 1e6, len(blob), o.bytes),
+      {k: round(v[0] / v[1], 3) for k, v in fpj.profile_read().items()})
