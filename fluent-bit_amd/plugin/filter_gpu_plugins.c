@@ -242,9 +242,9 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             flb_plg_error(f_ins, "requested parser '%s' not found", kv->val);
             continue;
         }
-        if (p->type != FLB_PARSER_REGEX || p->decoders != NULL || p->time_zone != NULL ||
-            p->time_system_timezone) {
-            flb_plg_error(f_ins, "parser '%s': only Format regex without decoders/time zones "
+        if ((p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON) || p->decoders != NULL ||
+            p->time_zone != NULL || p->time_system_timezone) {
+            flb_plg_error(f_ins, "parser '%s': only Format regex / json without decoders/time zones "
                           "is on the GPU path", kv->val);
             goto error;
         }
@@ -254,9 +254,16 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
         types = types_to_str(p);
         snprintf(off, sizeof(off), "%c%02d%02d", p->time_offset < 0 ? '-' : '+',
                  abs(p->time_offset) / 3600, (abs(p->time_offset) / 60) % 60);
-        ctx->parsers[ctx->n_parsers] =
-            flbgpu_parser_create(p->name, p->p_regex, p->skip_empty, p->time_fmt_full, p->time_key,
-                                 p->time_offset ? off : NULL, p->time_keep, p->time_strict, types);
+        if (p->type == FLB_PARSER_JSON) {
+            ctx->parsers[ctx->n_parsers] =
+                flbgpu_parser_create_json(p->name, p->time_fmt_full, p->time_key, p->time_offset ? off : NULL,
+                                          p->time_keep, p->time_strict);
+        }
+        else {
+            ctx->parsers[ctx->n_parsers] =
+                flbgpu_parser_create(p->name, p->p_regex, p->skip_empty, p->time_fmt_full, p->time_key,
+                                     p->time_offset ? off : NULL, p->time_keep, p->time_strict, types);
+        }
         flb_free(types);
         if (!ctx->parsers[ctx->n_parsers]) {
             flb_plg_error(f_ins, "%s", flbgpu_last_error());
