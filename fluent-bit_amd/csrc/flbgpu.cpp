@@ -712,6 +712,11 @@ extern "C" int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nf
 static inline bool h_skip(const uint8_t *d, size_t len, size_t *pos) {
     size_t p = *pos;
     uint64_t remaining = 1;
+    // the usual event head [[ext8(type 0) ...], meta, body]: four objects in one compare
+    if (len - p >= 13 && d[p] == 0x92 && d[p + 1] == 0x92 && d[p + 2] == 0xd7) {
+        p += 12;
+        remaining = 2;
+    }
     while (remaining > 0) {
         if (p >= len) return false;
         uint8_t c = d[p++];
@@ -778,6 +783,7 @@ extern "C" int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *r
     int64_t n = 0;
     while (pos < bytes) {
         size_t q = pos;
+        __builtin_prefetch(d + pos + 2048); __builtin_prefetch(d + pos + 2112);
         if (!h_skip(d, bytes, &q)) break;
         if ((size_t) n + 1 >= cap) break;
         row_off[n++] = pos;
@@ -789,15 +795,100 @@ extern "C" int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *r
 }
 
 // ------------------------------------------------------------------------------------------ run (host level)
+static const size_t STAGE_SLAB = 8u << 20;
+
+static bool stage_init(flbgpu_filter *f) {
+    for (int i = 0; i < 2; i++) {
+        if (!f->ev_stage[i] && hipEventCreateWithFlags(&f->ev_stage[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return true;
+}
+
+// Indexes `data` into f->hp_off (pinned) and copies it into f->h_in_data; returns the record count
+// (-1 on a HIP failure) and the bytes covered by whole records.
+static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed) {
+    hipStream_t st = f->stream;
+    if (!stage_init(f) || !f->h_in_data.ensure(bytes + 16)) return -1;
+    size_t cap = bytes / 96 + 1024;
+    if (!f->hp_off.ensure(cap * sizeof(uint64_t))) return -1;
+    const size_t slab = bytes < STAGE_SLAB ? bytes : STAGE_SLAB;
+    if (!f->hp_stage[0].ensure(slab) || (bytes > slab && !f->hp_stage[1].ensure(slab))) return -1;
+    uint64_t *off = f->hp_off.as<uint64_t>();
+    size_t pos = 0, sent = 0;
+    int64_t n = 0;
+    bool stop = false;
+    int k = 0;
+    while (sent < bytes) {
+        const size_t end = sent + slab < bytes ? sent + slab : bytes;
+        while (!stop && pos < end) {
+            size_t q = pos;
+            __builtin_prefetch(d + pos + 2048); __builtin_prefetch(d + pos + 2112);
+            if (!h_skip(d, bytes, &q)) { stop = true; break; }
+            if ((size_t) n + 2 > cap) {
+                cap *= 2;
+                if (!f->hp_off.ensure(cap * sizeof(uint64_t), (size_t) n * sizeof(uint64_t))) return -1;
+                off = f->hp_off.as<uint64_t>();
+            }
+            off[n++] = pos;
+            pos = q;
+        }
+        // bytes past the last whole record are never read by the kernels; they are not uploaded
+        const size_t upto = stop ? (pos < end ? pos : end) : end;
+        if (upto > sent) {
+            if (hipEventSynchronize(f->ev_stage[k]) != hipSuccess) return -1;
+            memcpy(f->hp_stage[k].p, d + sent, upto - sent);
+            if (hipMemcpyAsync((uint8_t *) f->h_in_data.p + sent, f->hp_stage[k].p, upto - sent, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventRecord(f->ev_stage[k], st) != hipSuccess) return -1;
+            k ^= 1;
+        }
+        if (stop) break;
+        sent = end;
+    }
+    off[n] = pos;
+    *consumed = pos;
+    if (n == 0) return 0;
+    if (!f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return -1;
+    if (hipMemcpyAsync(f->h_in_off.p, off, (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    // the staging slabs and the offsets are reused by the next call
+    if (hipStreamSynchronize(st) != hipSuccess) { set_err("host to device copy failed"); return -1; }
+    return n;
+}
+
+// device -> caller's (pageable) buffer through the two pinned slabs
+static bool staged_download(flbgpu_filter *f, void *dst, const void *src, size_t bytes) {
+    hipStream_t st = f->stream;
+    if (!stage_init(f)) return false;
+    const size_t slab = bytes < STAGE_SLAB ? bytes : STAGE_SLAB;
+    if (!f->hp_stage[0].ensure(slab) || (bytes > slab && !f->hp_stage[1].ensure(slab))) return false;
+    size_t issued = 0, done = 0, len[2] = {0, 0};
+    int ki = 0, kd = 0;
+    // one slab in flight while the previous one is copied out
+    while (done < bytes) {
+        while (issued < bytes && issued - done < 2 * slab && (issued == done || ki != kd)) {
+            len[ki] = bytes - issued < slab ? bytes - issued : slab;
+            if (hipMemcpyAsync(f->hp_stage[ki].p, (const uint8_t *) src + issued, len[ki], hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipEventRecord(f->ev_stage[ki], st) != hipSuccess) return false;
+            issued += len[ki];
+            ki ^= 1;
+        }
+        if (hipEventSynchronize(f->ev_stage[kd]) != hipSuccess) return false;
+        memcpy((uint8_t *) dst + done, f->hp_stage[kd].p, len[kd]);
+        done += len[kd];
+        kd ^= 1;
+    }
+    return true;
+}
+
 extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilters, const void *data, size_t bytes,
                                        void **out_buf, size_t *out_size, flbgpu_chain_stat *stats) {
     if (stats) memset(stats, 0, sizeof(*stats) * (size_t) (nfilters > 0 ? nfilters : 0));
     if (bytes == 0 || nfilters <= 0) return FLBGPU_FILTER_NOTOUCH;
     flbgpu_filter *f = filters[0];
-    // record boundaries: worst case one record per 3 bytes
-    std::vector<uint64_t> off(bytes / 3 + 2);
+    // Record boundaries are found on the host (msgpack is sequential) slab by slab; each slab goes
+    // through a pinned staging buffer to the device while the next one is being indexed.
     size_t consumed = 0;
-    int64_t n = flbgpu_index_host(data, bytes, off.data(), off.size(), &consumed);
+    int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed);
+    if (n < 0) return FLBGPU_FILTER_NOTOUCH;
     bool garbage = consumed != bytes;
     if (n == 0) {
         // nothing decodes: every callback's loop ends at once; log_to_metrics still answers
@@ -809,14 +900,6 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
         }
         return FLBGPU_FILTER_NOTOUCH;
     }
-    hipStream_t st = f->stream;
-    if (!f->h_in_data.ensure(consumed + 16) || !f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return FLBGPU_FILTER_NOTOUCH;
-    if (hipMemcpyAsync(f->h_in_data.p, data, consumed, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(f->h_in_off.p, off.data(), (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess) {
-        set_err("host to device copy failed");
-        return FLBGPU_FILTER_NOTOUCH;
-    }
     flbgpu_dev_chunk in, out;
     in.data = f->h_in_data.p; in.row_off = f->h_in_off.as<uint64_t>(); in.n = (uint64_t) n; in.bytes = consumed;
     memset(&out, 0, sizeof(out));
@@ -824,7 +907,7 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     if (out.bytes == 0) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
     void *hb = malloc(out.bytes);
     if (!hb) return FLBGPU_FILTER_NOTOUCH;
-    if (hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!staged_download(f, hb, out.data, out.bytes)) {
         free(hb);
         set_err("device to host copy failed");
         return FLBGPU_FILTER_NOTOUCH;

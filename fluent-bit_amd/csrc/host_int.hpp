@@ -43,6 +43,24 @@ struct DevBuf {
     template <class T> T *as() const { return (T *) p; }
 };
 
+// page-locked host memory (staging slabs and the record-offset column of the host-level call)
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // keeps the first `keep` bytes when it has to move
+    bool ensure(size_t bytes, size_t keep = 0) {
+        if (bytes <= cap) return true;
+        size_t want = bytes + bytes / 2 + 4096;
+        void *q = nullptr;
+        HIPOK(hipHostMalloc(&q, want, hipHostMallocDefault));
+        if (p) { if (keep) memcpy(q, p, keep); (void) hipHostFree(p); }
+        p = q; cap = want;
+        return true;
+    }
+    void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *) p; }
+};
+
 // uploads vectors of one table set into a single device allocation
 struct TableBlob {
     void *dev = nullptr;
@@ -84,6 +102,8 @@ struct flbgpu_filter {
     // working buffers
     flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
+    flbgpu::PinnedBuf hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     uint64_t last_in = 0, last_out = 0;
     // profiling
     bool prof = false;
@@ -97,6 +117,8 @@ struct flbgpu_filter {
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                                  &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
         for (auto *b : all) b->release();
+        hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
+        for (auto &e : ev_stage) if (e) (void) hipEventDestroy(e);
         if (ev0) (void) hipEventDestroy(ev0);
         if (ev1) (void) hipEventDestroy(ev1);
         if (stream) (void) hipStreamDestroy(stream);
