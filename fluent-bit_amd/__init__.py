@@ -63,6 +63,11 @@ def lib():
     L.flbgpu_filter_profile_read.argtypes = [c_void_p, c_int, POINTER(c_char_p), POINTER(c_double), POINTER(c_uint64)]
     L.flbgpu_index_host.restype = c_int64
     L.flbgpu_index_host.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]
+    L.flbgpu_indexer_create.restype = c_void_p
+    L.flbgpu_indexer_destroy.argtypes = [c_void_p]
+    L.flbgpu_index_dev.restype = c_int64
+    L.flbgpu_index_dev.argtypes = [c_void_p, c_void_p, c_size_t, POINTER(DevChunk), POINTER(c_size_t)]
+    L.flbgpu_indexer_stats.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
     L.flbgpu_dev_alloc.restype = c_void_p
     L.flbgpu_dev_alloc.argtypes = [c_size_t]
     L.flbgpu_dev_free.argtypes = [c_void_p]
@@ -258,10 +263,58 @@ class FilterChain:
 def index_host(data):
     """record boundaries of a host chunk: (n, offsets list[n+1], consumed)"""
     import numpy as np
-    off = np.zeros(len(data) // 3 + 2, dtype=np.uint64)
     consumed = c_size_t()
-    n = lib().flbgpu_index_host(data, len(data), off.ctypes.data, off.size, byref(consumed))
+    for cap in (len(data) // 64 + 1024, len(data) + 2):        # a record can be one byte long
+        off = np.zeros(cap, dtype=np.uint64)
+        n = lib().flbgpu_index_host(data, len(data), off.ctypes.data, off.size, byref(consumed))
+        if n + 1 < cap:
+            break
     return n, off[: n + 1], consumed.value
+
+
+class Indexer:
+    """record boundaries of a raw chunk found on the GPU (flbgpu_index_dev)"""
+
+    def __init__(self):
+        self.h = lib().flbgpu_indexer_create()
+        if not self.h:
+            raise RuntimeError(last_error())
+
+    def __del__(self):
+        if getattr(self, "h", None) and _L is not None:
+            _L.flbgpu_indexer_destroy(self.h)
+            self.h = None
+
+    def index_dev(self, dev_ptr, nbytes):
+        """-> (DevChunk with device row offsets, consumed)"""
+        ch = DevChunk()
+        consumed = c_size_t()
+        n = lib().flbgpu_index_dev(self.h, dev_ptr, nbytes, byref(ch), byref(consumed))
+        if n < 0:
+            raise RuntimeError(last_error())
+        return ch, consumed.value
+
+    def index(self, data):
+        """host bytes -> (n, offsets[n + 1] as numpy u64, consumed); uploads, indexes on the device, reads back"""
+        import numpy as np
+        L = lib()
+        d = L.flbgpu_dev_alloc(len(data) + 16)
+        if not d:
+            raise RuntimeError(last_error())
+        try:
+            L.flbgpu_memcpy_h2d(d, data, len(data))
+            ch, consumed = self.index_dev(d, len(data))
+            off = np.zeros(ch.n + 1, dtype=np.uint64)
+            if len(data):
+                L.flbgpu_memcpy_d2h(off.ctypes.data, ch.row_off, off.nbytes)
+            return int(ch.n), off, consumed
+        finally:
+            L.flbgpu_dev_free(d)
+
+    def stats(self):
+        a, b, c = c_uint64(), c_uint64(), c_uint64()
+        lib().flbgpu_indexer_stats(self.h, byref(a), byref(b), byref(c))
+        return dict(candidates=a.value, off_chain_rows=b.value, rounds=c.value)
 
 
 # ---- filter_log_to_metrics ---------------------------------------------------------------------

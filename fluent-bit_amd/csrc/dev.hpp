@@ -302,6 +302,17 @@ struct GatherArgs {
     uint8_t *out;
 };
 
+// progress of the device-side record indexer (index_kernels.inc)
+struct IdxState {
+    unsigned long long start_idx;        // chain kernels: candidate the chain (re)starts from
+    unsigned long long pos;              // k_idx_one: byte position to walk from
+    unsigned long long consumed;         // bytes covered by whole records once status is final
+    unsigned int kind;                   // how the chain ended (IDX_EOF / LAND / INVALID / LONG), IDX_NONE while open
+    unsigned int term;                   // candidate index it ended on
+    unsigned int n_extras;               // rows that are not candidates
+    unsigned int status;                 // 0 chain runs from start_idx, 1 finished (consumed valid), 2 side list full, 3 k_idx_one runs from pos
+};
+
 }  // namespace flbgpu
 
 // launchers implemented in kernels.hip
@@ -333,6 +344,18 @@ void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
 void launch_json_size(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_generic(const JsonArgs &a, bool emit, hipStream_t st);
+size_t idx_tiles(uint64_t bytes);
+size_t idx_blocks(uint64_t nc);
+void launch_idx_count(const uint8_t *data, uint64_t bytes, uint32_t *tile_cnt, hipStream_t st);
+void launch_idx_fill(const uint8_t *data, uint64_t bytes, const uint64_t *tile_off, uint64_t *cand_pos, hipStream_t st);
+void launch_idx_walk(const uint8_t *data, uint64_t bytes, const uint64_t *cand_pos, uint64_t nc, uint32_t *rec_len, uint32_t *succ, hipStream_t st);
+void launch_idx_exit(const uint32_t *succ, uint64_t nc, uint32_t *exitp, hipStream_t st);
+void launch_idx_chain_mark(const uint32_t *succ, const uint32_t *rec_len, const uint64_t *cand_pos, uint64_t nc, const uint32_t *exitp,
+                           uint32_t *entry, uint32_t *flags, uint64_t bytes, IdxState *state, hipStream_t st);
+void launch_idx_one(const uint8_t *data, uint64_t bytes, const uint64_t *cand_pos, uint64_t nc, uint64_t *extras, uint32_t extras_cap, IdxState *state,
+                    hipStream_t st);
+void launch_idx_emit(const uint64_t *cand_pos, uint64_t nc, const uint32_t *flags, const uint64_t *off, const uint64_t *extras, uint32_t n_extras,
+                     uint64_t consumed, uint64_t *row_off, hipStream_t st);
 bool l2m_test_numconv(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *status);
 
 }  // namespace flbgpu

@@ -516,7 +516,11 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     if (n == 0) return true;
     if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
     MiscWords *dm = f->d_misc.as<MiscWords>();
-    MiscWords hm;
+    // host mirror of the counters + the output size, page-locked so that the small copies are real
+    // asynchronous DMA transfers
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return false;
+    MiscWords &hm = *f->hp_misc.as<MiscWords>();
+    uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     const uint64_t *row_off = in->row_off;
     const uint8_t *data = (const uint8_t *) in->data;
     // scratch sizing: one state id per byte boundary of the longest record
@@ -591,7 +595,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     if (n == 0) return true;
     // write offsets + the number of emitted records (what flb_mp_count_log_records would report) in one pass
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st, &dm->counts[1]); }
-    uint64_t total = 0;
+    total = 0;
     HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -620,7 +624,11 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     if (n == 0) return true;
     if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
     MiscWords *dm = f->d_misc.as<MiscWords>();
-    MiscWords hm;
+    // host mirror of the counters + the output size, page-locked so that the small copies are real
+    // asynchronous DMA transfers
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return false;
+    MiscWords &hm = *f->hp_misc.as<MiscWords>();
+    uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     memset(&hm, 0, sizeof(hm));
     hm.first_bad = ~0ull;
     HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
@@ -633,7 +641,7 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     ga.status = f->d_status.as<uint32_t>(); ga.first_bad = &dm->first_bad; ga.counts = dm->counts;
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
-    uint64_t total = 0;
+    total = 0;
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -804,34 +812,46 @@ static bool stage_init(flbgpu_filter *f) {
     return true;
 }
 
-// Indexes `data` into f->hp_off (pinned) and copies it into f->h_in_data; returns the record count
-// (-1 on a HIP failure) and the bytes covered by whole records.
-static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed) {
+// chunks of this size and more are indexed on the device (flbgpu_index_dev); smaller ones are
+// cheaper to walk on the host than to launch the indexer's kernels for
+static const size_t DEV_INDEX_MIN = 8u << 20;
+
+// record boundaries of d[from..] appended to f->hp_off (pinned) until `until` is reached
+static bool host_index_range(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t until, size_t *pos, int64_t *n, size_t *cap, bool *stop) {
+    uint64_t *off = f->hp_off.as<uint64_t>();
+    while (!*stop && *pos < until) {
+        size_t q = *pos;
+        __builtin_prefetch(d + *pos + 2048); __builtin_prefetch(d + *pos + 2112);
+        if (!h_skip(d, bytes, &q)) { *stop = true; break; }
+        if ((size_t) *n + 2 > *cap) {
+            *cap *= 2;
+            if (!f->hp_off.ensure(*cap * sizeof(uint64_t), (size_t) *n * sizeof(uint64_t))) return false;
+            off = f->hp_off.as<uint64_t>();
+        }
+        off[(*n)++] = *pos;
+        *pos = q;
+    }
+    return true;
+}
+
+// Copies `data` into f->h_in_data through the pinned slabs and finds the record boundaries -- on the
+// host while the slabs are in flight, or on the device once the bytes are there.  Returns the
+// record count (-1 on a HIP failure), the bytes covered by whole records and the device offsets.
+static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off) {
     hipStream_t st = f->stream;
     if (!stage_init(f) || !f->h_in_data.ensure(bytes + 16)) return -1;
+    bool dev_index = bytes >= DEV_INDEX_MIN && !getenv("FLBGPU_HOST_INDEX");
     size_t cap = bytes / 96 + 1024;
     if (!f->hp_off.ensure(cap * sizeof(uint64_t))) return -1;
     const size_t slab = bytes < STAGE_SLAB ? bytes : STAGE_SLAB;
     if (!f->hp_stage[0].ensure(slab) || (bytes > slab && !f->hp_stage[1].ensure(slab))) return -1;
-    uint64_t *off = f->hp_off.as<uint64_t>();
     size_t pos = 0, sent = 0;
     int64_t n = 0;
     bool stop = false;
     int k = 0;
     while (sent < bytes) {
         const size_t end = sent + slab < bytes ? sent + slab : bytes;
-        while (!stop && pos < end) {
-            size_t q = pos;
-            __builtin_prefetch(d + pos + 2048); __builtin_prefetch(d + pos + 2112);
-            if (!h_skip(d, bytes, &q)) { stop = true; break; }
-            if ((size_t) n + 2 > cap) {
-                cap *= 2;
-                if (!f->hp_off.ensure(cap * sizeof(uint64_t), (size_t) n * sizeof(uint64_t))) return -1;
-                off = f->hp_off.as<uint64_t>();
-            }
-            off[n++] = pos;
-            pos = q;
-        }
+        if (!dev_index && !host_index_range(f, d, bytes, end, &pos, &n, &cap, &stop)) return -1;
         // bytes past the last whole record are never read by the kernels; they are not uploaded
         const size_t upto = stop ? (pos < end ? pos : end) : end;
         if (upto > sent) {
@@ -844,10 +864,22 @@ static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, s
         if (stop) break;
         sent = end;
     }
+    if (dev_index) {
+        if (hipStreamSynchronize(st) != hipSuccess) { set_err("host to device copy failed"); return -1; }
+        if (!f->indexer) f->indexer = flbgpu_indexer_create();
+        flbgpu_dev_chunk ch;
+        int64_t nd = f->indexer ? flbgpu_index_dev(f->indexer, f->h_in_data.p, bytes, &ch, consumed) : -1;
+        if (nd >= 0) { *row_off = ch.row_off; return nd; }
+        // a chunk the device indexer gives up on (see flbgpu_index_dev): sequential walk
+        if (!host_index_range(f, d, bytes, bytes, &pos, &n, &cap, &stop)) return -1;
+    }
+    uint64_t *off = f->hp_off.as<uint64_t>();
     off[n] = pos;
     *consumed = pos;
+    *row_off = f->h_in_off.as<uint64_t>();
     if (n == 0) return 0;
     if (!f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return -1;
+    *row_off = f->h_in_off.as<uint64_t>();
     if (hipMemcpyAsync(f->h_in_off.p, off, (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     // the staging slabs and the offsets are reused by the next call
     if (hipStreamSynchronize(st) != hipSuccess) { set_err("host to device copy failed"); return -1; }
@@ -887,7 +919,8 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     // Record boundaries are found on the host (msgpack is sequential) slab by slab; each slab goes
     // through a pinned staging buffer to the device while the next one is being indexed.
     size_t consumed = 0;
-    int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed);
+    const uint64_t *row_off = nullptr;
+    int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed, &row_off);
     if (n < 0) return FLBGPU_FILTER_NOTOUCH;
     bool garbage = consumed != bytes;
     if (n == 0) {
@@ -901,7 +934,7 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
         return FLBGPU_FILTER_NOTOUCH;
     }
     flbgpu_dev_chunk in, out;
-    in.data = f->h_in_data.p; in.row_off = f->h_in_off.as<uint64_t>(); in.n = (uint64_t) n; in.bytes = consumed;
+    in.data = f->h_in_data.p; in.row_off = row_off; in.n = (uint64_t) n; in.bytes = consumed;
     memset(&out, 0, sizeof(out));
     if (chain_dev(filters, nfilters, &in, &out, garbage, stats) != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
     if (out.bytes == 0) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }

@@ -102,8 +102,9 @@ struct flbgpu_filter {
     // working buffers
     flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
-    flbgpu::PinnedBuf hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
+    flbgpu::PinnedBuf hp_misc, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    flbgpu_indexer *indexer = nullptr;        // device record indexer of the host-level call (large chunks)
     uint64_t last_in = 0, last_out = 0;
     // profiling
     bool prof = false;
@@ -117,7 +118,8 @@ struct flbgpu_filter {
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                                  &d_misc, &d_status, &d_out_off, &h_in_data, &h_in_off};
         for (auto *b : all) b->release();
-        hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
+        if (indexer) flbgpu_indexer_destroy(indexer);
+        hp_misc.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
         for (auto &e : ev_stage) if (e) (void) hipEventDestroy(e);
         if (ev0) (void) hipEventDestroy(ev0);
         if (ev1) (void) hipEventDestroy(ev1);

@@ -208,14 +208,10 @@ DEV uint64_t ldu64(const uint8_t *p) {
 // load whenever 8 bytes remain before `end`; the 0xc0..0xdf family is decoded from two packed
 // nibble tables (type, number of length bytes) instead of a 32-way switch, which keeps this
 // function -- inlined at every token of every walker -- small.
-DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
+// w: the 8 bytes at p, little-endian (bytes at or past `end` read as 0); p < end
+DEV Tok mp_tok_w(uint64_t w, const uint8_t *p, const uint8_t *end) {
     Tok t;
     t.type = T_BAD; t.len = 0; t.u = 0; t.next = p;
-    if (p >= end) return t;
-    uint64_t w;
-    const uint32_t avail = (uint32_t) ((uint64_t) (end - p) < 9 ? (end - p) : 9);
-    if (avail >= 8) w = ldu64(p);
-    else { w = 0; for (uint32_t q = 0; q < avail; q++) w |= (uint64_t) ld8(p + q) << (8 * q); }
     const uint32_t c = (uint32_t) (w & 0xff);
     p++;
     uint32_t need = 0;
@@ -266,6 +262,19 @@ DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
     }
     t.next = p;
     return t;
+}
+
+DEV Tok mp_tok(const uint8_t *p, const uint8_t *end) {
+    if (p >= end) {
+        Tok t;
+        t.type = T_BAD; t.len = 0; t.u = 0; t.next = p;
+        return t;
+    }
+    uint64_t w;
+    const uint32_t avail = (uint32_t) ((uint64_t) (end - p) < 9 ? (end - p) : 9);
+    if (avail >= 8) w = ldu64(p);
+    else { w = 0; for (uint32_t q = 0; q < avail; q++) w |= (uint64_t) ld8(p + q) << (8 * q); }
+    return mp_tok_w(w, p, end);
 }
 
 // skips one complete object; nullptr when malformed / truncated
@@ -2346,5 +2355,6 @@ void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long 
 
 #include "l2m_kernels.inc"
 #include "pjson_kernels.inc"
+#include "index_kernels.inc"
 
 }  // namespace flbgpu

@@ -191,6 +191,20 @@ int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_of
  * Returns n; *consumed is the offset where decoding stopped (== bytes for a clean chunk). */
 int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap, size_t *consumed);
 
+/* The same boundaries found on the device from the raw bytes of a chunk that is already in HBM
+ * (what msgpack_unpack_next yields object by object, lib/msgpack-c/src/unpack.c via
+ * src/flb_log_event_decoder.c:296-333): every 0x92 byte is a candidate start, one lane skips the
+ * object behind each candidate, and the boundaries are the candidates reachable from byte 0; records
+ * that do not start with a 2-element fixarray are walked one by one.  out->row_off (n + 1 entries,
+ * row_off[n] == *consumed) belongs to the indexer and stays valid until its next call.  Returns n or
+ * -1 (flbgpu_last_error()).  dev_data should be 16-byte aligned (hipMalloc is). */
+typedef struct flbgpu_indexer flbgpu_indexer;
+flbgpu_indexer *flbgpu_indexer_create(void);
+void flbgpu_indexer_destroy(flbgpu_indexer *ix);
+int64_t flbgpu_index_dev(flbgpu_indexer *ix, const void *dev_data, size_t bytes, flbgpu_dev_chunk *out, size_t *consumed);
+/* last call: candidate bytes, rows found off the candidate chain, chain rounds */
+void flbgpu_indexer_stats(const flbgpu_indexer *ix, uint64_t *candidates, uint64_t *off_chain_rows, uint64_t *rounds);
+
 /* ---- device memory helpers for callers that have no HIP binding of their own ------------------ */
 void *flbgpu_dev_alloc(size_t bytes);
 void flbgpu_dev_free(void *p);
