@@ -51,7 +51,7 @@ def recorded_traffic(kernel, n):
         return None, None
 
 
-def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args):
+def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_chunk=None):
     """filter_log_to_metrics on the parsed chunk (BASELINE configs[3] shape: counter + histogram, partial
     aggregates all-reduced over RCCL when N > 1) and NDJSON -> msgpack events -> 32-rule filter_grep
     (configs[2] shape).  Reported next to the headline number, never folded into it."""
@@ -59,6 +59,20 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args):
     import random
     out = {}
     steps = 3
+    # -- record boundaries of the raw input chunk found on the device (what the decoder loop of every
+    #    cb_filter does first); the headline step takes them as part of the device-resident chunk format
+    if raw_chunk is not None:
+        ix = g.Indexer()
+        ch, consumed = ix.index_dev(raw_chunk.data, int(raw_chunk.bytes))
+        assert int(ch.n) == n and consumed == int(raw_chunk.bytes), (int(ch.n), consumed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ix.index_dev(raw_chunk.data, int(raw_chunk.bytes))
+        dt = (time.perf_counter() - t0) / steps
+        out["record_indexer"] = {"records_per_s_per_gpu": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                                 "chunk_GBps": round(int(raw_chunk.bytes) / dt / 1e9, 1), **ix.stats()}
+        del ix
     # -- log_to_metrics
     for name, mode, props, vf in (("l2m_counter", "counter", [("label_field", "method"), ("label_field", "code")], None),
                                   ("l2m_histogram", "histogram", [("label_field", "code")], "size")):
@@ -222,7 +236,7 @@ def main():
     secondary = None
     if not args.no_secondary:
         try:
-            secondary = measure_secondary(g, torch, dist, rank, world, o1, n, args)
+            secondary = measure_secondary(g, torch, dist, rank, world, o1, n, args, raw_chunk=chunk)
         except Exception as e:                      # the headline line must survive a failure here
             secondary = {"error": repr(e)[:300]}
 

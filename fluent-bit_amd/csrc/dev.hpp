@@ -346,8 +346,8 @@ void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_generic(const JsonArgs &a, bool emit, hipStream_t st);
 size_t idx_tiles(uint64_t bytes);
 size_t idx_blocks(uint64_t nc);
-void launch_idx_count(const uint8_t *data, uint64_t bytes, uint32_t *tile_cnt, hipStream_t st);
-void launch_idx_fill(const uint8_t *data, uint64_t bytes, const uint64_t *tile_off, uint64_t *cand_pos, hipStream_t st);
+void launch_idx_count(const uint8_t *data, uint64_t bytes, uint64_t *masks, uint32_t *tile_cnt, hipStream_t st);
+void launch_idx_fill(const uint64_t *masks, uint64_t bytes, const uint64_t *tile_off, uint64_t *cand_pos, hipStream_t st);
 void launch_idx_walk(const uint8_t *data, uint64_t bytes, const uint64_t *cand_pos, uint64_t nc, uint32_t *rec_len, uint32_t *succ, hipStream_t st);
 void launch_idx_exit(const uint32_t *succ, uint64_t nc, uint32_t *exitp, hipStream_t st);
 void launch_idx_chain_mark(const uint32_t *succ, const uint32_t *rec_len, const uint64_t *cand_pos, uint64_t nc, const uint32_t *exitp,

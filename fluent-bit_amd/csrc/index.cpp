@@ -5,11 +5,11 @@ using namespace flbgpu;
 
 struct flbgpu_indexer {
     hipStream_t stream = nullptr;
-    DevBuf tile_cnt, tile_off, scan_tmp, cand_pos, rec_len, succ, exitp, entry, flags, off, extras, state, row_off;
+    DevBuf masks, tile_cnt, tile_off, scan_tmp, cand_pos, rec_len, succ, exitp, entry, flags, off, extras, state, row_off;
     PinnedBuf hstate;
     uint64_t last_candidates = 0, last_extras = 0, last_rounds = 0;
     ~flbgpu_indexer() {
-        DevBuf *all[] = {&tile_cnt, &tile_off, &scan_tmp, &cand_pos, &rec_len, &succ, &exitp, &entry, &flags, &off, &extras, &state, &row_off};
+        DevBuf *all[] = {&masks, &tile_cnt, &tile_off, &scan_tmp, &cand_pos, &rec_len, &succ, &exitp, &entry, &flags, &off, &extras, &state, &row_off};
         for (auto *b : all) b->release();
         hstate.release();
         if (stream) (void) hipStreamDestroy(stream);
@@ -37,12 +37,12 @@ static bool index_dev_impl(flbgpu_indexer *ix, const uint8_t *data, size_t bytes
     if (!ix->hstate.ensure(sizeof(IdxState) + 2 * sizeof(uint64_t))) return false;
     IdxState &hs = *ix->hstate.as<IdxState>();
     uint64_t &h_count = *(uint64_t *) (ix->hstate.as<uint8_t>() + sizeof(IdxState));
-    if (!ix->tile_cnt.ensure(tiles * sizeof(uint32_t) + 4) || !ix->tile_off.ensure((tiles + 1) * sizeof(uint64_t)) ||
+    if (!ix->masks.ensure((bytes / 64 + 2) * sizeof(uint64_t)) || !ix->tile_cnt.ensure(tiles * sizeof(uint32_t) + 4) || !ix->tile_off.ensure((tiles + 1) * sizeof(uint64_t)) ||
         !ix->scan_tmp.ensure(scan_tmp_elems(tiles) * sizeof(uint64_t)) || !ix->state.ensure(sizeof(IdxState)) ||
         !ix->extras.ensure((size_t) EXTRAS_CAP * sizeof(uint64_t)))
         return false;
     // 1. candidates
-    launch_idx_count(data, bytes, ix->tile_cnt.as<uint32_t>(), st);
+    launch_idx_count(data, bytes, ix->masks.as<uint64_t>(), ix->tile_cnt.as<uint32_t>(), st);
     launch_scan(ix->tile_cnt.as<uint32_t>(), tiles, ix->scan_tmp.as<uint64_t>(), ix->tile_off.as<uint64_t>(), st);
     HIPOK(hipMemcpyAsync(&h_count, ix->tile_off.as<uint64_t>() + tiles, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -55,7 +55,7 @@ static bool index_dev_impl(flbgpu_indexer *ix, const uint8_t *data, size_t bytes
         !ix->entry.ensure((nblk + 1) * sizeof(uint32_t)) || !ix->scan_tmp.ensure(scan_tmp_elems(nc > tiles ? nc : tiles) * sizeof(uint64_t)))
         return false;
     // 2. one speculative skip per candidate, 3. the part of the succ graph inside each block
-    launch_idx_fill(data, bytes, ix->tile_off.as<uint64_t>(), ix->cand_pos.as<uint64_t>(), st);
+    launch_idx_fill(ix->masks.as<uint64_t>(), bytes, ix->tile_off.as<uint64_t>(), ix->cand_pos.as<uint64_t>(), st);
     launch_idx_walk(data, bytes, ix->cand_pos.as<uint64_t>(), nc, ix->rec_len.as<uint32_t>(), ix->succ.as<uint32_t>(), st);
     launch_idx_exit(ix->succ.as<uint32_t>(), nc, ix->exitp.as<uint32_t>(), st);
     HIPOK(hipMemsetAsync(ix->flags.p, 0, (nc + 1) * sizeof(uint32_t), st));

@@ -351,7 +351,7 @@ def test_parser_do_scalar_entry_point(g):
 
 def test_full_size_properties_10M(g):
     """BASELINE configs[1] at full size (10 M records, 2.77 GB): properties that do not need a 10 M-record
-    oracle run -- (a) filtering is linear over concatenation: the two halves filtered separately give
+    oracle run -- (0) the device indexer reproduces the record offsets from the raw bytes; (a) filtering is linear over concatenation: the two halves filtered separately give
     the bytes of the whole; (b) a random sample of output rows equals the oracle's output for the same
     input rows, byte for byte; (c) three independent kernels agree on the 5xx count (grep's kept
     records, log_to_metrics' counter by code, the sample)."""
@@ -381,6 +381,14 @@ def test_full_size_properties_10M(g):
 
     parsed, poff, kept, nkept = run(g.DevChunk(d_data, d_off, n, nbytes))
     assert len(poff) == n + 1 and int(poff[-1]) == len(parsed)
+    # (0) the device record indexer finds, from the raw bytes, exactly the boundaries the generator wrote
+    ix = g.Indexer()
+    ich, consumed = ix.index_dev(d_data, nbytes)
+    assert int(ich.n) == n and consumed == nbytes, (int(ich.n), consumed, ix.stats())
+    ioff = np.empty(n + 1, dtype=np.uint64)
+    L.flbgpu_memcpy_d2h(ioff.ctypes.data, ich.row_off, ioff.nbytes)
+    assert np.array_equal(ioff, np.asarray(off, dtype=np.uint64))
+    del ix
     # (a) halves: row offsets of the second half are rebased on the device copy of the same bytes
     h = n // 2
     off2 = (off[h:] - off[h]).astype(np.uint64)
