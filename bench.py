@@ -286,6 +286,11 @@ def main():
                "sample": "first %d records of the same seeded workload through oracle filter_parser(apache2)+filter_grep, "
                          "single thread (%d host cores present)" % (ns, os.cpu_count())}
 
+    if isinstance(secondary, dict) and "record_indexer" in secondary:
+        # what the step would sustain if it were handed raw bytes and had to find the rows first
+        step_s = dt / args.steps
+        secondary["record_indexer"]["headline_step_plus_indexing_records_per_s_per_gpu"] = round(
+            n / (step_s + secondary["record_indexer"]["ms_per_step"] / 1e3), 1)
     line = {
         "metric": "log records/sec (256B apache-combined lines) through parser+grep",
         "value": round(value, 1), "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -294,6 +299,8 @@ def main():
         "config": {"workload": "filter_parser(conf/parsers.conf apache2, Key_Name log) -> filter_grep(Regex code ^5\\d\\d$) "
                                "on %d x 256B apache-combined lines per GPU (277B V2 events), chained on device, unfused" % n,
                    "records_per_gpu": n, "in_bytes": in_bytes, "parsed_bytes": parsed_bytes, "kept_records": int(kept_records),
+                   "row_offsets": "part of the device-resident chunk (every filter's output carries them); finding them from "
+                                  "raw bytes is secondary.record_indexer",
                    "seed": synth.SEED, "parallelism": "shard%d" % world, "gen_seconds": round(gen_s, 1)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary,
     }

@@ -678,8 +678,41 @@ static int run_any_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_
     return ret;
 }
 
+// A device chunk handed over without its offset column (row_off == NULL): the filter's indexer finds
+// the records first (flbgpu_index_dev).  Returns false on failure; *garbage = undecodable bytes follow.
+static bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage) {
+    *resolved = *in;
+    *garbage = false;
+    if (in->row_off != nullptr || in->bytes == 0) return true;
+    if (!f->indexer) f->indexer = flbgpu_indexer_create();
+    if (!f->indexer) return false;
+    size_t consumed = 0;
+    if (flbgpu_index_dev(f->indexer, in->data, (size_t) in->bytes, resolved, &consumed) < 0) return false;
+    *garbage = consumed != in->bytes;
+    return true;
+}
+
+// nothing decodes: every callback's loop ends at once; log_to_metrics still answers
+// MODIFIED/empty when discard_logs is set (log_to_metrics.c:1141-1145)
+static int empty_chunk_result(flbgpu_filter *const *filters, int nfilters, bool garbage, flbgpu_dev_chunk *out) {
+    flbgpu_filter *f = filters[0];
+    if (nfilters == 1 && f->kind == F_L2M) {
+        flbgpu_dev_chunk in0;
+        memset(&in0, 0, sizeof(in0));
+        if (run_any_dev(f, &in0, out, f->stream, garbage) == FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_MODIFIED;
+    }
+    return FLBGPU_FILTER_NOTOUCH;
+}
+
 extern "C" int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream) {
-    return run_any_dev(f, in, out, stream ? (hipStream_t) stream : f->stream, false);
+    flbgpu_dev_chunk r;
+    bool garbage = false;
+    if (!resolve_raw_chunk(f, in, &r, &garbage)) return FLBGPU_FILTER_NOTOUCH;
+    if (in->row_off == nullptr && in->bytes > 0 && r.n == 0) {
+        flbgpu_filter *one[1] = {f};
+        return empty_chunk_result(one, 1, garbage, out);
+    }
+    return run_any_dev(f, &r, out, stream ? (hipStream_t) stream : f->stream, garbage);
 }
 
 // flb_filter_do (src/flb_filter.c:121-325) over device-resident chunks: every MODIFIED output
@@ -713,7 +746,13 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
 
 extern "C" int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nfilters, const flbgpu_dev_chunk *in,
                                            flbgpu_dev_chunk *out, flbgpu_chain_stat *stats) {
-    return chain_dev(filters, nfilters, in, out, false, stats);
+    if (stats) memset(stats, 0, sizeof(*stats) * (size_t) (nfilters > 0 ? nfilters : 0));
+    if (nfilters <= 0) return FLBGPU_FILTER_NOTOUCH;
+    flbgpu_dev_chunk r;
+    bool garbage = false;
+    if (!resolve_raw_chunk(filters[0], in, &r, &garbage)) return FLBGPU_FILTER_NOTOUCH;
+    if (in->row_off == nullptr && in->bytes > 0 && r.n == 0) return empty_chunk_result(filters, nfilters, garbage, out);
+    return chain_dev(filters, nfilters, &r, out, garbage, stats);
 }
 
 // ------------------------------------------------------------------------------------------ host indexer
@@ -924,13 +963,9 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     if (n < 0) return FLBGPU_FILTER_NOTOUCH;
     bool garbage = consumed != bytes;
     if (n == 0) {
-        // nothing decodes: every callback's loop ends at once; log_to_metrics still answers
-        // MODIFIED/empty when discard_logs is set (log_to_metrics.c:1141-1145)
-        if (nfilters == 1 && f->kind == F_L2M) {
-            flbgpu_dev_chunk in0, o0;
-            memset(&in0, 0, sizeof(in0));
-            if (run_any_dev(f, &in0, &o0, f->stream, garbage) == FLBGPU_FILTER_MODIFIED) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
-        }
+        flbgpu_dev_chunk o0;
+        memset(&o0, 0, sizeof(o0));
+        if (empty_chunk_result(filters, nfilters, garbage, &o0) == FLBGPU_FILTER_MODIFIED) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
         return FLBGPU_FILTER_NOTOUCH;
     }
     flbgpu_dev_chunk in, out;

@@ -128,7 +128,9 @@ int flbgpu_filter_run(flbgpu_filter *f, const void *data, size_t bytes, void **o
 /* Device-level cb_filter: `in` lives in HBM.  On MODIFIED, *out describes filter-owned device
  * buffers that stay valid until the next call on the same filter (or its destruction).  `stream`
  * is a hipStream_t (NULL = the filter's own stream); the call returns after the stream work it
- * enqueued has completed (sizes are needed on the host to size the output). */
+ * enqueued has completed (sizes are needed on the host to size the output).
+ * in->row_off == NULL means "raw chunk bytes": the records are found on the device first
+ * (flbgpu_index_dev below), exactly as the decoder loop at the top of every cb_filter would. */
 int flbgpu_filter_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, void *stream);
 
 /* ---- flb_filter_do: replaces the filter loop of src/flb_filter.c:121-325 for GPU filters -------------

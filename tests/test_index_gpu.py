@@ -160,3 +160,32 @@ def test_host_level_call_uses_device_indexer(g):
     cutpos = int(off[20000])
     blob2 = blob[:cutpos] + msgpack.packb({"x": 1}) + blob[cutpos:-7]
     assert fg.filter(blob2) == og.filter(blob2)
+
+
+def test_device_filters_take_raw_chunks(g):
+    """flbgpu_filter_run_dev / chain_run_dev with row_off == NULL index the chunk themselves"""
+    import oracle_binding as ob
+    L = g.lib()
+    recs = [event({"log": "GET /x %d" % i, "code": str(200 + (i * 7) % 400)}) for i in range(30000)]
+    for blob in (b"".join(recs), b"".join(recs)[:-3], b"".join(recs[:100]) + msgpack.packb(7) + b"".join(recs[100:]), b"\xc1"):
+        d = L.flbgpu_dev_alloc(len(blob) + 16)
+        L.flbgpu_memcpy_h2d(d, blob, len(blob))
+        fg = g.FilterGrep([("regex", r"code ^5\d\d$")])
+        fm = g.FilterLogToMetrics("counter", [("label_field", "code")])
+        raw = g.DevChunk(d, None, 0, len(blob))
+        r, o = fg.filter_dev(raw)
+        want_r, want = ob.Grep([("regex", r"code ^5\d\d$")]).filter(blob)
+        assert r == want_r
+        if r == g.MODIFIED:
+            got = np.empty(int(o.bytes), dtype=np.uint8)
+            L.flbgpu_memcpy_d2h(got.ctypes.data, o.data, int(o.bytes))
+            assert got.tobytes() == want
+        om = ob.L2M("counter", [("label_field", "code")])
+        assert fm.filter_dev(raw)[0] == om.filter(blob)
+        assert [(x["labels"], x["value"]) for x in fm.snapshot()] == [(x["labels"], x["value"]) for x in om.snapshot()[2]]
+        ch = g.FilterChain([g.FilterGrep([("exclude", "code ^2")]), fg])
+        r3, o3 = ch.filter_dev(raw)
+        q1, w1 = ob.Grep([("exclude", "code ^2")]).filter(blob)
+        q3, w3 = ob.Grep([("regex", r"code ^5\d\d$")]).filter(w1 if q1 == g.MODIFIED else blob)
+        assert r3 == (g.MODIFIED if g.MODIFIED in (q1, q3) else g.NOTOUCH)
+        L.flbgpu_dev_free(d)
