@@ -44,6 +44,18 @@ constexpr int MAX_SUBKEYS = 8;
 // Types cast (src/flb_parser.c:2067-2164)
 enum { TY_NONE = 0, TY_INT = 1, TY_FLOAT = 2, TY_BOOL = 3, TY_STRING = 4, TY_HEX = 5 };
 
+// Fixed-layout plan of a Time_Format (no %L): when every directive of the format has exactly one
+// width the text can be checked and read at fixed offsets; anything else about the input -- another
+// length, a one-digit day, a full month name -- sends the record to the strptime interpreter.
+enum { TP_LIT = 1, TP_SPACE, TP_NUM2, TP_YEAR4, TP_MON3, TP_TZ5 };
+enum { TPF_MDAY = 0, TPF_HOUR, TPF_MIN, TPF_SEC, TPF_MON1 };
+struct TimeOp { uint8_t kind, off, a, b; };   // LIT: a = the character; NUM2: a = TPF_* field, b = upper limit
+struct TimePlan {
+    int ok, len, nops;
+    TimeOp ops[32];
+    uint8_t lo[32];                      // NUM2: lower limit
+};
+
 // ---- one regex parser (struct flb_parser, include/fluent-bit/flb_parser.h:41-70)
 struct DevParser {
     DevCap ascii, utf8;
@@ -74,6 +86,7 @@ struct DevParser {
                                          // paying for the reverse pass (any match that starts at 0 is the leftmost one)
     int time_field;                      // the ONE named field that is the time key, -1 if none or several
     int plain_types;                     // no Types cast changes a value's encoded size (all string / none)
+    TimePlan plan;                       // fast path of fmt1 (ok == 0: interpreter only)
 };
 
 // ---- record accessor / key

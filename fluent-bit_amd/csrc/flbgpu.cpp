@@ -155,6 +155,56 @@ static bool expand_time_fmt(const char *fmt, std::string &out, std::string &why)
     return true;
 }
 
+// Fixed-layout plan of an expanded Time_Format (dev.hpp TimePlan).  Conservative: every directive must
+// have one width (%d %m %H %M %S two digits, %Y four, %b/%B/%h a three-letter abbreviation, %z
+// sign + hhmm), whitespace in the format must be single and followed by something that is not
+// whitespace, and year, month and day must all be there.  The limits are src/flb_strptime.c's.
+static void build_time_plan(const std::string &fmt, bool has_frac, TimePlan &pl) {
+    memset(&pl, 0, sizeof(pl));
+    if (has_frac || fmt.empty()) return;
+    int off = 0, n = 0;
+    bool year = false, mon = false, mday = false, prev_space = false;
+    auto push = [&](int kind, int width, int a, int b, int lo) -> bool {
+        if (n >= 32 || off + width > 32) return false;
+        pl.ops[n].kind = (uint8_t) kind; pl.ops[n].off = (uint8_t) off; pl.ops[n].a = (uint8_t) a; pl.ops[n].b = (uint8_t) b;
+        pl.lo[n] = (uint8_t) lo;
+        n++; off += width;
+        return true;
+    };
+    for (size_t i = 0; i < fmt.size(); i++) {
+        const unsigned char c = (unsigned char) fmt[i];
+        if (c == ' ' || (c >= 9 && c <= 13)) {
+            if (prev_space || i + 1 == fmt.size()) return;
+            if (!push(TP_SPACE, 1, 0, 0, 0)) return;
+            prev_space = true;
+            continue;
+        }
+        prev_space = false;
+        if (c != '%') {
+            if (c == 0 || !push(TP_LIT, 1, c, 0, 0)) return;
+            continue;
+        }
+        if (++i >= fmt.size()) return;
+        bool ok;
+        switch (fmt[i]) {
+        case 'd': ok = push(TP_NUM2, 2, TPF_MDAY, 31, 1); mday = true; break;
+        case 'H': ok = push(TP_NUM2, 2, TPF_HOUR, 23, 0); break;
+        case 'M': ok = push(TP_NUM2, 2, TPF_MIN, 59, 0); break;
+        case 'S': ok = push(TP_NUM2, 2, TPF_SEC, 60, 0); break;
+        case 'm': ok = push(TP_NUM2, 2, TPF_MON1, 12, 1); mon = true; break;
+        case 'Y': ok = push(TP_YEAR4, 4, 0, 0, 0); year = true; break;
+        case 'b': case 'B': case 'h': ok = push(TP_MON3, 3, 0, 0, 0); mon = true; break;
+        case 'z': ok = push(TP_TZ5, 5, 0, 0, 0); break;
+        default: return;
+        }
+        if (!ok) return;
+    }
+    if (!year || !mon || !mday) return;
+    pl.len = off;
+    pl.nops = n;
+    pl.ok = 1;
+}
+
 // Format regex (regex != NULL) or Format json (is_json)
 static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const char *regex, int skip_empty,
                                          const char *time_fmt, const char *time_key, const char *time_offset,
@@ -209,6 +259,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         if (x1.size() >= MAX_TIMEFMT || x2.size() >= MAX_TIMEFMT) { set_err("parser '%s': Time_Format too long", p->name.c_str()); delete p; return nullptr; }
         strcpy(d.fmt1, x1.c_str());
         strcpy(d.fmt2, x2.c_str());
+        build_time_plan(x1, d.has_frac != 0, d.plan);
         if (time_offset && time_offset[0]) {
             int diff = 0;
             if (tzone_offset(time_offset, (int) strlen(time_offset), &diff) == -1) { set_err("parser '%s': invalid Time_Offset", p->name.c_str()); delete p; return nullptr; }

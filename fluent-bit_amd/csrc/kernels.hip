@@ -1238,6 +1238,87 @@ DEV int time_lookup_in(const DevParser &ps, TStr &in, const uint8_t *v, uint32_t
     *sec = tm2time(tm);
     return 0;
 }
+// The format's fixed-layout plan on a time text of exactly plan.len bytes in the lane's LDS slot
+// (zero padded to 32).  true: *sec is what time_lookup_in would return for this text (and frac 0);
+// false: let the interpreter decide.  Every byte of the text is checked by some op, so there is no
+// embedded NUL; a two-digit number whose first digit alone exceeds the limit / 10 is left to the
+// interpreter (it reads one digit there), and so is a month whose next character continues the
+// full name.
+DEV bool time_fast(const DevParser &ps, LDS_AS const uint8_t *t, int64_t *sec) {
+    const TimePlan &pl = ps.plan;
+    Tm tm;
+    tm.year = tm.mon = tm.mday = tm.hour = tm.min = tm.sec = tm.yday = tm.wday = 0;
+    tm.gmtoff = 0; tm.have_epoch = 0; tm.epoch = 0;
+    for (int k = 0; k < pl.nops; k++) {
+        const TimeOp op = pl.ops[k];
+        const uint32_t o = op.off;
+        switch (op.kind) {
+        case TP_LIT:
+            if (t[o] != op.a) return false;
+            break;
+        case TP_SPACE:
+            if (!d_isspace(t[o])) return false;
+            break;
+        case TP_NUM2: {
+            const uint32_t d0 = (uint32_t) t[o] - '0', d1 = (uint32_t) t[o + 1] - '0';
+            if (d0 > 9 || d1 > 9 || d0 * 10 > op.b) return false;
+            const int v = (int) (d0 * 10 + d1);
+            if (v < (int) pl.lo[k] || v > (int) op.b) return false;
+            if (op.a == TPF_MDAY) tm.mday = v;
+            else if (op.a == TPF_HOUR) tm.hour = v;
+            else if (op.a == TPF_MIN) tm.min = v;
+            else if (op.a == TPF_SEC) tm.sec = v;
+            else tm.mon = v - 1;
+            break;
+        }
+        case TP_YEAR4: {
+            const uint32_t d0 = (uint32_t) t[o] - '0', d1 = (uint32_t) t[o + 1] - '0', d2 = (uint32_t) t[o + 2] - '0', d3 = (uint32_t) t[o + 3] - '0';
+            if (d0 > 9 || d1 > 9 || d2 > 9 || d3 > 9) return false;
+            tm.year = (int) (d0 * 1000 + d1 * 100 + d2 * 10 + d3) - 1900;
+            break;
+        }
+        case TP_MON3: {
+            const uint32_t key = d_lower(t[o]) | (d_lower(t[o + 1]) << 8) | (d_lower(t[o + 2]) << 16);
+            const uint32_t nxt = o + 3 < (uint32_t) pl.len ? d_lower(t[o + 3]) : 0;
+            #define P3(a, b, c) ((uint32_t) (a) | ((uint32_t) (b) << 8) | ((uint32_t) (c) << 16))
+            int m; uint32_t cont;                  // first character of the rest of the full name
+            switch (key) {
+            case P3('j', 'a', 'n'): m = 0; cont = 'u'; break;
+            case P3('f', 'e', 'b'): m = 1; cont = 'r'; break;
+            case P3('m', 'a', 'r'): m = 2; cont = 'c'; break;
+            case P3('a', 'p', 'r'): m = 3; cont = 'i'; break;
+            case P3('m', 'a', 'y'): m = 4; cont = 0; break;
+            case P3('j', 'u', 'n'): m = 5; cont = 'e'; break;
+            case P3('j', 'u', 'l'): m = 6; cont = 'y'; break;
+            case P3('a', 'u', 'g'): m = 7; cont = 'u'; break;
+            case P3('s', 'e', 'p'): m = 8; cont = 't'; break;
+            case P3('o', 'c', 't'): m = 9; cont = 'o'; break;
+            case P3('n', 'o', 'v'): m = 10; cont = 'e'; break;
+            case P3('d', 'e', 'c'): m = 11; cont = 'e'; break;
+            default: return false;
+            }
+            #undef P3
+            if (cont && nxt == cont) return false;
+            tm.mon = m;
+            break;
+        }
+        case TP_TZ5: {
+            const uint32_t sg = t[o];
+            const uint32_t d0 = (uint32_t) t[o + 1] - '0', d1 = (uint32_t) t[o + 2] - '0', d2 = (uint32_t) t[o + 3] - '0', d3 = (uint32_t) t[o + 4] - '0';
+            if ((sg != '+' && sg != '-') || d0 > 9 || d1 > 9 || d2 > 9 || d3 > 9) return false;
+            const long offs = (long) (d0 * 10 + d1) * 3600 + (long) (d2 * 10 + d3) * 60;
+            tm.gmtoff = sg == '-' ? -offs : offs;
+            break;
+        }
+        default:
+            return false;
+        }
+    }
+    if (!ps.time_with_tz) tm.gmtoff = ps.time_offset;
+    *sec = tm2time(tm);
+    return true;
+}
+
 DEV int time_lookup(const DevParser &ps, const uint8_t *v, uint32_t vlen, int64_t *sec, double *frac) {
     TStr in;
     return time_lookup_in(ps, in, v, vlen, sec, frac, (const char *) ps.fmt1, (const char *) ps.fmt2);
@@ -1746,7 +1827,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const uint8_t *val = a.data + a.row_off[r] + a.info[1 * n + r];
                     tv = set ? val + b : val;
                 }
-                if (time_lookup_in(ps, in, tv, fl, &s2, &f2, lfmt1, lfmt2) == -1) { drop |= 1u << f; continue; }
+                if (in.in_lds && ps.plan.ok && fl == (uint32_t) ps.plan.len && time_fast(ps, in.lds, &s2)) f2 = 0;
+                else if (time_lookup_in(ps, in, tv, fl, &s2, &f2, lfmt1, lfmt2) == -1) { drop |= 1u << f; continue; }
                 sec = s2; frac = f2;
                 if (!ps.time_keep) { drop |= 1u << f; continue; }
             }

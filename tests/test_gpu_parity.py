@@ -138,6 +138,38 @@ def test_filter_parser_semantics(g):
     assert o == q, first_diff(o[1], q[1])
 
 
+def test_time_text_fixed_layout_and_interpreter_agree(g):
+    """k_parser_finish reads fixed-width time texts at fixed offsets and leaves everything else to the
+    strptime interpreter: both must give flb_parser_time_lookup's answer (src/flb_parser.c:1899-2040,
+    src/flb_strptime.c) for texts on either side of every condition of the fast path."""
+    rng = random.Random(21)
+    texts = ["10/Oct/2000:13:55:36 -0700", "01/jan/1970:00:00:00 +0000", "31/DEC/9999:23:59:60 +1430", "7/Oct/2000:13:55:36 -0700",
+             "07/October/2000:13:55:36 -0700", "07/Octo/2000:13:55:36 -0700", "07/May/2000:13:55:36 -0700", "07/Mayo/2000:13:55:36 +0100",
+             "07/Mar/2000:13:55:36 +0100", "07/Marc/200:13:55:36 +0100", "45/Oct/2000:13:55:36 -0700", "32/Oct/2000:13:55:36 -0700",
+             "00/Oct/2000:13:55:36 -0700", "10/Oct/2000:24:55:36 -0700", "10/Oct/2000:23:60:36 -0700", "10/Oct/2000:23:59:61 -0700",
+             "10/Oct/2000:23:59:59  -0700", "10/Oct/2000:23:59:59\t-0700", "10/Oct/2000:23:59:59-0700", "10/Oct/2000:23:59:59 -07:00",
+             "10/Oct/2000:23:59:59 -07", "10/Oct/2000:23:59:59 -070", "10/Oct/2000:23:59:59 Z", "10/Oct/2000:23:59:59 GMT",
+             "10/Oct/2000:23:59:59 -07x0", "10/Oct/2000:23:59:59 +9999", "10/Oct/20000:23:59:59 +0000", "10/Oct/0000:23:59:59 +0000",
+             "10/Oct/2000:23:59:59 *0700", "1O/Oct/2000:23:59:59 +0700", "10/Oct/2000:23:59:5 +0700", "10/Oct/2000:23:59:59 +0700 trailing",
+             "10/0ct/2000:23:59:59 +0700", "29/Feb/2001:12:00:00 +0000", "31/Apr/2024:12:00:00 +0000", "", "x"]
+    for _ in range(300):
+        t = list(rng.choice(texts[:3]))
+        for _ in range(rng.randrange(1, 3)):
+            t[rng.randrange(len(t))] = rng.choice("0123456789/: +-OctZ\x00")
+        texts.append("".join(t))
+    recs = b"".join(_rec({"log": "h - u [%s] \"GET /x HTTP/1.1\" 200 5" % t}) for t in texts)
+    for extra in (dict(), dict(time_keep=True), dict(time_strict=False)):
+        o, q = both_parser(g, recs, "log", [dict(regex=APACHE2, time_fmt=TF, time_key="time", **extra)])
+        assert o == q, (extra, first_diff(o[1], q[1]))
+    # a format without %z (fixed Time_Offset), numeric month, seconds right before the end
+    t2 = ["2017-11-01 22:25:21", "2017-11-1 22:25:21", "2017-13-01 22:25:21", "2017-00-01 22:25:21", "2017-11-01  22:25:21",
+          "2017-11-01 22:25:2", "2017-11-01 22:25:211", "201-11-01 22:25:21", "2017-11-01T22:25:21", "0000-01-01 00:00:00"]
+    recs = b"".join(_rec({"log": "%s|msg" % t}) for t in t2)
+    for off in (None, "+0530", "-0100"):
+        o, q = both_parser(g, recs, "log", [dict(regex=r"^(?<time>[^|]*)\|(?<m>.*)$", time_fmt="%Y-%m-%d %H:%M:%S", time_key="time", time_offset=off)])
+        assert o == q, (off, first_diff(o[1], q[1]))
+
+
 def test_map16_header_width(g):
     names = ["g%02d" % i for i in range(16)]
     rx = "^" + " ".join("(?<%s>[a-z]*)" % n for n in names) + "$"
