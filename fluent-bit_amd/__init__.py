@@ -49,6 +49,8 @@ def lib():
     L.flbgpu_parser_create.argtypes = [c_char_p, c_char_p, c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_char_p]
     L.flbgpu_parser_create_json.restype = c_void_p
     L.flbgpu_parser_create_json.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int]
+    L.flbgpu_parser_create_kv.restype = c_void_p
+    L.flbgpu_parser_create_kv.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int, c_char_p]
     L.flbgpu_parser_destroy.argtypes = [c_void_p]
     L.flbgpu_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int64), POINTER(c_int64)]
     L.flbgpu_filter_parser_create.restype = c_void_p
@@ -138,8 +140,11 @@ class Parser:
     flb_parser_create.  Defaults are the parsers-file defaults (src/flb_parser.c:1277-1304)."""
 
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex"):
-        if format == "json":
+                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex", no_bare_keys=False):
+        if format in ("logfmt", "ltsv"):
+            self.h = lib().flbgpu_parser_create_kv(_b(name), _b(format), _b(time_fmt), _b(time_key), _b(time_offset), int(time_keep),
+                                                   int(time_strict), int(no_bare_keys), _b(types))
+        elif format == "json":
             self.h = lib().flbgpu_parser_create_json(_b(name), _b(time_fmt), _b(time_key), _b(time_offset), int(time_keep),
                                                      int(time_strict))
         else:

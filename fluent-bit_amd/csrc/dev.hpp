@@ -80,6 +80,9 @@ struct DevParser {
     int kw_off[MAX_NAMES];               // first dword of field f in keywords[]
     int kw_bytes[MAX_NAMES];             // header + name bytes
     int is_json;                         // Format json (src/flb_parser_json.c): no regex, the value is a JSON object
+                                         // (also set for the other walker formats below: same kernels)
+    int kv_format;                       // 1 Format logfmt, 2 Format ltsv (pkv_dev.inc); 0 otherwise
+    int no_bare_keys;                    // Logfmt_No_Bare_Keys
     int tkey_len;                        // time key of a json parser (default "time")
     char tkey[64];
     int fwd_first;                       // the pattern is anchored at the start: try the forward walk from boundary 0 before

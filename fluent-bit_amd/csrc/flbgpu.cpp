@@ -356,6 +356,26 @@ extern "C" flbgpu_parser *flbgpu_parser_create_json(const char *name, const char
     return parser_create_impl(true, name, nullptr, 1, time_fmt, time_key, time_offset, time_keep, time_strict, nullptr);
 }
 
+// Format logfmt / ltsv (src/flb_parser_logfmt.c, src/flb_parser_ltsv.c): same plumbing as Format json
+// (no regex; the value is walked pair by pair on the device), other scanner (pkv_dev.inc)
+extern "C" flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *format, const char *time_fmt, const char *time_key,
+                                                  const char *time_offset, int time_keep, int time_strict, int logfmt_no_bare_keys,
+                                                  const char *types) {
+    int kv = 0;
+    if (format && !strcasecmp(format, "logfmt")) kv = 1;
+    else if (format && !strcasecmp(format, "ltsv")) kv = 2;
+    if (!kv) { set_err("parser '%s': format '%s' is not logfmt or ltsv", name ? name : "", format ? format : ""); return nullptr; }
+    if (types && types[0]) {
+        set_err("parser '%s': Types on a %s parser (flb_parser_typecast per pair) are not supported on the GPU path", name ? name : "", format);
+        return nullptr;
+    }
+    flbgpu_parser *p = parser_create_impl(true, name, nullptr, 1, time_fmt, time_key, time_offset, time_keep, time_strict, nullptr);
+    if (!p) return nullptr;
+    p->dev.kv_format = kv;
+    p->dev.no_bare_keys = (kv == 1 && logfmt_no_bare_keys) ? 1 : 0;
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------ keys
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool flbgpu::parse_ra(const char *pat, DevKey &k, std::string &why) {

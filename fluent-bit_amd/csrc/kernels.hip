@@ -1394,6 +1394,7 @@ struct CapsView {
 
 #include "json_kernels.inc"
 #include "pjson_dev.inc"
+#include "pkv_dev.inc"
 
 // ------------------------------------------------------------------------------------------
 // parsed-record body writer shared by the size pass and the emit pass
@@ -1464,7 +1465,8 @@ DEV void write_record(S &s, const FParserCfg &cfg, const DevParser *parsers, con
         else { s.put(0xdf); pk_be(s, ri.nkept, 4); }
     }
     const uint8_t *val = rec + ri.val_off;
-    if (ps.is_json) {
+    if (ps.kv_format) pkv_emit_pairs(ps, val, ri.val_len, s);          // Format logfmt / ltsv: the kept pairs of the text
+    else if (ps.is_json) {
         // the kept pairs of the JSON object (drop_mask holds the index of the time pair that goes away);
         // the first capture columns of a json parser hold the record's container counts
         JsonCounts cc;

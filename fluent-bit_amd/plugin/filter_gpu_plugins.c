@@ -242,9 +242,10 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             flb_plg_error(f_ins, "requested parser '%s' not found", kv->val);
             continue;
         }
-        if ((p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON) || p->decoders != NULL ||
+        if ((p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON && p->type != FLB_PARSER_LOGFMT &&
+             p->type != FLB_PARSER_LTSV) || p->decoders != NULL ||
             p->time_zone != NULL || p->time_system_timezone) {
-            flb_plg_error(f_ins, "parser '%s': only Format regex / json without decoders/time zones "
+            flb_plg_error(f_ins, "parser '%s': only Format regex / json / logfmt / ltsv without decoders/time zones "
                           "is on the GPU path", kv->val);
             goto error;
         }
@@ -258,6 +259,12 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             ctx->parsers[ctx->n_parsers] =
                 flbgpu_parser_create_json(p->name, p->time_fmt_full, p->time_key, p->time_offset ? off : NULL,
                                           p->time_keep, p->time_strict);
+        }
+        else if (p->type == FLB_PARSER_LOGFMT || p->type == FLB_PARSER_LTSV) {
+            ctx->parsers[ctx->n_parsers] =
+                flbgpu_parser_create_kv(p->name, p->type == FLB_PARSER_LOGFMT ? "logfmt" : "ltsv", p->time_fmt_full,
+                                        p->time_key, p->time_offset ? off : NULL, p->time_keep, p->time_strict,
+                                        p->logfmt_no_bare_keys, types);
         }
         else {
             ctx->parsers[ctx->n_parsers] =

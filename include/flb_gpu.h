@@ -61,6 +61,16 @@ flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int ski
  * Time_Format / Time_Keep as in the parsers file.  Types and Decode_Field do not apply. */
 flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt, const char *time_key,
                                          const char *time_offset, int time_keep, int time_strict);
+
+/* Format logfmt / Format ltsv parsers for filter_parser: replaces flb_parser_create(name, "logfmt" | "ltsv",
+ * NULL, ...) + flb_parser_logfmt_do / flb_parser_ltsv_do (src/flb_parser_logfmt.c:63-325,
+ * src/flb_parser_ltsv.c:82-268; quoted logfmt values are decoded like flb_unescape_string_utf8,
+ * src/flb_unescape.c:186-277).  logfmt_no_bare_keys = the Logfmt_No_Bare_Keys property
+ * (src/flb_parser.c:1319-1324).  Types (non-empty `types`) and decoders are refused: NULL +
+ * flbgpu_last_error(). */
+flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *format, const char *time_fmt, const char *time_key,
+                                       const char *time_offset, int time_keep, int time_strict, int logfmt_no_bare_keys,
+                                       const char *types);
 void flbgpu_parser_destroy(flbgpu_parser *p);
 /* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
  * consumed (>= 0: the end of the last named group that took part in the match, src/flb_regex.c:52-54)

@@ -89,8 +89,11 @@ int oflb_regex_match(oflb_regex *r, const char *s, size_t len) { return orx_matc
 enum { T_INT = 1, T_FLOAT, T_BOOL, T_STRING, T_HEX };
 struct ptype { char *key; int key_len; int type; };
 
+enum { KV_NONE = 0, KV_LOGFMT = 1, KV_LTSV = 2 };
 typedef struct oflb_parser {
     int is_json;             /* Format json (src/flb_parser_json.c) instead of Format regex */
+    int kv_format;           /* Format logfmt / ltsv (src/flb_parser_logfmt.c, src/flb_parser_ltsv.c) */
+    int no_bare_keys;        /* Logfmt_No_Bare_Keys */
     oflb_regex *regex;
     int skip_empty;
     char *time_fmt;          /* cut at %L */
@@ -204,6 +207,18 @@ oflb_parser *oflb_parser_create(const char *regex, int skip_empty, const char *t
     p->time_keep = time_keep;
     p->time_strict = time_strict;
     if (types_str && types_str[0]) p->types_len = proc_types(types_str, &p->types);
+    return p;
+}
+
+/* Format logfmt (1) / ltsv (2): flb_parser_create(name, "logfmt" | "ltsv", NULL, ...) */
+oflb_parser *oflb_parser_create_kv(int kv_format, const char *time_fmt, const char *time_key, const char *time_offset,
+                                   int time_keep, int time_strict, int no_bare_keys)
+{
+    oflb_parser *p = oflb_parser_create(NULL, 0, time_fmt, time_key, time_offset, time_keep, time_strict, NULL);
+    if (!p) return NULL;
+    p->is_json = 0;
+    p->kv_format = kv_format;
+    p->no_bare_keys = no_bare_keys;
     return p;
 }
 
@@ -422,9 +437,278 @@ static int oflb_parser_json_do(oflb_parser *parser, const char *buf, size_t leng
     return (int) consumed;
 }
 
+
+/* ------------------------------------------------------------------ Format logfmt / ltsv
+ * flb_unescape_string_utf8 (src/flb_unescape.c:186-277) with u8_read_escape_sequence (:78-184) and
+ * u8_wc_toutf8 (:40-64), restated.  `char` is signed there (x86-64): a byte >= 0x80 that is not part
+ * of an escape becomes a code point >= 0xffffff80, which u8_wc_toutf8 refuses (0 bytes) and the byte
+ * is copied as it is.  Returns the bytes written; out holds sz + 1 bytes.
+ */
+static int kv_is_oct(int c) { return c >= '0' && c <= '7'; }
+static int kv_is_hex(int c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'F') || (c >= 'a' && c <= 'f'); }
+static uint32_t kv_hexval(const char *d, int n)
+{
+    uint32_t v = 0;
+    int i;
+    for (i = 0; i < n; i++) {
+        int c = (unsigned char) d[i];
+        v = v * 16 + (uint32_t) (c <= '9' ? c - '0' : (c | 32) - 'a' + 10);
+    }
+    return v;
+}
+static int kv_wc_toutf8(char *dest, uint32_t ch)
+{
+    if (ch < 0x80) { dest[0] = (char) ch; return 1; }
+    if (ch < 0x800) { dest[0] = (char) ((ch >> 6) | 0xC0); dest[1] = (char) ((ch & 0x3F) | 0x80); return 2; }
+    if (ch < 0x10000) {
+        dest[0] = (char) ((ch >> 12) | 0xE0); dest[1] = (char) (((ch >> 6) & 0x3F) | 0x80); dest[2] = (char) ((ch & 0x3F) | 0x80);
+        return 3;
+    }
+    if (ch < 0x110000) {
+        dest[0] = (char) ((ch >> 18) | 0xF0); dest[1] = (char) (((ch >> 12) & 0x3F) | 0x80);
+        dest[2] = (char) (((ch >> 6) & 0x3F) | 0x80); dest[3] = (char) ((ch & 0x3F) | 0x80);
+        return 4;
+    }
+    return 0;
+}
+/* str points behind the backslash; returns the characters consumed from there */
+static int kv_read_escape(const char *str, int size, uint32_t *dest)
+{
+    uint32_t ch = (uint32_t) (signed char) str[0];      /* the literal character */
+    int i = 1, dno = 0;
+    switch (str[0]) {
+    case 'n': ch = '\n'; break;
+    case 't': ch = '\t'; break;
+    case 'r': ch = '\r'; break;
+    case 'b': ch = '\b'; break;
+    case 'f': ch = '\f'; break;
+    case 'v': ch = '\v'; break;
+    case 'a': ch = '\a'; break;
+    default:
+        if (kv_is_oct(str[0])) {
+            uint32_t v = 0;
+            i = 0;
+            do { v = v * 8 + (uint32_t) (str[i++] - '0'); dno++; } while (i < size && kv_is_oct(str[i]) && dno < 3);
+            ch = v;
+        }
+        else if (str[0] == 'x') {
+            while (i < size && kv_is_hex(str[i]) && dno < 2) { i++; dno++; }
+            if (dno > 0) ch = kv_hexval(str + 1, dno);
+        }
+        else if (str[0] == 'u') {
+            while (i < size && kv_is_hex(str[i]) && dno < 4) { i++; dno++; }
+            if (dno != 4 && dno > 0) { ch = 0xFFFD; break; }          /* incomplete */
+            ch = kv_hexval(str + 1, dno);                            /* (no digit at all: strtol("") = 0) */
+            if (ch >= 0xDC00 && ch <= 0xDFFF) ch = 0xFFFD;           /* low surrogate first */
+            else if (ch >= 0xD800 && ch <= 0xDBFF) {
+                if (i + 2 < size && str[i] == '\\' && str[i + 1] == 'u') {
+                    int ls;
+                    uint32_t low;
+                    dno = 0;
+                    i += 2;
+                    ls = i;
+                    while (i < size && kv_is_hex(str[i]) && dno < 4) { i++; dno++; }
+                    if (dno != 4 && dno > 0) { ch = 0xFFFD; break; }
+                    low = kv_hexval(str + ls, dno);
+                    if (low >= 0xDC00 && low <= 0xDFFF) ch = 0x10000 + (((ch - 0xD800) << 10) | (low - 0xDC00));
+                    else ch = 0xFFFD;
+                }
+                else ch = 0xFFFD;
+            }
+        }
+        else if (str[0] == 'U') {
+            while (i < size && kv_is_hex(str[i]) && dno < 8) { i++; dno++; }
+            if (dno > 0) ch = kv_hexval(str + 1, dno);               /* strtol on <= 8 hex digits fits a long */
+        }
+    }
+    *dest = ch;
+    return i;
+}
+static int kv_unescape_utf8(const char *in_buf, int sz, char *out_buf)
+{
+    const char *end = in_buf + sz;
+    int count_out = 0, count_in = 0;
+    while (in_buf < end && *in_buf && count_in < sz) {
+        const char *next = in_buf + 1;
+        uint32_t ch;
+        int esc_in, esc_out;
+        char temp[4];
+        if (next < end && *in_buf == '\\') {
+            esc_in = 2;
+            switch (*next) {
+            case '"': ch = '"'; break;
+            case '\'': ch = '\''; break;
+            case '\\': ch = '\\'; break;
+            case '/': ch = '/'; break;
+            case 'n': ch = '\n'; break;
+            case 'b': ch = '\b'; break;
+            case 't': ch = '\t'; break;
+            case 'f': ch = '\f'; break;
+            case 'r': ch = '\r'; break;
+            default: esc_in = kv_read_escape(next, (int) (end - next), &ch) + 1;
+            }
+        }
+        else { ch = (uint32_t) (signed char) *in_buf; esc_in = 1; }
+        in_buf += esc_in;
+        count_in += esc_in;
+        esc_out = kv_wc_toutf8(temp, ch);
+        if (esc_out > sz - count_out) break;
+        if (esc_out == 0) { out_buf[count_out] = (char) ch; esc_out = 1; }
+        else memcpy(out_buf + count_out, temp, (size_t) esc_out);
+        count_out += esc_out;
+    }
+    out_buf[count_out] = 0;
+    return count_out;
+}
+/* exported for the pin against the reference's own flb_unescape.c (oracle/_ref/libunescape_ref.so) */
+int oflb_unescape_utf8(const char *in_buf, int sz, char *out_buf) { return kv_unescape_utf8(in_buf, sz, out_buf); }
+
+static int kv_ident(int c) { return c > ' ' && c != '=' && c != '"'; }                    /* flb_parser_logfmt.c:44-61 */
+static int kv_label(int c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_' || c == '.' || c == '-'; }
+static int kv_field(int c) { return c != 0 && c != '\t' && c != '\n' && c != '\r'; }      /* flb_parser_ltsv.c:43-79 */
+
+/*
+ * logfmt_parser / ltsv_parser (src/flb_parser_logfmt.c:63-240, src/flb_parser_ltsv.c:82-193): one walk
+ * that either counts the pairs that will be packed (pck == NULL) or packs them.  Returns -1 when a
+ * time value does not parse (strict), -2 for a bare key under Logfmt_No_Bare_Keys, else the bytes
+ * consumed.
+ */
+static int kv_walk(oflb_parser *parser, const char *in_buf, size_t in_size, omp_buf *pck, const char *time_key, size_t time_key_len,
+                   time_t *time_out, double *tmfrac, size_t *count)
+{
+    const unsigned char *c = (const unsigned char *) in_buf, *end = c + in_size;
+    struct otm tm;
+    memset(&tm, 0, sizeof(tm));
+    while (c < end) {
+        const unsigned char *key, *value = NULL;
+        size_t key_len, value_len = 0;
+        int value_set = 0, value_str = 0, value_escape = 0;
+        if (parser->kv_format == KV_LOGFMT) {
+            while (c < end && !kv_ident(*c)) c++;
+            if (c == end) break;
+            key = c;
+            while (c < end && kv_ident(*c)) c++;
+            key_len = (size_t) (c - key);
+            if (c < end && *c == '=') {
+                value_set = 1;
+                c++;
+                if (c < end) {
+                    if (*c == '"') {
+                        c++;
+                        value = c;
+                        value_str = 1;
+                        while (c < end) {
+                            if (*c != '\\' && *c != '"') c++;
+                            else if (*c == '\\') {
+                                value_escape = 1;
+                                c++;
+                                if (c == end) break;
+                                c++;
+                            }
+                            else break;
+                        }
+                        value_len = (size_t) (c - value);
+                        if (c < end && *c == '"') c++;
+                    }
+                    else {
+                        value = c;
+                        while (c < end && kv_ident(*c)) c++;
+                        value_len = (size_t) (c - value);
+                    }
+                }
+            }
+        }
+        else {
+            key = c;
+            while (c < end && kv_label(*c)) c++;
+            key_len = (size_t) (c - key);
+            if (c == end) break;
+            if (*c != ':') break;
+            c++;
+            value = c;
+            while (c < end && kv_field(*c)) c++;
+            value_len = (size_t) (c - value);
+        }
+        if (key_len > 0) {
+            int time_found = 0;
+            if (parser->kv_format == KV_LOGFMT && parser->no_bare_keys && value_len == 0 && !value_set) return -2;
+            if (parser->time_fmt && key_len == time_key_len && value_len > 0 && !strncmp((const char *) key, time_key, key_len)) {
+                if (pck) {
+                    if (time_lookup((const char *) value, value_len, 0, parser, &tm, tmfrac) == -1) return -1;
+                    *time_out = tm2time(&tm);
+                }
+                time_found = 1;
+            }
+            if (!time_found || parser->time_keep) {
+                if (!pck) (*count)++;
+                else {
+                    omp_pack_str(pck, key_len);
+                    omp_buf_write(pck, key, key_len);
+                    if (parser->kv_format == KV_LOGFMT && value_len == 0) {
+                        if (value_str) omp_pack_str(pck, 0);
+                        else omp_pack_bool(pck, 1);
+                    }
+                    else if (value_escape) {
+                        char *tmp = malloc(value_len + 1);
+                        size_t n;
+                        tmp[0] = 0;
+                        kv_unescape_utf8((const char *) value, (int) value_len, tmp);
+                        n = strlen(tmp);
+                        omp_pack_str(pck, n);
+                        omp_buf_write(pck, tmp, n);
+                        free(tmp);
+                    }
+                    else {
+                        omp_pack_str(pck, value_len);
+                        omp_buf_write(pck, value, value_len);
+                    }
+                }
+            }
+        }
+        if (c == end) break;
+        if (parser->kv_format == KV_LTSV) {
+            if (*c == '\t') c++;
+            if (c == end) break;
+        }
+        if (*c == '\r') {
+            c++;
+            if (c == end) break;
+            if (*c == '\n') c++;
+            break;
+        }
+        if (*c == '\n') { c++; break; }
+    }
+    return (int) ((const char *) c - in_buf);
+}
+
+/* flb_parser_logfmt_do / flb_parser_ltsv_do (src/flb_parser_logfmt.c:242-325, src/flb_parser_ltsv.c:195-268);
+ * Types (flb_parser_typecast per pair) and decoders are not restated. */
+static int oflb_parser_kv_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
+                             int64_t *out_sec, int64_t *out_nsec)
+{
+    const char *time_key = parser->time_key ? parser->time_key : "time";
+    size_t time_key_len = strlen(time_key), map_size = 0;
+    time_t tl = 0;
+    double tmfrac = 0;
+    omp_buf pck;
+    int last;
+    *out_sec = 0; *out_nsec = 0;
+    if (kv_walk(parser, buf, length, NULL, time_key, time_key_len, &tl, &tmfrac, &map_size) == -2) return -1;
+    if (map_size == 0) return -1;
+    omp_buf_init(&pck);
+    omp_pack_map(&pck, map_size);
+    last = kv_walk(parser, buf, length, &pck, time_key, time_key_len, &tl, &tmfrac, &map_size);
+    if (last < 0) { free(pck.data); return -1; }
+    *out = pck.data; *out_size = pck.size;
+    *out_sec = (int64_t) tl;
+    *out_nsec = (int64_t) (long) (tmfrac * 1000000000);
+    return last;
+}
+
 int oflb_parser_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
                    int64_t *out_sec, int64_t *out_nsec)
 {
+    if (parser->kv_format) return oflb_parser_kv_do(parser, buf, length, out, out_size, out_sec, out_nsec);
     if (parser->is_json) return oflb_parser_json_do(parser, buf, length, out, out_size, out_sec, out_nsec);
     int beg[ORX_MAX_GROUPS], end[ORX_MAX_GROUPS];
     int nregs, n, i, k, last_pos = -1, num_skipped = 0;

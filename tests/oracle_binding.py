@@ -13,6 +13,9 @@ def lib():
         L = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         L.oflb_parser_create.restype = c_void_p
         L.oflb_parser_create.argtypes = [c_char_p, c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_char_p]
+        L.oflb_parser_create_kv.restype = c_void_p
+        L.oflb_parser_create_kv.argtypes = [c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int]
+        L.oflb_unescape_utf8.argtypes = [c_char_p, c_int, c_char_p]
         L.oflb_parser_destroy.argtypes = [c_void_p]
         L.oflb_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t),
                                      POINTER(c_int64), POINTER(c_int64)]
@@ -60,12 +63,16 @@ class Parser:
     time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.
     Defaults are the conf-file defaults (src/flb_parser.c:1277-1304)."""
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, format="regex"):
+                 time_strict=True, skip_empty=True, types=None, format="regex", no_bare_keys=False):
         e = lambda s: s.encode() if isinstance(s, str) else s
         if format == "json":
             regex = None                      # Format json (src/flb_parser_json.c)
-        self.h = lib().oflb_parser_create(e(regex), int(skip_empty), e(time_fmt), e(time_key), e(time_offset),
-                                          int(time_keep), int(time_strict), e(types))
+        if format in ("logfmt", "ltsv"):      # src/flb_parser_logfmt.c, src/flb_parser_ltsv.c
+            self.h = lib().oflb_parser_create_kv(1 if format == "logfmt" else 2, e(time_fmt), e(time_key), e(time_offset),
+                                                 int(time_keep), int(time_strict), int(no_bare_keys))
+        else:
+            self.h = lib().oflb_parser_create(e(regex), int(skip_empty), e(time_fmt), e(time_key), e(time_offset),
+                                              int(time_keep), int(time_strict), e(types))
         if not self.h:
             raise ValueError("oracle: parser create failed")
     def do(self, buf):

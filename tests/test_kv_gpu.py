@@ -1,0 +1,91 @@
+"""filter_parser with Format logfmt / ltsv parsers on the GPU (pkv_dev.inc) against the oracle
+(src/flb_parser_logfmt.c, src/flb_parser_ltsv.c, src/flb_unescape.c restated in oracle/oflb.c):
+byte-identical filter output on the grammar corners and on random texts."""
+import random
+
+import pytest
+
+import flbamd_loader
+import oracle_binding as ob
+import synth
+from test_kv_oracle import ESC_CASES
+
+pytestmark = pytest.mark.gpu
+TFMT = "%Y-%m-%dT%H:%M:%S.%L"
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def rec(body, sec=1700000000, nsec=7):
+    return synth.mp([[synth.ext_ts(sec, nsec), {}], body])
+
+
+def both(g, data, pargs, reserve=False, preserve=False, key="log"):
+    po, pg = ob.Parser(**pargs), g.Parser(**pargs)
+    want = ob.FilterParser(key, [po], reserve, preserve).filter(data)
+    f = g.FilterParser(key, [pg], reserve, preserve)
+    got = f.filter(data)
+    f.close(); pg.close()
+    return want, got
+
+
+def diff(a, b):
+    if a is None or b is None:
+        return "one side None"
+    for i in range(min(len(a), len(b))):
+        if a[i] != b[i]:
+            return "byte %d: oracle %r gpu %r" % (i, a[max(0, i - 24):i + 24], b[max(0, i - 24):i + 24])
+    return "length %d vs %d" % (len(a), len(b))
+
+
+LOGFMT_TEXTS = [b'str="text" int=100 double=1.23 bool=true', b'str="text" int=100 time=2022-10-31T12:00:01.123 z=1', b"", b'  ="= ', b"bare",
+                b"k= j=", b'k="" j="x', b'k="a\\"b" z=1', b'k="a\\', b"a=1\nb=2", b"a=1 \nb=2", b"a=1\r\nb=2", b"a=1\rb=2", b"k=v=w x",
+                b"k\x80\xff=\x01v", b"a=1 bare b=2", b"a=1 b= c=3", b"time=2020-01-02T03:04:05.5 a=1 time=2021-03-04T00:00:00.25",
+                b"time=garbage a=1", b"time=2020-01-02T03:04:05.0", b"time= a=1", b"time=20x a=1", b'time="2022-10-31T12:00:01.123" q="w"',
+                b'level=info msg="request done" path=/v1/x?y=1 dur=12ms ok', b"x" * 300 + b"=" + b"y" * 70000, b'a="' + b"\\n" * 200 + b'"']
+LOGFMT_TEXTS += [b'k="' + e + b'" tail=1' for e in ESC_CASES]
+LTSV_TEXTS = [b"str:text\tint:100\tdouble:1.23\tbool:true", b"str:text\ttime:2022-10-31T12:00:01.123\tz:1", b"", b"nolabel", b":v\ta:1",
+              b"a:\tb:x y:z", b"a:1\t\tb:2", b"a:1\nb:2", b"a:1\r\nb:2", b"a b:1", b"a:1\tb", b"a:x\x00y\tb:2", b"time:garbage\ta:1",
+              b"time:2020-01-02T03:04:05.5", b"host:10.0.0.1\tident:-\tuser:bob\treq:GET /x HTTP/1.1\tstatus:200\tsize:512",
+              b'json_str:{"str":"text", "int":100}', b"l-a.b_c:" + b"v" * 40000]
+
+
+@pytest.mark.parametrize("fmt,texts", [("logfmt", LOGFMT_TEXTS), ("ltsv", LTSV_TEXTS)])
+def test_kv_corner_cases(g, fmt, texts):
+    data = b"".join(rec({"log": t, "other": 1}) for t in texts)
+    for pargs in (dict(format=fmt), dict(format=fmt, time_fmt=TFMT, time_key="time"), dict(format=fmt, time_fmt=TFMT, time_key="time", time_keep=True),
+                  dict(format=fmt, time_fmt=TFMT, time_key="time", time_strict=False), dict(format=fmt, no_bare_keys=True)):
+        for reserve, preserve in ((False, False), (True, False), (True, True)):
+            want, got = both(g, data, pargs, reserve, preserve)
+            assert want[0] == got[0] and want[1] == got[1], (fmt, pargs, reserve, preserve, diff(want[1], got[1]))
+
+
+@pytest.mark.parametrize("fmt", ["logfmt", "ltsv"])
+def test_kv_random_texts(g, fmt):
+    rng = random.Random(5 if fmt == "logfmt" else 6)
+    if fmt == "logfmt":
+        atoms = [b"key", b"k2", b"=", b'"', b"\\", b" ", b"\t", b"\n", b"\r", b"time", b"2022-10-31T12:00:01.5", b"u00e9", b"uD83D", b"\\uDE00", b"x41",
+                 b"\x00", b"\xc3\xa9", b"v", b"1", b"n", b'\\"', b"\\\\"]
+    else:
+        atoms = [b"key", b"k-2", b":", b"\t", b" ", b"\n", b"\r", b"time", b"2022-10-31T12:00:01.5", b"\x00", b"\xc3\xa9", b"v", b"1", b"_", b".", b'"']
+    recs = []
+    for i in range(6000):
+        t = b"".join(rng.choice(atoms) for _ in range(rng.randrange(0, 14)))
+        body = {"log": t} if i % 7 else synth.KV([("log", t), ("n", i), ("log", b"a=1" if fmt == "logfmt" else b"a:1")])
+        recs.append(rec(body, sec=i))
+    data = b"".join(recs)
+    for pargs in (dict(format=fmt, time_fmt=TFMT, time_key="time"), dict(format=fmt, time_fmt=TFMT, time_key="time", time_keep=True, time_strict=False),
+                  dict(format=fmt, no_bare_keys=True)):
+        for reserve, preserve in ((False, False), (True, True)):
+            want, got = both(g, data, pargs, reserve, preserve)
+            assert want[0] == got[0] and want[1] == got[1], (fmt, pargs, reserve, preserve, diff(want[1], got[1]))
+
+
+def test_kv_parsers_refuse_types(g):
+    with pytest.raises(ValueError):
+        g.Parser(format="logfmt", types="a:integer")
