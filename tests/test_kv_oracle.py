@@ -112,6 +112,16 @@ def test_unescape_matches_the_real_reference():
         assert _oracle_unescape(s) == want.raw[:n], s
 
 
+def test_unescape_golden_vectors():
+    """answers of the real flb_unescape.c, committed (tests/golden/gen_unescape_kat.py): the check that travels"""
+    import json
+    kat = json.load(open(os.path.join(HERE, "golden", "unescape_kat.json")))
+    assert len(kat["cases"]) > 6000
+    for c in kat["cases"]:
+        s = bytes.fromhex(c["in"])
+        assert _oracle_unescape(s) == bytes.fromhex(c["out"]), s
+
+
 def test_unescape_known_answers():
     # kept as goldens so that the GPU box (no /root/reference) still checks the restatement
     assert _oracle_unescape(b"a\\nb\\u00e9\\uD83D\\uDE00\\x41\\101") == "a\nb\u00e9\U0001F600AA".encode()
