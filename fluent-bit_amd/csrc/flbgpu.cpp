@@ -485,12 +485,6 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         memcpy(f->pcfg.key.key, key_name, n);
         f->pcfg.key.key_len = (int) n;
     }
-    for (int i = 0; i < nparsers; i++)
-        if (parsers[i]->dev.is_json && nparsers > 1) {
-            set_err("filter_parser: a json parser in a list of several parsers is not on the GPU path yet");
-            delete f;
-            return nullptr;
-        }
     std::vector<DevParser> dp;
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
@@ -498,7 +492,8 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
     }
     if (f->caps_stride == 0) f->caps_stride = 2;
-    if (parsers[0]->dev.is_json) f->caps_stride = 8;         // the span columns hold the JSON container counts
+    for (int i = 0; i < nparsers; i++)
+        if (parsers[i]->dev.is_json && f->caps_stride < 8) f->caps_stride = 8;   // the span columns also hold JSON container counts
     f->caps_stride = (f->caps_stride + 3) & ~3u;             // 16-byte rows
     if (!filter_common_init(f) || !f->d_parsers.ensure(dp.size() * sizeof(DevParser))) { delete f; return nullptr; }
     if (hipMemcpy(f->d_parsers.p, dp.data(), dp.size() * sizeof(DevParser), hipMemcpyHostToDevice) != hipSuccess) { set_err("upload failed"); delete f; return nullptr; }
@@ -634,12 +629,30 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
+    // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...): one general kernel
+    auto run_generic = [&]() -> bool {
+        launch_max_row_len(row_off, n, &dm->max_row, st);
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
+        int ggrid = cus * 8;
+        while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
+        if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
+        ParserMatchArgs mg = ma;
+        mg.chk = f->d_rid2.as<uint16_t>();
+        mg.chk_len = gchk_len;
+        { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
+        return true;
+    };
     if (f->parsers[0]->dev.is_json) {
         // Format json: one size kernel replaces locate / rx / finish
         { ProfScope ps(f, st, "k_pjson_size"); launch_pjson_size(ma, cus, st); }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
-        if (hm.counts[2] > 0) { ProfScope ps(f, st, "k_pjson_size_generic"); launch_pjson_size_generic(ma, st); }
+        if (hm.counts[2] > 0) {
+            if (f->pcfg.nparsers > 1) { if (!run_generic()) return false; }      // the other parsers of the list get their turn
+            else { ProfScope ps(f, st, "k_pjson_size_generic"); launch_pjson_size_generic(ma, st); }
+        }
     }
     else {
         { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
@@ -647,20 +660,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
         { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
-        if (hm.counts[2] > 0) {
-            // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...)
-            launch_max_row_len(row_off, n, &dm->max_row, st);
-            HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
-            HIPOK(hipStreamSynchronize(st));
-            const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
-            int ggrid = cus * 8;
-            while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
-            if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
-            ParserMatchArgs mg = ma;
-            mg.chk = f->d_rid2.as<uint16_t>();
-            mg.chk_len = gchk_len;
-            { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
-        }
+        if (hm.counts[2] > 0 && !run_generic()) return false;
     }
     if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
     if (n == 0) return true;

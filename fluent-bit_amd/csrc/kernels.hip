@@ -1884,7 +1884,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 
 // The complete per-record algorithm (every candidate key, every parser, UTF-8 tables, values of
 // any length), for the records the fast phases flagged RF_GENERIC.
+// The wide json walker (4096-level stack, exact decimals) is big: one out-of-line copy serves the
+// slow-path kernels instead of one inlined copy per call site.
+__device__ __noinline__ void pjson_try_wide(const DevParser *ps, const uint8_t *v, uint32_t vlen, uint32_t *caps_base, uint64_t n, uint64_t r,
+                                            LDS_AS uint8_t *slot, PjsonTry *out) {
+    JsonCounts cc;
+    cc.col = caps_base; cc.n = n; cc.r = r; cc.store = true; cc.next = 0;
+    *out = pjson_try<true, JSON_GENERIC_WORDS>(*ps, v, vlen, cc, slot);
+}
+__device__ __noinline__ uint32_t size_record_wide(const FParserCfg *cfg, const DevParser *parsers, const uint8_t *rec, const uint8_t *rec_end,
+                                                  const RecInfo *ri, const uint32_t *caps_base, uint64_t n, uint64_t r, uint64_t null_mask) {
+    CapsView caps;
+    caps.base = caps_base; caps.n = n; caps.r = r;
+    CountSink cs;
+    write_record<true, JSON_GENERIC_WORDS>(cs, *cfg, parsers, rec, rec_end, *ri, caps, null_mask);
+    return (uint32_t) cs.n;
+}
+
 __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t gen_slots[256 * 64];       // per-lane scratch of a json parser's time text
+    LDS_AS uint8_t *slot = (LDS_AS uint8_t *) gen_slots + threadIdx.x * 64;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
@@ -1932,6 +1951,16 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
                 int64_t ps = 0, pn = 0; uint32_t nk = 0, dm = 0;
                 CapGlobal capg;
                 capg.base = a.caps; capg.n = a.n; capg.r = r;
+                if (a.parsers[q].is_json) {
+                    // Format json / logfmt / ltsv in a list of parsers: the walkers of pjson_dev.inc / pkv_dev.inc
+                    // (json with the wide stack and the exact decimals: such a record is emitted by k_parser_emit_exact)
+                    PjsonTry t;
+                    if (a.parsers[q].kv_format) t = pkv_try(a.parsers[q], vptr, vlen);
+                    else pjson_try_wide(&a.parsers[q], vptr, vlen, a.caps, a.n, r, slot, &t);
+                    last_ok = t.ok;
+                    ps = t.sec; pn = t.nsec; nk = t.npairs; dm = t.skip;
+                }
+                else
                 last_ok = try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, 0u);
                 if (last_ok) {
                     have_out = true;
@@ -1954,7 +1983,12 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
         CountSink cs;
-        write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
+        const bool json_won = (ri.flags & RF_PARSED) && a.parsers[ri.parser_idx].is_json && !a.parsers[ri.parser_idx].kv_format;
+        if (json_won) {
+            cs.n = size_record_wide(&a.cfg, a.parsers, rec, rec_end, &ri, a.caps, a.n, r, null_mask);
+            if (cs.n) cs.need_exact = true;                    // sized with the wide walker: emitted by the same one
+        }
+        else write_record(cs, a.cfg, a.parsers, rec, rec_end, ri, caps, null_mask);
         if (cs.need_exact) { ri.flags |= RF_EXACT; atomicAdd(&a.counts[3], 1ull); }
         rec_store(a.info, a.n, r, ri);
         a.null_mask[r] = null_mask;

@@ -89,3 +89,40 @@ def test_kv_random_texts(g, fmt):
 def test_kv_parsers_refuse_types(g):
     with pytest.raises(ValueError):
         g.Parser(format="logfmt", types="a:integer")
+
+
+def both_list(g, data, pargs_list, reserve=False, preserve=False, key="log"):
+    po = [ob.Parser(**a) for a in pargs_list]
+    pg = [g.Parser(**a) for a in pargs_list]
+    want = ob.FilterParser(key, po, reserve, preserve).filter(data)
+    f = g.FilterParser(key, pg, reserve, preserve)
+    got = f.filter(data)
+    f.close()
+    for p in pg:
+        p.close()
+    return want, got
+
+
+def test_lists_that_mix_parser_formats(g):
+    """filter_parser tries its parsers in order on every candidate value (filter_parser.c:259-300):
+    json / logfmt / ltsv / regex parsers in one list, in every position"""
+    rng = random.Random(31)
+    APACHE = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)$'
+    texts = [b'{"a":1,"time":"2022-10-31T12:00:01.123","n":{"x":[1,2.5,null]}}', b'{"broken": ', b'[1,2]', b'{"f":0.1,"g":1e400,"h":123456789012345678901234567890}',
+             b'10.0.0.1 - bob [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326', b'level=info msg="hi there" time=2022-10-31T12:00:01.5 ok',
+             b"host:h1\tstatus:200\ttime:2022-10-31T12:00:01.25", b"", b"plain words only", b"k=v", b"a:1", b'{"k":"v"} trailing', b"=", b"\xff\xfe",
+             b'{"deep":' + b"[" * 70 + b"]" * 70 + b"}", b'msg="caf\\u00e9 \\uD83D\\uDE00" n=1']
+    recs = []
+    for i in range(3000):
+        t = rng.choice(texts)
+        body = {"log": t, "i": i} if i % 5 else synth.KV([("log", rng.choice(texts)), ("i", i), ("log", t)])
+        recs.append(rec(body, sec=1000 + i))
+    data = b"".join(recs)
+    js = dict(format="json", time_fmt=TFMT, time_key="time")
+    lf = dict(format="logfmt", time_fmt=TFMT, time_key="time")
+    lt = dict(format="ltsv", time_fmt=TFMT, time_key="time")
+    rx = dict(regex=APACHE, time_fmt="%d/%b/%Y:%H:%M:%S %z", time_key="time")
+    for plist in ([js, rx], [rx, js], [js, lt, rx, lf], [lt, js], [rx, lf], [lf, js], [dict(js, time_keep=True), dict(rx, time_keep=True)]):
+        for reserve, preserve in ((False, False), (True, True)):
+            want, got = both_list(g, data, plist, reserve, preserve)
+            assert want[0] == got[0] and want[1] == got[1], ([p.get("format", "regex") for p in plist], reserve, preserve, diff(want[1], got[1]))
