@@ -26,7 +26,7 @@ def build(force=False):
     """Compile every HIP/C++ source for gfx950 (hipcc cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", CSRC, "all"], check=True)
+    subprocess.run(["make", "-j8", "-C", CSRC, "all"], check=True)
 
 
 class DevChunk(Structure):
