@@ -151,6 +151,11 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints its own path there)
+    # are pointed at stderr for the whole run, the line goes to the saved descriptor at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -304,9 +309,10 @@ def main():
                    "seed": synth.SEED, "parallelism": "shard%d" % world, "gen_seconds": round(gen_s, 1)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary,
     }
-    print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":
