@@ -1,0 +1,15 @@
+// kernels_l2m.hip -- filter_log_to_metrics kernels (shares kdev.inc with kernels.hip)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <type_traits>
+#include "dev.hpp"
+#include "numconv.hpp"
+
+namespace flbgpu {
+
+#include "kdev.inc"
+
+#include "l2m_kernels.inc"
+
+}  // namespace flbgpu

@@ -30,7 +30,10 @@ namespace nc {
 constexpr int P5_QMIN = -342, P5_QMAX = 308;
 
 #if defined(__HIP_DEVICE_COMPILE__)
-extern __device__ const uint64_t g_pow5_dev[2 * (P5_QMAX - P5_QMIN + 1)];
+// (static: every translation unit that converts on the device carries its own copy)
+static __device__ const uint64_t g_pow5_dev[2 * (P5_QMAX - P5_QMIN + 1)] = {
+#include "pow5_table.inc"
+};
 #define NC_P5(i) (::flbgpu::nc::g_pow5_dev[i])
 #else
 extern const uint64_t g_pow5_host[2 * (P5_QMAX - P5_QMIN + 1)];
