@@ -173,15 +173,95 @@ map_body:
 #undef NEED
 }
 
+/*
+ * What msgpack-c's template_execute (lib/msgpack-c/include/msgpack/unpack_template.h:82-452) reports for
+ * an object it cannot finish: the return code (0 = CONTINUE, -1 = PARSE_ERROR, -2 = NOMEM_ERROR) and the
+ * offset it leaves in *off.  The executor consumes complete fields -- a type byte, a length field, a
+ * payload -- and stops in front of the first field that is cut short (:242-247, :439-447), at the
+ * reserved byte 0xc1 (:415-417), or at the 33rd open container (MSGPACK_EMBED_STACK_SIZE 32, :139-143).
+ * A buffer that ends exactly on a field boundary therefore comes back as CONTINUE with *off == len, which
+ * flb_log_event_decoder_get_last_result / filter_grep read as a clean end
+ * (src/flb_log_event_decoder.c:334-342, plugins/filter_grep/grep.c:357-360).
+ * Returns 1 if the object is complete after all (the caller's recursive reader said otherwise: never).
+ */
+#define OMP_STACK 32
+static int exec_tail(const unsigned char *d, size_t len, size_t start, size_t *off)
+{
+    uint64_t count[OMP_STACK];
+    int top = 0;
+    size_t p = start;
+    for (;;) {
+        unsigned char c;
+        size_t q, e, k = 0, lb = 0;
+        uint64_t n = 0;
+        int container = 0;
+        if (p >= len) { *off = len; return 0; }
+        c = d[p];
+        q = p + 1;
+        if (c <= 0x7f || c >= 0xe0 || c == 0xc0 || c == 0xc2 || c == 0xc3) e = q;
+        else if (c == 0xc1) { *off = p; return -1; }
+        else if (c >= 0xa0 && c <= 0xbf) { k = c & 0x1f; if (len - q < k) { *off = q; return 0; } e = q + k; }
+        else if (c >= 0x90 && c <= 0x9f) { container = 1; n = c & 0x0f; e = q; }
+        else if (c >= 0x80 && c <= 0x8f) { container = 1; n = 2u * (c & 0x0f); e = q; }
+        else {
+            switch (c) {
+            case 0xcc: case 0xd0: k = 1; break;
+            case 0xcd: case 0xd1: k = 2; break;
+            case 0xce: case 0xd2: case 0xca: k = 4; break;
+            case 0xcf: case 0xd3: case 0xcb: k = 8; break;
+            case 0xd4: k = 2; break;
+            case 0xd5: k = 3; break;
+            case 0xd6: k = 5; break;
+            case 0xd7: k = 9; break;
+            case 0xd8: k = 17; break;
+            case 0xc4: case 0xc7: case 0xd9: lb = 1; break;
+            case 0xc5: case 0xc8: case 0xda: case 0xdc: case 0xde: lb = 2; break;
+            default: lb = 4; break;                          /* c6 c9 db dd df */
+            }
+            if (lb == 0) { if (len - q < k) { *off = q; return 0; } e = q + k; }
+            else {
+                size_t q2;
+                if (len - q < lb) { *off = q; return 0; }
+                n = be(d + q, (int) lb);
+                q2 = q + lb;
+                if (c == 0xdc || c == 0xdd) { container = 1; e = q2; }
+                else if (c == 0xde || c == 0xdf) { container = 1; n *= 2; e = q2; }
+                else {
+                    k = (size_t) n + ((c == 0xc7 || c == 0xc8 || c == 0xc9) ? 1 : 0);       /* ext: type byte + data */
+                    if (len - q2 < k) { *off = q2; return 0; }
+                    e = q2 + k;
+                }
+            }
+        }
+        if (container && n > 0) {
+            if (top >= OMP_STACK) { *off = p; return -2; }
+            count[top++] = n;
+            p = e;
+            continue;
+        }
+        if (container && top >= OMP_STACK) { *off = p; return -2; }          /* the check precedes the count test (:139-146) */
+        /* a value is complete: close every container it finishes */
+        p = e;
+        for (;;) {
+            if (top == 0) { *off = p; return 1; }
+            if (--count[top - 1] > 0) break;
+            top--;
+        }
+    }
+}
+
 int omp_unpack_next(omp_arena *a, omp_obj *out, const char *data, size_t len, size_t *off)
 {
     size_t p = *off;
     int r;
     if (len <= p) return OMP_UNPACK_CONTINUE;
+    /* the container stack of the real executor is 32 deep: deeper objects are NOMEM errors there */
+    r = exec_tail((const unsigned char *) data, len, p, &p);
+    if (r != 1) { *off = p; return r == 0 ? OMP_UNPACK_CONTINUE : r; }
+    p = *off;
     r = unpack_obj(a, out, (const unsigned char *) data, len, &p, 0);
     if (r == 1) { *off = p; return OMP_UNPACK_SUCCESS; }
-    if (r == 0) return OMP_UNPACK_CONTINUE;
-    return OMP_UNPACK_PARSE_ERROR;
+    return OMP_UNPACK_PARSE_ERROR;                           /* (not reached: exec_tail accepted the object) */
 }
 
 /* ------------------------------------------------------------------ pack */
@@ -421,5 +501,33 @@ int oev_count_records(const char *buf, size_t len)
     oev_decoder_init(&d, buf, len);
     while (oev_decoder_next(&d, &ev) == OEV_SUCCESS) n++;
     oev_decoder_destroy(&d);
+    return n;
+}
+
+/* ------------------------------------------------------------------ pin helper (tests/test_msgpack_pin.py)
+ * Same loop as oracle/ref_msgpack_shim.c drives on the real msgpack-c: unpack every object of `data`,
+ * re-pack it; codes[i] / ends[i] = return value and offset of the i-th omp_unpack_next call. */
+int omp_roundtrip(const char *data, size_t len, char **out, size_t *out_size, int *codes, size_t *ends, int max_calls)
+{
+    omp_arena arena;
+    omp_buf b;
+    size_t off = 0;
+    int n = 0;
+    omp_arena_init(&arena);
+    omp_buf_init(&b);
+    while (n < max_calls) {
+        omp_obj o;
+        int r = omp_unpack_next(&arena, &o, data, len, &off);
+        codes[n] = r;
+        ends[n] = off;
+        n++;
+        if (r != OMP_UNPACK_SUCCESS) break;
+        omp_pack_object(&b, &o);
+    }
+    omp_arena_free(&arena);
+    *out = malloc(b.size ? b.size : 1);
+    if (b.size) memcpy(*out, b.data, b.size);
+    *out_size = b.size;
+    omp_buf_free(&b);
     return n;
 }
