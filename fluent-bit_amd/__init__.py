@@ -70,6 +70,7 @@ def lib():
     L.flbgpu_index_dev.restype = c_int64
     L.flbgpu_index_dev.argtypes = [c_void_p, c_void_p, c_size_t, POINTER(DevChunk), POINTER(c_size_t)]
     L.flbgpu_indexer_stats.argtypes = [c_void_p, POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]
+    L.flbgpu_tail_clean_host.argtypes = [c_char_p, c_size_t, c_size_t]
     L.flbgpu_dev_alloc.restype = c_void_p
     L.flbgpu_dev_alloc.argtypes = [c_size_t]
     L.flbgpu_dev_free.argtypes = [c_void_p]

@@ -749,6 +749,75 @@ static int run_any_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_
     return ret;
 }
 
+// Whether the bytes behind the last whole record end where msgpack-c's executor would have consumed
+// everything it was given: it takes complete fields (a type byte, a length field, a payload) and stops in
+// front of the first one that is cut short, so a chunk that ends exactly on a field boundary leaves the
+// decoder's offset at the end of the buffer -- which flb_log_event_decoder_get_last_result and filter_grep
+// read as a clean end (lib/msgpack-c/include/msgpack/unpack_template.h:242-247,439-447;
+// src/flb_log_event_decoder.c:334-342; plugins/filter_grep/grep.c:357-360).  The reserved byte 0xc1 and a
+// 33rd open container (MSGPACK_EMBED_STACK_SIZE) are errors wherever they stand.
+static bool tail_is_clean(const uint8_t *d, size_t len, size_t start) {
+    uint64_t count[32];
+    int top = 0;
+    size_t p = start;
+    for (;;) {
+        if (p >= len) return true;
+        const uint8_t c = d[p];
+        const size_t q = p + 1;
+        size_t e, k = 0, lb = 0;
+        uint64_t n = 0;
+        bool container = false;
+        if (c <= 0x7f || c >= 0xe0 || c == 0xc0 || c == 0xc2 || c == 0xc3) e = q;
+        else if (c == 0xc1) return false;
+        else if (c >= 0xa0 && c <= 0xbf) { k = c & 0x1f; if (len - q < k) return q == len; e = q + k; }
+        else if (c >= 0x90 && c <= 0x9f) { container = true; n = c & 0x0f; e = q; }
+        else if (c >= 0x80 && c <= 0x8f) { container = true; n = 2u * (c & 0x0f); e = q; }
+        else {
+            switch (c) {
+            case 0xcc: case 0xd0: k = 1; break;
+            case 0xcd: case 0xd1: k = 2; break;
+            case 0xce: case 0xd2: case 0xca: k = 4; break;
+            case 0xcf: case 0xd3: case 0xcb: k = 8; break;
+            case 0xd4: k = 2; break;
+            case 0xd5: k = 3; break;
+            case 0xd6: k = 5; break;
+            case 0xd7: k = 9; break;
+            case 0xd8: k = 17; break;
+            case 0xc4: case 0xc7: case 0xd9: lb = 1; break;
+            case 0xc5: case 0xc8: case 0xda: case 0xdc: case 0xde: lb = 2; break;
+            default: lb = 4; break;                          // c6 c9 db dd df
+            }
+            if (lb == 0) { if (len - q < k) return q == len; e = q + k; }
+            else {
+                if (len - q < lb) return q == len;
+                for (size_t i = 0; i < lb; i++) n = (n << 8) | d[q + i];
+                const size_t q2 = q + lb;
+                if (c == 0xdc || c == 0xdd) { container = true; e = q2; }
+                else if (c == 0xde || c == 0xdf) { container = true; n *= 2; e = q2; }
+                else {
+                    k = (size_t) n + ((c == 0xc7 || c == 0xc8 || c == 0xc9) ? 1 : 0);       // ext: type byte + data
+                    if (len - q2 < k) return q2 == len;
+                    e = q2 + k;
+                }
+            }
+        }
+        if (container) {
+            if (top >= 32) return false;
+            if (n > 0) { count[top++] = n; p = e; continue; }
+        }
+        p = e;
+        for (;;) {
+            if (top == 0) return false;                      // a whole object after all: the caller's walk said otherwise
+            if (--count[top - 1] > 0) break;
+            top--;
+        }
+    }
+}
+
+extern "C" int flbgpu_tail_clean_host(const void *data, size_t bytes, size_t consumed) {
+    return consumed >= bytes || tail_is_clean((const uint8_t *) data, bytes, consumed) ? 1 : 0;
+}
+
 // A device chunk handed over without its offset column (row_off == NULL): the filter's indexer finds
 // the records first (flbgpu_index_dev).  Returns false on failure; *garbage = undecodable bytes follow.
 static bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage) {
@@ -759,7 +828,15 @@ static bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbg
     if (!f->indexer) return false;
     size_t consumed = 0;
     if (flbgpu_index_dev(f->indexer, in->data, (size_t) in->bytes, resolved, &consumed) < 0) return false;
-    *garbage = consumed != in->bytes;
+    *garbage = false;
+    if (consumed != in->bytes) {
+        // the unfinished object behind the last record (at most one record long) decides: cut inside a
+        // field = a decoder error, cut on a field boundary = a clean end
+        const size_t tl = (size_t) in->bytes - consumed;
+        std::vector<uint8_t> tail(tl);
+        if (hipMemcpy(tail.data(), (const uint8_t *) in->data + consumed, tl, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        *garbage = !tail_is_clean(tail.data(), tl, 0);
+    }
     return true;
 }
 
@@ -1032,7 +1109,7 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     const uint64_t *row_off = nullptr;
     int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed, &row_off);
     if (n < 0) return FLBGPU_FILTER_NOTOUCH;
-    bool garbage = consumed != bytes;
+    bool garbage = consumed != bytes && !tail_is_clean((const uint8_t *) data, bytes, consumed);
     if (n == 0) {
         flbgpu_dev_chunk o0;
         memset(&o0, 0, sizeof(o0));

@@ -202,6 +202,11 @@ int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_of
  * Walks concatenated msgpack objects in host memory; fills row_off[0..n] (capacity cap entries).
  * Returns n; *consumed is the offset where decoding stopped (== bytes for a clean chunk). */
 int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap, size_t *consumed);
+/* 1 when the bytes behind `consumed` end exactly on a msgpack field boundary (or there are none): msgpack-c's
+ * executor then leaves the decoder offset at the end of the chunk and filter_grep treats the chunk as clean
+ * (lib/msgpack-c/include/msgpack/unpack_template.h:242-247,439-447; src/flb_log_event_decoder.c:334-342;
+ * plugins/filter_grep/grep.c:357-360); 0 when a field is cut short, at 0xc1, or past 32 open containers. */
+int flbgpu_tail_clean_host(const void *data, size_t bytes, size_t consumed);
 
 /* The same boundaries found on the device from the raw bytes of a chunk that is already in HBM
  * (what msgpack_unpack_next yields object by object, lib/msgpack-c/src/unpack.c via

@@ -112,6 +112,8 @@ def test_lists_that_mix_parser_formats(g):
              b'10.0.0.1 - bob [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.0" 200 2326', b'level=info msg="hi there" time=2022-10-31T12:00:01.5 ok',
              b"host:h1\tstatus:200\ttime:2022-10-31T12:00:01.25", b"", b"plain words only", b"k=v", b"a:1", b'{"k":"v"} trailing', b"=", b"\xff\xfe",
              b'{"deep":' + b"[" * 70 + b"]" * 70 + b"}", b'msg="caf\\u00e9 \\uD83D\\uDE00" n=1']
+    # around msgpack-c's 32-deep container stack (flb_parser_json_do unpacks what it packed)
+    texts += [b'{"d":' + b"[" * k + b"]" * k + b"}" for k in (30, 31, 32, 33)] + [b'{"d":' + b'{"o":' * k + b"1" + b"}" * k + b"}" for k in (30, 31, 32)]
     recs = []
     for i in range(3000):
         t = rng.choice(texts)
