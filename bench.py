@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=5_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the log_to_metrics / JSON side measurements")
     args = ap.parse_args()
