@@ -13,6 +13,7 @@ struct DevCap {
     const uint32_t *ft2;           // [nmulti][1 << fc_shift] one-byte-lookahead rows
     const uint8_t *cls;            // [256] byte -> class
     const uint8_t *col;            // [256] byte -> kind << fc_shift | class
+    const uint8_t *xl;             // [512] utf8 set: symbol of a stray byte / of a truncated sequence's lead (rx.cpp SymbolMap)
     // cold tables (only when several candidates remain for a byte)
     const uint8_t *r_info;         // [nR]
     const uint32_t *vmask;         // [nR][VW]
@@ -146,6 +147,12 @@ struct FParserCfg {
     DevKey key;
     int reserve_data, preserve_key;
     int nparsers;
+    // Key_Name entries a parser succeeded on are remembered per record in a 64-bit mask (body map index
+    // 0..63); successes at index 64 and up go to this side list of (record, index) pairs, filled by the size
+    // pass and read by both passes (set per run by the host; normally empty)
+    unsigned long long *ov_pairs;
+    unsigned int *ov_count;          // entries appended (may exceed ov_cap: the run then fails loudly)
+    unsigned int ov_cap;
 };
 
 struct ParserMatchArgs {

@@ -74,12 +74,13 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     b.resize(hot_end);
     size_t o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
     size_t o_lo = put(b, t.list_off), o_le = put(b, t.list_ent), o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
+    size_t o_xl = put(b, std::vector<uint8_t>(t.xl, t.xl + 512));
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     const uint8_t *d = (const uint8_t *) blob.dev;
     memset(&out, 0, sizeof(out));
     out.rdelta = (const uint16_t *) (d + o_rd); out.ft = (const uint32_t *) (d + o_ft); out.ft2 = (const uint32_t *) (d + o_f2);
-    out.cls = d + o_cls; out.col = d + o_col;
+    out.cls = d + o_cls; out.col = d + o_col; out.xl = d + o_xl;
     out.r_info = d + o_ri; out.vmask = (const uint32_t *) (d + o_vm); out.list_off = (const uint32_t *) (d + o_lo);
     out.list_ent = (const uint32_t *) (d + o_le); out.tag_off = (const uint32_t *) (d + o_to); out.tag_data = d + o_td;
     out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK; out.NKp = t.NKp;
@@ -573,7 +574,8 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[4]; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[4]; unsigned int ov_count; unsigned int pad; };
+static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FParserCfg's side list
 
 static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
     uint64_t n = in->n;
@@ -621,6 +623,8 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
         !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)) ||
         !f->d_status.ensure(n * TBUF_WORDS * sizeof(uint32_t)))
         return false;
+    if (!f->d_ov.ensure((size_t) OV_CAP * 2 * sizeof(unsigned long long))) return false;
+    f->pcfg.ov_pairs = f->d_ov.as<unsigned long long>(); f->pcfg.ov_count = &dm->ov_count; f->pcfg.ov_cap = OV_CAP;
     ParserMatchArgs ma;
     ma.tbuf = f->d_status.as<uint32_t>();                    // (the status buffer is grep's; a parser filter uses it for the time text)
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
@@ -671,6 +675,10 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
     f->last_in = hm.counts[0];
+    if (hm.ov_count > OV_CAP) {
+        set_err("filter_parser: more than %u parsed Key_Name entries at body map index 64 and up in one chunk", OV_CAP);
+        return false;
+    }
     if (total == 0) return true;                            // encoder produced nothing: NOTOUCH (+ error log)
     if (!f->d_out.ensure(total + 16)) return false;
     ParserEmitArgs ea;
@@ -1157,23 +1165,18 @@ extern "C" int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length
     if (flbgpu_filter_run(p->self_filter, rec.data(), rec.size(), &ob, &os) != FLBGPU_FILTER_MODIFIED || os < 13) { free(ob); return -1; }
     const uint8_t *o = (const uint8_t *) ob;
     size_t body = 13;       // 92 92 d7 00 <8> 80
-    // an unparsed record comes back as the canonical re-pack of the wrapper body {"k": value}
-    bool parsed;
-    {
-        std::vector<uint8_t> canon = {0x81, 0xa1, 'k'};
-        if (length < 32) canon.push_back((uint8_t) (0xa0 | length));
-        else if (length < 256) { canon.push_back(0xd9); canon.push_back((uint8_t) length); }
-        else if (length < 65536) { canon.push_back(0xda); canon.push_back((uint8_t) (length >> 8)); canon.push_back((uint8_t) length); }
-        else { canon.push_back(0xdb); for (int i = 3; i >= 0; i--) canon.push_back((uint8_t) (length >> (8 * i))); }
-        parsed = !(os - body == canon.size() + length && !memcmp(o + body, canon.data(), canon.size()) &&
-                   !memcmp(o + body + canon.size(), buf, length));
-    }
-    if (!parsed) { free(ob); return -1; }
+    // whether a parser accepted the value: the record's RF_PARSED flag (column 0 of the filter's record columns;
+    // an unparsed record comes back as the canonical re-pack of the wrapper, which a pattern like
+    // ^(?<k>.*)$ would reproduce byte for byte)
+    uint32_t flags = 0;
+    if (hipMemcpy(&flags, p->self_filter->d_info.p, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) { set_err("device read failed"); free(ob); return -1; }
+    if (!(flags & RF_PARSED)) { free(ob); return -1; }
     uint32_t sec = ((uint32_t) o[4] << 24) | (o[5] << 16) | (o[6] << 8) | o[7];
     uint32_t nsec = ((uint32_t) o[8] << 24) | (o[9] << 16) | (o[10] << 8) | o[11];
     *out_sec = sec; *out_nsec = nsec;
     size_t ms = os - body;
     void *m = malloc(ms ? ms : 1);
+    if (!m) { free(ob); set_err("out of memory"); return -1; }
     memcpy(m, o + body, ms);
     free(ob);
     *out_buf = m; *out_size = ms;

@@ -57,7 +57,7 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         return 0;
     }
     if (ev.flags & RF_SKIP) {
-        if (rec != rec_end && mp_skip(ev.body, rec_end) != rec_end) {        // a marker with a broken body is a decoder error too
+        if (rec != rec_end && mp_skip(ev.body, rec_end, 1) != rec_end) {     // a marker with a broken body is a decoder error too
             ri.flags = RF_BAD;
             atomicMin(a.first_bad, (unsigned long long) r);
         }
@@ -123,7 +123,7 @@ DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec
         cs.n = 12;
         if (ev.meta) mp_canon(ev.meta, ev.meta_end, cs); else cs.n += 1;
         ri.meta_canon = (uint32_t) cs.n - 12;
-        if (have_canon) cs.n += canon.n; else mp_canon(ev.body, ev.body_end, cs);
+        if (have_canon) cs.n += canon.n; else mp_canon(ev.body, ev.body_end, cs, 1);
         out_len = (uint32_t) cs.n;
     }
     rec_store(a.info, a.n, r, ri);
@@ -320,7 +320,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         }
         uint32_t flags = (fl0 | RF_PARSED) & ~(uint32_t) RF_BADTS;
         const uint32_t key_index = a.info[3 * n + r];
-        uint64_t null_mask = (!a.cfg.key.is_ra && key_index < 64) ? 1ull << key_index : 0;
+        uint64_t null_mask = 0;
+        if (!a.cfg.key.is_ra) null_note(a.cfg, r, key_index, null_mask);
         int64_t tsec = a.info[4 * n + r], tnsec = a.info[5 * n + r];
         if (fl0 & RF_BADTS) { tsec = -1; tnsec = 0; }                        // the event time was out of range
         int64_t psec = sec, pnsec = (int64_t) (frac * 1000000000);
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
                     ri.val_off = (uint32_t) (vptr - rec); ri.val_len = vlen; ri.parser_idx = q; ri.nkept = nk; ri.drop_mask = dm;
                     if (!a.cfg.key.is_ra) {
                         ri.key_index = i;
-                        if (i < 64) null_mask |= 1ull << i;
+                        null_note(a.cfg, r, i, null_mask);
                     }
                     if ((uint64_t) ps * 1000000000ull + (uint64_t) pn != 0) { tsec = ps; tnsec = pn; }
                     break;
@@ -616,10 +617,10 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
                 if (!(ev.flags & (RF_BAD | RF_SKIP))) {
                     bool valid = false;
                     keep = grep_decide(a, ev, &valid);
-                    if (!valid) valid = mp_skip(ev.body, rec_end) == rec_end;     // no rule walked the map
+                    if (!valid) valid = mp_skip(ev.body, rec_end, 1) == rec_end;  // no rule walked the map
                     if (!valid) ev.flags = RF_BAD;
                 }
-                else if ((ev.flags & RF_SKIP) && rec != rec_end && mp_skip(ev.body, rec_end) != rec_end) ev.flags = RF_BAD;
+                else if ((ev.flags & RF_SKIP) && rec != rec_end && mp_skip(ev.body, rec_end, 1) != rec_end) ev.flags = RF_BAD;
                 a.status[r] = ev.flags;
                 if (ev.flags & RF_BAD) { atomicMin(a.first_bad, (unsigned long long) r); a.keep_len[r] = 0; }
                 else if (ev.flags & RF_SKIP) a.keep_len[r] = 0;

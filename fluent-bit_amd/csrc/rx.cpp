@@ -64,31 +64,218 @@ struct CodeSet {
     }
 };
 
-void add_ctype(CodeSet &s, char t) {
-    switch (t) {
-    case 'd': s.add('0', '9'); break;
-    case 'w': s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); s.add('_', '_'); break;
-    case 's': s.add(9, 13); s.add(' ', ' '); break;
-    case 'h': s.add('0', '9'); s.add('A', 'F'); s.add('a', 'f'); break;
+// ---------------------------------------------------------------- character class model
+// What one "character" node of the pattern accepts, kept in the two-part form the reference's engine
+// compiles a class to (lib/onigmo/regcomp.c compile_cclass_node, regexec.c OP_CCLASS* :2018-2138),
+// because the two parts are consulted differently on input that is not well-formed UTF-8:
+//   bs   256 bits tested on the FIRST BYTE whenever the character is not a multi-byte head (ASCII, a byte
+//        that cannot start or continue a sequence here, a lone lead byte at the end) -- and, when the class
+//        has no code-range part at all, on the first byte of EVERY character;
+//   mb   code points >= 0x80, tested on the decoded character when it is a multi-byte head: a well-formed
+//        sequence, or a prefix-valid sequence cut by the end of the text, which counts as ONE character
+//        that spans the rest of the text and whose code is its lead byte (enc/utf_8.c mbc_to_code with a
+//        NEEDMORE length; regenc.c onigenc_mbclen);
+//   neg  the class is negated as a whole (kept as a flag: [^ ] has bs = {' '}, no mb, neg).
+constexpr uint32_t LASTCP = 0x7fffffffu;          // ONIG_LAST_CODE_POINT: the complement of a code-range part
+
+struct ByteSet {
+    uint64_t w[4] = {0, 0, 0, 0};
+    void set(int b) { w[b >> 6] |= 1ull << (b & 63); }
+    void clear(int b) { w[b >> 6] &= ~(1ull << (b & 63)); }
+    void set_range(int lo, int hi) { for (int b = lo; b <= hi; b++) set(b); }
+    bool has(int b) const { return (w[b >> 6] >> (b & 63)) & 1; }
+    bool empty() const { return !(w[0] | w[1] | w[2] | w[3]); }
+    void invert() { for (auto &x : w) x = ~x; }
+    void merge(const ByteSet &o) { for (int i = 0; i < 4; i++) w[i] |= o.w[i]; }
+};
+
+// complement of a code-range part inside [0x80, LASTCP] (regparse.c not_code_range_buf)
+CodeSet mb_complement(const CodeSet &in) {
+    CodeSet s = in, o;
+    s.norm();
+    uint32_t next = 0x80;
+    bool done = false;
+    for (auto &x : s.r) {
+        if (x.second < 0x80) continue;
+        uint32_t lo = std::max<uint32_t>(x.first, 0x80);
+        if (lo > next) o.add(next, lo - 1);
+        if (x.second >= LASTCP) { done = true; break; }
+        next = x.second + 1;
     }
+    if (!done) o.add(next, LASTCP);
+    return o;
 }
 
-bool add_posix(CodeSet &s, const std::string &n) {
-    if (n == "alpha") { s.add('A', 'Z'); s.add('a', 'z'); }
-    else if (n == "digit") s.add('0', '9');
-    else if (n == "alnum") { s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); }
-    else if (n == "upper") s.add('A', 'Z');
-    else if (n == "lower") s.add('a', 'z');
-    else if (n == "space") { s.add(9, 13); s.add(' ', ' '); }
-    else if (n == "blank") { s.add(9, 9); s.add(' ', ' '); }
-    else if (n == "cntrl") { s.add(0, 31); s.add(127, 127); }
-    else if (n == "punct") { s.add(33, 47); s.add(58, 64); s.add(91, 96); s.add(123, 126); }
-    else if (n == "graph") s.add(33, 126);
-    else if (n == "print") s.add(32, 126);
-    else if (n == "xdigit") { s.add('0', '9'); s.add('A', 'F'); s.add('a', 'f'); }
-    else if (n == "word") { s.add('0', '9'); s.add('A', 'Z'); s.add('a', 'z'); s.add('_', '_'); }
-    else if (n == "ascii") s.add(0, 127);
+struct CC {
+    enum Kind { CLASS, ANY, WORD, LIT } kind = CLASS;
+    ByteSet bs;
+    CodeSet mb;
+    // what the automaton is BUILT from for well-formed multi-byte characters: equal to mb except that the
+    // non-ASCII members of a POSIX bracket are left out ([[:alpha:]] accepts no non-ASCII letter here, the
+    // reference accepts the Unicode ones -- DESIGN.md "known deviations": the byte-class budget of the tables
+    // cannot hold the Unicode categories).  mb itself stays exact: it decides how ill-formed bytes are treated.
+    CodeSet mbx;
+    bool neg = false;
+    uint32_t lit = 0;                 // LIT: the code point (matched as its exact byte sequence)
+    bool any_nl = false;              // ANY: also matches \n  ((?m))
+
+    bool has_mb() const { for (auto &x : mb.r) if (x.second >= 0x80 && x.first <= x.second) return true; return false; }
+    // dest |= o, o's negation resolved first (regparse.c or_cclass / or_code_range_buf with not1 == 0)
+    void merge_class(const CC &o) {
+        ByteSet b2 = o.bs;
+        if (o.neg) b2.invert();
+        bs.merge(b2);
+        if (o.neg) { CodeSet c = mb_complement(o.mb); mb.merge(c); CodeSet cx = mb_complement(o.mbx); mbx.merge(cx); }
+        else { mb.merge(o.mb); mbx.merge(o.mbx); }
+        mb.norm(); mbx.norm();
+    }
+    void add_cp(uint32_t lo, uint32_t hi) {
+        // regparse.c next_state_val: single-byte values go to the bit set, code points to the range part; a
+        // range that starts single-byte and ends above sets the bits up to min(end, 0xff) AND the whole range
+        if (hi < 0x80) { bs.set_range((int) lo, (int) hi); return; }
+        if (lo < 0x80) bs.set_range((int) lo, (int) std::min<uint32_t>(hi, 0xff));
+        mb.add(lo, hi);
+        mbx.add(lo, hi);
+    }
+
+    // ---- what the class accepts, by the kind of character at the position
+    bool ascii(int b) const {
+        switch (kind) {
+        case CLASS: return bs.has(b) != neg;
+        case ANY: return b != '\n' || any_nl;
+        case WORD: return (((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_')) != neg;
+        case LIT: return (uint32_t) b == lit;
+        }
+        return false;
+    }
+    // a byte >= 0x80 that is a character of its own (no sequence starts here)
+    bool invalid_byte(int b) const {
+        switch (kind) {
+        case CLASS: return bs.has(b) != neg;
+        case ANY: return true;
+        case WORD: return neg;
+        case LIT: return false;
+        }
+        return false;
+    }
+    // a prefix-valid sequence of two or more bytes cut by the end of the text, lead byte b
+    bool truncated(int b) const {
+        switch (kind) {
+        case CLASS: return (has_mb() ? mb.has((uint32_t) b) : bs.has(b)) != neg;
+        case ANY: return true;
+        case WORD: return neg;
+        case LIT: return false;
+        }
+        return false;
+    }
+    // the well-formed multi-byte characters accepted, as a code point set within [0x80, MAXCP]
+    CodeSet valid_multibyte() const {
+        CodeSet o;
+        switch (kind) {
+        case CLASS:
+            if (has_mb()) {
+                CodeSet m = neg ? mb_complement(mbx) : mbx;
+                m.norm();
+                for (auto &x : m.r) if (x.second >= 0x80 && x.first <= MAXCP) o.add(std::max<uint32_t>(x.first, 0x80), std::min(x.second, MAXCP));
+            }
+            else {
+                // no code-range part: the bit of the LEAD byte decides for the whole character
+                for (int b = 0xc2; b <= 0xf4; b++) {
+                    if (bs.has(b) == neg) continue;
+                    if (b <= 0xdf) o.add((uint32_t) (b & 0x1f) << 6, ((uint32_t) (b & 0x1f) << 6) | 0x3f);
+                    else if (b <= 0xef) o.add(std::max<uint32_t>((uint32_t) (b & 0x0f) << 12, 0x800), ((uint32_t) (b & 0x0f) << 12) | 0xfff);
+                    else o.add(std::max<uint32_t>((uint32_t) (b & 0x07) << 18, 0x10000), std::min<uint32_t>(((uint32_t) (b & 0x07) << 18) | 0x3ffff, MAXCP));
+                }
+            }
+            break;
+        case ANY: o.add(0x80, MAXCP); break;
+        case WORD: if (neg) o.add(0x80, MAXCP); break;
+        case LIT: if (lit >= 0x80) o.add(lit, lit); break;
+        }
+        o.norm();
+        return o;
+    }
+};
+
+#include "posix_ranges.inc"
+
+// \d \s \w \h inside or outside brackets: ASCII-range under Ruby syntax (ONIG_OPTION_ASCII_RANGE).  The
+// positive form has no code-range part; the negated form is "ASCII complement + every code point >= 0x80"
+// (regparse.c add_ctype_to_cc with ascii_range)
+void ctype_ascii(ByteSet &bs, char t) {
+    switch (t) {
+    case 'd': bs.set_range('0', '9'); break;
+    case 'w': bs.set_range('0', '9'); bs.set_range('A', 'Z'); bs.set_range('a', 'z'); bs.set('_'); break;
+    case 's': bs.set_range(9, 13); bs.set(' '); break;
+    case 'h': bs.set_range('0', '9'); bs.set_range('A', 'F'); bs.set_range('a', 'f'); break;
+    }
+}
+void add_ctype(CC &cc, char t, bool negated) {
+    ByteSet a;
+    ctype_ascii(a, t);
+    if (!negated) { cc.bs.merge(a); return; }
+    for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
+    cc.mb.add(0x80, LASTCP);
+    cc.mb.norm();
+    cc.mbx.add(0x80, LASTCP);
+    cc.mbx.norm();
+}
+
+// [[:name:]] / [[:^name:]]: NOT ASCII-range (ONIG_OPTION_POSIX_BRACKET_ALL_RANGE): the code points >= 0x80
+// come from posix_ranges.inc (generated by probing the reference's engine, tools/gen_posix_ranges.py)
+bool add_posix(CC &cc, const std::string &n, bool negated) {
+    ByteSet a;
+    const unsigned int (*u)[2] = nullptr;
+    int un = 0;
+#define PX(nm) u = posix_u_##nm; un = posix_u_##nm##_n
+    if (n == "alpha") { a.set_range('A', 'Z'); a.set_range('a', 'z'); PX(alpha); }
+    else if (n == "digit") { a.set_range('0', '9'); PX(digit); }
+    else if (n == "alnum") { a.set_range('0', '9'); a.set_range('A', 'Z'); a.set_range('a', 'z'); PX(alnum); }
+    else if (n == "upper") { a.set_range('A', 'Z'); PX(upper); }
+    else if (n == "lower") { a.set_range('a', 'z'); PX(lower); }
+    else if (n == "space") { a.set_range(9, 13); a.set(' '); PX(space); }
+    else if (n == "blank") { a.set(9); a.set(' '); PX(blank); }
+    else if (n == "cntrl") { a.set_range(0, 31); a.set(127); PX(cntrl); }
+    else if (n == "punct") { a.set_range(33, 47); a.set_range(58, 64); a.set_range(91, 96); a.set_range(123, 126); PX(punct); }
+    else if (n == "graph") { a.set_range(33, 126); PX(graph); }
+    else if (n == "print") { a.set_range(32, 126); PX(print); }
+    else if (n == "xdigit") { a.set_range('0', '9'); a.set_range('A', 'F'); a.set_range('a', 'f'); PX(xdigit); }
+    else if (n == "word") { a.set_range('0', '9'); a.set_range('A', 'Z'); a.set_range('a', 'z'); a.set('_'); PX(word); }
+    else if (n == "ascii") { a.set_range(0, 127); PX(ascii); }
     else return false;
+#undef PX
+    CodeSet m;
+    for (int i = 0; i < un; i++) m.add(u[i][0], u[i][1]);
+    if (!negated) { cc.bs.merge(a); cc.mb.merge(m); }
+    else {
+        for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
+        CodeSet c = mb_complement(m);
+        cc.mb.merge(c);
+        cc.mbx.add(0x80, LASTCP);
+    }
+    cc.mb.norm(); cc.mbx.norm();
+    return true;
+}
+
+// (?i): the class is closed under case folding.  ASCII letters fold among themselves and 'k' / 's' also
+// with U+212A KELVIN SIGN / U+017F LONG S (the only single-character folds that reach an ASCII letter);
+// a class that holds part of the non-ASCII range would need the full fold tables: refused.
+bool fold_case(CC &cc) {
+    for (int c = 'a'; c <= 'z'; c++) {
+        if (cc.bs.has(c) || cc.bs.has(c - 32)) { cc.bs.set(c); cc.bs.set(c - 32); }
+    }
+    CodeSet rest = mb_complement(cc.mb);
+    bool partial = cc.has_mb() && !rest.r.empty();
+    if (partial) {
+        // only the two letters' partners may be there (added by this very function on an enclosing level)
+        for (auto &x : cc.mb.r) {
+            if (x.second < 0x80) continue;
+            if (x.first != x.second || (x.first != 0x212a && x.first != 0x17f)) return false;
+        }
+    }
+    if (cc.bs.has('k') || cc.mb.has(0x212a)) { cc.bs.set('k'); cc.bs.set('K'); cc.mb.add(0x212a, 0x212a); cc.mbx.add(0x212a, 0x212a); }
+    if (cc.bs.has('s') || cc.mb.has(0x17f)) { cc.bs.set('s'); cc.bs.set('S'); cc.mb.add(0x17f, 0x17f); cc.mbx.add(0x17f, 0x17f); }
+    cc.mb.norm(); cc.mbx.norm();
     return true;
 }
 
@@ -97,7 +284,7 @@ enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB };
 
 struct Ast {
     enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR } t = EMPTY;
-    CodeSet set;
+    CC cc;
     std::vector<std::unique_ptr<Ast>> kids;
     int cap = 0;
     int min = 0, max = 0;       // max < 0: unbounded
@@ -204,10 +391,10 @@ struct Syntax {
         name_groups.push_back({group});
     }
 
-    // '[' already consumed
-    bool char_class(CodeSet &out, unsigned opts) {
+    // '[' already consumed; fills `out` (empty on entry) with the class up to the matching ']'
+    bool char_class(CC &out, unsigned opts) {
         bool neg = false, first = true;
-        CodeSet s;
+        CC s;
         if (!eof() && *p == '^') { neg = true; p++; }
         for (;;) {
             uint32_t lo = 0, hi;
@@ -227,19 +414,15 @@ struct Syntax {
                         const unsigned char *nm = q;
                         while (q < e && *q >= 'a' && *q <= 'z') q++;
                         if (q + 1 < e && q[0] == ':' && q[1] == ']') {
-                            CodeSet t;
-                            if (!add_posix(t, std::string((const char *) nm, q - nm))) return fail("unknown POSIX bracket");
-                            t.norm();
-                            if (pneg) t.negate();
-                            s.merge(t);
+                            if (!add_posix(s, std::string((const char *) nm, q - nm), pneg)) return fail("unknown POSIX bracket");
                             p = q + 2;
                             continue;
                         }
                     }
                     p++;
-                    CodeSet t;
+                    CC t;
                     if (!char_class(t, opts)) return false;
-                    s.merge(t);
+                    s.merge_class(t);
                     continue;
                 }
                 if (*p == '&' && p + 1 < e && p[1] == '&') return fail("class intersection (&&) is not supported");
@@ -247,15 +430,8 @@ struct Syntax {
                     p++;
                     if (eof()) return fail("end pattern at escape");
                     int c = *p;
-                    if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c); continue; }
-                    if (c == 'D' || c == 'W' || c == 'S' || c == 'H') {
-                        CodeSet t;
-                        p++;
-                        add_ctype(t, (char) (c + 32));
-                        t.negate();
-                        s.merge(t);
-                        continue;
-                    }
+                    if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c, false); continue; }
+                    if (c == 'D' || c == 'W' || c == 'S' || c == 'H') { p++; add_ctype(s, (char) (c + 32), true); continue; }
                     if (c == 'p' || c == 'P' || c == 'R' || c == 'X') return fail("property escapes are not supported");
                     if (escape_cp(lo, true)) { if (failed()) return false; }
                     else if (c >= '1' && c <= '7') {
@@ -285,21 +461,27 @@ struct Syntax {
                 if (failed()) return false;
                 if (hi < lo) return fail("empty range in char class");
             }
-            s.add(lo, hi);
+            s.add_cp(lo, hi);
         }
-        if (opts & OPT_IGNORECASE) s.fold_ascii_case();
-        s.norm();
-        if (neg) s.negate();
-        out.merge(s);
+        s.mb.norm();
+        if ((opts & OPT_IGNORECASE) && !fold_case(s)) return fail("case-insensitive classes with non-ASCII members are not supported");
+        s.neg = neg;
+        out = s;
         return true;
     }
 
     AstP literal(uint32_t c, unsigned opts) {
         AstP a = mk(Ast::SET);
         if ((opts & OPT_IGNORECASE) && c >= 0x80) { fail("case-insensitive non-ASCII literals are not supported"); return a; }
-        a->set.add(c, c);
-        if (opts & OPT_IGNORECASE) a->set.fold_ascii_case();
-        a->set.norm();
+        if ((opts & OPT_IGNORECASE) && ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) {
+            // a folded letter is a small class (both cases; k and s also reach U+212A / U+017F)
+            a->cc.kind = CC::CLASS;
+            a->cc.bs.set((int) c);
+            fold_case(a->cc);
+            return a;
+        }
+        a->cc.kind = CC::LIT;
+        a->cc.lit = c;
         return a;
     }
 
@@ -388,15 +570,14 @@ struct Syntax {
         if (c == '[') {
             p++;
             AstP a = mk(Ast::SET);
-            if (!char_class(a->set, opts)) return nullptr;
-            a->set.norm();
+            if (!char_class(a->cc, opts)) return nullptr;
             return a;
         }
         if (c == '.') {
             p++;
             AstP a = mk(Ast::SET);
-            if (opts & OPT_MULTILINE) a->set.add(0, MAXCP);
-            else { a->set.add(0, 9); a->set.add(11, MAXCP); }
+            a->cc.kind = CC::ANY;
+            a->cc.any_nl = (opts & OPT_MULTILINE) != 0;
             return a;
         }
         if (c == '^') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BOL; return a; }
@@ -408,10 +589,11 @@ struct Syntax {
             c = *p;
             if (strchr("dwshDWSH", c)) {
                 p++;
+                // \w \W compile to the word opcodes, \d \s \h (and negations) to a bit-set class whose NOT is
+                // a flag (regparse.c parse_exp TK_CHAR_TYPE)
                 AstP a = mk(Ast::SET);
-                add_ctype(a->set, (char) (c | 32));
-                a->set.norm();
-                if (!(c & 32)) a->set.negate();
+                if ((c | 32) == 'w') { a->cc.kind = CC::WORD; a->cc.neg = !(c & 32); }
+                else { ctype_ascii(a->cc.bs, (char) (c | 32)); a->cc.neg = !(c & 32); }
                 return a;
             }
             if (c == 'A') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BOS; return a; }
@@ -519,14 +701,6 @@ bool scan_named(const unsigned char *s, const unsigned char *e) {
 }
 
 // ---------------------------------------------------------------- byte-level NFA
-struct ByteSet {
-    uint64_t w[4] = {0, 0, 0, 0};
-    void set(int b) { w[b >> 6] |= 1ull << (b & 63); }
-    void set_range(int lo, int hi) { for (int b = lo; b <= hi; b++) set(b); }
-    bool has(int b) const { return (w[b >> 6] >> (b & 63)) & 1; }
-    bool empty() const { return !(w[0] | w[1] | w[2] | w[3]); }
-};
-
 enum NType { N_CONSUME, N_SPLIT, N_ASSERT, N_SAVE, N_MATCH };
 
 struct NNode {
@@ -588,29 +762,84 @@ void utf8_split(uint32_t lo, uint32_t hi, std::vector<Seq> &out) {
     out.push_back(s);
 }
 
+// ---- input that is not well-formed UTF-8 (utf8 table set only)
+// The walkers do not step on raw bytes there but on SYMBOLS: every byte of a well-formed sequence is itself;
+// a byte >= 0x80 that is a character of its own (never-valid lead, stray continuation, lead whose sequence
+// breaks off -- regenc.c onigenc_mbclen gives such a byte the length 1) and the lead of a prefix-valid
+// sequence cut by the end of the text (one character that spans the rest of the text; the walkers shorten the
+// text to end right after that lead) are replaced by one of the eleven byte values that never occur in
+// well-formed UTF-8.  Two bytes share a symbol when every character node of the pattern treats them alike,
+// so the symbol alone tells the automaton what the byte matches.
+const uint8_t SPARE_BYTES[11] = {0xc0, 0xc1, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa, 0xfb, 0xfc, 0xfd};
+
+struct SymbolMap {
+    uint8_t xl[512];                                   // [b]: stray byte b, [256 + b]: truncated sequence with lead b
+    SymbolMap() { for (int b = 0; b < 256; b++) { xl[b] = (uint8_t) b; xl[256 + b] = (uint8_t) b; } }
+    std::map<const Ast *, ByteSet> accepts;            // per character node: the symbols it accepts
+    bool build(const Ast *root, std::string &err) {
+        std::vector<const Ast *> atoms;
+        collect(root, atoms);
+        std::map<std::vector<bool>, int> ids;
+        std::vector<std::vector<bool>> sigs;
+        auto sym_of = [&](const std::vector<bool> &sig) -> int {
+            auto it = ids.find(sig);
+            if (it != ids.end()) return it->second;
+            int id = (int) sigs.size();
+            ids[sig] = id;
+            sigs.push_back(sig);
+            return id;
+        };
+        memset(xl, 0, sizeof(xl));
+        for (int b = 0; b < 256; b++) { xl[b] = (uint8_t) b; xl[256 + b] = (uint8_t) b; }
+        for (int b = 0x80; b < 256; b++) {
+            std::vector<bool> sig(atoms.size());
+            for (size_t i = 0; i < atoms.size(); i++) sig[i] = atoms[i]->cc.invalid_byte(b);
+            int id = sym_of(sig);
+            if (id >= 11) { err = "too many kinds of ill-formed UTF-8 bytes for the GPU tables"; return false; }
+            xl[b] = SPARE_BYTES[id];
+            if (b >= 0xc2 && b <= 0xf4) {
+                for (size_t i = 0; i < atoms.size(); i++) sig[i] = atoms[i]->cc.truncated(b);
+                id = sym_of(sig);
+                if (id >= 11) { err = "too many kinds of ill-formed UTF-8 bytes for the GPU tables"; return false; }
+                xl[256 + b] = SPARE_BYTES[id];
+            }
+            else xl[256 + b] = xl[b];
+        }
+        for (size_t i = 0; i < atoms.size(); i++) {
+            ByteSet bs;
+            for (size_t k = 0; k < sigs.size(); k++) if (sigs[k][i]) bs.set(SPARE_BYTES[k]);
+            accepts[atoms[i]] = bs;
+        }
+        return true;
+    }
+    static void collect(const Ast *a, std::vector<const Ast *> &out) {
+        if (a->t == Ast::SET) out.push_back(a);
+        for (auto &k : a->kids) collect(k.get(), out);
+    }
+};
+
 struct Builder {
     Nfa &nfa;
     bool ascii_only;
-    Builder(Nfa &n, bool ascii) : nfa(n), ascii_only(ascii) {}
+    const SymbolMap *syms;
+    Builder(Nfa &n, bool ascii, const SymbolMap *sm) : nfa(n), ascii_only(ascii), syms(sm) {}
 
-    // node matching one character of `set`, continuing at `next`
-    int build_set(const CodeSet &set, int next) {
-        ByteSet ascii;
+    // node matching one character accepted by the character node `a`, continuing at `next`
+    int build_set(const Ast *a, int next) {
+        const CC &cc = a->cc;
+        ByteSet single;
+        for (int b = 0; b < 0x80; b++) if (cc.ascii(b)) single.set(b);
         std::vector<Seq> seqs;
-        for (auto &r : set.r) {
-            uint32_t lo = r.first, hi = std::min(r.second, MAXCP);
-            if (lo <= 0x7f) { ascii.set_range((int) lo, (int) std::min<uint32_t>(hi, 0x7f)); lo = 0x80; }
-            if (lo > hi || ascii_only) continue;
-            // surrogates are not encodable
-            if (lo <= 0xd7ff) utf8_split(lo, std::min<uint32_t>(hi, 0xd7ff), seqs);
-            if (hi >= 0xe000) utf8_split(std::max<uint32_t>(lo, 0xe000), hi, seqs);
-        }
-        // bytes that can never start a well-formed sequence are 1-byte characters whose code is
-        // the byte value (Onigmo: mbc_enc_len INVALID => length 1, mbc_to_code => the byte)
-        ByteSet single = ascii;
-        for (int b = 0x80; b <= 0xff; b++) {
-            bool never_lead = (b <= 0xbf) || b == 0xc0 || b == 0xc1 || b >= 0xf5;
-            if (never_lead && !ascii_only && set.has((uint32_t) b)) single.set(b);
+        if (!ascii_only) {
+            auto it = syms->accepts.find(a);
+            if (it != syms->accepts.end()) single.merge(it->second);
+            CodeSet v = cc.valid_multibyte();
+            for (auto &r : v.r) {
+                uint32_t lo = r.first, hi = std::min(r.second, MAXCP);
+                // surrogates are not encodable
+                if (lo <= 0xd7ff) utf8_split(lo, std::min<uint32_t>(hi, 0xd7ff), seqs);
+                if (hi >= 0xe000) utf8_split(std::max<uint32_t>(lo, 0xe000), hi, seqs);
+            }
         }
         std::vector<int> alts;
         if (!single.empty()) alts.push_back(nfa.consume(single, next));
@@ -651,7 +880,7 @@ struct Builder {
         if (!nfa.err.empty()) return next;
         switch (a->t) {
         case Ast::EMPTY: return next;
-        case Ast::SET: return build_set(a->set, next);
+        case Ast::SET: return build_set(a, next);
         case Ast::CAT: {
             int cur = next;
             for (int i = (int) a->kids.size() - 1; i >= 0; i--) cur = build(a->kids[i].get(), cur);
@@ -864,19 +1093,22 @@ void split_flb_pattern(const char *pattern, const char **start, const char **end
 namespace {
 
 bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool want_capture, const std::vector<uint8_t> &slot2cap, TableSet &out, std::string &err) {
+    SymbolMap syms;
+    if (!ascii_only && !syms.build(root, err)) return false;
     Nfa nfa;
     {
         NNode m; m.t = N_MATCH;
         int match = nfa.add(m);
         NNode close; close.t = N_SAVE; close.slot = 1; close.next = match;     // group 0 end
         int c = nfa.add(close);
-        Builder b(nfa, ascii_only);
+        Builder b(nfa, ascii_only, &syms);
         nfa.start = b.build(root, c);           // group 0 begin is the start boundary itself
     }
     if (!nfa.err.empty()) { err = nfa.err; return false; }
     if (nfa.npos > 4000) { err = "pattern too large for the GPU tables (positions)"; return false; }
     out = TableSet();
     out.ascii_only = ascii_only;
+    memcpy(out.xl, syms.xl, sizeof(out.xl));
 
     // ---- context kinds actually distinguished by this pattern
     bool any_assert = false;
@@ -1252,6 +1484,43 @@ int utf8_seq_len(const uint8_t *s, int i, int len) {
     return need + 1;
 }
 
+// the text the UTF-8 tables walk: its length (a prefix-valid sequence of two or more bytes cut by the end
+// of the text is ONE symbol, the text ends right behind its lead) ...
+int utf8_walk_len(const uint8_t *s, int len) {
+    for (int k = 2; k <= 3 && k <= len; k++) {
+        int j = len - k, b = s[j];
+        if (b >= 0xc2 && b <= 0xf4 && utf8_seq_len(s, j, len) > k) return j + 1;
+    }
+    return len;
+}
+// ... and the symbol at position i (i < walk length; len = the real length)
+int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen) {
+    int b = s[i];
+    if (seqlen) *seqlen = 1;
+    if (b < 0x80) return b;
+    if (b >= 0xc2 && b <= 0xf4) {
+        int L = utf8_seq_len(s, i, len);
+        if (L == 1) return xl[b];                          // the sequence breaks off: a character of its own
+        if (i + L > len) return len - i >= 2 ? xl[256 + b] : xl[b];      // cut by the end of the text
+        if (seqlen) *seqlen = L;
+        return b;
+    }
+    if (b <= 0xbf) {
+        // a continuation byte belongs to the sequence whose lead is the nearest non-continuation byte
+        // to its left, when that sequence is well-formed and reaches this far
+        for (int d = 1; d <= 3 && d <= i; d++) {
+            int c = s[i - d];
+            if (c >= 0x80 && c <= 0xbf) continue;
+            if (c >= 0xc2 && c <= 0xf4) {
+                int L = utf8_seq_len(s, i - d, len);
+                if (L > d && i - d + L <= len) return b;
+            }
+            break;
+        }
+    }
+    return xl[b];
+}
+
 namespace {
 
 // returns 1 match, 0 no match, -3 poisoned (needs the utf8 tables).  Mirrors the kernels:
@@ -1261,13 +1530,17 @@ namespace {
 constexpr int CHK = 16;
 thread_local long g_stat_fast = 0, g_stat_look = 0, g_stat_multi = 0;
 
-int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *beg, int *end) {
+int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int olen, int *beg, int *end) {
+    // the utf8 set walks symbols over a possibly shortened text (see utf8_walk_len)
+    const int len = t.ascii_only ? olen : utf8_walk_len(s, olen);
+    auto sym = [&](int i, int *L) -> int { if (t.ascii_only) { if (L) *L = 1; return s[i]; } return utf8_symbol(t.xl, s, i, olen, L); };
     std::vector<uint16_t> chk(len / CHK + 2);
     int R = t.r_init, best = -1;
     int h1 = -1, h2 = -1;                     // best as it was 1/2 boundaries to the right
     chk[0] = (uint16_t) R;
     for (int i = len - 1; i >= 0; i--) {
-        uint16_t e = t.rdelta[(size_t) R * t.ncls + t.cls[s[i]]];
+        int L = 1;
+        uint16_t e = t.rdelta[(size_t) R * t.ncls + t.cls[sym(i, &L)]];
         if ((e & 0x7FFF) == R_POISON) return -3;
         int before = best;
         if (e & 0x8000) best = i + 1;
@@ -1275,14 +1548,11 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *
         int tt = len - i;                     // distance of boundary i from the end
         if (tt % CHK == 0) chk[tt / CHK] = (uint16_t) R;
         if (!t.ascii_only) {
-            if (s[i] >= 0xc2) {
-                // a match may only start on a character boundary (onig_search advances by enclen):
-                // boundaries strictly inside the sequence that starts here are not start candidates
-                int L = utf8_seq_len(s, i, len);
-                if (L == 2) best = before;
-                else if (L == 3) best = h1;
-                else if (L == 4) best = h2;
-            }
+            // a match may only start on a character boundary (onig_search advances by enclen):
+            // boundaries strictly inside the well-formed sequence that starts here are not start candidates
+            if (L == 2) best = before;
+            else if (L == 3) best = h1;
+            else if (L == 4) best = h2;
             h2 = h1; h1 = before;
         }
     }
@@ -1291,15 +1561,15 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *
     std::vector<int> slot(2 * (ngroups + 1), -1);
     slot[0] = best;
     int j = best;
-    int pk0 = j == 0 ? t.kind_edge : t.kind_of_cls[t.cls[s[j - 1]]];
+    int pk0 = j == 0 ? t.kind_edge : t.kind_of_cls[t.cls[sym(j - 1, nullptr)]];
     uint32_t S = (uint32_t) ((t.nX - 1) * t.NKp + pk0);
     const int ncols = 1 << t.fc_shift;
     for (;;) {
-        int colc = j < len ? t.col[s[j]] : t.col_eot;
+        int colc = j < len ? t.col[sym(j, nullptr)] : t.col_eot;
         uint32_t e = t.ft[((size_t) S << t.wsh) + colc];
         if ((e & FT_SPECIAL) && ft_type(e) == FT_LOOK) {
             g_stat_look++;
-            int c2 = j + 1 < len ? t.cls[s[j + 1]] : t.ncls;
+            int c2 = j + 1 < len ? t.cls[sym(j + 1, nullptr)] : t.ncls;
             e = t.ft2[(size_t) (e & 0xFFFFFF) * ncols + c2];
         }
         int x = (int) (S / t.NKp), pk = (int) (S % t.NKp), nk = colc >> t.fc_shift;
@@ -1323,7 +1593,7 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *
             g_stat_multi++;
             int t0 = ((len - j) / CHK) * CHK, b0 = len - t0;
             int r = chk[t0 / CHK];
-            for (int i = b0 - 1; i >= j; i--) r = t.rdelta_p[((size_t) r << t.cls_shift) + t.cls[s[i]]] & 0x7FFF;   // never poisoned here
+            for (int i = b0 - 1; i >= j; i--) r = t.rdelta_p[((size_t) r << t.cls_shift) + t.cls[sym(i, nullptr)]] & 0x7FFF;   // never poisoned here
             for (uint32_t k = t.list_off[li]; k < t.list_off[li + 1]; k++) {
                 uint32_t ent = t.list_ent[k];
                 uint32_t tg = ent & 0xFFFF;
@@ -1339,7 +1609,11 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int len, int *
         if (j > len) return -2;
     }
     for (int g = 0; g <= ngroups; g++) {
-        if (slot[2 * g] >= 0 && slot[2 * g + 1] >= 0) { beg[g] = slot[2 * g]; end[g] = slot[2 * g + 1]; }
+        if (slot[2 * g] >= 0 && slot[2 * g + 1] >= 0) {
+            // the boundary behind a truncated last character is the end of the real text
+            beg[g] = slot[2 * g] == len ? olen : slot[2 * g];
+            end[g] = slot[2 * g + 1] == len ? olen : slot[2 * g + 1];
+        }
         else { beg[g] = -1; end[g] = -1; }
     }
     return 1;

@@ -47,6 +47,9 @@ struct TableSet {
     uint8_t cls[256];
     int ncls = 0;
     int high_cls = -1;
+    // utf8 set only: symbol of a byte >= 0x80 that is a character of its own ([b]) / of the lead of a
+    // sequence cut by the end of the text ([256 + b]); see SymbolMap in rx.cpp
+    uint8_t xl[512];
 
     // match-only forward DFA (built for the ascii set only)
     int nD = 0, d_init = 0;
@@ -144,6 +147,9 @@ int simulate_match(const Program &p, const uint8_t *s, int len);
 // UTF-8 sequence length rule shared with the kernels: length (2..4) of the well-formed or
 // end-truncated sequence starting at s[i], else 1
 int utf8_seq_len(const uint8_t *s, int i, int len);
+// what the utf8 table set steps on: the length of the walked text and the symbol at position i
+int utf8_walk_len(const uint8_t *s, int len);
+int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen);
 // forward-walk step counters of simulate_capture since the last call: {fast, lookahead, slow}
 void debug_stats(long *out);
 

@@ -124,3 +124,21 @@ double ref_onig_bench(void *reg, const char *data, const long long *off, long lo
     *matched = m;
     return (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
 }
+
+/* membership probe for tools/gen_posix_ranges.py: out[c - lo] = 1 when the one-character text holding
+ * code point c (UTF-8; surrogates skipped) is matched by reg */
+void ref_onig_probe_codepoints(void *reg, unsigned lo, unsigned hi, unsigned char *out)
+{
+    unsigned c;
+    for (c = lo; c <= hi; c++) {
+        OnigUChar b[4];
+        int n;
+        out[c - lo] = 0;
+        if (c >= 0xd800 && c <= 0xdfff) continue;
+        if (c < 0x80) { b[0] = (OnigUChar) c; n = 1; }
+        else if (c < 0x800) { b[0] = 0xc0 | (c >> 6); b[1] = 0x80 | (c & 0x3f); n = 2; }
+        else if (c < 0x10000) { b[0] = 0xe0 | (c >> 12); b[1] = 0x80 | ((c >> 6) & 0x3f); b[2] = 0x80 | (c & 0x3f); n = 3; }
+        else { b[0] = 0xf0 | (c >> 18); b[1] = 0x80 | ((c >> 12) & 0x3f); b[2] = 0x80 | ((c >> 6) & 0x3f); b[3] = 0x80 | (c & 0x3f); n = 4; }
+        if (onig_search((OnigRegex) reg, b, b + n, b, b + n, NULL, ONIG_OPTION_NONE) >= 0) out[c - lo] = 1;
+    }
+}

@@ -10,12 +10,13 @@ pinned on boxes where the reference is absent.
 import json, os, random, sys, base64
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from rxdiff import load_ref, RefRegex, PATTERNS, rand_input
+from rxdiff import load_ref, RefRegex, PATTERNS, rand_input, rand_input_illformed
 
 def main():
     R = load_ref()
     assert R is not None, "build oracle/_ref first (make -C oracle ref)"
     rng = random.Random(0xF1B17)
+    rng2 = random.Random(0x111F0)          # ill-formed inputs: their own stream, the first 60 cases of a pattern stay what they were
     out = []
     for pat in PATTERNS:
         r = RefRegex(R, pat)
@@ -31,6 +32,12 @@ def main():
                 seen.add(s)
                 m = r.search(s)
                 ent["cases"].append([base64.b64encode(s).decode(), m])
+            for i in range(30):
+                s = rand_input_illformed(rng2, pat, maxlen=20)
+                if s in seen:
+                    continue
+                seen.add(s)
+                ent["cases"].append([base64.b64encode(s).decode(), r.search(s)])
         out.append(ent)
     with open(os.path.join(HERE, "regex_kat.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))

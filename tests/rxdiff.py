@@ -103,9 +103,35 @@ PATTERNS = [
     "é+".encode(), "[é-ü]+".encode(), "[^é]+".encode(), "(?<w>\\S+) é".encode(), "日本(?<x>.)".encode(),
     rb'a**', rb'a+*', rb'(a*)*b', rb'(a*?)*b', rb'(|a)*b', rb'(a|)*b', rb'()*', rb'(a?)*?b', rb'(?:a?){3}', rb'(?:a?){2,}b', rb'(a|b*)*c',
     rb'\n', rb'a\nb', rb'^b', rb'a$\nb', rb'(?m).*', rb'\s', rb'[\n]', rb'[^\n]+',
+    # how each class form treats input that is not well-formed UTF-8 (bit set only / code-range part / mixed,
+    # positive and negated, the word opcodes, folded letters)
+    rb'[\S]+', rb'[\W]+', rb'[^\w]+', rb'[^\s]+x', rb'[\D]+', rb'[\H]x', rb'[[:^alpha:]]+', rb'[[:^digit:]]+x', rb'(?i)[^a]+', rb'(?i)k+', rb'(?i)[r-t]+',
+    rb'[a\x{e9}]+', rb'[\x{80}-\x{ff}]+', rb'[^\x{80}-\x{ff}]+', rb'[a-\x{e9}]+', rb'\x{e9}', rb'[^\x{e2}]+', rb'[a[^b]]+', rb'[^a[^b]]+', rb'\W\w', rb'x.y', rb'(?m)x.y',
+    rb'^(?<a>[^ ]*) (?<b>\S+) (?<c>.*)$', rb'^(?<a>[^"]*)"(?<b>[\w]*)', rb'(?<a>\W+)(?<b>\w+)',
 ]
 
 ALPH_ASCII = b'abcxyz019 _-.:/"[]=\n\tAB5'
+
+def rand_input_illformed(rng, pat=None, maxlen=24):
+    """text with stray bytes >= 0x80: Latin-1 letters, lone leads, stray continuations, sequences cut by
+    the next character or by the end of the text, overlongs, surrogates, bytes that never occur"""
+    n = rng.randint(1, maxlen)
+    out = bytearray()
+    lits = bytes(c for c in (pat or b'') if c < 0x80 and (chr(c).isalnum() or c in b' _-.:/"=')) or b'a'
+    frag = [b'\xe9', b'\xc3', b'\xa9', b'\x80', b'\xbf', b'\xe2\x82', b'\xf0\x9f', b'\xf0\x9f\x98', b'\xff', b'\xfe', b'\xc0\x80', b'\xc1',
+            b'\xed\xa0\x80', b'\xf4\x90\x80\x80', b'\xf5', b'\xe0\x80\x80', b'\xc3\xa9', b'\xe2\x82\xac', b'\xf0\x9f\x98\x80', b'\xc5\xbf', b'\xe2\x84\xaa',
+            b'\xe2', b'\xf0', b'\xdf']
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.3:
+            out += rng.choice(frag)
+        elif r < 0.4:
+            out.append(rng.randrange(0x80, 0x100))
+        elif r < 0.7:
+            out.append(rng.choice(lits))
+        else:
+            out.append(rng.choice(ALPH_ASCII))
+    return bytes(out[:maxlen + 4])
 
 def rand_input(rng, pat=None, maxlen=24, utf8=False):
     n = rng.randint(0, maxlen)

@@ -58,7 +58,9 @@ def test_regex_tables_against_golden(g):
         L.flbgpu_rx_names(h, buf, 4096)
         names = [[l.rsplit("=", 1)[0], int(l.rsplit("=", 1)[1])] for l in buf.value.decode().splitlines()]
         assert names == ent["names"], pat
-        dev = any(t in pat for t in (rb'[[:', rb'\b', rb'\B'))
+        # the two documented deviations: the non-ASCII members of POSIX brackets and \b / \B next to
+        # non-ASCII characters.  Everything else -- ill-formed UTF-8 included -- must agree with the real engine.
+        dev = any(t in pat for t in (rb'[:', rb'\b', rb'\B'))
         for s64, want in ent["cases"]:
             s = base64.b64decode(s64)
             if dev and any(c >= 0x80 for c in s):
@@ -70,7 +72,7 @@ def test_regex_tables_against_golden(g):
             assert L.flbgpu_rx_simulate_match(h, s, len(s)) == (0 if want is None else 1), (pat, s)
             checked += 1
         L.flbgpu_rx_free(h)
-    assert checked > 8000
+    assert checked > 15000
 
 
 def test_index_host(g):
