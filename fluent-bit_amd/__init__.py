@@ -44,6 +44,8 @@ def lib():
         raise ImportError("%s is missing: run `make -C %s` (hipcc, gfx950). There is no CPU fallback." % (LIB_PATH, CSRC))
     L = ctypes.CDLL(LIB_PATH)
     L.flbgpu_init.argtypes = [c_int]
+    L.flbgpu_set_time_now.argtypes = [ctypes.c_int64]
+    L.flbgpu_set_time_now.restype = None
     L.flbgpu_last_error.restype = c_char_p
     L.flbgpu_parser_create.restype = c_void_p
     L.flbgpu_parser_create.argtypes = [c_char_p, c_char_p, c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_char_p]
@@ -119,6 +121,11 @@ _libc.free.argtypes = [c_void_p]
 
 def _b(s):
     return s.encode() if isinstance(s, str) else s
+
+
+def set_time_now(now):
+    """pins the clock year-less Time_Formats read (0: time(NULL) again)"""
+    lib().flbgpu_set_time_now(ctypes.c_int64(int(now)))
 
 
 def last_error():

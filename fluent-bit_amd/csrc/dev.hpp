@@ -91,6 +91,11 @@ struct DevParser {
     int time_field;                      // the ONE named field that is the time key, -1 if none or several
     int plain_types;                     // no Types cast changes a value's encoded size (all string / none)
     TimePlan plan;                       // fast path of fmt1 (ok == 0: interpreter only)
+    // Time_Format without %Y / %y / %s (src/flb_parser.c:922-941): every lookup reads "<current year> " in front
+    // of the text and starts from today's month and day (:1945-2001).  The three numbers are written into the
+    // filter's device copy of this struct at the start of every run (time(NULL), UTC).
+    int yearless;
+    int now_year, now_mon, now_mday;     // 4-digit year, tm_mon (0..11), tm_mday
 };
 
 // ---- record accessor / key

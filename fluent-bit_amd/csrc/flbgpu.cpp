@@ -46,6 +46,10 @@ extern "C" int flbgpu_init(int device) {
 
 extern "C" int flbgpu_device_cus(void) { return g_cus; }
 
+// the "now" of year-less Time_Formats: time(NULL) unless a test pinned it
+static int64_t g_time_now = 0;
+extern "C" void flbgpu_set_time_now(int64_t now) { g_time_now = now; }
+
 // ------------------------------------------------------------------------------------------ device buffers
 template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vector<T> &v) {
     size_t off = (blob.size() + 15) & ~(size_t) 15;
@@ -140,12 +144,13 @@ static bool expand_time_fmt(const char *fmt, std::string &out, std::string &why)
         p++;
         while (*p == 'E' || *p == 'O') p++;
         switch (*p) {
-        case 'T': case 'X': out += "%H:%M:%S"; break;
-        case 'D': case 'x': out += "%m/%d/%y"; break;
-        case 'F': out += "%Y-%m-%d"; break;
-        case 'R': out += "%H:%M"; break;
-        case 'r': out += "%I:%M:%S %p"; break;
-        case 'c': out += "%a %b %e %H:%M:%S %Y"; break;
+        // "%\x01" marks where the reference's recursive call for the composite returns (kdev.inc DK_FINAL)
+        case 'T': case 'X': out += "%H:%M:%S%\x01"; break;
+        case 'D': case 'x': out += "%m/%d/%y%\x01"; break;
+        case 'F': out += "%Y-%m-%d%\x01"; break;
+        case 'R': out += "%H:%M%\x01"; break;
+        case 'r': out += "%I:%M:%S %p%\x01"; break;
+        case 'c': out += "%a %b %e %H:%M:%S %Y%\x01"; break;
         case 'Z': why = "%Z (time zone abbreviations) is not supported on the GPU path"; return false;
         case '\0': why = "dangling % in time format"; return false;
         default:
@@ -186,6 +191,7 @@ static void build_time_plan(const std::string &fmt, bool has_frac, TimePlan &pl)
             continue;
         }
         if (++i >= fmt.size()) return;
+        if (fmt[i] == '\x01') continue;           // end of a composite directive: nothing to read
         bool ok;
         switch (fmt[i]) {
         case 'd': ok = push(TP_NUM2, 2, TPF_MDAY, 31, 1); mday = true; break;
@@ -240,11 +246,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
     if (time_fmt && time_fmt[0]) {
         std::string tf = time_fmt;
         bool with_year = tf.find("%Y") != std::string::npos || tf.find("%y") != std::string::npos || tf.find("%s") != std::string::npos;
-        if (!with_year) {
-            set_err("parser '%s': year-less Time_Format depends on the wall clock (src/flb_parser.c:1945-2001) and is not supported on the GPU path", p->name.c_str());
-            delete p;
-            return nullptr;
-        }
+        d.yearless = with_year ? 0 : 1;       // "%Y " + fmt over "<current year> " + text, see DevParser::yearless
         d.has_time = 1;
         d.time_with_tz = (tf.find("%z") != std::string::npos || tf.find("%Z") != std::string::npos ||
                           tf.find("%SZ") != std::string::npos || tf.find("%S.%LZ") != std::string::npos) ? 1 : 0;
@@ -623,6 +625,23 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
         !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)) ||
         !f->d_status.ensure(n * TBUF_WORDS * sizeof(uint32_t)))
         return false;
+    {
+        // year-less Time_Formats: today's date (UTC, src/flb_parser.c:1982) into the device copies of the parsers
+        bool any = false;
+        for (auto *pp : f->parsers) any = any || pp->dev.yearless;
+        if (any) {
+            time_t now = g_time_now > 0 ? (time_t) g_time_now : time(NULL);
+            struct tm tmy;
+            gmtime_r(&now, &tmy);
+            for (size_t q = 0; q < f->parsers.size(); q++) {
+                DevParser &d = f->parsers[q]->dev;
+                if (!d.yearless) continue;
+                d.now_year = tmy.tm_year + 1900; d.now_mon = tmy.tm_mon; d.now_mday = tmy.tm_mday;
+                HIPOK(hipMemcpyAsync((uint8_t *) (f->d_parsers.as<DevParser>() + q) + offsetof(DevParser, now_year), &d.now_year, 3 * sizeof(int),
+                                     hipMemcpyHostToDevice, st));
+            }
+        }
+    }
     if (!f->d_ov.ensure((size_t) OV_CAP * 2 * sizeof(unsigned long long))) return false;
     f->pcfg.ov_pairs = f->d_ov.as<unsigned long long>(); f->pcfg.ov_count = &dm->ov_count; f->pcfg.ov_cap = OV_CAP;
     ParserMatchArgs ma;

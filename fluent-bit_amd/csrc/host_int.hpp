@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

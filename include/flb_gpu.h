@@ -78,6 +78,11 @@ void flbgpu_parser_destroy(flbgpu_parser *p);
 int flbgpu_parser_do(flbgpu_parser *p, const char *buf, size_t length, void **out_buf, size_t *out_size,
                      int64_t *out_sec, int64_t *out_nsec);
 
+/* Year-less Time_Formats ("%b %d %H:%M:%S", src/flb_parser.c:922-941) read the current year, month and day
+ * from the clock at every lookup (flb_parser_time_lookup with now == 0 -> time(NULL), :1966-1971).  Tests pin
+ * that clock: now > 0 replaces time(NULL) for every later run of this process, 0 restores it. */
+void flbgpu_set_time_now(int64_t now);
+
 /* ---- filter_parser: replaces cb_parser_init / cb_parser_filter / cb_parser_exit ----------------
  * plugins/filter_parser/filter_parser.c:96-149,174-442.  Properties Key_Name / Parser (repeated) /
  * Reserve_Data / Preserve_Key keep their names and meaning (:460-489). */

@@ -249,6 +249,10 @@ static int parse_subseconds(const char *str, int len, double *subsec)
     return consumed;
 }
 
+/* test hook: pins the time(NULL) of year-less formats (the filters call the lookup with now == 0) */
+static time_t g_now_override = 0;
+void oflb_set_time_now(int64_t now) { g_now_override = (time_t) now; }
+
 /* src/flb_parser.c:1899-2065 (time_zone / system timezone branches not restated) */
 static int time_lookup(const char *time_str, size_t tsize, time_t now, oflb_parser *parser,
                        struct otm *tm, double *ns)
@@ -269,7 +273,7 @@ static int time_lookup(const char *time_str, size_t tsize, time_t now, oflb_pars
         struct tm tmy;
         char *fmt;
         if (time_len + 6 >= (int) buf_size) { free(time_buf); return -1; }
-        time_now = now <= 0 ? time(NULL) : now;
+        time_now = now <= 0 ? (g_now_override > 0 ? g_now_override : time(NULL)) : now;
         gmtime_r(&time_now, &tmy);
         tm->tm.tm_mon = tmy.tm_mon;
         tm->tm.tm_mday = tmy.tm_mday;

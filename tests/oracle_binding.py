@@ -58,6 +58,11 @@ def _take(ptr, size):
         lib().oflb_free(ptr)
     return data
 
+def set_time_now(now):
+    """pins the time(NULL) of year-less Time_Formats (0: the wall clock again)"""
+    lib().oflb_set_time_now(c_int64(int(now)))
+
+
 class Parser:
     """mirrors flb_parser_create(name, "regex", regex, skip_empty, time_fmt, time_key, time_offset,
     time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.

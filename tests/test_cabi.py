@@ -37,7 +37,7 @@ def test_unsupported_constructs_fail_at_create(g):
         with pytest.raises(ValueError):
             g.Parser("^(?<x>" + rx + ")$")
     with pytest.raises(ValueError):
-        g.Parser(r"^(?<time>.*)$", time_fmt="%b %d %H:%M:%S", time_key="time")     # year-less
+        g.Parser(r"^(?<time>.*)$", time_fmt="%Y %Z", time_key="time")              # zone abbreviations
     with pytest.raises(ValueError):
         g.FilterGrep([("regex", "log a"), ("exclude", "log b")], "AND")
 

@@ -94,6 +94,8 @@ def test_strptime_kat_on_device(g):
         by_fmt.setdefault(c["fmt"], []).append(c["text"].encode("latin-1") if isinstance(c["text"], str) else bytes(c["text"]))
     n_fmt = n_cases = refused = 0
     rx = r"\A(?<t>(?m:.*))\z"
+    now = 1709164800 + 86399                          # 2024-02-29 23:59:59 UTC: what year-less formats read from the clock
+    g.set_time_now(now); ob.set_time_now(now)
     for fmt, texts in by_fmt.items():
         blob = b"".join(_rec({"log": t}, 11, i) for i, t in enumerate(texts))
         for strict in (True, False):
@@ -114,7 +116,39 @@ def test_strptime_kat_on_device(g):
                 assert x == y, (fmt, strict, keep, first_diff(x[1], y[1]))
         n_fmt += 1
         n_cases += len(texts)
+    g.set_time_now(0); ob.set_time_now(0)
     assert n_fmt > 20 and n_cases > 5000, (n_fmt, n_cases, refused)
+
+
+def test_yearless_time_formats(g):
+    """Time_Format without a year (conf/parsers.conf syslog-rfc3164-local, src/flb_parser.c:922-941,1945-2001): the
+    current year is read in front of the text, month and day default to today's, texts of 58..63 bytes fail."""
+    SYSLOG = r'^\<(?<pri>[0-9]+)\>(?<time>[^ ]* {1,2}[^ ]* [^ ]*) (?<host>[^ ]*) (?<ident>[a-zA-Z0-9_\/\.\-]*)(?:\[(?<pid>[0-9]+)\])?(?:[^\:]*\:)? *(?<message>.*)$'
+    lines = [b"<34>Oct 11 22:14:15 mymachine su[123]: 'su root' failed", b"<13>Feb  5 17:32:18 10.0.0.99 app: hello", b"<13>Feb 29 00:00:00 h a: leap",
+             b"<13>Feb 30 00:00:00 h a: no such day", b"<1>  Mar 1 01:02:03 h a: leading blanks", b"<1>Dec 31 23:59:60 h a: leap second", b"<1>junk h a: x",
+             b"<1>Jan 1 1:2:3 h a: short"]
+    blob = b"".join(_rec({"log": l}, 3, i) for i, l in enumerate(lines))
+    for now in (1709164800 + 5, 1735689599, 1735689600, 951782400):
+        g.set_time_now(now); ob.set_time_now(now)
+        for strict in (True, False):
+            for fmt in ("%b %d %H:%M:%S", "%b %e %T", "%H:%M:%S", "%d %b", "%b %d %H:%M:%S.%L"):
+                kw = dict(regex=SYSLOG, time_fmt=fmt, time_key="time", time_strict=strict)
+                po = ob.Parser(**kw); pg = g.Parser(**kw)
+                fp = g.FilterParser("log", [pg])
+                x, y = ob.FilterParser("log", [po]).filter(blob), fp.filter(blob)
+                fp.close(); pg.close()
+                assert x == y, (now, strict, fmt, first_diff(x[1], y[1]))
+        # the 64-byte buffer rule: text lengths around 57 / 58 / 63 / 64
+        rx = r"^(?<time>.*)$"
+        texts = [b"Oct 11 22:14:15" + b" " * k for k in (0, 40, 41, 42, 43, 47, 48, 49, 60, 200)]
+        tb = b"".join(_rec({"log": t}, 3, i) for i, t in enumerate(texts))
+        kw = dict(regex=rx, time_fmt="%b %d %H:%M:%S", time_key="time", time_keep=True)
+        po = ob.Parser(**kw); pg = g.Parser(**kw)
+        fp = g.FilterParser("log", [pg])
+        x, y = ob.FilterParser("log", [po]).filter(tb), fp.filter(tb)
+        fp.close(); pg.close()
+        assert x == y, (now, first_diff(x[1], y[1]))
+    g.set_time_now(0); ob.set_time_now(0)
 
 
 def _nest(depth, leaf=b"\x01"):
