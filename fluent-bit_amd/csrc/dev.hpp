@@ -231,6 +231,42 @@ struct GrepArgs {
 };
 
 
+// ---- fused flb_filter_do over [filter_parser, filter_grep] (fused_kernels.inc)
+struct FusedArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n, bytes;
+    FParserCfg cfg;
+    const DevParser *parsers;
+    uint16_t *chk;                   // reverse-DFA checkpoints [wave slots][chk_len][64]
+    uint32_t chk_len;
+    uint32_t lds_src_off, lds_bytes; // block of parser 0's hot ASCII tables staged into LDS (0 bytes: none)
+    uint32_t full_tables;            // the staged block holds the reverse tables too
+    uint32_t caps_lds_off, lds_total;
+    uint32_t caps_stride;
+    const GrepRule *rules;
+    int nrules, logical_op;
+    uint32_t rule_fmask[MAX_RULES];  // per rule: the parser's named fields its key names (bit f)
+    uint32_t *keep_len;              // [n] size of the parsed record when grep keeps it, else 0
+    uint32_t *kept;                  // entries of the kept records
+    uint32_t kept_cap;
+    unsigned int *kept_count;
+    unsigned long long *first_bad;
+    unsigned long long *counts;      // [0] decoded, [1] records filter_parser emits, [2] records outside the fast shape,
+                                     // [4] bytes filter_parser emits, [5] records filter_grep keeps
+};
+struct FusedEmitArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    FParserCfg cfg;
+    const DevParser *parsers;
+    const uint32_t *kept;
+    uint64_t n_kept, n_valid;
+    uint32_t caps_stride;
+    const uint64_t *out_off;
+    uint8_t *out;
+};
+
 // ---- filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c)
 enum { L2M_COUNTER = 0, L2M_GAUGE = 1, L2M_HISTOGRAM = 2 };
 constexpr int L2M_MAX_LABELS = 128;          // MAX_LABEL_COUNT (log_to_metrics.h:50)
@@ -355,6 +391,9 @@ void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *o
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
+void launch_pg_match(const FusedArgs &a, int grid, int threads, hipStream_t st);
+void launch_pg_emit(const FusedEmitArgs &a, hipStream_t st);
+uint32_t pg_kept_stride_words(uint32_t caps_stride);
 void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);

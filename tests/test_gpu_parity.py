@@ -452,3 +452,71 @@ def test_full_size_properties_10M(g):
     p.close()
     for d in (d_data, d_off, d_off2):
         L.flbgpu_dev_free(d)
+
+
+def _chain_both(g, blob, pargs, rules, op=None):
+    """flb_filter_do over [filter_parser, filter_grep]: the device chain (fused pair when the configuration allows)
+    against the oracle's two filters run one after the other."""
+    po = ob.Parser(**pargs)
+    r1, o1 = ob.FilterParser("log", [po]).filter(blob)
+    cur = o1 if r1 == ob.MODIFIED else blob
+    r2, o2 = ob.Grep(rules, op).filter(cur)
+    want = (ob.MODIFIED, o2) if r2 == ob.MODIFIED else ((ob.MODIFIED, o1) if r1 == ob.MODIFIED else (ob.NOTOUCH, None))
+    pg = g.Parser(**pargs)
+    fp = g.FilterParser("log", [pg]); fg = g.FilterGrep(rules, op)
+    ch = g.FilterChain([fp, fg])
+    got = ch.filter(blob)
+    stats = ch.last_stats()
+    fp.close(); fg.close(); pg.close()
+    return want, got, stats, (r1, o1, r2, o2)
+
+
+def test_fused_parser_grep_pair(g):
+    """the one-pass evaluation of [filter_parser, filter_grep] (fused_kernels.inc) is flb_filter_do over the two"""
+    rng = random.Random(21)
+    data, off, ep = synth.apache_records(6000)
+    recs = []
+    for i in range(6000):
+        m = bytearray(data[int(off[i]) + 21:int(off[i + 1])])
+        t = rng.random()
+        if t < 0.15:                                   # lines the parser refuses / parses differently
+            k = rng.randrange(len(m))
+            m[k] = rng.choice(b' "[]\nx')
+        elif t < 0.2:
+            m = m[:rng.randrange(1, len(m))]
+        body = {"log": bytes(m)}
+        if t > 0.97: body = {"other": b"x", "code": b"503"}            # no Key_Name: unparsed, grep sees the original keys
+        if 0.95 < t <= 0.97: body = {"log": 5}
+        sec = rng.randrange(2**31)
+        if t < 0.01: sec = 0xffffffff                                   # group marker
+        recs.append(synth.mp([[synth.ext_ts(sec, 0 if sec == 0xffffffff else rng.randrange(10**9)), {}], body]))
+    blob = b"".join(recs)
+    base = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    cases = [
+        (base, [("regex", r"code ^5\d\d$")], None),
+        (base, [("exclude", "method GET")], None),
+        (base, [("regex", "code ^2"), ("regex", "agent curl")], "AND"),
+        (base, [("regex", "code ^404$"), ("regex", "method ^P"), ("regex", "nokey x")], "OR"),
+        (base, [("exclude", "code ^2"), ("exclude", "code ^3")], "OR"),
+        (base, [("regex", "nokey x")], None),                           # nothing kept
+        (base, [("regex", "log .")], None),                             # key only in unparsed records
+        (base, [("regex", "time 2")], None),                            # the time field is consumed (Time_Keep off): key absent
+        (dict(base, time_keep=True), [("regex", "time ^1")], None),
+        (dict(base, skip_empty=False), [("regex", "user ^-$"), ("exclude", "referer ^$")], None),
+        (dict(regex=r"^(?<x>\S+) (?<x>\S+) (?<y>.*)$"), [("regex", r"x ^-$")], None),          # duplicate name: the LAST entry decides
+        (dict(regex=r"(?<w>[a-z]+)/(?<v>\d)"), [("regex", "w ^(http|curl)$")], None),       # not start-anchored: reverse pass
+        (base, [("regex", "host ."), ("exclude", "nokey x")], None),    # keeps every parsed record: grep is NOTOUCH
+    ]
+    for pargs, rules, op in cases:
+        want, got, stats, parts = _chain_both(g, blob, pargs, rules, op)
+        assert got[0] == want[0], (rules, op, got[0], want[0])
+        assert got[1] == want[1], (rules, op, first_diff(want[1], got[1]))
+        r1, o1, r2, o2 = parts
+        if r1 == ob.MODIFIED:
+            assert stats[0]["out_records"] == ob.count_records(o1) and stats[0]["out_bytes"] == len(o1), (rules, stats)
+        if r2 == ob.MODIFIED:
+            assert stats[1]["out_records"] == ob.count_records(o2) and stats[1]["out_bytes"] == len(o2), (rules, stats)
+    # a malformed record ends the parser's loop: everything from it on is missing
+    broken = blob[:len(blob) // 2] + b"\x93\x01\x02\x03" + blob[len(blob) // 2:]
+    want, got, stats, parts = _chain_both(g, broken, base, [("regex", r"code ^5\d\d$")], None)
+    assert got == want, first_diff(want[1], got[1])
