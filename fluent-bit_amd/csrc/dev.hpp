@@ -243,7 +243,9 @@ struct FusedArgs {
     uint32_t lds_src_off, lds_bytes; // block of parser 0's hot ASCII tables staged into LDS (0 bytes: none)
     uint32_t full_tables;            // the staged block holds the reverse tables too
     uint32_t caps_lds_off, lds_total;
+    uint32_t slot_lds_off, have_slots;   // per-lane 36-byte slots for the time text (0: LDS too small, read from global memory)
     uint32_t caps_stride;
+    uint32_t debug;                  // timing aid (FLBGPU_PG_DEBUG): 1 skip the capture program, 2 skip the field pass, 4 skip grep
     const GrepRule *rules;
     int nrules, logical_op;
     uint32_t rule_fmask[MAX_RULES];  // per rule: the parser's named fields its key names (bit f)

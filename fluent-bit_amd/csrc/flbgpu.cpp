@@ -815,6 +815,11 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     if (getenv("FLBGPU_NO_LDS") || tab_bytes + caps_bytes > 160 * 1024) { tab_bytes = 0; src_off = 0; }
     fa.lds_src_off = src_off; fa.lds_bytes = tab_bytes; fa.full_tables = (tab_bytes && src_off == 0) ? 1 : 0;
     fa.caps_lds_off = tab_bytes; fa.lds_total = tab_bytes + caps_bytes; fa.caps_stride = fp->caps_stride;
+    {
+        const uint32_t slot_bytes = (uint32_t) threads * 36;       // PG_SLOT
+        const uint32_t at = (fa.lds_total + 15) & ~15u;
+        if (at + slot_bytes <= 160 * 1024) { fa.slot_lds_off = at; fa.have_slots = 1; fa.lds_total = at + slot_bytes; }
+    }
     fa.rules = fg->d_rules.as<GrepRule>(); fa.nrules = (int) fg->rules.size(); fa.logical_op = fg->logical_op;
     for (size_t i = 0; i < fg->rules.size(); i++) {
         // the parser's named fields the rule's key names (flb_ra_key.c:118: the last one present decides)
@@ -824,12 +829,17 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
             if (d0.field_name_len[f] == k.key_len && !memcmp(d0.names + d0.field_name_off[f], k.key, (size_t) k.key_len)) m |= 1u << f;
         fa.rule_fmask[i] = m;
     }
+    fa.debug = getenv("FLBGPU_PG_DEBUG") ? (uint32_t) atoi(getenv("FLBGPU_PG_DEBUG")) : 0;
     fa.keep_len = fp->d_len.as<uint32_t>(); fa.kept = fp->d_kept.as<uint32_t>(); fa.kept_cap = (uint32_t) (n > 0xFFFFFFFFull ? 0xFFFFFFFFu : n);
     fa.kept_count = &dm->kept_count; fa.first_bad = &dm->first_bad; fa.counts = dm->counts;
     { ProfScope ps(fp, st, "k_pg_match"); launch_pg_match(fa, grid, threads, st); }
     if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (getenv("FLBGPU_DEBUG"))
+        fprintf(stderr, "[flbgpu] pg_match: n %llu decoded %llu parser_out %llu generic %llu bytes %llu kept %llu kept_count %u first_bad %llu lds %u+%u src_off %u\n",
+                (unsigned long long) n, hm.counts[0], hm.counts[1], hm.counts[2], hm.counts[4], hm.counts[5], hm.kept_count, hm.first_bad, tab_bytes, caps_bytes, src_off);
     // records outside the fast shape, a parser that emits nothing (NOTOUCH: grep would see the ORIGINAL chunk), a
     // grep that keeps everything (NOTOUCH: the chain's output is the parser's): the unfused kernels
+    if (fa.debug) { fp->last_in = hm.counts[0]; memset(out, 0, sizeof(*out)); return 1; }
     if (hm.counts[2] > 0 || hm.counts[1] == 0 || hm.first_bad != ~0ull) return 0;
     if (hm.counts[5] == hm.counts[1]) return 0;
     fp->last_in = hm.counts[0]; fp->last_out = hm.counts[1];

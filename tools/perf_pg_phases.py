@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""time of k_pg_match with phases switched off (FLBGPU_PG_DEBUG bits: 1 no capture program, 2 no field pass, 4 no grep)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import flbamd_loader, synth
+from bench import APACHE2, TIME_FMT, GREP_RULE
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+g = flbamd_loader.load(); g.init(0); L = g.lib()
+data, off, ep = synth.apache_records(n)
+d_data = L.flbgpu_dev_alloc(data.nbytes); d_off = L.flbgpu_dev_alloc(off.nbytes)
+L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, data.nbytes); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
+chunk = g.DevChunk(d_data, d_off, n, data.nbytes)
+p = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+fp = g.FilterParser("log", [p]); fg = g.FilterGrep([GREP_RULE]); ch = g.FilterChain([fp, fg])
+for dbg in (0, 4, 12, 20, 6, 7):
+    if dbg: os.environ["FLBGPU_PG_DEBUG"] = str(dbg)
+    else: os.environ.pop("FLBGPU_PG_DEBUG", None)
+    ch.filter_dev(chunk)
+    fp.profile(True)
+    for _ in range(3): ch.filter_dev(chunk)
+    prof = dict(fp.profile_read()); fp.profile(False)
+    print("debug=%d  " % dbg + "  ".join("%s %.3f" % (k, v[0] / max(v[1], 1)) for k, v in prof.items()), flush=True)
