@@ -231,40 +231,33 @@ struct GrepArgs {
 };
 
 
-// ---- fused flb_filter_do over [filter_parser, filter_grep] (fused_kernels.inc)
-struct FusedArgs {
+// ---- flb_filter_do over [filter_parser, filter_grep] without materialising the parsed chunk (fused_kernels.inc)
+struct PgDecideArgs {
     const uint8_t *data;
     const uint64_t *row_off;
-    uint64_t n, bytes;
-    FParserCfg cfg;
-    const DevParser *parsers;
-    uint16_t *chk;                   // reverse-DFA checkpoints [wave slots][chk_len][64]
-    uint32_t chk_len;
-    uint32_t lds_src_off, lds_bytes; // block of parser 0's hot ASCII tables staged into LDS (0 bytes: none)
-    uint32_t full_tables;            // the staged block holds the reverse tables too
-    uint32_t caps_lds_off, lds_total;
-    uint32_t slot_lds_off, have_slots;   // per-lane 36-byte slots for the time text (0: LDS too small, read from global memory)
-    uint32_t caps_stride;
-    uint32_t debug;                  // timing aid (FLBGPU_PG_DEBUG): 1 skip the capture program, 2 skip the field pass, 4 skip grep
+    uint64_t n, n_cols;              // rows in front of the first decoder error / column length
+    const uint32_t *info;            // record columns of filter_parser's pass 1
+    const uint32_t *caps;            // capture span columns
+    const uint32_t *out_len;         // [n] size of the record filter_parser would emit
     const GrepRule *rules;
     int nrules, logical_op;
     uint32_t rule_fmask[MAX_RULES];  // per rule: the parser's named fields its key names (bit f)
-    uint32_t *keep_len;              // [n] size of the parsed record when grep keeps it, else 0
-    uint32_t *kept;                  // entries of the kept records
-    uint32_t kept_cap;
+    uint32_t *keep_len;              // [n] out_len when filter_grep keeps the record, else 0
+    uint32_t *kept;                  // indices of the kept records (wave-aggregated append, any order)
     unsigned int *kept_count;
-    unsigned long long *first_bad;
-    unsigned long long *counts;      // [0] decoded, [1] records filter_parser emits, [2] records outside the fast shape,
-                                     // [4] bytes filter_parser emits, [5] records filter_grep keeps
+    unsigned long long *counts;      // [4] bytes filter_parser emits, [5] records filter_grep keeps, [6] records filter_parser emits
 };
-struct FusedEmitArgs {
+struct PgEmitArgs {
     const uint8_t *data;
     const uint64_t *row_off;
     FParserCfg cfg;
     const DevParser *parsers;
+    uint64_t n_cols;
+    const uint32_t *info;
+    const uint32_t *caps;
+    const uint64_t *null_mask;
     const uint32_t *kept;
-    uint64_t n_kept, n_valid;
-    uint32_t caps_stride;
+    uint64_t n_kept;
     const uint64_t *out_off;
     uint8_t *out;
 };
@@ -393,9 +386,8 @@ void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *o
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
-void launch_pg_match(const FusedArgs &a, int grid, int threads, hipStream_t st);
-void launch_pg_emit(const FusedEmitArgs &a, hipStream_t st);
-uint32_t pg_kept_stride_words(uint32_t caps_stride);
+void launch_pg_decide(const PgDecideArgs &a, hipStream_t st);
+void launch_pg_emit(const PgEmitArgs &a, hipStream_t st);
 void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);

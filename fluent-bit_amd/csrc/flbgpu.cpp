@@ -579,18 +579,19 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[8]; unsigned int ov_count; unsigned int kept_count; };
 static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FParserCfg's side list
 
-static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
+// Pass 1 of filter_parser on a device chunk: every record decoded, located, matched and sized (locate / rx /
+// finish, the generic kernel for the records outside the fast shape).  On return out_len[r] (f->d_len) holds the
+// size of record r's output (0: nothing is emitted for it), *n_valid the rows in front of the first decoder
+// error, hm the counters.  The emit pass (or the fused pair's decide + emit) follows.
+static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid) {
     uint64_t n = in->n;
-    *ret = FLBGPU_FILTER_NOTOUCH;
-    f->last_in = 0; f->last_out = 0;
-    if (n == 0) return true;
     if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
     MiscWords *dm = f->d_misc.as<MiscWords>();
     // host mirror of the counters + the output size, page-locked so that the small copies are real
     // asynchronous DMA transfers
     if (!f->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return false;
     MiscWords &hm = *f->hp_misc.as<MiscWords>();
-    uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
+    *dm_out = dm; *hm_out = &hm;
     const uint64_t *row_off = in->row_off;
     const uint8_t *data = (const uint8_t *) in->data;
     // scratch sizing: one state id per byte boundary of the longest record
@@ -686,6 +687,22 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
         if (hm.counts[2] > 0 && !run_generic()) return false;
     }
     if (hm.first_bad < n) n = hm.first_bad;                 // the decoder loop ends at the first bad record
+    *n_valid = n;
+    return true;
+}
+
+static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
+    uint64_t n = in->n;
+    *ret = FLBGPU_FILTER_NOTOUCH;
+    f->last_in = 0; f->last_out = 0;
+    if (n == 0) return true;
+    MiscWords *dm = nullptr, *hmp = nullptr;
+    if (!parser_size_pass(f, in, st, &dm, &hmp, &n)) return false;
+    MiscWords &hm = *hmp;
+    uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
+    const uint64_t *row_off = in->row_off;
+    const uint8_t *data = (const uint8_t *) in->data;
+    const int cus = g_cus > 0 ? g_cus : 256;
     if (n == 0) return true;
     // write offsets + the number of emitted records (what flb_mp_count_log_records would report) in one pass
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st, &dm->counts[1]); }
@@ -764,10 +781,12 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
 }
 
 // ------------------------------------------------------------------------------------------ fused pair
-// flb_filter_do over [filter_parser, filter_grep] in one pass (fused_kernels.inc).  Only grep's output and the
-// two filters' record / byte counts are observable, so the parsed chunk is never materialised.
-// Configuration the fused kernels cover: one Format regex parser without Types casts, plain Key_Name,
-// Reserve_Data / Preserve_Key off; any rule set.
+// flb_filter_do over [filter_parser, filter_grep] without the parsed chunk (fused_kernels.inc).  Only grep's output
+// and the two filters' record / byte counts are observable, so filter_parser's emit pass, grep's decode of the
+// parsed chunk and the gather are replaced by: rules evaluated on the capture spans (k_pg_decide), a scan, and an
+// emit of the kept records only (k_pg_emit).
+// Configuration covered: one Format regex parser without Types casts, plain Key_Name, Reserve_Data / Preserve_Key
+// off; any rule set.
 static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     if (getenv("FLBGPU_NO_FUSE")) return false;
     if (fp->kind != F_PARSER || fg->kind != F_GREP) return false;
@@ -778,88 +797,56 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     return true;
 }
 
-// 1: ran fused (*ret / *out / stats set), 0: this chunk needs the unfused kernels, -1: failure
+// 1: ran fused (*out / stats set), 0: this chunk needs the unfused kernels, -1: failure
 static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, flbgpu_chain_stat *stats2) {
     hipStream_t st = fp->stream;
     uint64_t n = in->n;
     if (n == 0) return 0;
-    if (!fp->d_misc.ensure(sizeof(MiscWords)) || !fp->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return -1;
-    MiscWords *dm = fp->d_misc.as<MiscWords>();
-    MiscWords &hm = *fp->hp_misc.as<MiscWords>();
+    MiscWords *dm = nullptr, *hmp = nullptr;
+    // filter_parser's pass 1: every record sized (out_len), spans and record columns in HBM
+    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n)) return -1;
+    MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
-    memset(&hm, 0, sizeof(hm));
-    hm.first_bad = ~0ull;
-    if (hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0) return 0;           // (records for k_parser_emit_exact: unfused)
     const DevParser &d0 = fp->parsers[0]->dev;
-    const uint32_t chk_len = 4096 / CHK_STEP + 3;
-    const int cus = g_cus > 0 ? g_cus : 256;
-    const int threads = MATCH_BLOCK;
-    int grid = cus;
-    const uint64_t need_blocks = (n + threads - 1) / threads;
-    if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
-    const uint32_t stride_w = pg_kept_stride_words(fp->caps_stride);
-    if (!fp->d_rid.ensure((size_t) grid * (threads / 64) * 64 * chk_len * sizeof(uint16_t)) || !fp->d_len.ensure(n * sizeof(uint32_t)) ||
-        !fp->d_off.ensure((n + 1) * sizeof(uint64_t)) || !fp->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t)) ||
-        !fp->d_kept.ensure((size_t) n * stride_w * sizeof(uint32_t)))
-        return -1;
-    FusedArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.data = (const uint8_t *) in->data; fa.row_off = in->row_off; fa.n = n; fa.bytes = in->bytes;
-    fa.cfg = fp->pcfg; fa.parsers = fp->d_parsers.as<DevParser>();
-    fa.chk = fp->d_rid.as<uint16_t>(); fa.chk_len = chk_len;
-    // LDS: a start-anchored pattern walks forward only -> the forward tables alone (ft | ft2 | cls | col, the tail of
-    // the hot block); otherwise the whole hot block.  Tables that do not fit stay in global memory.
-    const uint32_t caps_bytes = (uint32_t) threads * (fp->caps_stride + 1) * (uint32_t) sizeof(uint16_t);
-    uint32_t src_off = d0.fwd_first ? (d0.ascii.off_ft & ~15u) : 0;
-    uint32_t tab_bytes = d0.ascii.hot_bytes - src_off;
-    if (getenv("FLBGPU_NO_LDS") || tab_bytes + caps_bytes > 160 * 1024) { tab_bytes = 0; src_off = 0; }
-    fa.lds_src_off = src_off; fa.lds_bytes = tab_bytes; fa.full_tables = (tab_bytes && src_off == 0) ? 1 : 0;
-    fa.caps_lds_off = tab_bytes; fa.lds_total = tab_bytes + caps_bytes; fa.caps_stride = fp->caps_stride;
-    {
-        const uint32_t slot_bytes = (uint32_t) threads * 36;       // PG_SLOT
-        const uint32_t at = (fa.lds_total + 15) & ~15u;
-        if (at + slot_bytes <= 160 * 1024) { fa.slot_lds_off = at; fa.have_slots = 1; fa.lds_total = at + slot_bytes; }
-    }
-    fa.rules = fg->d_rules.as<GrepRule>(); fa.nrules = (int) fg->rules.size(); fa.logical_op = fg->logical_op;
+    if (!fp->d_keep.ensure(n * sizeof(uint32_t)) || !fp->d_kept.ensure((size_t) n * sizeof(uint32_t))) return -1;
+    PgDecideArgs da;
+    memset(&da, 0, sizeof(da));
+    da.data = (const uint8_t *) in->data; da.row_off = in->row_off; da.n = n; da.n_cols = in->n;
+    da.info = fp->d_info.as<uint32_t>(); da.caps = fp->d_caps.as<uint32_t>(); da.out_len = fp->d_len.as<uint32_t>();
+    da.rules = fg->d_rules.as<GrepRule>(); da.nrules = (int) fg->rules.size(); da.logical_op = fg->logical_op;
     for (size_t i = 0; i < fg->rules.size(); i++) {
         // the parser's named fields the rule's key names (flb_ra_key.c:118: the last one present decides)
         uint32_t m = 0;
         const DevKey &k = fg->rules[i].key;
         for (int f = 0; f < d0.nfields; f++)
             if (d0.field_name_len[f] == k.key_len && !memcmp(d0.names + d0.field_name_off[f], k.key, (size_t) k.key_len)) m |= 1u << f;
-        fa.rule_fmask[i] = m;
+        da.rule_fmask[i] = m;
     }
-    fa.debug = getenv("FLBGPU_PG_DEBUG") ? (uint32_t) atoi(getenv("FLBGPU_PG_DEBUG")) : 0;
-    fa.keep_len = fp->d_len.as<uint32_t>(); fa.kept = fp->d_kept.as<uint32_t>(); fa.kept_cap = (uint32_t) (n > 0xFFFFFFFFull ? 0xFFFFFFFFu : n);
-    fa.kept_count = &dm->kept_count; fa.first_bad = &dm->first_bad; fa.counts = dm->counts;
-    { ProfScope ps(fp, st, "k_pg_match"); launch_pg_match(fa, grid, threads, st); }
-    if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-    if (getenv("FLBGPU_DEBUG"))
-        fprintf(stderr, "[flbgpu] pg_match: n %llu decoded %llu parser_out %llu generic %llu bytes %llu kept %llu kept_count %u first_bad %llu lds %u+%u src_off %u\n",
-                (unsigned long long) n, hm.counts[0], hm.counts[1], hm.counts[2], hm.counts[4], hm.counts[5], hm.kept_count, hm.first_bad, tab_bytes, caps_bytes, src_off);
-    // records outside the fast shape, a parser that emits nothing (NOTOUCH: grep would see the ORIGINAL chunk), a
-    // grep that keeps everything (NOTOUCH: the chain's output is the parser's): the unfused kernels
-    if (fa.debug) { fp->last_in = hm.counts[0]; memset(out, 0, sizeof(*out)); return 1; }
-    if (hm.counts[2] > 0 || hm.counts[1] == 0 || hm.first_bad != ~0ull) return 0;
-    if (hm.counts[5] == hm.counts[1]) return 0;
-    fp->last_in = hm.counts[0]; fp->last_out = hm.counts[1];
-    fg->last_in = hm.counts[1]; fg->last_out = hm.counts[5];
-    if (stats2) {
-        stats2[0].ret = FLBGPU_FILTER_MODIFIED; stats2[0].in_records = hm.counts[0]; stats2[0].out_records = hm.counts[1]; stats2[0].out_bytes = hm.counts[4];
-        stats2[1].ret = FLBGPU_FILTER_MODIFIED; stats2[1].in_records = hm.counts[1]; stats2[1].out_records = hm.counts[5];
-    }
-    { ProfScope ps(fp, st, "k_scan"); launch_scan(fp->d_len.as<uint32_t>(), n, fp->d_scan_tmp.as<uint64_t>(), fp->d_off.as<uint64_t>(), st); }
+    da.keep_len = fp->d_keep.as<uint32_t>(); da.kept = fp->d_kept.as<uint32_t>(); da.kept_count = &dm->kept_count; da.counts = dm->counts;
+    { ProfScope ps(fp, st, "k_pg_decide"); launch_pg_decide(da, st); }
+    { ProfScope ps(fp, st, "k_scan"); launch_scan(da.keep_len, n, fp->d_scan_tmp.as<uint64_t>(), fp->d_off.as<uint64_t>(), st); }
     total = 0;
-    if (hipMemcpyAsync(&total, fp->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&total, fp->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) return -1;
-    if (stats2) stats2[1].out_bytes = total;
+    // a parser that emits nothing (NOTOUCH: grep would see the ORIGINAL chunk) or a grep that keeps everything
+    // (NOTOUCH: the chain's output is the parser's): the unfused kernels
+    if (hm.counts[6] == 0 || hm.counts[5] == hm.counts[6]) return 0;
+    fp->last_in = hm.counts[0]; fp->last_out = hm.counts[6];
+    fg->last_in = hm.counts[6]; fg->last_out = hm.counts[5];
+    if (stats2) {
+        stats2[0].ret = FLBGPU_FILTER_MODIFIED; stats2[0].in_records = hm.counts[0]; stats2[0].out_records = hm.counts[6]; stats2[0].out_bytes = hm.counts[4];
+        stats2[1].ret = FLBGPU_FILTER_MODIFIED; stats2[1].in_records = hm.counts[6]; stats2[1].out_records = hm.counts[5]; stats2[1].out_bytes = total;
+    }
     memset(out, 0, sizeof(*out));
     if (total == 0) return 1;                               // every record dropped: MODIFIED with an empty output
     if (!fg->d_out.ensure(total + 16)) return -1;
-    FusedEmitArgs ea;
+    PgEmitArgs ea;
     memset(&ea, 0, sizeof(ea));
-    ea.data = fa.data; ea.row_off = fa.row_off; ea.cfg = fp->pcfg; ea.parsers = fa.parsers; ea.kept = fa.kept;
-    ea.n_kept = hm.kept_count; ea.n_valid = n; ea.caps_stride = fp->caps_stride; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
+    ea.data = da.data; ea.row_off = da.row_off; ea.cfg = fp->pcfg; ea.parsers = fp->d_parsers.as<DevParser>(); ea.n_cols = in->n;
+    ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
+    ea.kept = da.kept; ea.n_kept = hm.kept_count; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
     { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, st); }
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
