@@ -36,6 +36,7 @@ struct DevDfa {
     uint32_t lds_bytes;
 };
 
+constexpr int MAX_RULES_PG = 64;         // (= MAX_RULES of filter_grep)
 constexpr int MAX_GROUPS = 32;           // capture registers incl. group 0
 constexpr int MAX_NAMES = 32;
 constexpr int MAX_TIMEFMT = 96;
@@ -139,6 +140,20 @@ enum {
     RF_RXOK = 64,          // parser 0's regex matched, spans published
     RF_GENERIC = 128,      // needs k_parser_generic
     RF_EXACT = 256,        // a Types float value needs the exact decimal conversion: k_parser_emit_exact rewrites the record
+    RF_PGDONE = 512,       // pair [filter_parser, filter_grep]: grep's rules were evaluated on the spans by k_parser_rx ...
+    RF_PGKEEP = 1024,      // ... and keep the record
+};
+constexpr uint32_t PG_UNDECIDED = 0xFFFFFFFFu;   // keep_len of a row whose rules k_pg_decide still has to evaluate
+
+struct GrepRule;
+// grep's rules handed to filter_parser's kernels when the two filters run as a pair (device memory)
+struct PgInline {
+    const GrepRule *rules;
+    int nrules, logical_op;
+    uint32_t rule_fmask[MAX_RULES_PG];    // per rule: the parser's named fields its key names
+    uint32_t rule_lds_off[MAX_RULES_PG], rule_lds_bytes[MAX_RULES_PG];   // match-only DFA block in LDS, relative to pg_lds_off (0xFFFFFFFF: global)
+    uint32_t static_drop;                 // named fields never packed: time fields consumed when Time_Keep is off
+    uint32_t time_fields;                 // named fields whose presence depends on the time lookup
 };
 
 constexpr uint32_t CAP_UNSET = 0xFFFFFFFFu;
@@ -185,6 +200,10 @@ struct ParserMatchArgs {
     unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel,
                                      // [3] records for k_parser_emit_exact
     uint64_t bytes;                  // chunk size (bounds the coalesced tile loads)
+    // pair mode (fused_kernels.inc): grep's rules evaluated inline; nullptr otherwise
+    const PgInline *pg;
+    uint32_t pg_lds_off;             // k_parser_rx: where the rules' DFA blocks are staged in its dynamic LDS
+    uint32_t *pg_keep_len;           // [n] written by k_parser_finish: out_len when kept, 0, or PG_UNDECIDED
 };
 
 struct ParserEmitArgs {
@@ -242,9 +261,9 @@ struct PgDecideArgs {
     const GrepRule *rules;
     int nrules, logical_op;
     uint32_t rule_fmask[MAX_RULES];  // per rule: the parser's named fields its key names (bit f)
+    uint32_t rule_lds_off[MAX_RULES], rule_lds_bytes[MAX_RULES];   // the rule's match-only DFA block in LDS (off 0xFFFFFFFF: not staged)
+    uint32_t lds_total;
     uint32_t *keep_len;              // [n] out_len when filter_grep keeps the record, else 0
-    uint32_t *kept;                  // indices of the kept records (wave-aggregated append, any order)
-    unsigned int *kept_count;
     unsigned long long *counts;      // [4] bytes filter_parser emits, [5] records filter_grep keeps, [6] records filter_parser emits
 };
 struct PgEmitArgs {
@@ -256,8 +275,8 @@ struct PgEmitArgs {
     const uint32_t *info;
     const uint32_t *caps;
     const uint64_t *null_mask;
-    const uint32_t *kept;
-    uint64_t n_kept;
+    const uint32_t *keep_len;
+    uint64_t n;
     const uint64_t *out_off;
     uint8_t *out;
 };
@@ -386,8 +405,8 @@ void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *o
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
-void launch_pg_decide(const PgDecideArgs &a, hipStream_t st);
-void launch_pg_emit(const PgEmitArgs &a, hipStream_t st);
+void launch_pg_decide(const PgDecideArgs &a, int cus, hipStream_t st);
+void launch_pg_emit(const PgEmitArgs &a, int cus, hipStream_t st);
 void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);

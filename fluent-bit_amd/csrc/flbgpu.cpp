@@ -583,7 +583,11 @@ static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FP
 // finish, the generic kernel for the records outside the fast shape).  On return out_len[r] (f->d_len) holds the
 // size of record r's output (0: nothing is emitted for it), *n_valid the rows in front of the first decoder
 // error, hm the counters.  The emit pass (or the fused pair's decide + emit) follows.
-static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid) {
+// pair mode (filter_grep follows and is evaluated inline): grep's rules for k_parser_rx, keep_len for k_parser_finish
+struct PairCtx { PgInline pg; uint32_t *keep_len; };
+
+static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
+                             PairCtx *pair = nullptr) {
     uint64_t n = in->n;
     if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
     MiscWords *dm = f->d_misc.as<MiscWords>();
@@ -653,6 +657,22 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr;
+    if (pair) {
+        // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
+        uint32_t at = (ma.lds_total + 15) & ~15u, used = 0;
+        ma.pg_lds_off = at;
+        for (int i = 0; i < pair->pg.nrules; i++) {
+            const uint32_t blob = pair->pg.rule_lds_bytes[i];
+            pair->pg.rule_lds_off[i] = 0xFFFFFFFFu;
+            if (at + used + blob <= lds_cap) { pair->pg.rule_lds_off[i] = used; used += (blob + 15) & ~15u; }
+        }
+        ma.lds_total = at + used;
+        if (!f->d_pg.ensure(sizeof(PgInline))) return false;
+        HIPOK(hipMemcpyAsync(f->d_pg.p, &pair->pg, sizeof(PgInline), hipMemcpyHostToDevice, st));
+        ma.pg = f->d_pg.as<PgInline>();
+        ma.pg_keep_len = pair->keep_len;
+    }
     // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...): one general kernel
     auto run_generic = [&]() -> bool {
         launch_max_row_len(row_off, n, &dm->max_row, st);
@@ -803,28 +823,49 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     uint64_t n = in->n;
     if (n == 0) return 0;
     MiscWords *dm = nullptr, *hmp = nullptr;
-    // filter_parser's pass 1: every record sized (out_len), spans and record columns in HBM
-    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n)) return -1;
-    MiscWords &hm = *hmp;
-    uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
-    if (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0) return 0;           // (records for k_parser_emit_exact: unfused)
     const DevParser &d0 = fp->parsers[0]->dev;
-    if (!fp->d_keep.ensure(n * sizeof(uint32_t)) || !fp->d_kept.ensure((size_t) n * sizeof(uint32_t))) return -1;
-    PgDecideArgs da;
-    memset(&da, 0, sizeof(da));
-    da.data = (const uint8_t *) in->data; da.row_off = in->row_off; da.n = n; da.n_cols = in->n;
-    da.info = fp->d_info.as<uint32_t>(); da.caps = fp->d_caps.as<uint32_t>(); da.out_len = fp->d_len.as<uint32_t>();
-    da.rules = fg->d_rules.as<GrepRule>(); da.nrules = (int) fg->rules.size(); da.logical_op = fg->logical_op;
+    if (!fp->d_keep.ensure(n * sizeof(uint32_t))) return -1;
+    // grep's rules for the inline evaluation (k_parser_rx on the spans in LDS) and for k_pg_decide
+    static thread_local PairCtx pc;                    // (page of host memory the async upload reads from)
+    memset(&pc.pg, 0, sizeof(pc.pg));
+    pc.keep_len = fp->d_keep.as<uint32_t>();
+    pc.pg.rules = fg->d_rules.as<GrepRule>(); pc.pg.nrules = (int) fg->rules.size(); pc.pg.logical_op = fg->logical_op;
+    for (int f = 0; f < d0.nfields; f++) {
+        if (!d0.field_is_time[f]) continue;
+        if (d0.time_keep) pc.pg.time_fields |= 1u << f; else pc.pg.static_drop |= 1u << f;
+    }
     for (size_t i = 0; i < fg->rules.size(); i++) {
         // the parser's named fields the rule's key names (flb_ra_key.c:118: the last one present decides)
         uint32_t m = 0;
         const DevKey &k = fg->rules[i].key;
         for (int f = 0; f < d0.nfields; f++)
             if (d0.field_name_len[f] == k.key_len && !memcmp(d0.names + d0.field_name_off[f], k.key, (size_t) k.key_len)) m |= 1u << f;
-        da.rule_fmask[i] = m;
+        pc.pg.rule_fmask[i] = m;
+        // the rule's match-only DFA (cls | ddelta | d_final, one blob: upload_dfa)
+        const DevDfa &df = fg->rules[i].dfa;
+        pc.pg.rule_lds_bytes[i] = (uint32_t) ((df.d_final + df.nD) - df.cls);
     }
-    da.keep_len = fp->d_keep.as<uint32_t>(); da.kept = fp->d_kept.as<uint32_t>(); da.kept_count = &dm->kept_count; da.counts = dm->counts;
-    { ProfScope ps(fp, st, "k_pg_decide"); launch_pg_decide(da, st); }
+    // filter_parser's pass 1: every record sized (out_len), spans and record columns in HBM; keep_len of the records
+    // whose rules could be settled on the spans
+    if (hipMemsetAsync(pc.keep_len, 0xFF, n * sizeof(uint32_t), st) != hipSuccess) return -1;
+    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc)) return -1;
+    MiscWords &hm = *hmp;
+    uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
+    if (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0) return 0;           // (records for k_parser_emit_exact: unfused)
+    const int cus = g_cus > 0 ? g_cus : 256;
+    PgDecideArgs da;
+    memset(&da, 0, sizeof(da));
+    da.data = (const uint8_t *) in->data; da.row_off = in->row_off; da.n = n; da.n_cols = in->n;
+    da.info = fp->d_info.as<uint32_t>(); da.caps = fp->d_caps.as<uint32_t>(); da.out_len = fp->d_len.as<uint32_t>();
+    da.rules = pc.pg.rules; da.nrules = pc.pg.nrules; da.logical_op = pc.pg.logical_op;
+    for (int i = 0; i < pc.pg.nrules; i++) {
+        da.rule_fmask[i] = pc.pg.rule_fmask[i];
+        da.rule_lds_off[i] = 0xFFFFFFFFu;
+        if (da.lds_total + pc.pg.rule_lds_bytes[i] <= 48 * 1024) { da.rule_lds_off[i] = da.lds_total; da.rule_lds_bytes[i] = pc.pg.rule_lds_bytes[i]; da.lds_total += (pc.pg.rule_lds_bytes[i] + 15) & ~15u; }
+    }
+    da.keep_len = pc.keep_len; da.counts = dm->counts;
+    // rows the inline evaluation left open (unparsed records, records of the generic kernel, rules on a kept time field)
+    if (hm.counts[7] > 0 || hm.counts[2] > 0) { ProfScope ps(fp, st, "k_pg_decide"); launch_pg_decide(da, cus, st); }
     { ProfScope ps(fp, st, "k_scan"); launch_scan(da.keep_len, n, fp->d_scan_tmp.as<uint64_t>(), fp->d_off.as<uint64_t>(), st); }
     total = 0;
     if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -846,8 +887,8 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     memset(&ea, 0, sizeof(ea));
     ea.data = da.data; ea.row_off = da.row_off; ea.cfg = fp->pcfg; ea.parsers = fp->d_parsers.as<DevParser>(); ea.n_cols = in->n;
     ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
-    ea.kept = da.kept; ea.n_kept = hm.kept_count; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
-    { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, st); }
+    ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
+    { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, cus, st); }
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     return 1;

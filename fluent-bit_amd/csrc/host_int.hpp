@@ -102,7 +102,7 @@ struct flbgpu_filter {
     // filter_log_to_metrics
     L2mState *l2m = nullptr;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     flbgpu::PinnedBuf hp_misc, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -118,7 +118,7 @@ struct flbgpu_filter {
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &h_in_data, &h_in_off};
+                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
         hp_misc.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();

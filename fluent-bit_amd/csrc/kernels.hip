@@ -207,6 +207,16 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
     capl.stride_b = 2 * blockDim.x;
     const int ncap = 2 * ps.nfields;
     uint32_t n_gen = 0;
+    // pair mode: the match-only DFAs of grep's rules next to the tables
+    LDS_AS uint8_t *pg_lds = (LDS_AS uint8_t *) g_lds + a.pg_lds_off;
+    if (a.pg) {
+        for (int i = 0; i < a.pg->nrules; i++) {
+            if (a.pg->rule_lds_off[i] == 0xFFFFFFFFu) continue;
+            const uint8_t *src = a.pg->rules[i].dfa.cls;
+            for (uint32_t k = threadIdx.x; k < a.pg->rule_lds_bytes[i]; k += blockDim.x) pg_lds[a.pg->rule_lds_off[i] + k] = src[k];
+        }
+        __syncthreads();
+    }
     for (uint64_t base = (uint64_t) wave_slot * 64; base < a.n; base += nwaves * 64) {
         const uint64_t r = base + lane;
         if (r >= a.n) continue;
@@ -234,7 +244,28 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
         if (endb >= 0) {
             // publish the spans: [span][record] columns, a wave stores 64 consecutive words
             for (int c = 0; c < ncap; c++) a.caps[(uint64_t) c * a.n + r] = capl.get((uint32_t) c);
-            a.info[r] = flags | RF_RXOK;
+            uint32_t pgbits = 0;
+            if (a.pg) {
+                // filter_grep's rules on the record filter_parser will emit, while the spans are in LDS and the value
+                // bytes in cache.  Fields dropped as empty (Skip_Empty_Values) or consumed (the time field without
+                // Time_Keep) are known here; a rule that names a time field that is kept waits for the time lookup.
+                uint32_t drop = a.pg->static_drop, any = 0;
+                for (int f = 0; f < ps.nfields; f++) {
+                    const uint32_t b = capl.get((uint32_t) (2 * f)), e = capl.get((uint32_t) (2 * f + 1));
+                    const bool set = b != CAP_UNSET && e != CAP_UNSET;
+                    any |= set ? 1u : 0u;
+                    if ((!set || e == b) && ps.skip_empty) drop |= 1u << f;
+                }
+                uint32_t named = 0;
+                for (int i = 0; i < a.pg->nrules; i++) named |= a.pg->rule_fmask[i];
+                if (any && !(named & a.pg->time_fields & ~drop)) {
+                    struct { const CapLds *c; DEV uint32_t operator[](uint32_t i) const { return c->get(i); } } cv{&capl};
+                    const bool keep = pg_grep_parsed(a.pg->rules, a.pg->nrules, a.pg->logical_op, a.pg->rule_fmask, a.pg->rule_lds_off, drop, val, cv,
+                                                     (LDS_AS const uint8_t *) pg_lds);
+                    pgbits = RF_PGDONE | (keep ? RF_PGKEEP : 0u);
+                }
+            }
+            a.info[r] = flags | RF_RXOK | pgbits;
             if (ps.time_field >= 0) {
                 // the time text (cache-hot here) goes to its own coalesced column
                 const uint32_t tb = capl.get((uint32_t) (2 * ps.time_field)), te = capl.get((uint32_t) (2 * ps.time_field + 1));
@@ -268,7 +299,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     for (uint32_t i = threadIdx.x; i < 2 * MAX_TIMEFMT; i += blockDim.x) fmt_mem[i] = i < MAX_TIMEFMT ? ps.fmt1[i] : ps.fmt2[i - MAX_TIMEFMT];
     __syncthreads();
     LDS_AS const char *lfmt1 = (LDS_AS const char *) fmt_mem, *lfmt2 = lfmt1 + MAX_TIMEFMT;
-    uint32_t n_gen = 0;
+    uint32_t n_gen = 0, pg_out = 0, pg_keep = 0, pg_pending = 0;
+    unsigned long long pg_bytes = 0;
     // When the record's size does not depend on bytes of the chunk (no reserved / preserved kvs, no
     // Types cast) and the time text sits in the tbuf column, this kernel reads and writes nothing
     // but coalesced columns.
@@ -276,7 +308,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint64_t n = a.n;
     for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t fl0 = a.info[r];
-        if (!(fl0 & RF_RXOK) || (fl0 & RF_GENERIC)) { if (!(fl0 & RF_GENERIC)) a.null_mask[r] = 0; continue; }
+        if (!(fl0 & RF_RXOK) || (fl0 & RF_GENERIC)) {
+            if (!(fl0 & RF_GENERIC)) a.null_mask[r] = 0;
+            if (a.pg_keep_len) { a.pg_keep_len[r] = PG_UNDECIDED; pg_pending++; }
+            continue;
+        }
         CapsView caps;
         caps.base = a.caps; caps.n = n; caps.r = r;
         bool any = false;
@@ -316,6 +352,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             // flb_regex_parse found no participating named group: the parser fails
             if (a.cfg.nparsers > 1) { a.info[r] = fl0 | RF_GENERIC; n_gen++; }
             else a.null_mask[r] = 0;
+            if (a.pg_keep_len) { a.pg_keep_len[r] = PG_UNDECIDED; pg_pending++; }
             continue;
         }
         uint32_t flags = (fl0 | RF_PARSED) & ~(uint32_t) RF_BADTS;
@@ -335,6 +372,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
             a.info[r] = flags | RF_BADTS;
             a.out_len[r] = 0;
+            if (a.pg_keep_len) a.pg_keep_len[r] = 0;
             continue;
         }
         a.info[r] = flags;
@@ -352,9 +390,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
             a.out_len[r] = (uint32_t) cs.n;
             if (cs.need_exact) { a.info[r] = flags | RF_EXACT; atomicAdd(&a.counts[3], 1ull); }
         }
+        if (a.pg_keep_len) {
+            // pair mode: the record's fate under filter_grep, settled by k_parser_rx on the spans (else k_pg_decide's)
+            const uint32_t ol = a.out_len[r];
+            if (fl0 & RF_PGDONE) {
+                const bool keep = (fl0 & RF_PGKEEP) != 0;
+                a.pg_keep_len[r] = keep ? ol : 0;
+                pg_out++; pg_bytes += ol; pg_keep += keep ? 1u : 0u;
+            }
+            else { a.pg_keep_len[r] = PG_UNDECIDED; pg_pending++; }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) n_gen += __shfl_down(n_gen, o, 64);
-    if ((threadIdx.x & 63) == 0 && n_gen) atomicAdd(&a.counts[2], (unsigned long long) n_gen);
+    for (int o = 32; o > 0; o >>= 1) {
+        n_gen += __shfl_down(n_gen, o, 64);
+        pg_out += __shfl_down(pg_out, o, 64); pg_keep += __shfl_down(pg_keep, o, 64); pg_pending += __shfl_down(pg_pending, o, 64);
+        pg_bytes += __shfl_down(pg_bytes, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_gen) atomicAdd(&a.counts[2], (unsigned long long) n_gen);
+        if (pg_bytes) atomicAdd(&a.counts[4], pg_bytes);
+        if (pg_keep) atomicAdd(&a.counts[5], (unsigned long long) pg_keep);
+        if (pg_out) atomicAdd(&a.counts[6], (unsigned long long) pg_out);
+        if (pg_pending) atomicAdd(&a.counts[7], (unsigned long long) pg_pending);
+    }
 }
 
 // The complete per-record algorithm (every candidate key, every parser, UTF-8 tables, values of
