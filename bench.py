@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- records/sec through filter_parser(apache2) -> filter_grep on MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: the chunk (10 M seeded apache-combined lines of 256 B wrapped as 277 B V2 log events,
-BASELINE.json configs[1]) goes through filter_parser (conf/parsers.conf 'apache2', Key_Name log)
-and the parser's output chunk goes through filter_grep (Regex code ^5\\d\\d$), chained on the
-device exactly like flb_filter_do chains cb_filter calls (src/flb_filter.c:179-272).
+One "step" = one flb_filter_do (src/flb_filter.c:121-325) over one batch of synthetic input that is already
+resident in HBM: the chunk (10 M seeded apache-combined lines of 256 B wrapped as 277 B V2 log events,
+BASELINE.json configs[1]) goes through the chain [filter_parser (conf/parsers.conf 'apache2', Key_Name log),
+filter_grep (Regex code ^5\\d\\d$)] -- flbgpu_filter_chain_run_dev, which runs the two as a pair: the rules
+are evaluated on the capture spans and only the kept records are written (fused_kernels.inc; SURVEY 8(d)
+"fused": 552 + 275 x keep algorithmic bytes per record).
 
     python bench.py --gpus N --steps K --warmup W [--records R]
 
@@ -30,25 +31,77 @@ TIME_FMT = "%d/%b/%Y:%H:%M:%S %z"
 GREP_RULE = ("regex", r"code ^5\d\d$")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# BASELINE configs[2]: 32 patterns on NDJSON-derived records = 16 Regex rules in OR mode, then an
+# Exclude-only set of 16 (two filter_grep instances: AND / OR need one rule type, grep.c:90-98); literal-heavy
+# with four class / quantifier patterns in each set
+GREP32_REGEX = [("regex", r) for r in (
+    "level ^(error|warn)$", "msg timeout", "msg refused", "$svc['name'] db", "path ^/v1/items/1", "msg request 9", "level debug", "path x=7",
+    "msg finished ok$", "$svc['name'] ^cache$", "path /items/[0-9]{5}", r"msg ^request \d+ finished", "level ^i", "path [?]x=[0-9]$",
+    "msg 00 finished", r"path ^/v1/\w+/\d*0[?]")]
+GREP32_EXCLUDE = [("exclude", r) for r in (
+    "msg request 1", "level ^warn$", "path x=1$", "$svc['pod'] ^pod-1", "msg 77", "path /items/4", "level nothing", "msg never",
+    "path ^/v2", "$svc['name'] ^$", r"path x=\d\d$", "msg [5-6]{3} finished", r"level ^\s", "path items/[1-2]{2}", "msg ok ", "$svc['name'] b$")]
+
+
+PMC_FILE = os.path.join("profiles", "r2_pmc_hbm_bench_10M.json")
+
 
 def recorded_traffic(kernel, n):
-    """HBM bytes per launch of `kernel` from the committed PMC pass of this same command (rocprofv3 cannot
-    run inside the timed process): FETCH_SIZE + WRITE_SIZE (KiB), FETCH doubled for the kernels whose reads
-    are wide coalesced streams as the microarchitecture guide prescribes for gfx950.  None when the
-    workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r1_final_pmc_hbm_bench_10M.json")
+    """HBM bytes per launch of `kernel` from the committed PMC pass of this same command (rocprofv3 cannot run
+    inside the timed process): FETCH_SIZE + WRITE_SIZE (KiB) scaled by the factors tools/calib_counters.py
+    measured for this access pattern on a kernel with a known byte count (profiles/r2_counter_calibration.json).
+    None when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, PMC_FILE)
     if n != 10_000_000 or not os.path.exists(path):
         return None, None
     try:
         ks = json.load(open(path))["kernels"]
-        hit = [v for k, v in ks.items() if k.split("::")[-1].split("<")[0] == kernel]
+        hit = [v for k, v in ks.items() if k.split("::")[-1].split("<")[0].split("(")[0] == kernel]
         if not hit:
             return None, None
-        coalesced = kernel in ("k_parser_locate", "k_grep_match", "k_gather")
-        b = hit[0].get("FETCH_SIZE", 0) * 1024 * (2 if coalesced else 1) + hit[0].get("WRITE_SIZE", 0) * 1024
-        return int(b), "profiles/r1_final_pmc_hbm_bench_10M.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        cal = {}
+        cpath = os.path.join(ROOT, "profiles", "r2_counter_calibration.json")
+        if os.path.exists(cpath):
+            cal = json.load(open(cpath)).get("fetch_factor", {})
+        pattern = {"k_parser_locate": "coalesced16", "k_grep_match": "coalesced16", "k_gather": "coalesced16",
+                   "k_parser_rx": "per_lane64", "k_parser_finish": "column4", "k_parser_emit": "per_lane16", "k_pg_emit": "per_lane16"}.get(kernel, "column4")
+        ff = float(cal.get(pattern, 1.0))
+        b = hit[0].get("FETCH_SIZE", 0) * 1024 * ff + hit[0].get("WRITE_SIZE", 0) * 1024
+        return int(b), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x %.2f: calibrated for '%s' reads)" % (ff, pattern)
     except Exception:
         return None, None
+
+
+def cpu_nproc_leg(sample, nproc, seconds=6.0):
+    """N independent processes (one oracle filter pair each, its own shard of `sample`), wall-clock records/s of
+    the lot -- the baseline SURVEY 8(d) asks for next to the single thread.  Runs before the GPU is touched."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    blob, off = sample
+
+    def work(i):
+        import oracle_binding as ob
+        n = len(off) - 1
+        lo, hi = n * i // nproc, n * (i + 1) // nproc
+        part = blob[int(off[lo]):int(off[hi])]
+        po = ob.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+        fo = ob.FilterParser("log", [po]); go = ob.Grep([GREP_RULE])
+        done = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            r, parsed = fo.filter(part)
+            go.filter(parsed)
+            done += hi - lo
+        q.put((done, time.perf_counter() - t0))
+
+    ps = [ctx.Process(target=work, args=(i,)) for i in range(nproc)]
+    t0 = time.perf_counter()
+    for p_ in ps: p_.start()
+    res = [q.get() for _ in ps]
+    for p_ in ps: p_.join()
+    wall = time.perf_counter() - t0
+    return sum(r[0] for r in res) / wall
 
 
 def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_chunk=None):
@@ -117,24 +170,35 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
     L.flbgpu_memcpy_h2d(d_data, data, len(data)); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
     chunk = g.DevChunk(d_data, d_off, nl, len(data))
     pk = g.JsonPacker()
-    rules = [("regex", "level ^(error|warn)$")] + [("exclude", "msg pattern%d" % i) for i in range(31)]
-    fg = g.FilterGrep(rules)
+    fg1 = g.FilterGrep(GREP32_REGEX, "OR"); fg2 = g.FilterGrep(GREP32_EXCLUDE, "OR")
+    ch32 = g.FilterChain([fg1, fg2])
     ev = pk.run_dev(chunk, events=True, ts=(1, 0))
-    fg.filter_dev(ev)
+    ch32.filter_dev(ev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         ev = pk.run_dev(chunk, events=True, ts=(1, 0))
     torch.cuda.synchronize()
     dt_j = (time.perf_counter() - t0) / steps
+    fg1.profile(True); fg2.profile(True)
     t0 = time.perf_counter()
     for _ in range(steps):
-        fg.filter_dev(ev)
+        r32, o32 = ch32.filter_dev(ev)
     torch.cuda.synchronize()
     dt_g = (time.perf_counter() - t0) / steps
+    p32 = fg1.profile_read()
+    st32 = ch32.last_stats()
     out["ndjson_to_events"] = {"lines_per_s_per_gpu": round(nl / dt_j, 1), "ms_per_step": round(dt_j * 1e3, 3), "lines": nl,
                                "text_bytes": len(data), "text_GBps": round(len(data) / dt_j / 1e9, 2)}
-    out["grep_32_rules"] = {"records_per_s_per_gpu": round(nl / dt_g, 1), "ms_per_step": round(dt_g * 1e3, 3), "kept": int(fg.counts()[1])}
+    ev_bytes = int(ev.bytes)
+    gm = p32.get("k_grep_match", (0, 1))
+    out["grep_32_rules"] = {"records_per_s_per_gpu": round(nl / dt_g, 1), "ms_per_step": round(dt_g * 1e3, 3),
+                            "rules": "16 Regex (OR) then 16 Exclude (OR): two filter_grep instances chained",
+                            "kept_after_regex": int(st32[0]["out_records"]), "kept": int(st32[1]["out_records"]), "event_bytes": ev_bytes,
+                            "roofline": {"kernel": "k_grep_match (first instance)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                         "achieved": round(ev_bytes / (gm[0] / max(gm[1], 1) / 1e3) / 1e9, 1) if gm[0] else None,
+                                         "frac": round(ev_bytes / (gm[0] / max(gm[1], 1) / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if gm[0] else None}}
+    fg = fg1
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
@@ -145,8 +209,78 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         r = o(sample)
         cdt = time.perf_counter() - t0
         out["ndjson_to_events"]["cpu_port_lines_per_s"] = round(r[3] / cdt, 1)
-    fg.close(); pk.close()
+    fg1.close(); fg2.close(); pk.close()
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+    return out
+
+
+def measure_cpu(data, off, n, args):
+    """cpu_baseline: the oracle's filter_parser(apache2) + filter_grep, one thread, on a bounded sample of the same
+    workload; plus the reference's own regex engine on the same lines (oracle/_ref/libonig_ref.so, the real Onigmo:
+    the regex half of the reference's cost) and the N-process leg."""
+    import numpy as np
+    import oracle_binding as ob
+    ns = min(args.cpu_sample, n)
+    sample = bytes(data[: int(off[ns])])
+    po = ob.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+    fo = ob.FilterParser("log", [po])
+    go = ob.Grep([GREP_RULE])
+    t0 = time.perf_counter()
+    r, parsed = fo.filter(sample)
+    r2_, kept = go.filter(parsed)
+    cdt = time.perf_counter() - t0
+    cpu = {"value": round(ns / cdt, 1), "unit": "records/s", "cores": 1, "kind": "port",
+           "sample": "first %d records of the same seeded workload through oracle filter_parser(apache2)+filter_grep, "
+                     "single thread (%d host cores present)" % (ns, os.cpu_count())}
+    try:
+        from rxdiff import load_ref, RefRegex
+        R = load_ref()
+        if R is not None and hasattr(R, "ref_onig_bench"):
+            # the reference's own regex engine (Onigmo 6.2.0 built from its sources) on the same lines: rows = the
+            # `log` values (21 B of event framing in front of each 256 B line)
+            m = min(ns, 1_000_000)
+            vals = np.ascontiguousarray(np.asarray(data[: int(off[m])]).reshape(m, -1)[:, 21:]) if (int(off[m]) % m == 0) else None
+            if vals is not None:
+                rows = np.arange(m + 1, dtype=np.int64) * vals.shape[1]
+                R.ref_onig_bench.restype = ctypes.c_double
+                R.ref_onig_bench.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+                rr = RefRegex(R, APACHE2.encode())
+                matched = ctypes.c_longlong(0)
+                sec = R.ref_onig_bench(rr.reg, vals.ctypes.data, rows.ctypes.data, m, ctypes.byref(matched))
+                cpu["reference_onigmo"] = {"lines_per_s": round(m / sec, 1), "lines": m, "matched": int(matched.value), "cores": 1,
+                                           "what": "onig_search with a region, the real Onigmo 6.2.0 compiled from the reference's sources, apache2 pattern, same lines"}
+    except Exception as e:
+        cpu["reference_onigmo_error"] = repr(e)[:200]
+    try:
+        nproc = os.cpu_count() or 1
+        m = min(n, 2_000_000)
+        v = cpu_nproc_leg((bytes(data[: int(off[m])]), np.array(off[: m + 1])), nproc)
+        cpu["nproc"] = {"processes": nproc, "value": round(v, 1), "unit": "records/s",
+                        "note": "%d independent processes, each the oracle pair on its own shard for ~6 s, wall-clock aggregate" % nproc}
+    except Exception as e:
+        cpu["nproc_error"] = repr(e)[:200]
+    return cpu
+
+
+def measure_host_level(g, data, off, n):
+    """what one cb_filter / flb_filter_do call sees from host memory (PCIe inclusive; never `value`): the chain on
+    an engine-sized chunk (~2 MB, what the engine appends at a time) and on a 28 MB chunk"""
+    out = {}
+    p = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep([GREP_RULE])
+    ch = g.FilterChain([fp, fg])
+    for name, nrec in (("chunk_2MB", 7000), ("chunk_28MB", 100000)):
+        nrec = min(nrec, n)
+        blob = bytes(data[: int(off[nrec])])
+        ch.filter(blob)
+        reps = 20 if nrec < 50000 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ch.filter(blob)
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"records": nrec, "bytes": len(blob), "ms_per_call": round(dt * 1e3, 3), "records_per_s": round(nrec / dt, 1),
+                     "in_GBps": round(len(blob) / dt / 1e9, 2)}
+    fp.close(); fg.close(); p.close()
     return out
 
 
@@ -166,13 +300,26 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the log_to_metrics / JSON side measurements")
     args = ap.parse_args()
 
-    import torch
     import flbamd_loader
     import synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ---- synthetic shard for this rank (seeded; per-GPU work is fixed => weak scaling)
+    n = args.records
+    t0 = time.time()
+    data, off, ep = synth.apache_records(n, seed=synth.SEED + rank)
+    gen_s = time.time() - t0
+    in_bytes = int(data.nbytes)
+
+    # ---- CPU baselines first (rank 0, N = 1), before this process owns a GPU context: the forked workers of the
+    #      N-process leg only run the oracle
+    cpu = None
+    if not args.no_cpu and world == 1 and rank == 0:
+        cpu = measure_cpu(data, off, n, args)
+
+    import torch
     dist = None
     if world > 1 or os.environ.get("FLBGPU_BENCH_FORCE_DIST"):       # (forced: exercises the RCCL path on one GPU)
         import torch.distributed as dist
@@ -186,12 +333,6 @@ def main():
     g.init(local_rank if world > 1 else 0)
     L = g.lib()
 
-    # ---- synthetic shard for this rank (seeded; per-GPU work is fixed => weak scaling)
-    n = args.records
-    t0 = time.time()
-    data, off, ep = synth.apache_records(n, seed=synth.SEED + rank)
-    gen_s = time.time() - t0
-    in_bytes = int(data.nbytes)
     d_data = L.flbgpu_dev_alloc(in_bytes)
     d_off = L.flbgpu_dev_alloc(off.nbytes)
     assert d_data and d_off, g.last_error()
@@ -203,11 +344,13 @@ def main():
     fparser = g.FilterParser("log", [parser])
     fgrep = g.FilterGrep([GREP_RULE])
 
+    chain = g.FilterChain([fparser, fgrep])
+
     def step():
-        r1, o1 = fparser.filter_dev(chunk)
-        assert r1 == g.MODIFIED, g.last_error()
-        r2, o2 = fgrep.filter_dev(o1)
-        return o1, o2, r2
+        # flb_filter_do over the two filters (flbgpu_filter_chain_run_dev): the pair path of fused_kernels.inc
+        r2, o2 = chain.filter_dev(chunk)
+        assert r2 == g.MODIFIED, g.last_error()
+        return o2, r2
 
     for _ in range(args.warmup):
         step()
@@ -223,14 +366,20 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        o1, o2, r2 = step()
+        o2, r2 = step()
     sync_all()
     dt = time.perf_counter() - t0
     prof = dict(fparser.profile_read())
     prof.update({"grep:" + k if k == "k_scan" else k: v for k, v in fgrep.profile_read().items()})
-    parsed_bytes = int(o1.bytes)
-    kept_bytes = int(o2.bytes) if r2 == g.MODIFIED else parsed_bytes
-    kept_records = fgrep.counts()[1]
+    fparser.profile(False); fgrep.profile(False)
+    st = chain.last_stats()
+    parsed_bytes = int(st[0]["out_bytes"])             # what filter_parser alone would emit (counted, not written)
+    kept_bytes = int(o2.bytes)
+    kept_records = int(st[1]["out_records"])
+    fused = "k_pg_emit" in prof
+    # the parsed chunk itself, for the side measurements below (one unfused filter_parser run, untimed)
+    r1, o1 = fparser.filter_dev(chunk)
+    assert r1 == g.MODIFIED and int(o1.bytes) == parsed_bytes, (g.last_error(), int(o1.bytes), parsed_bytes)
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -242,6 +391,8 @@ def main():
     if not args.no_secondary:
         try:
             secondary = measure_secondary(g, torch, dist, rank, world, o1, n, args, raw_chunk=chunk)
+            if rank == 0 and world == 1:
+                secondary["host_level"] = measure_host_level(g, data, off, n)
         except Exception as e:                      # the headline line must survive a failure here
             secondary = {"error": repr(e)[:300]}
 
@@ -260,6 +411,7 @@ def main():
         "k_parser_rx": value_bytes,                      # the capture program consumes each value byte once
         "k_parser_finish": 8 * n,                        # time field + sizes
         "k_parser_emit": value_bytes + parsed_bytes,     # re-reads the values, writes the output once
+        "k_pg_emit": 2 * kept_bytes,                     # kept records: their field bytes in, the parsed records out
         "k_grep_match": parsed_bytes,
         "k_gather": 2 * kept_bytes,
     }
@@ -273,23 +425,15 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(launches),
                 "algorithmic_bytes_per_launch": int(alg_bytes_per_launch.get(dom, in_bytes))}
+        # the whole step against the same roof: SURVEY 8(d) wire-format bytes of the fused pair = input once + what
+        # filter_parser emits + what filter_grep keeps (552 + 275 x keep B/record), over the step's kernel time
+        step_bytes = in_bytes + parsed_bytes + kept_bytes
+        kern_ms = sum(v[0] for v in prof.values()) / args.steps
+        tr = [recorded_traffic(k, n)[0] for k in prof]
+        roof["step"] = {"algorithmic_bytes": int(step_bytes), "kernel_ms": round(kern_ms, 3), "achieved": round(step_bytes / (kern_ms / 1e3) / 1e9, 1),
+                        "frac": round(step_bytes / (kern_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": int(sum(tr)) if tr and all(t is not None for t in tr) else None}
     kernels = {k: {"total_ms": round(v[0], 3), "launches": int(v[1])} for k, v in prof.items()}
-
-    cpu = None
-    if not args.no_cpu and world == 1:
-        import oracle_binding as ob
-        ns = min(args.cpu_sample, n)
-        sample = bytes(data[: int(off[ns])])
-        po = ob.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
-        fo = ob.FilterParser("log", [po])
-        go = ob.Grep([GREP_RULE])
-        t0 = time.perf_counter()
-        r, parsed = fo.filter(sample)
-        r2_, kept = go.filter(parsed)
-        cdt = time.perf_counter() - t0
-        cpu = {"value": round(ns / cdt, 1), "unit": "records/s", "cores": 1, "kind": "port",
-               "sample": "first %d records of the same seeded workload through oracle filter_parser(apache2)+filter_grep, "
-                         "single thread (%d host cores present)" % (ns, os.cpu_count())}
 
     if isinstance(secondary, dict) and "record_indexer" in secondary:
         # what the step would sustain if it were handed raw bytes and had to find the rows first
@@ -302,7 +446,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "filter_parser(conf/parsers.conf apache2, Key_Name log) -> filter_grep(Regex code ^5\\d\\d$) "
-                               "on %d x 256B apache-combined lines per GPU (277B V2 events), chained on device, unfused" % n,
+                               "on %d x 256B apache-combined lines per GPU (277B V2 events), flb_filter_do on device, %s" % (n, "fused pair: rules evaluated on the capture spans, only the kept records written" if fused else "unfused"),
                    "records_per_gpu": n, "in_bytes": in_bytes, "parsed_bytes": parsed_bytes, "kept_records": int(kept_records),
                    "row_offsets": "part of the device-resident chunk (every filter's output carries them); finding them from "
                                   "raw bytes is secondary.record_indexer",

@@ -520,3 +520,42 @@ def test_fused_parser_grep_pair(g):
     broken = blob[:len(blob) // 2] + b"\x93\x01\x02\x03" + blob[len(blob) // 2:]
     want, got, stats, parts = _chain_both(g, broken, base, [("regex", r"code ^5\d\d$")], None)
     assert got == want, first_diff(want[1], got[1])
+
+
+def test_grep_32_rules_baseline_config2(g):
+    """BASELINE configs[2]: the 32-pattern set of bench.py (16 Regex rules in OR mode, then 16 Exclude rules in OR
+    mode: two filter_grep instances, grep.c:90-98) on NDJSON-shaped records, every rule / both instances / the
+    chain against the oracle."""
+    import json as _json
+    from bench import GREP32_REGEX, GREP32_EXCLUDE
+    rng = random.Random(77)
+    recs = []
+    for i in range(20000):
+        d = {"time": "2026-09-21T10:%02d:%02d.%03dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(1000)),
+             "level": rng.choice(["info", "warn", "error", "debug", "nothing", " info"]),
+             "msg": "request %d finished %s" % (rng.randrange(10 ** 6), rng.choice(["ok", "timeout", "refused", "ok again"])),
+             "code": rng.randrange(200, 600), "latency": round(rng.random() * 100, 3),
+             "svc": {"name": rng.choice(["api", "db", "cache", ""]), "pod": "pod-%d" % rng.randrange(1000)},
+             "path": "/v%d/items/%d?x=%d" % (rng.choice([1, 1, 1, 2]), rng.randrange(10 ** 5), rng.randrange(100)), "bytes": rng.randrange(10 ** 6)}
+        if rng.random() < 0.03: d.pop("msg")
+        if rng.random() < 0.03: d["svc"] = "db"                       # not a map: the sub-key rules see no STR
+        recs.append(_rec({k: (v.encode() if isinstance(v, str) else ({kk: vv.encode() for kk, vv in v.items()} if isinstance(v, dict) else v))
+                          for k, v in d.items()}, 5, i))
+    blob = b"".join(recs)
+    assert len(GREP32_REGEX) == 16 and len(GREP32_EXCLUDE) == 16
+    for rule in GREP32_REGEX + GREP32_EXCLUDE:                       # each of the 32 patterns on its own
+        a, b = both_grep(g, blob, [rule])
+        assert a == b, (rule, a[0], b[0], first_diff(a[1], b[1]))
+    a1, b1 = both_grep(g, blob, GREP32_REGEX, "OR")
+    assert a1 == b1 and a1[0] == ob.MODIFIED, first_diff(a1[1], b1[1])
+    a2, b2 = both_grep(g, a1[1], GREP32_EXCLUDE, "OR")
+    assert a2 == b2 and a2[0] == ob.MODIFIED, first_diff(a2[1], b2[1])
+    assert 0 < ob.count_records(a2[1]) < ob.count_records(a1[1]) < 20000
+    f1 = g.FilterGrep(GREP32_REGEX, "OR"); f2 = g.FilterGrep(GREP32_EXCLUDE, "OR")
+    got = g.FilterChain([f1, f2]).filter(blob)
+    f1.close(); f2.close()
+    assert got == a2
+    # the same 32 in AND mode and as one legacy list
+    for rules, op in ((GREP32_REGEX, "AND"), (GREP32_EXCLUDE, "AND"), (GREP32_REGEX[:3] + GREP32_EXCLUDE, None)):
+        a, b = both_grep(g, blob, rules, op)
+        assert a == b, (op, first_diff(a[1], b[1]))
