@@ -140,9 +140,18 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         dt = (time.perf_counter() - t0) / steps
         e = {"records_per_s_per_gpu": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 3)}
         if dist is not None:
+            # the collective behind the C ABI (flbgpu_l2m_all_reduce: RCCL all-gather of the label tuples, all-reduce
+            # MAX / SUM of the rows); the communicator's id travels over the process group that launched the ranks
+            if "rccl" not in out:
+                def exchange(raw):
+                    box = [raw]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+                out["rccl"] = g.RcclComm(world, rank, exchange)
             t0 = time.perf_counter()
-            keys, rows = g.l2m_all_reduce(f, dist)
+            keys, rows = g.l2m_all_reduce_rccl(f, out["rccl"])
             e["all_reduce_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            e["rccl_ranks"] = world
             snap = f.snapshot((keys, rows))
         else:
             snap = f.snapshot()
@@ -211,6 +220,9 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         out["ndjson_to_events"]["cpu_port_lines_per_s"] = round(r[3] / cdt, 1)
     fg1.close(); fg2.close(); pk.close()
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+    if "rccl" in out:
+        out.pop("rccl").close()
+        out["rccl_ranks"] = world
     return out
 
 
@@ -452,6 +464,7 @@ def main():
                                   "raw bytes is secondary.record_indexer",
                    "seed": synth.SEED, "parallelism": "shard%d" % world, "gen_seconds": round(gen_s, 1)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary,
+        "rccl_ranks": world if dist is not None else 0,
     }
     if dist is not None:
         dist.destroy_process_group()

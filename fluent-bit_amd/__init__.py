@@ -406,6 +406,56 @@ class FilterLogToMetrics(_Filter):
         return out
 
 
+class RcclComm:
+    """an ncclComm_t made through libflbgpu (flbgpu_rccl_unique_id / flbgpu_rccl_comm_init): rank 0 creates the id,
+    `exchange(id_bytes) -> id_bytes` ships it to the other ranks (e.g. a torch.distributed broadcast)"""
+
+    def __init__(self, nranks, rank, exchange=None):
+        L = lib()
+        L.flbgpu_rccl_unique_id.argtypes = [c_void_p]
+        L.flbgpu_rccl_comm_init.argtypes = [POINTER(c_void_p), c_int, c_void_p, c_int]
+        L.flbgpu_rccl_comm_destroy.argtypes = [c_void_p]
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0 and L.flbgpu_rccl_unique_id(buf) != 0:
+            raise RuntimeError("flbgpu_rccl_unique_id: " + last_error())
+        raw = buf.raw
+        if exchange is not None:
+            raw = exchange(raw)
+        self.h = c_void_p()
+        idb = ctypes.create_string_buffer(raw, 128)
+        if L.flbgpu_rccl_comm_init(byref(self.h), nranks, idb, rank) != 0:
+            raise RuntimeError("flbgpu_rccl_comm_init: " + last_error())
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_rccl_comm_destroy(self.h)
+            self.h = None
+
+
+def l2m_all_reduce_rccl(flt, comm):
+    """flbgpu_l2m_all_reduce: the merge of every rank's FilterLogToMetrics over RCCL, inside libflbgpu.so.
+    -> (keys, rows) like FilterLogToMetrics.export(), identical on every rank"""
+    import numpy as np
+    L = lib()
+    L.flbgpu_l2m_all_reduce.restype = c_int64
+    L.flbgpu_l2m_all_reduce.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_size_t)]
+    cap, kcap = 1024, 1 << 16
+    while True:
+        rows = np.zeros((cap, flt.row_words), dtype=np.uint64)
+        off = np.zeros(cap + 1, dtype=np.uint64)
+        keys = ctypes.create_string_buffer(kcap)
+        need = c_size_t(0)
+        n = L.flbgpu_l2m_all_reduce(flt.h, comm.h, None, cap, rows.ctypes.data, off.ctypes.data, keys, kcap, byref(need))
+        if n >= 0:
+            raw = keys.raw
+            return [raw[int(off[i]): int(off[i + 1])] for i in range(n)], rows[:n].copy()
+        if n == -1:
+            raise RuntimeError("flbgpu_l2m_all_reduce: " + last_error())
+        cap = max(cap, -n - 2)
+        kcap = max(kcap, need.value)
+
+
 def l2m_all_reduce(flt, dist, device=None):
     """Merges the series state of every rank's FilterLogToMetrics (same configuration on all ranks, each
     fed its own shard of the records) -- SURVEY.md section 8e: one all-reduce of the partial

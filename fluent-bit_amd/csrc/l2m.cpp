@@ -13,6 +13,8 @@
 #include "numconv.hpp"
 
 #include <algorithm>
+#include <string>
+#include <unordered_map>
 
 using namespace flbgpu;
 
@@ -465,4 +467,169 @@ extern "C" int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, 
     (void) hipFree(d_s); (void) hipFree(d_o); (void) hipFree(d_b); (void) hipFree(d_c);
     if (!ok) set_err("numconv device self-test failed to run");
     return ok ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------ RCCL
+// The collective of SURVEY 8(e) behind the C ABI: a C engine process per GPU merges its log_to_metrics state with
+// the other ranks' without leaving libflbgpu.so.  librccl is loaded on first use (the filters themselves never
+// need it), so the library still loads on a box without RCCL.
+#include <dlfcn.h>
+namespace {
+typedef int (*nccl_allreduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_count_t)(void *, int *);
+typedef int (*nccl_getid_t)(void *);
+struct NcclId { char b[128]; };                      // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+typedef int (*nccl_initrank_t)(void **, int, NcclId, int);
+typedef int (*nccl_destroy_t)(void *);
+typedef const char *(*nccl_errstr_t)(int);
+struct Rccl {
+    void *h = nullptr;
+    nccl_allreduce_t all_reduce = nullptr;
+    nccl_allgather_t all_gather = nullptr;
+    nccl_count_t comm_count = nullptr, comm_rank = nullptr;
+    nccl_getid_t get_id = nullptr;
+    nccl_initrank_t init_rank = nullptr;
+    nccl_destroy_t destroy = nullptr;
+    nccl_errstr_t errstr = nullptr;
+};
+Rccl g_rccl;
+constexpr int NCCL_UINT64 = 5, NCCL_UINT8 = 1, NCCL_SUM = 0, NCCL_MAX = 2;     // rccl.h: ncclDataType_t / ncclRedOp_t
+
+bool rccl_load() {
+    if (g_rccl.h) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_err("RCCL: librccl.so not found (%s)", dlerror()); return false; }
+    Rccl r;
+    r.h = h;
+    r.all_reduce = (nccl_allreduce_t) dlsym(h, "ncclAllReduce"); r.all_gather = (nccl_allgather_t) dlsym(h, "ncclAllGather");
+    r.comm_count = (nccl_count_t) dlsym(h, "ncclCommCount"); r.comm_rank = (nccl_count_t) dlsym(h, "ncclCommUserRank");
+    r.get_id = (nccl_getid_t) dlsym(h, "ncclGetUniqueId"); r.init_rank = (nccl_initrank_t) dlsym(h, "ncclCommInitRank");
+    r.destroy = (nccl_destroy_t) dlsym(h, "ncclCommDestroy"); r.errstr = (nccl_errstr_t) dlsym(h, "ncclGetErrorString");
+    if (!r.all_reduce || !r.all_gather || !r.comm_count || !r.comm_rank || !r.get_id || !r.init_rank || !r.destroy) { set_err("RCCL: symbols missing in librccl"); return false; }
+    g_rccl = r;
+    return true;
+}
+#define NCCLOK(call)                                                                                           \
+    do {                                                                                                       \
+        int e_ = (call);                                                                                       \
+        if (e_ != 0) { set_err("%s failed: %s", #call, g_rccl.errstr ? g_rccl.errstr(e_) : "?"); return -1; }  \
+    } while (0)
+}  // namespace
+
+extern "C" int flbgpu_rccl_unique_id(void *id128) { if (!rccl_load()) return -1; NCCLOK(g_rccl.get_id(id128)); return 0; }
+extern "C" int flbgpu_rccl_comm_init(void **comm, int nranks, const void *id128, int rank) {
+    if (!rccl_load()) return -1;
+    NcclId id;
+    memcpy(id.b, id128, 128);
+    NCCLOK(g_rccl.init_rank(comm, nranks, id, rank));
+    return 0;
+}
+extern "C" int flbgpu_rccl_comm_destroy(void *comm) { if (!rccl_load()) return -1; NCCLOK(g_rccl.destroy(comm)); return 0; }
+
+// One all-reduce of the partial aggregates per flush: the label dictionaries are made identical first
+// (all-gather of the tuples), then the rows -- exact integer words -- merge with MAX (the two index words; the gauge
+// value follows the winning index) and SUM (counts, bucket counts, fixed-point sum digits), on device buffers over
+// RCCL.  Every rank receives the merged state in the format of flbgpu_l2m_export; the result does not depend on
+// the rank count or on how the records were sharded.
+extern "C" int64_t flbgpu_l2m_all_reduce(flbgpu_filter *f, void *rccl_comm, void *stream, uint64_t max_series, uint64_t *rows, uint64_t *key_off,
+                                         char *keys, size_t keys_cap, size_t *keys_needed) {
+    if (!f || f->kind != F_L2M) return -1;
+    if (!rccl_load()) return -1;
+    L2mState *s = f->l2m;
+    hipStream_t st = stream ? (hipStream_t) stream : f->stream;
+    const int W = s->W;
+    int world = 0, rank = 0;
+    NCCLOK(g_rccl.comm_count(rccl_comm, &world));
+    NCCLOK(g_rccl.comm_rank(rccl_comm, &rank));
+    // ---- this rank's live series
+    std::vector<uint64_t> lrows, loff;
+    std::vector<char> lkeys;
+    size_t need = 0;
+    uint64_t cap = 1024;
+    int64_t ln;
+    for (;;) {
+        lrows.resize(cap * W); loff.resize(cap + 1); lkeys.resize(need + 16);
+        ln = flbgpu_l2m_export(f, cap, lrows.data(), loff.data(), lkeys.data(), lkeys.size(), &need);
+        if (ln >= 0) break;
+        if (ln == -1) return -1;
+        cap = (uint64_t) (-ln - 2) + 16;
+    }
+    // ---- all-gather of the label tuples: sizes, then the blobs padded to the largest
+    DevBuf d_a, d_b;
+    const size_t hdr = 2 * sizeof(uint64_t);
+    uint64_t mine[2] = {(uint64_t) ln, (uint64_t) loff[ln]};
+    std::vector<uint64_t> sizes((size_t) world * 2);
+    if (!d_a.ensure(hdr) || !d_b.ensure(hdr * world)) return -1;
+    if (hipMemcpyAsync(d_a.p, mine, hdr, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    NCCLOK(g_rccl.all_gather(d_a.p, d_b.p, 2, NCCL_UINT64, rccl_comm, st));
+    if (hipMemcpyAsync(sizes.data(), d_b.p, hdr * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    size_t max_blob = 0;
+    for (int r = 0; r < world; r++) { const size_t b = (size_t) (sizes[2 * r] + 1) * 8 + (size_t) sizes[2 * r + 1]; if (b > max_blob) max_blob = b; }
+    max_blob = (max_blob + 7) & ~(size_t) 7;
+    std::vector<uint8_t> blob(max_blob, 0), all(max_blob * world);
+    memcpy(blob.data(), loff.data(), (size_t) (ln + 1) * 8);
+    memcpy(blob.data() + (size_t) (ln + 1) * 8, lkeys.data(), (size_t) loff[ln]);
+    if (!d_a.ensure(max_blob) || !d_b.ensure(max_blob * world)) return -1;
+    if (hipMemcpyAsync(d_a.p, blob.data(), max_blob, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    NCCLOK(g_rccl.all_gather(d_a.p, d_b.p, max_blob, NCCL_UINT8, rccl_comm, st));
+    if (hipMemcpyAsync(all.data(), d_b.p, max_blob * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    // ---- union of the tuples in (rank, local order): the same dictionary on every rank
+    std::vector<std::string> ukeys;
+    std::unordered_map<std::string, uint32_t> index;
+    for (int r = 0; r < world; r++) {
+        const uint8_t *b = all.data() + (size_t) r * max_blob;
+        const uint64_t n = sizes[2 * r];
+        const uint64_t *off = (const uint64_t *) b;
+        const char *kb = (const char *) b + (n + 1) * 8;
+        for (uint64_t i = 0; i < n; i++) {
+            std::string k(kb + off[i], (size_t) (off[i + 1] - off[i]));
+            if (index.emplace(k, (uint32_t) ukeys.size()).second) ukeys.push_back(k);
+        }
+    }
+    const size_t n = ukeys.size();
+    // ---- dense rows: [n][2] index words for MAX, [n][W - 2] for SUM (the gauge value travels with its index)
+    std::vector<uint64_t> mx(n * 2, 0), sm(n * (size_t) (W - 2), 0);
+    for (int64_t i = 0; i < ln; i++) {
+        const std::string k(lkeys.data() + loff[i], (size_t) (loff[i + 1] - loff[i]));
+        const size_t u = index[k];
+        mx[2 * u] = lrows[(size_t) i * W]; mx[2 * u + 1] = lrows[(size_t) i * W + 1];
+        memcpy(&sm[u * (size_t) (W - 2)], &lrows[(size_t) i * W + 2], (size_t) (W - 2) * 8);
+    }
+    std::vector<uint64_t> mine_idx(n);
+    for (size_t u = 0; u < n; u++) mine_idx[u] = mx[2 * u + 1];
+    if (n) {
+        if (!d_a.ensure(mx.size() * 8)) return -1;
+        if (hipMemcpyAsync(d_a.p, mx.data(), mx.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        NCCLOK(g_rccl.all_reduce(d_a.p, d_a.p, mx.size(), NCCL_UINT64, NCCL_MAX, rccl_comm, st));
+        if (hipMemcpyAsync(mx.data(), d_a.p, mx.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        // ranks that do not own the winning index contribute 0 to the value word (word 2 = the first SUM word)
+        for (size_t u = 0; u < n; u++) if (!(mine_idx[u] == mx[2 * u + 1] && mine_idx[u] != 0)) sm[u * (size_t) (W - 2)] = 0;
+        if (!d_b.ensure(sm.size() * 8)) return -1;
+        if (hipMemcpyAsync(d_b.p, sm.data(), sm.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        NCCLOK(g_rccl.all_reduce(d_b.p, d_b.p, sm.size(), NCCL_UINT64, NCCL_SUM, rccl_comm, st));
+        if (hipMemcpyAsync(sm.data(), d_b.p, sm.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    }
+    d_a.release(); d_b.release();
+    // ---- snapshot order = first appearance (word 0 holds ~index of the creating record)
+    std::vector<uint32_t> order(n);
+    for (size_t u = 0; u < n; u++) order[u] = (uint32_t) u;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ~mx[2 * (size_t) a] < ~mx[2 * (size_t) b]; });
+    size_t kneed = 0;
+    for (auto &k : ukeys) kneed += k.size();
+    if (keys_needed) *keys_needed = kneed;
+    if (n > max_series || kneed > keys_cap) return -(int64_t) n - 2;
+    size_t ko = 0;
+    for (size_t j = 0; j < n; j++) {
+        const uint32_t u = order[j];
+        rows[j * W] = mx[2 * (size_t) u]; rows[j * W + 1] = mx[2 * (size_t) u + 1];
+        memcpy(&rows[j * W + 2], &sm[(size_t) u * (W - 2)], (size_t) (W - 2) * 8);
+        key_off[j] = ko;
+        memcpy(keys + ko, ukeys[u].data(), ukeys[u].size());
+        ko += ukeys[u].size();
+    }
+    key_off[n] = ko;
+    return (int64_t) n;
 }

@@ -31,6 +31,19 @@
 #define FLBGPU_PLUGIN_SUFFIX "_gpu"
 #endif
 
+/* One source, three shared objects (plugin/Makefile): FLBGPU_ONLY = 1 grep, 2 parser, 3 log_to_metrics keeps one
+ * plugin per object, so that flb-filter_grep_gpu.so does not drag in the cmetrics / emitter symbols
+ * log_to_metrics needs from the engine.  Undefined: all three (the built-in / static build). */
+#if !defined(FLBGPU_ONLY) || FLBGPU_ONLY == 1
+#define FLBGPU_WITH_GREP 1
+#endif
+#if !defined(FLBGPU_ONLY) || FLBGPU_ONLY == 2
+#define FLBGPU_WITH_PARSER 1
+#endif
+#if !defined(FLBGPU_ONLY) || FLBGPU_ONLY == 3
+#define FLBGPU_WITH_L2M 1
+#endif
+
 static int gpu_ready = 0;
 
 static int ensure_gpu(struct flb_filter_instance *ins)
@@ -52,6 +65,7 @@ struct grep_gpu_ctx {
     struct flb_filter_instance *ins;
 };
 
+#ifdef FLBGPU_WITH_GREP
 static int cb_grep_gpu_init(struct flb_filter_instance *f_ins, struct flb_config *config, void *data)
 {
     int n = 0;
@@ -110,6 +124,8 @@ static int cb_grep_gpu_init(struct flb_filter_instance *f_ins, struct flb_config
     return 0;
 }
 
+#endif /* FLBGPU_WITH_GREP */
+
 static int cb_gpu_filter(const void *data, size_t bytes, const char *tag, int tag_len,
                          void **out_buf, size_t *out_size,
                          struct flb_filter_instance *f_ins, struct flb_input_instance *i_ins,
@@ -139,6 +155,7 @@ static int cb_gpu_exit(void *data, struct flb_config *config)
     return 0;
 }
 
+#ifdef FLBGPU_WITH_GREP
 static struct flb_config_map grep_config_map[] = {
     { FLB_CONFIG_MAP_STR, "regex", NULL, FLB_CONFIG_MAP_MULT, FLB_FALSE, 0,
       "Keep records in which the content of KEY matches the regular expression." },
@@ -159,7 +176,10 @@ struct flb_filter_plugin filter_grep_gpu_plugin = {
     .flags        = 0
 };
 
+#endif /* FLBGPU_WITH_GREP */
+
 /* ------------------------------------------------------------------ parser */
+#ifdef FLBGPU_WITH_PARSER
 #define MAX_GPU_PARSERS 16
 
 struct parser_gpu_ctx {
@@ -337,7 +357,64 @@ struct flb_filter_plugin filter_parser_gpu_plugin = {
     .flags        = 0
 };
 
+/* flb_parser_do() on the GPU path: same signature and results as the reference's
+ * (include/fluent-bit/flb_parser.h:149, src/flb_parser.c:1784: last byte consumed or -1, *out_buf a msgpack map
+ * released with flb_free, *out_time the parsed time or zero).  The GPU twin of a struct flb_parser is created on
+ * first use and kept in a small table keyed by the parser's address. */
+#include <fluent-bit/flb_time.h>
+#define MAX_TWINS 64
+static struct { struct flb_parser *p; flbgpu_parser *g; } twins[MAX_TWINS];
+static int n_twins = 0;
+
+int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
+                      void **out_buf, size_t *out_size, struct flb_time *out_time)
+{
+    int i;
+    int ret;
+    int64_t sec = 0;
+    int64_t nsec = 0;
+    char off[16];
+    char *types;
+    flbgpu_parser *g = NULL;
+
+    for (i = 0; i < n_twins; i++) {
+        if (twins[i].p == parser) {
+            g = twins[i].g;
+            break;
+        }
+    }
+    if (!g) {
+        if (n_twins >= MAX_TWINS || flbgpu_init(0) != 0) {
+            return -1;
+        }
+        if (parser->type != FLB_PARSER_REGEX || parser->decoders != NULL || parser->time_zone != NULL ||
+            parser->time_system_timezone) {
+            return -1;
+        }
+        types = types_to_str(parser);
+        snprintf(off, sizeof(off), "%c%02d%02d", parser->time_offset < 0 ? '-' : '+',
+                 abs(parser->time_offset) / 3600, (abs(parser->time_offset) / 60) % 60);
+        g = flbgpu_parser_create(parser->name, parser->p_regex, parser->skip_empty, parser->time_fmt_full,
+                                 parser->time_key, parser->time_offset ? off : NULL, parser->time_keep,
+                                 parser->time_strict, types);
+        flb_free(types);
+        if (!g) {
+            return -1;
+        }
+        twins[n_twins].p = parser;
+        twins[n_twins].g = g;
+        n_twins++;
+    }
+    ret = flbgpu_parser_do(g, buf, length, out_buf, out_size, &sec, &nsec);
+    if (ret >= 0 && out_time) {
+        flb_time_set(out_time, (time_t) sec, (long) nsec);
+    }
+    return ret;
+}
+#endif /* FLBGPU_WITH_PARSER */
+
 /* ------------------------------------------------------------------ log_to_metrics */
+#ifdef FLBGPU_WITH_L2M
 /*
  * The device keeps the series state (flbgpu_filter_l2m_create / flbgpu_filter_run); this shim keeps
  * what the reference plugin keeps around it (plugins/filter_log_to_metrics/log_to_metrics.c:655-968,
@@ -650,3 +727,4 @@ struct flb_filter_plugin filter_log_to_metrics_gpu_plugin = {
     .config_map   = l2m_config_map,
     .flags        = 0
 };
+#endif /* FLBGPU_WITH_L2M */

@@ -127,6 +127,20 @@ int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint64_t *rows,
  * arithmetic on integers only; the sum is the exact sum of the observations rounded once. */
 int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
                             double *sum);
+/* ---- multi-GPU: the collective of the log_to_metrics aggregates (one process per GPU, records sharded) --------
+ * Same configuration on every rank; each rank runs the filter on its own shard (flbgpu_l2m_set_index_base gives
+ * the ranks disjoint record index ranges).  flbgpu_l2m_all_reduce makes the label dictionaries identical
+ * (all-gather of the tuples) and merges the rows over RCCL -- MAX for the two index words, SUM for counts, bucket
+ * counts and fixed-point sum digits, on device buffers over xGMI -- and returns the merged state in
+ * flbgpu_l2m_export's format, identical on every rank and independent of the rank count.  rccl_comm is an
+ * ncclComm_t (the caller's, or one made with the helpers below, which exist so that a C engine needs no RCCL
+ * headers: rank 0 calls flbgpu_rccl_unique_id, ships the 128 bytes to the others by its own means, every rank calls
+ * flbgpu_rccl_comm_init); stream a hipStream_t or NULL.  librccl is loaded on first use. */
+int flbgpu_rccl_unique_id(void *id128);
+int flbgpu_rccl_comm_init(void **rccl_comm, int nranks, const void *id128, int rank);
+int flbgpu_rccl_comm_destroy(void *rccl_comm);
+int64_t flbgpu_l2m_all_reduce(flbgpu_filter *f, void *rccl_comm, void *stream, uint64_t max_series, uint64_t *rows,
+                              uint64_t *key_off, char *keys, size_t keys_cap, size_t *keys_needed);
 /* Global index of the next record (orders first-appearance / last-writer across shards). */
 void flbgpu_l2m_set_index_base(flbgpu_filter *f, uint64_t base);
 /* last run: observations, rows sent to the exact-arithmetic kernel, rows with a stale value; total

@@ -304,3 +304,26 @@ def test_numconv_on_device(g):
                 assert cons[i] == cn.value and (int(bits_[i]) == hb or (math.isnan(out.value))), (c, mode)
             else:
                 assert cons[i] == -1, (c, mode)
+
+
+def test_rccl_all_reduce_in_c_single_rank(g):
+    """flbgpu_l2m_all_reduce (librccl loaded by libflbgpu.so, ncclAllGather + ncclAllReduce MAX / SUM on device
+    buffers): with one rank the merged state is the rank's own export, through the same code path N ranks take.
+    (The merge algebra across ranks is tests/test_l2m_merge.py, gloo, world_size 2.)"""
+    import numpy as np
+    data, off, ep = synth.apache_records(20000)
+    po = ob.Parser(APACHE2, time_fmt=TF, time_key="time")
+    _, parsed = ob.FilterParser("log", [po]).filter(bytes(data))
+    comm = g.RcclComm(1, 0)
+    for mode, props, vf in (("counter", [("label_field", "method"), ("label_field", "code")], None),
+                            ("histogram", [("label_field", "code"), ("bucket", "1000"), ("bucket", "100000")], "size"),
+                            ("gauge", [("label_field", "code")], "size")):
+        f = g.FilterLogToMetrics(mode, props, value_field=vf)
+        f.set_index_base(3 << 40)
+        assert f.filter(parsed)[0] == g.NOTOUCH
+        keys0, rows0 = f.export()
+        keys1, rows1 = g.l2m_all_reduce_rccl(f, comm)
+        assert keys1 == keys0 and np.array_equal(rows1, rows0), mode
+        assert f.snapshot((keys1, rows1)) == f.snapshot()
+        f.close()
+    comm.close()
