@@ -500,7 +500,9 @@ bool rccl_load() {
     if (g_rccl.h) return true;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
-    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // one RCCL runtime per process: a copy the host program already loaded (e.g. the one bundled with PyTorch) is reused
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (h) break; }
+    if (!h) for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { set_err("RCCL: librccl.so not found (%s)", dlerror()); return false; }
     Rccl r;
     r.h = h;
