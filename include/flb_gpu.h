@@ -270,6 +270,12 @@ int flbgpu_nc_fmt_f6(double v, char *buf, int cap);
 int flbgpu_nc_fmt_ld(long long v, char *buf);
 int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *consumed);
 
+/* ---- diagnostics: counter calibration (csrc/calib.hip, tools/calib_counters.py) ------------------------------
+ * Runs one kernel whose HBM byte count is known (mode 0 coalesced 16 B/lane reads, 1 coalesced 4 B/lane reads,
+ * 2 one whole 128 B line per lane, 3 16 B of a 128 B line per lane, 4 coalesced 16 B/lane writes) over n bytes of
+ * dev_in / dev_out, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled per request shape. */
+int flbgpu_calib_run(int mode, void *dev_in, void *dev_out, uint64_t n, int cus);
+
 #ifdef __cplusplus
 }
 #endif
