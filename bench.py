@@ -56,18 +56,26 @@ def recorded_traffic(kernel, n):
         return None, None
     try:
         ks = json.load(open(path))["kernels"]
-        hit = [v for k, v in ks.items() if k.split("::")[-1].split("<")[0].split("(")[0] == kernel]
+        base = lambda k: k.split("::")[-1].split("<")[0].split("(")[0]
+        hit = [v for k, v in ks.items() if base(k) == kernel or (kernel.endswith("k_scan") and base(k).startswith("k_scan_"))]
         if not hit:
             return None, None
+        if len(hit) > 1:                                  # the scan is three small kernels
+            hit = [{c: sum(h.get(c, 0) for h in hit) for c in ("FETCH_SIZE", "WRITE_SIZE")}]
+        # profiles/r2_counter_calibration.json (tools/calib_counters.py, kernels with a known HBM byte count): on this
+        # GPU FETCH_SIZE x 1024 is HALF the bytes fetched for every read shape measured -- 16 B/lane and 4 B/lane
+        # coalesced, a whole 128 B line per lane, 16 B of a line per lane (which pulls the whole line) -- and
+        # WRITE_SIZE x 1024 is the bytes written.
         cal = {}
         cpath = os.path.join(ROOT, "profiles", "r2_counter_calibration.json")
         if os.path.exists(cpath):
-            cal = json.load(open(cpath)).get("fetch_factor", {})
+            cal = json.load(open(cpath))
         pattern = {"k_parser_locate": "coalesced16", "k_grep_match": "coalesced16", "k_gather": "coalesced16",
-                   "k_parser_rx": "per_lane64", "k_parser_finish": "column4", "k_parser_emit": "per_lane16", "k_pg_emit": "per_lane16"}.get(kernel, "column4")
-        ff = float(cal.get(pattern, 1.0))
-        b = hit[0].get("FETCH_SIZE", 0) * 1024 * ff + hit[0].get("WRITE_SIZE", 0) * 1024
-        return int(b), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x %.2f: calibrated for '%s' reads)" % (ff, pattern)
+                   "k_parser_rx": "lane_line128", "k_parser_finish": "column4", "k_parser_emit": "lane_line128", "k_pg_emit": "lane_line128"}.get(kernel, "column4")
+        ff = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
+        wf = float(cal.get("write_factor", {}).get("write16", 1.0))
+        b = hit[0].get("FETCH_SIZE", 0) * 1024 * ff + hit[0].get("WRITE_SIZE", 0) * 1024 * wf
+        return int(b), PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH x %.2f, WRITE x %.2f: profiles/r2_counter_calibration.json)" % (ff, wf)
     except Exception:
         return None, None
 
