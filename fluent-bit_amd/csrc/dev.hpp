@@ -97,6 +97,10 @@ struct DevParser {
     // filter's device copy of this struct at the start of every run (time(NULL), UTC).
     int yearless;
     int now_year, now_mon, now_mday;     // 4-digit year, tm_mon (0..11), tm_mday
+    // Types of a logfmt / ltsv parser (keys come from the text, so the casts are looked up by name per pair:
+    // flb_parser_typecast, src/flb_parser.c:2067-2164); names live in names[]
+    int nkvtypes;
+    int kvtype_off[MAX_NAMES], kvtype_len[MAX_NAMES], kvtype_kind[MAX_NAMES];
 };
 
 // ---- record accessor / key

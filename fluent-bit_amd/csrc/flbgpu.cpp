@@ -368,12 +368,35 @@ extern "C" flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *
     if (format && !strcasecmp(format, "logfmt")) kv = 1;
     else if (format && !strcasecmp(format, "ltsv")) kv = 2;
     if (!kv) { set_err("parser '%s': format '%s' is not logfmt or ltsv", name ? name : "", format ? format : ""); return nullptr; }
-    if (types && types[0]) {
-        set_err("parser '%s': Types on a %s parser (flb_parser_typecast per pair) are not supported on the GPU path", name ? name : "", format);
-        return nullptr;
-    }
     flbgpu_parser *p = parser_create_impl(true, name, nullptr, 1, time_fmt, time_key, time_offset, time_keep, time_strict, nullptr);
     if (!p) return nullptr;
+    // Types: "key:type key:type" (src/flb_parser.c:1130-1182); the pair writer looks the cast up by key name
+    if (types && types[0]) {
+        const char *q = types;
+        size_t noff = 0;
+        while (*q) {
+            while (*q == ' ') q++;
+            if (!*q) break;
+            const char *sp = strchr(q, ' ');
+            if (!sp) sp = q + strlen(q);
+            const char *colon = (const char *) memchr(q, ':', sp - q);
+            if (colon) {
+                const size_t kl = (size_t) (colon - q);
+                std::string ty(colon + 1, sp - colon - 1);
+                int t = TY_STRING;
+                if (!strcasecmp(ty.c_str(), "integer")) t = TY_INT;
+                else if (!strcasecmp(ty.c_str(), "bool")) t = TY_BOOL;
+                else if (!strcasecmp(ty.c_str(), "float")) t = TY_FLOAT;
+                else if (!strcasecmp(ty.c_str(), "hex")) t = TY_HEX;
+                if (p->dev.nkvtypes >= MAX_NAMES || noff + kl > sizeof(p->dev.names)) { set_err("parser '%s': too many Types", name ? name : ""); flbgpu_parser_destroy(p); return nullptr; }
+                const int i = p->dev.nkvtypes++;
+                p->dev.kvtype_off[i] = (int) noff; p->dev.kvtype_len[i] = (int) kl; p->dev.kvtype_kind[i] = t;
+                memcpy(p->dev.names + noff, q, kl);
+                noff += kl;
+            }
+            q = *sp ? sp + 1 : sp;
+        }
+    }
     p->dev.kv_format = kv;
     p->dev.no_bare_keys = (kv == 1 && logfmt_no_bare_keys) ? 1 : 0;
     return p;

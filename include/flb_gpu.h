@@ -66,8 +66,9 @@ flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt,
  * NULL, ...) + flb_parser_logfmt_do / flb_parser_ltsv_do (src/flb_parser_logfmt.c:63-325,
  * src/flb_parser_ltsv.c:82-268; quoted logfmt values are decoded like flb_unescape_string_utf8,
  * src/flb_unescape.c:186-277).  logfmt_no_bare_keys = the Logfmt_No_Bare_Keys property
- * (src/flb_parser.c:1319-1324).  Types (non-empty `types`) and decoders are refused: NULL +
- * flbgpu_last_error(). */
+ * (src/flb_parser.c:1319-1324).  `types` = "key:type ..." as for regex parsers: with Types every kept pair goes
+ * through flb_parser_typecast on the raw value text (src/flb_parser_logfmt.c:176-182, src/flb_parser_ltsv.c:149-155).
+ * Decoders have no place in this ABI. */
 flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *format, const char *time_fmt, const char *time_key,
                                        const char *time_offset, int time_keep, int time_strict, int logfmt_no_bare_keys,
                                        const char *types);

@@ -211,6 +211,17 @@ oflb_parser *oflb_parser_create(const char *regex, int skip_empty, const char *t
 }
 
 /* Format logfmt (1) / ltsv (2): flb_parser_create(name, "logfmt" | "ltsv", NULL, ...) */
+oflb_parser *oflb_parser_create_kv2(int kv_format, const char *time_fmt, const char *time_key, const char *time_offset,
+                                    int time_keep, int time_strict, int no_bare_keys, const char *types_str)
+{
+    oflb_parser *p = oflb_parser_create(NULL, 0, time_fmt, time_key, time_offset, time_keep, time_strict, types_str);
+    if (!p) return NULL;
+    p->is_json = 0;
+    p->kv_format = kv_format;
+    p->no_bare_keys = no_bare_keys;
+    return p;
+}
+
 oflb_parser *oflb_parser_create_kv(int kv_format, const char *time_fmt, const char *time_key, const char *time_offset,
                                    int time_keep, int time_strict, int no_bare_keys)
 {
@@ -645,6 +656,9 @@ static int kv_walk(oflb_parser *parser, const char *in_buf, size_t in_size, omp_
             }
             if (!time_found || parser->time_keep) {
                 if (!pck) (*count)++;
+                /* with Types every pair goes through flb_parser_typecast on the RAW value text: no "true" for an
+                 * empty value, no unescaping (src/flb_parser_logfmt.c:176-182, src/flb_parser_ltsv.c:149-155) */
+                else if (parser->types_len != 0) typecast(parser, (const char *) key, (int) key_len, (const char *) value, (int) value_len, pck);
                 else {
                     omp_pack_str(pck, key_len);
                     omp_buf_write(pck, key, key_len);

@@ -73,8 +73,10 @@ class Parser:
         if format == "json":
             regex = None                      # Format json (src/flb_parser_json.c)
         if format in ("logfmt", "ltsv"):      # src/flb_parser_logfmt.c, src/flb_parser_ltsv.c
-            self.h = lib().oflb_parser_create_kv(1 if format == "logfmt" else 2, e(time_fmt), e(time_key), e(time_offset),
-                                                 int(time_keep), int(time_strict), int(no_bare_keys))
+            lib().oflb_parser_create_kv2.restype = c_void_p
+            lib().oflb_parser_create_kv2.argtypes = [c_int, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int, c_char_p]
+            self.h = lib().oflb_parser_create_kv2(1 if format == "logfmt" else 2, e(time_fmt), e(time_key), e(time_offset),
+                                                  int(time_keep), int(time_strict), int(no_bare_keys), e(types))
         else:
             self.h = lib().oflb_parser_create(e(regex), int(skip_empty), e(time_fmt), e(time_key), e(time_offset),
                                               int(time_keep), int(time_strict), e(types))

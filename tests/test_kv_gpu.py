@@ -86,9 +86,31 @@ def test_kv_random_texts(g, fmt):
             assert want[0] == got[0] and want[1] == got[1], (fmt, pargs, reserve, preserve, diff(want[1], got[1]))
 
 
-def test_kv_parsers_refuse_types(g):
-    with pytest.raises(ValueError):
-        g.Parser(format="logfmt", types="a:integer")
+@pytest.mark.parametrize("fmt", ["logfmt", "ltsv"])
+def test_kv_parsers_with_types(g, fmt):
+    """Types on logfmt / ltsv parsers: flb_parser_typecast per pair on the raw value text
+    (src/flb_parser_logfmt.c:176-182, src/flb_parser_ltsv.c:149-155, src/flb_parser.c:2067-2164)"""
+    rng = random.Random(9)
+    sep, kvs = (" ", "=") if fmt == "logfmt" else ("\t", ":")
+    vals = ["100", "-7", "0x1F", "ff", "1.5", "0.1", "1e400", "9007199254740993", "2.4703282292062328e-324", "8.41e21", "true", "FALSE", "maybe", "",
+            "12abc", " 5", "3.141592653589793238462643383279", "text"]
+    recs = []
+    for i in range(4000):
+        pairs = [(k, rng.choice(vals)) for k in rng.sample(["i", "h", "f", "b", "s", "other", "time"], rng.randrange(1, 6))]
+        t = sep.join(k + kvs + (v if k != "time" else "2022-10-31T12:00:01.5") for k, v in pairs)
+        if fmt == "logfmt" and rng.random() < 0.2:
+            t += ' q="a\\nb" bare'
+        recs.append(rec({"log": t.encode()}, sec=i))
+    data = b"".join(recs)
+    for pargs in (dict(format=fmt, types="i:integer h:hex f:float b:bool s:string"),
+                  dict(format=fmt, types="f:float i:integer", time_fmt=TFMT, time_key="time"),
+                  dict(format=fmt, types="other:float f:float f:integer", time_fmt=TFMT, time_key="time", time_keep=True)):
+        for reserve, preserve in ((False, False), (True, True)):
+            want, got = both(g, data, pargs, reserve, preserve)
+            assert want[0] == got[0] and want[1] == got[1], (fmt, pargs, reserve, preserve, diff(want[1], got[1]))
+    # in a list behind a regex parser (the generic kernel tries the whole list)
+    want, got = both_list(g, data, [dict(regex=r"^(?<never>ZZZ)$"), dict(format=fmt, types="i:integer f:float")])
+    assert want == got, diff(want[1], got[1])
 
 
 def both_list(g, data, pargs_list, reserve=False, preserve=False, key="log"):

@@ -33,6 +33,18 @@ def test_logfmt_reference_vectors():
     assert m[b"time"] == b"2022-10-31T12:00:01.123" and len(m) == 5 and t == (1667217601, 123000000)
 
 
+def test_logfmt_types_reference_vector():
+    # tests/internal/parser_logfmt.c:322-392 test_types: int:hex on "int=100" -> 256, everything else a string
+    s = b'str="text" int=100 double=1.23 bool=true'
+    r, m, t = do(ob.Parser(format="logfmt", types="int:hex"), s)
+    assert r == len(s) and m == {b"str": b"text", b"int": 256, b"double": b"1.23", b"bool": b"true"}
+    # with Types every pair goes through flb_parser_typecast on the raw text: no `true` for a bare key, no unescaping
+    r, m, t = do(ob.Parser(format="logfmt", types="n:integer f:float b:bool"), b'bare n=12x f=1e2 b=TRUE q="a\\nb" e= b=maybe')
+    assert m == {b"bare": b"", b"n": 12, b"f": 100.0, b"b": b"maybe", b"q": b"a\\nb", b"e": b""}
+    r, m, t = do(ob.Parser(format="ltsv", types="size:integer ok:bool"), b"size:512\tok:false\thost:h")
+    assert m == {b"size": 512, b"ok": False, b"host": b"h"}
+
+
 def test_ltsv_reference_vectors():
     # tests/internal/parser_ltsv.c: test_basic / test_time_key / test_time_keep / the json_str field
     s = b"str:text\tint:100\tdouble:1.23\tbool:true"
