@@ -400,12 +400,13 @@ void oev_decoder_init(oev_decoder *d, const char *buf, size_t len)
     d->buf = buf; d->len = len; d->off = 0;
     d->last_result = OEV_ERR_INSUFFICIENT_DATA;
     omp_arena_init(&d->arena);
+    omp_arena_init(&d->garena);
     d->empty_map.type = OMP_MAP;
     d->empty_map.via.map.size = 0;
     d->empty_map.via.map.ptr = NULL;
 }
 
-void oev_decoder_destroy(oev_decoder *d) { omp_arena_free(&d->arena); }
+void oev_decoder_destroy(oev_decoder *d) { omp_arena_free(&d->arena); omp_arena_free(&d->garena); }
 
 /* src/flb_log_event_decoder.c:182-245 */
 static int decode_timestamp(const omp_obj *in, oev_time *out)
@@ -474,9 +475,12 @@ static int decode_object(oev_decoder *d, oev_event *ev, omp_obj *root, size_t pr
     return OEV_SUCCESS;
 }
 
-/* src/flb_log_event_decoder.c:342-489 with read_groups == FALSE (the filters' setting) */
+/* src/flb_log_event_decoder.c:342-489 with read_groups == FALSE (the filters' and the formatters' setting).
+ * The reference recurses once per skipped record (group markers, "invalid group markers") and refuses to
+ * decode at depth 1000 (:27,:389-394): a record that follows 1000 consecutive skipped ones ends the walk. */
 int oev_decoder_next(oev_decoder *d, oev_event *ev)
 {
+    d->recursion_depth = 0;
     for (;;) {
         size_t prev = d->off;
         int r;
@@ -487,9 +491,32 @@ int oev_decoder_next(oev_decoder *d, oev_event *ev)
         if (r != OMP_UNPACK_SUCCESS) { d->last_result = OEV_ERR_DESERIALIZATION; return d->last_result; }
         d->last_result = decode_object(d, ev, &d->root, prev);
         if (d->last_result != OEV_SUCCESS) return d->last_result;
+        if (d->recursion_depth >= 1000) { d->last_result = OEV_ERR_DESERIALIZATION; return d->last_result; }
         /* record type: src/flb_log_event_decoder.c:491-511.  sec >= 0 normal; -1/-2 group
-         * markers (skipped); any other negative value: "invalid group marker", skipped. */
-        if (ev->ts.sec >= 0) return OEV_SUCCESS;
+         * markers (skipped); any other negative value: "invalid group marker", skipped with the
+         * group state preserved (:396-413). */
+        if (ev->ts.sec >= 0) {
+            ev->group_metadata = d->cur_group_metadata;
+            ev->group_attributes = d->cur_group_attributes;
+            return OEV_SUCCESS;
+        }
+        if (ev->ts.sec == -1) {
+            /* group opener: the decoder keeps this record's objects (:427-461) */
+            size_t goff = prev;
+            omp_arena_reset(&d->garena);
+            omp_unpack_next(&d->garena, &d->groot, d->buf, d->len, &goff);
+            {
+                omp_obj *header = &d->groot.via.array.ptr[0];
+                if (header->type == OMP_ARRAY && header->via.array.size == 2) d->cur_group_metadata = &header->via.array.ptr[1];
+                else d->cur_group_metadata = &d->empty_map;
+                d->cur_group_attributes = &d->groot.via.array.ptr[1];
+            }
+        }
+        else if (ev->ts.sec == -2) {
+            d->cur_group_metadata = NULL;
+            d->cur_group_attributes = NULL;
+        }
+        d->recursion_depth++;
     }
 }
 

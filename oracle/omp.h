@@ -101,6 +101,8 @@ typedef struct oev_event {
     omp_obj *root;
     const char *record_base;
     size_t record_length;
+    omp_obj *group_metadata;     /* of the enclosing group (NULL outside groups): decoder :483-484 */
+    omp_obj *group_attributes;
 } oev_event;
 
 typedef struct oev_decoder {
@@ -111,6 +113,10 @@ typedef struct oev_decoder {
     omp_arena arena;
     omp_obj root;
     omp_obj empty_map;
+    omp_arena garena;           /* the last group opener (unpacked_group_record) */
+    omp_obj groot;
+    omp_obj *cur_group_metadata, *cur_group_attributes;
+    int recursion_depth;        /* consecutive skipped records (the reference recurses once per skip) */
 } oev_decoder;
 
 void oev_decoder_init(oev_decoder *d, const char *buf, size_t len);

@@ -129,6 +129,19 @@ class FilterParser:
         ob = c_size_t()
         return lib().oflb_bench_fparser(self.h, data, len(data), iters, byref(ob)), ob.value
 
+def msgpack_to_json_format(data, json_format, date_format, date_key, escape_unicode=1, nan_to_null=0):
+    """flb_pack_msgpack_to_json_format (src/flb_pack.c:1320): bytes, or None where the reference returns NULL"""
+    L = lib()
+    L.oflb_msgpack_to_json_format.argtypes = [c_char_p, c_size_t, c_int, c_int, c_char_p, c_int, c_int, c_int,
+                                              POINTER(c_void_p), POINTER(c_size_t)]
+    out = c_void_p(); n = c_size_t()
+    r = L.oflb_msgpack_to_json_format(data, len(data), json_format, date_format, date_key, -1 if date_key is None else len(date_key),
+                                      escape_unicode, nan_to_null, byref(out), byref(n))
+    if r != 0:
+        return None
+    return _take(out, n)
+
+
 def count_records(data):
     return lib().oflb_count_records(data, len(data))
 
