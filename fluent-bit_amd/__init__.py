@@ -107,6 +107,12 @@ def lib():
     L.flbgpu_l2m_finalize_row.argtypes = [c_int, c_int, c_void_p, POINTER(c_double), c_void_p, POINTER(c_uint64), POINTER(c_double)]
     L.flbgpu_l2m_set_index_base.argtypes = [c_void_p, c_uint64]
     L.flbgpu_l2m_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+    L.flbgpu_jsonfmt_create.restype = c_void_p
+    L.flbgpu_jsonfmt_create.argtypes = [c_int, c_int, c_char_p, c_int, c_int, c_int]
+    L.flbgpu_jsonfmt_run.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]
+    L.flbgpu_jsonfmt_run_dev.argtypes = [c_void_p, POINTER(DevChunk), POINTER(DevChunk)]
+    L.flbgpu_pack_msgpack_to_json_format.argtypes = [c_char_p, c_uint64, c_int, c_int, c_char_p, c_int, c_int, c_int,
+                                                     POINTER(c_void_p), POINTER(c_size_t)]
     L.flbgpu_nc_scan_double.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]
     L.flbgpu_nc_fmt_f6.argtypes = [c_double, c_char_p, c_int]
     L.flbgpu_nc_fmt_ld.argtypes = [ctypes.c_longlong, c_char_p]
@@ -238,6 +244,54 @@ class FilterGrep(_Filter):
         self.h = lib().flbgpu_filter_grep_create(n, kinds, vals, _b(logical_op))
         if not self.h:
             raise ValueError("flbgpu_filter_grep_create: " + last_error())
+
+
+JSON_FORMAT = {"json": 1, "stream": 2, "lines": 3}                                        # flb_pack_to_json_format_type
+JSON_DATE = {"double": 0, "iso8601": 1, "epoch": 2, "java_sql_timestamp": 3, "epoch_ms": 4}    # flb_pack_to_json_date_type
+
+
+class JsonFormatter(_Filter):
+    """flb_pack_msgpack_to_json_format (src/flb_pack.c:1320-1600): a chunk of log events as JSON text."""
+
+    def __init__(self, json_format="lines", date_format="double", date_key=b"date", escape_unicode=True, nan_to_null=False):
+        jf = JSON_FORMAT.get(json_format, json_format)
+        df = JSON_DATE.get(date_format, date_format)
+        dk = None if date_key is None else _b(date_key)
+        self.h = lib().flbgpu_jsonfmt_create(jf, df, dk, -1 if dk is None else len(dk), int(bool(escape_unicode)), int(bool(nan_to_null)))
+        if not self.h:
+            raise ValueError(last_error())
+
+    def format(self, data):
+        """host chunk -> bytes, or None where the reference returns NULL"""
+        out = c_void_p(); sz = c_size_t()
+        r = lib().flbgpu_jsonfmt_run(self.h, data, len(data), byref(out), byref(sz))
+        if r != 0:
+            if last_error():
+                raise RuntimeError(last_error())
+            return None
+        b = ctypes.string_at(out, sz.value)
+        _libc.free(out)
+        return b
+
+    def format_dev(self, chunk):
+        """device chunk -> (0 | -1, DevChunk of the text in HBM)"""
+        out = DevChunk()
+        r = lib().flbgpu_jsonfmt_run_dev(self.h, byref(chunk), byref(out))
+        if r != 0 and last_error():
+            raise RuntimeError(last_error())
+        return r, out
+
+
+def msgpack_to_json_format(data, json_format, date_format, date_key, escape_unicode=1, nan_to_null=0):
+    """the one-shot C entry with the reference's argument list"""
+    out = c_void_p(); sz = c_size_t()
+    r = lib().flbgpu_pack_msgpack_to_json_format(data, len(data), json_format, date_format, date_key, -1 if date_key is None else len(date_key),
+                                                 escape_unicode, nan_to_null, byref(out), byref(sz))
+    if r != 0:
+        return None
+    b = ctypes.string_at(out, sz.value)
+    _libc.free(out)
+    return b
 
 
 class ChainStat(Structure):

@@ -254,6 +254,41 @@ struct GrepArgs {
 };
 
 
+// ---- msgpack -> JSON output formatter (fmt_dev.inc / kernels_fmt.hip): flb_pack_msgpack_to_json_format
+struct JsonFmtCfg {
+    int json_format;            // FLB_PACK_JSON_FORMAT_JSON 1 / STREAM 2 / LINES 3 (include/fluent-bit/flb_pack.h:57-60)
+    int date_format;            // FLB_PACK_JSON_DATE_* (:38-42)
+    int escape_unicode;
+    int nan_to_null;            // json.convert_nan_to_null (src/flb_pack.c:54-61)
+    int has_date;               // date_key != NULL
+    int date_key_is_internal;   // date_key == "__internal__"
+    uint32_t date_key_len;
+    const uint8_t *date_key;    // device copy
+};
+struct JsonFmtArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    JsonFmtCfg cfg;
+    uint32_t *len;              // [n] bytes the row contributes to the output (0: markers, rows past the end)
+    const uint32_t *g_row;      // [n] 1 + row of the group opener that governs the row, 0 = none; nullptr: chunk without groups
+    unsigned long long *first_bad;   // first row the decoder refuses
+    unsigned long long *first_fail;  // first row whose temporary map would not unpack (the reference returns NULL)
+    unsigned long long *counts;      // [0] records, [1] group markers (-1 / -2), [2] skipped rows (all negative times)
+    const uint64_t *out_off;    // [n + 1] exclusive scan of len
+    uint8_t *out;
+};
+struct JsonGroupArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n;
+    uint32_t *g_row;
+    unsigned long long *skip_limit;  // first row that follows 1000 consecutive skipped rows (decoder :27,:389-394), else ~0
+};
+void launch_fmt_size(const JsonFmtArgs &a, int cus, hipStream_t st);
+void launch_fmt_emit(const JsonFmtArgs &a, int cus, hipStream_t st);
+void launch_fmt_groups(const JsonGroupArgs &a, hipStream_t st);
+
 // ---- flb_filter_do over [filter_parser, filter_grep] without materialising the parsed chunk (fused_kernels.inc)
 struct PgDecideArgs {
     const uint8_t *data;

@@ -1001,7 +1001,7 @@ extern "C" int flbgpu_tail_clean_host(const void *data, size_t bytes, size_t con
 
 // A device chunk handed over without its offset column (row_off == NULL): the filter's indexer finds
 // the records first (flbgpu_index_dev).  Returns false on failure; *garbage = undecodable bytes follow.
-static bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage) {
+bool flbgpu::resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage) {
     *resolved = *in;
     *garbage = false;
     if (in->row_off != nullptr || in->bytes == 0) return true;
@@ -1222,7 +1222,7 @@ static bool host_index_range(flbgpu_filter *f, const uint8_t *d, size_t bytes, s
 // Copies `data` into f->h_in_data through the pinned slabs and finds the record boundaries -- on the
 // host while the slabs are in flight, or on the device once the bytes are there.  Returns the
 // record count (-1 on a HIP failure), the bytes covered by whole records and the device offsets.
-static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off) {
+int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off) {
     hipStream_t st = f->stream;
     if (!stage_init(f) || !f->h_in_data.ensure(bytes + 16)) return -1;
     bool dev_index = bytes >= DEV_INDEX_MIN && !getenv("FLBGPU_HOST_INDEX");
@@ -1272,7 +1272,7 @@ static int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, s
 }
 
 // device -> caller's (pageable) buffer through the two pinned slabs
-static bool staged_download(flbgpu_filter *f, void *dst, const void *src, size_t bytes) {
+bool flbgpu::staged_download(flbgpu_filter *f, void *dst, const void *src, size_t bytes) {
     hipStream_t st = f->stream;
     if (!stage_init(f)) return false;
     const size_t slab = bytes < STAGE_SLAB ? bytes : STAGE_SLAB;

@@ -84,7 +84,7 @@ void l2m_state_destroy(L2mState *);
 struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
 struct ProfPending { const char *name; hipEvent_t e0, e1; };
 
-enum { F_PARSER = 1, F_GREP = 2, F_L2M = 3 };
+enum { F_PARSER = 1, F_GREP = 2, F_L2M = 3, F_JSONFMT = 4 };
 
 struct flbgpu_filter {
     int kind = 0;
@@ -101,6 +101,9 @@ struct flbgpu_filter {
     int logical_op = 0;
     // filter_log_to_metrics
     L2mState *l2m = nullptr;
+    // msgpack -> JSON output formatter (packfmt.cpp)
+    flbgpu::JsonFmtCfg jcfg = {};
+    flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
     flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
@@ -118,7 +121,7 @@ struct flbgpu_filter {
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off};
+                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
         hp_misc.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
@@ -148,6 +151,14 @@ struct ProfScope {
     }
 };
 void prof_resolve(flbgpu_filter *f);
+
+namespace flbgpu {
+// host chunk -> device (pinned slabs, record boundaries found on the host or the device); device -> host buffer
+int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off);
+bool staged_download(flbgpu_filter *f, void *dst, const void *src, size_t bytes);
+// row_off == NULL ("raw chunk bytes" in HBM): the records are found on the device
+bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage);
+}
 
 // filter_log_to_metrics entry used by flbgpu_filter_run / flbgpu_filter_run_dev
 bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, int *ret);

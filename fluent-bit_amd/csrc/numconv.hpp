@@ -532,5 +532,183 @@ NC_HD_NOINL int fmt_f6(uint64_t bits, Dst &out, int cap) {
     return w;
 }
 
+// ------------------------------------------------------------------------------------------
+// "%.16g" / "%.1f": the float rule of the reference's msgpack -> JSON writer (src/flb_pack.c:1020-1034)
+// ------------------------------------------------------------------------------------------
+NC_HD_NOINL uint32_t big_divsmall(Big &b, uint32_t d) {
+    uint64_t rem = 0;
+    for (int i = b.n - 1; i >= 0; i--) {
+        uint64_t cur = (rem << 32) | b.d[i];
+        b.d[i] = (uint32_t) (cur / d);
+        rem = cur % d;
+    }
+    while (b.n > 0 && b.d[b.n - 1] == 0) b.n--;
+    return (uint32_t) rem;
+}
+// b >>= s; returns whether a discarded bit was set
+NC_HD_NOINL bool big_shr(Big &b, int64_t s) {
+    if (b.n == 0 || s == 0) return false;
+    const int64_t ws = s / 32;
+    const int bs = (int) (s % 32);
+    bool sticky = false;
+    if (ws >= b.n) { sticky = true; b.n = 0; return sticky; }      // b != 0 and everything is shifted out
+    for (int i = 0; i < (int) ws; i++) if (b.d[i]) sticky = true;
+    if (bs && (b.d[ws] & ((1u << bs) - 1))) sticky = true;
+    const int nn = b.n - (int) ws;
+    for (int i = 0; i < nn; i++) {
+        uint64_t v = (uint64_t) b.d[i + ws] >> bs;
+        if (bs && i + ws + 1 < b.n) v |= (uint64_t) b.d[i + ws + 1] << (32 - bs);
+        b.d[i] = (uint32_t) v;
+    }
+    b.n = nn;
+    while (b.n > 0 && b.d[b.n - 1] == 0) b.n--;
+    return sticky;
+}
+
+// floor(M * 2^E * 10^s * 2) for M * 2^E > 0, with `sticky` = the floor discarded something.
+// Returns false when the result does not fit 63 bits (the caller's decimal exponent is too small).
+NC_HD_NOINL bool scaled_floor2(uint64_t M, int64_t E, int64_t s, uint64_t &q2, bool &sticky) {
+    sticky = false;
+    const int64_t sh = E + s + 1;
+    if (s >= 0 && s <= 27) {
+        // M * 5^s in 128 bits (M < 2^53, 5^27 < 2^63)
+        uint64_t p5 = 1;
+        for (int64_t i = 0; i < s; i++) p5 *= 5;
+        uint64_t hi, lo;
+        mul64(M, p5, hi, lo);
+        if (sh >= 0) {
+            const int bl = hi ? 128 - clz64(hi) : (lo ? 64 - clz64(lo) : 0);
+            if (bl + sh > 63) return false;
+            q2 = lo << sh;
+            return true;
+        }
+        const int64_t rs = -sh;
+        if (rs >= 128) { q2 = 0; sticky = (hi | lo) != 0; return true; }
+        if (rs >= 64) {
+            q2 = rs == 64 ? hi : hi >> (rs - 64);
+            sticky = lo != 0 || (rs > 64 && (hi & ((1ull << (rs - 64)) - 1)) != 0);
+            return (q2 >> 63) == 0;
+        }
+        if (hi >> rs) return false;                                  // 0 < rs < 64
+        q2 = (hi << (64 - rs)) | (lo >> rs);
+        sticky = (lo & ((1ull << rs) - 1)) != 0;
+        return (q2 >> 63) == 0;
+    }
+    Big N;
+    big_set(N, M);
+    if (s >= 0) {
+        big_mul_pow5(N, s);
+        if (sh >= 0) big_shl(N, sh); else sticky = big_shr(N, -sh);
+    }
+    else {
+        if (sh > 0) big_shl(N, sh);
+        int64_t j = -s;
+        while (j >= 13) { if (big_divsmall(N, 1220703125u)) sticky = true; j -= 13; }
+        uint32_t m = 1;
+        while (j-- > 0) m *= 5;
+        if (m > 1 && big_divsmall(N, m)) sticky = true;
+        if (sh < 0 && big_shr(N, -sh)) sticky = true;
+    }
+    if (N.n > 2) return false;
+    q2 = (N.n > 0 ? N.d[0] : 0) | ((uint64_t) (N.n > 1 ? N.d[1] : 0) << 32);
+    return (q2 >> 63) == 0;
+}
+
+// "%.16g" of a binary64, exactly rounded like glibc's printf (round-half-even on the exact value)
+template <class Dst>
+NC_HD_NOINL int fmt_g16(uint64_t bits, Dst &out) {
+    int w = 0;
+    if (bits & DBL_SIGN) { out.put('-'); w++; }
+    bits &= ~DBL_SIGN;
+    if (bits >= DBL_INF_BITS) {
+        const char *t = bits == DBL_INF_BITS ? "inf" : "nan";
+        for (int i = 0; i < 3; i++) { out.put((uint32_t) t[i]); w++; }
+        return w;
+    }
+    if (bits == 0) { out.put('0'); return w + 1; }
+    uint64_t M;
+    int64_t E;
+    bits_to_me(bits, false, M, E);
+    const int64_t e2 = (64 - clz64(M)) + E - 1;                    // floor(log2 v)
+    int64_t k = (e2 * 78913) >> 18;                                // ~ floor(e2 * log10 2); corrected below
+    uint64_t D = 0;
+    for (int guard = 0; guard < 8; guard++) {
+        uint64_t q2;
+        bool sticky;
+        if (!scaled_floor2(M, E, 15 - k, q2, sticky)) { k++; continue; }
+        const uint64_t pre = q2 >> 1;
+        if (pre >= 10000000000000000ull) { k++; continue; }
+        if (pre < 1000000000000000ull) { k--; continue; }
+        D = pre;
+        if ((q2 & 1) && (sticky || (D & 1))) D++;
+        if (D == 10000000000000000ull) { D = 1000000000000000ull; k++; }
+        break;
+    }
+    char dg[16];
+    { uint64_t u = D; for (int i = 15; i >= 0; i--) { dg[i] = (char) ('0' + u % 10); u /= 10; } }
+    int nd = 16;
+    while (nd > 1 && dg[nd - 1] == '0') nd--;
+    auto put = [&](uint32_t c) { out.put(c); w++; };
+    if (k < -4 || k >= 16) {
+        put((uint32_t) dg[0]);
+        if (nd > 1) { put('.'); for (int i = 1; i < nd; i++) put((uint32_t) dg[i]); }
+        put('e');
+        int64_t x = k;
+        if (x < 0) { put('-'); x = -x; } else put('+');
+        if (x >= 100) { put((uint32_t) ('0' + x / 100)); x %= 100; }
+        put((uint32_t) ('0' + x / 10));
+        put((uint32_t) ('0' + x % 10));
+    }
+    else if (k >= 0) {
+        for (int i = 0; i <= (int) k; i++) put(i < nd ? (uint32_t) dg[i] : '0');
+        if (nd > (int) k + 1) { put('.'); for (int i = (int) k + 1; i < nd; i++) put((uint32_t) dg[i]); }
+    }
+    else {
+        put('0'); put('.');
+        for (int64_t i = 0; i < -k - 1; i++) put('0');
+        for (int i = 0; i < nd; i++) put((uint32_t) dg[i]);
+    }
+    return w;
+}
+
+// the number a msgpack float becomes in the reference's JSON (src/flb_pack.c:1020-1034):
+//   f == (double)(long long) f  ->  "%.1f"      (the conversion as x86-64 performs it: out of range -> LLONG_MIN)
+//   NaN with json.convert_nan_to_null -> "null"
+//   otherwise "%.16g"
+template <class Dst>
+NC_HD_NOINL int fmt_json_double(uint64_t bits, bool nan_to_null, Dst &out) {
+    const uint64_t mag = bits & ~DBL_SIGN;
+    bool integral = false;
+    uint64_t ival = 0;
+    if (mag == 0) integral = true;
+    else if (mag < DBL_INF_BITS) {
+        uint64_t M;
+        int64_t E;
+        bits_to_me(mag, false, M, E);
+        if (E >= 0) {
+            if (E <= 10 && (M << E) >> E == M && ((M << E) >> 63) == 0) { integral = true; ival = M << E; }
+            else if (bits == 0xC3E0000000000000ull) { integral = true; ival = 1ull << 63; }          // -2^63
+        }
+        else if (-E < 53) {
+            if ((M & ((1ull << -E) - 1)) == 0) { integral = true; ival = M >> -E; }
+        }
+    }
+    if (integral) {
+        int w = 0;
+        if (bits & DBL_SIGN) { out.put('-'); w++; }
+        char t[20];
+        int n = 0;
+        do { t[n++] = (char) ('0' + ival % 10); ival /= 10; } while (ival);
+        while (n > 0) { out.put((uint32_t) (uint8_t) t[--n]); w++; }
+        out.put('.'); out.put('0');
+        return w + 2;
+    }
+    if (nan_to_null && mag > DBL_INF_BITS) {
+        out.put('n'); out.put('u'); out.put('l'); out.put('l');
+        return 4;
+    }
+    return fmt_g16(bits, out);
+}
+
 }  // namespace nc
 }  // namespace flbgpu

@@ -27,6 +27,12 @@ int flbgpu_nc_fmt_f6(double v, char *buf, int cap) {
     BufDst d{buf, 0};
     return fmt_f6(bits, d, cap);
 }
+int flbgpu_nc_fmt_json_double(double v, int nan_to_null, char *buf) {
+    uint64_t bits;
+    memcpy(&bits, &v, 8);
+    BufDst d{buf, 0};
+    return fmt_json_double(bits, nan_to_null != 0, d);
+}
 int flbgpu_nc_fmt_ld(long long v, char *buf) {
     BufDst d{buf, 0};
     return fmt_ld((int64_t) v, d);

@@ -191,6 +191,24 @@ void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t 
 void flbgpu_filter_profile(flbgpu_filter *f, int enable);
 int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char **names, double *ms, uint64_t *launches);
 
+/* ---- msgpack -> JSON: replaces flb_pack_msgpack_to_json_format ------------------------------------
+ * src/flb_pack.c:1320-1600 (what out_stdout / out_http / out_kafka / out_file ... call on every flushed chunk) with
+ * msgpack2json :984-1145 and flb_utils_write_str src/flb_utils.c:877-1368 underneath.  Same arguments:
+ * json_format FLB_PACK_JSON_FORMAT_JSON 1 / STREAM 2 / LINES 3, date_format FLB_PACK_JSON_DATE_DOUBLE 0 / ISO8601 1 /
+ * EPOCH 2 / JAVA_SQL_TIMESTAMP 3 / EPOCH_MS 4 (include/fluent-bit/flb_pack.h:38-60), date_key NULL or date_key_len < 0
+ * = no date entry, escape_unicode = json.escape_unicode, convert_nan_to_null = json.convert_nan_to_null
+ * (flb_pack_init, src/flb_pack.c:1740).  Returns 0 with *out_buf malloc()'d (NUL terminated, *out_size bytes;
+ * flb_sds_t there) or -1 where the reference returns NULL. */
+int flbgpu_pack_msgpack_to_json_format(const char *data, uint64_t bytes, int json_format, int date_format, const char *date_key,
+                                       int date_key_len, int escape_unicode, int convert_nan_to_null, char **out_buf, size_t *out_size);
+/* The same as an object that keeps its device buffers between chunks; release with flbgpu_filter_destroy.
+ * _run_dev: the chunk is in HBM (row_off == NULL: raw bytes) and the text stays there: out->data / out->bytes, and
+ * out->row_off[0..n] = where each input row's text starts (rows that print nothing are empty). */
+flbgpu_filter *flbgpu_jsonfmt_create(int json_format, int date_format, const char *date_key, int date_key_len,
+                                     int escape_unicode, int convert_nan_to_null);
+int flbgpu_jsonfmt_run(flbgpu_filter *f, const void *data, size_t bytes, char **out_buf, size_t *out_size);
+int flbgpu_jsonfmt_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out);
+
 /* ---- JSON -> msgpack: replaces flb_pack_json / flb_pack_json_recs --------------------------------
  * src/flb_pack.c:670-688 -> :389-508 (default backend: the yyjson reader with STOP_WHEN_DONE | INSITU |
  * ALLOW_INVALID_UNICODE | REPLACE_INVALID_UNICODE, then yyjson_val_to_msgpack :328-387).  Same arguments
@@ -268,6 +286,7 @@ void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call:
  * 2 = needs the exact path (only when exact == 0). */
 int flbgpu_nc_scan_double(const char *s, int len, int mode, int exact, double *out, int *consumed);
 int flbgpu_nc_fmt_f6(double v, char *buf, int cap);
+int flbgpu_nc_fmt_json_double(double v, int nan_to_null, char *buf);   /* src/flb_pack.c:1020-1034: "%.1f" / "null" / "%.16g"; <= 32 chars */
 int flbgpu_nc_fmt_ld(long long v, char *buf);
 int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, uint32_t n, int mode, uint64_t *bits, int *consumed);
 

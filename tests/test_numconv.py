@@ -105,3 +105,31 @@ def test_printf_f_and_ld_against_glibc():
     for v in [0, 1, -1, 9, 10, 2 ** 63 - 1, -2 ** 63, 10 ** 18, -10 ** 18 + 1] + [rng.randrange(-2 ** 63, 2 ** 63) for _ in range(2000)]:
         n = L.flbgpu_nc_fmt_ld(v, buf)
         assert buf.raw[:n] == str(v).encode()
+
+
+def test_json_double_against_glibc():
+    """the float rule of the reference's JSON writer (src/flb_pack.c:1020-1034): "%.1f" when the value survives the
+    round trip through long long (as x86-64 converts), else "%.16g"; both as glibc prints them"""
+    rng = random.Random(5)
+    vals = [0.0, -0.0, 1.0, -1.0, 1.5, 0.1, 1e15, 1e15 + 0.5, 1e16, 1e17, 1e22, 1e23, 2.0 ** 53, 2.0 ** 62, 2.0 ** 63, -(2.0 ** 63), 2.0 ** 64,
+            9223372036854774784.0, 1e300, 1.7976931348623157e308, 5e-324, 2.2250738585072014e-308, 1e-4, 1e-5, 0.00001234, 9999999999999998.0,
+            9999999999999999.0, 0.99999999999999994, 99999.99999999999, float("inf"), float("-inf"), float("nan"), -float("nan"), 1700000000.123456789]
+    for _ in range(120000):
+        t = rng.randrange(5)
+        if t == 0: vals.append(struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0])
+        elif t == 1: vals.append(rng.randrange(-10 ** 15, 10 ** 15) / 10 ** rng.randrange(0, 18))
+        elif t == 2: vals.append(float(struct.unpack("<f", struct.pack("<I", rng.getrandbits(32)))[0]))
+        elif t == 3: vals.append(1.6e9 + rng.randrange(4 * 10 ** 8) + rng.randrange(10 ** 9) / 1e9)
+        else: vals.append(rng.uniform(-1, 1) * 10.0 ** rng.randrange(-320, 309))
+    L.flbgpu_nc_fmt_json_double.argtypes = [ctypes.c_double, ctypes.c_int, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(64)
+    ref = ctypes.create_string_buffer(400)
+    for v in vals:
+        n = L.flbgpu_nc_fmt_json_double(v, 0, buf)
+        r = float(int(v)) if v == v and -2.0 ** 63 <= v < 2.0 ** 63 else -2.0 ** 63
+        libc.snprintf(ref, 399, b"%.1f" if v == r else b"%.16g", ctypes.c_double(v))
+        assert buf.raw[:n] == ref.value, (v, buf.raw[:n], ref.value)
+    n = L.flbgpu_nc_fmt_json_double(float("nan"), 1, buf)
+    assert buf.raw[:n] == b"null"
+    n = L.flbgpu_nc_fmt_json_double(float("inf"), 1, buf)
+    assert buf.raw[:n] == b"inf"
