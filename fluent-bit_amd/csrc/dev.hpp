@@ -270,7 +270,9 @@ struct JsonFmtArgs {
     const uint64_t *row_off;
     uint64_t n;
     JsonFmtCfg cfg;
+    uint64_t bytes;             // size of the chunk (16-byte loads stop in front of its end)
     uint32_t *len;              // [n] bytes the row contributes to the output (0: markers, rows past the end)
+    uint64_t *slow;             // [(n + 63) / 64] bit r % 64: row r holds a key twice in one map (printed by the look-ahead walker)
     const uint32_t *g_row;      // [n] 1 + row of the group opener that governs the row, 0 = none; nullptr: chunk without groups
     unsigned long long *first_bad;   // first row the decoder refuses
     unsigned long long *first_fail;  // first row whose temporary map would not unpack (the reference returns NULL)

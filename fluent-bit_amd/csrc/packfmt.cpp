@@ -60,10 +60,11 @@ extern "C" int flbgpu_jsonfmt_run_dev(flbgpu_filter *f, const flbgpu_dev_chunk *
         FmtWords *dm = f->d_misc.as<FmtWords>();
         FmtWords &hm = *f->hp_misc.as<FmtWords>();
         uint64_t &htotal = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(FmtWords));
-        if (!f->d_len.ensure(n * sizeof(uint32_t)) || !f->d_off.ensure((n + 1) * sizeof(uint64_t)) ||
+        if (!f->d_len.ensure(n * sizeof(uint32_t)) || !f->d_off.ensure((n + 1) * sizeof(uint64_t)) || !f->d_status.ensure(((n + 63) / 64) * sizeof(uint64_t)) ||
             !f->d_scan_tmp.ensure(scan_tmp_elems(n) * sizeof(uint64_t))) return -1;
         JsonFmtArgs a;
         a.data = (const uint8_t *) in.data; a.row_off = in.row_off; a.n = n; a.cfg = f->jcfg; a.len = f->d_len.as<uint32_t>();
+        a.bytes = in.bytes; a.slow = f->d_status.as<uint64_t>();
         a.g_row = nullptr; a.first_bad = &dm->first_bad; a.first_fail = &dm->first_fail; a.counts = dm->counts;
         a.out_off = nullptr; a.out = nullptr;
         auto size_pass = [&]() -> bool {
