@@ -216,6 +216,46 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
                                          "achieved": round(ev_bytes / (gm[0] / max(gm[1], 1) / 1e3) / 1e9, 1) if gm[0] else None,
                                          "frac": round(ev_bytes / (gm[0] / max(gm[1], 1) / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if gm[0] else None}}
     fg = fg1
+    # -- msgpack -> JSON lines of the parsed chunk (flb_pack_msgpack_to_json_format: what out_stdout / out_http / out_kafka
+    #    call on every flushed chunk), text left in HBM
+    jf_ = g.JsonFormatter("lines", "double", b"date")
+    jf_.format_dev(parsed_chunk)
+    jf_.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rcj, oj = jf_.format_dev(parsed_chunk)
+    torch.cuda.synchronize()
+    dt_f = (time.perf_counter() - t0) / steps
+    pj = jf_.profile_read()
+    in_b, out_b = int(parsed_chunk.bytes), int(oj.bytes)
+    ke = pj.get("k_fmt_emit", (0, 1))
+    ke_ms = ke[0] / max(ke[1], 1)
+    out["msgpack_to_json"] = {"records_per_s_per_gpu": round(n / dt_f, 1), "ms_per_step": round(dt_f * 1e3, 3), "format": "lines, date double, escape_unicode on",
+                              "msgpack_bytes": in_b, "json_bytes": out_b,
+                              "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in pj.items()},
+                              "roofline": {"kernel": "k_fmt_emit", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                           "achieved": round((in_b + out_b) / (ke_ms / 1e3) / 1e9, 1) if ke_ms else None,
+                                           "frac": round((in_b + out_b) / (ke_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if ke_ms else None,
+                                           "step": {"achieved": round((2 * in_b + out_b) / dt_f / 1e9, 1), "note": "size pass reads the chunk once more"}}}
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_binding as ob_
+        import numpy as _np
+        # CPU leg: the oracle's formatter on the first 200 k parsed records (copied back from HBM)
+        offs = _np.zeros(200_001 if n > 200_000 else n + 1, dtype=_np.uint64)
+        L.flbgpu_memcpy_d2h(offs.ctypes.data, parsed_chunk.row_off, offs.nbytes)
+        nb = int(offs[-1])
+        hb = ctypes.create_string_buffer(nb)
+        L.flbgpu_memcpy_d2h(hb, parsed_chunk.data, nb)
+        t0 = time.perf_counter()
+        ref = ob_.msgpack_to_json_format(hb.raw, 3, 0, b"date", 1, 0)
+        cdt = time.perf_counter() - t0
+        out["msgpack_to_json"]["cpu_port_records_per_s"] = round((len(offs) - 1) / cdt, 1)
+        got = ctypes.create_string_buffer(len(ref))
+        L.flbgpu_memcpy_d2h(got, oj.data, len(ref))
+        out["msgpack_to_json"]["matches_oracle_prefix"] = bool(got.raw == ref)
+    jf_.close()
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_binding as ob
