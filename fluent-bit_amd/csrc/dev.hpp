@@ -27,6 +27,28 @@ struct DevCap {
     uint32_t off_rdelta, off_ft, off_ft2, off_cls, off_col;   // byte offsets inside the hot block
 };
 
+// ---- compact forward tables of the single-pass tile kernel (k_parser_tile, tile_kernels.inc), built from the ascii
+// table set by upload_fx (flbgpu.cpp) and staged at offset 0 of the kernel's dynamic LDS: cls | ft | ft2 | p2.
+// cls[256] (u32) maps a byte to class * 4; ft / ft2 hold one dword per (row, byte class | end of text).  Every offset
+// is an LDS BYTE address, so that a step is: address = (entry & 0xFFFF) + class * 4, one ds_read_b32:
+//   plain   bit31 = 0 | capture slot * 128 << 16 | address of the next row           (ONE capture write, slot 0 = none)
+//   LOOK    bit31 = 1, bit30 = 0 | address of the ft2 row indexed by the class of the NEXT byte
+//   PAIR    bit31 = 1, bit30 = 1 | index of a p2 entry {plain entry, second slot * 128}  (two capture writes: rare)
+// MATCH, dead ends and multi-candidate cells are plain entries into the absorbing row whose capture write records
+// what happened (slots ncap+1 ..: END_EOT, END_MID, DEAD_EOT, FAIL); a byte >= 0x80 leads to the POISON row.  Byte
+// 0xFF is the END-OF-TEXT column: the kernel writes it behind the value in its LDS tile, a real 0xFF in the text is
+// recognised by the position the slot holds (!= length) and sends the record to the UTF-8 tables.
+struct DevFx {
+    const uint8_t *base;           // cls | ft | ft2 | p2 (staged into LDS as one piece)
+    uint32_t bytes;
+    uint32_t off_p2;               // LDS address of p2
+    uint32_t start_off, absorb_off, poison_off;   // row addresses
+    uint32_t nslots;               // capture columns per lane: dummy + 2 * fields + 4
+    int ok;                        // 0: the pattern has no compact tables (classic kernels only)
+};
+constexpr uint32_t FX_SLOT_SHIFT = 16, FX_ROW_MASK = 0xFFFFu, FX_LOOK = 0x80000000u, FX_PAIR = 0xC0000000u;
+enum { FXS_END_EOT = 1, FXS_END_MID = 2, FXS_DEAD_EOT = 3, FXS_FAIL = 4 };   // + ncap
+
 // ---- match-only DFA
 struct DevDfa {
     const uint8_t *cls;            // [256]
@@ -101,6 +123,7 @@ struct DevParser {
     // flb_parser_typecast, src/flb_parser.c:2067-2164); names live in names[]
     int nkvtypes;
     int kvtype_off[MAX_NAMES], kvtype_len[MAX_NAMES], kvtype_kind[MAX_NAMES];
+    DevFx fx;                            // compact forward tables of the tile kernel (ok == 0: none)
 };
 
 // ---- record accessor / key
@@ -179,6 +202,23 @@ struct FParserCfg {
     unsigned int ov_cap;
 };
 
+// What k_parser_reg / k_parser_tile read per record of the parser's and the rules' configuration, passed by value in
+// the kernel arguments: a uniform load from the argument segment is a scalar load the compiler may hoist, while the same
+// field read through a pointer into global memory is a vector load per use (and the uses are serialised by the branches
+// that depend on them: ~100 loads of several hundred cycles per record).
+struct TileRule { uint32_t type, fmask, lds_off, ncls, d_init, o_dd, o_df; };   // a grep rule whose match-only DFA is staged in the LDS
+constexpr int TILE_RULES = 8;
+struct TileCfg {
+    int nfields, skip_empty, time_field, time_keep, nregs_minus1, time_with_tz, time_offset, plain_types;
+    uint32_t is_time_mask;               // bit f: named field f is the time key
+    uint8_t name_cost[MAX_NAMES];        // bytes of field f's key in the output map (str header + name)
+    TimePlan plan;
+    int pg_on, pg_nrules, pg_logical_op;
+    int pg_fast;                         // every rule is in rule[] (at most TILE_RULES, DFAs staged in the LDS)
+    uint32_t pg_static_drop, pg_time_fields, pg_named;
+    TileRule rule[TILE_RULES];
+};
+
 struct ParserMatchArgs {
     const uint8_t *data;
     const uint64_t *row_off;
@@ -202,12 +242,18 @@ struct ParserMatchArgs {
     uint32_t debug_skip;        // reserved (0)
     unsigned long long *first_bad;   // min index of a record that stops the decoder loop
     unsigned long long *counts;      // [0] decoded log records, [1] records emitted, [2] records for the generic kernel,
-                                     // [3] records for k_parser_emit_exact
+                                     // [3] records for k_parser_emit_exact, [8] records k_parser_tile leaves to k_parser_finish
     uint64_t bytes;                  // chunk size (bounds the coalesced tile loads)
     // pair mode (fused_kernels.inc): grep's rules evaluated inline; nullptr otherwise
     const PgInline *pg;
     uint32_t pg_lds_off;             // k_parser_rx: where the rules' DFA blocks are staged in its dynamic LDS
     uint32_t *pg_keep_len;           // [n] written by k_parser_finish: out_len when kept, 0, or PG_UNDECIDED
+    // k_parser_tile: dynamic LDS layout = fx tables | rule DFAs (pg_lds_off) | per wave: record tile + capture columns
+    uint32_t tile_lds_off;           // first wave's area
+    uint32_t tile_wave_bytes;        // bytes per wave (tile + capture columns)
+    TileCfg tc;
+    const ParserMatchArgs *self;     // this structure in device memory: what the out-of-line slow paths read (taking the address of a
+                                     // kernel argument makes the compiler keep the whole argument block in scratch memory)
 };
 
 struct ParserEmitArgs {
@@ -441,6 +487,9 @@ bool upload_time_tables();
 void launch_parser_locate(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_parser_rx(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
 void launch_parser_finish(const ParserMatchArgs &a, int cus, hipStream_t st);
+constexpr int TILE_BYTES = 17920;         // k_parser_tile: LDS bytes of a wave's record tile (64 records of 277 B + slack)
+void launch_parser_tile(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
+void launch_parser_reg(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
 void launch_parser_generic(const ParserMatchArgs &a, int grid, hipStream_t st);
 void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out, hipStream_t st);
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match

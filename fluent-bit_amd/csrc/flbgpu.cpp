@@ -96,6 +96,15 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     return true;
 }
 
+bool flbgpu::upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out) {
+    std::vector<uint8_t> b;
+    if (!build_fx(t, ncap, b, out) || !out.ok) { out.ok = 0; return true; }
+    HIPOK(hipMalloc(&blob.dev, b.size()));
+    HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
+    out.base = (const uint8_t *) blob.dev;
+    return true;
+}
+
 bool flbgpu::upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
     std::vector<uint8_t> b;
     std::vector<uint8_t> cls(t.cls, t.cls + 256);
@@ -113,7 +122,7 @@ bool flbgpu::upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
 struct flbgpu_parser {
     std::string name;
     rx::Program prog;
-    TableBlob blob_ascii, blob_utf8;
+    TableBlob blob_ascii, blob_utf8, blob_fx;
     DevParser dev;                 // host copy (device pointers inside)
     flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
 };
@@ -342,6 +351,10 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
             if (d.field_type[f] != TY_NONE && d.field_type[f] != TY_STRING) d.plain_types = 0;
         }
         if (ntime != 1) d.time_field = -1;
+    }
+    // compact forward tables of the single-pass tile kernel (start-anchored patterns: the forward walk needs no reverse pass)
+    if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE")) {
+        if (!upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx, d.fx)) { delete p; return nullptr; }
     }
     return p;
 }
@@ -599,7 +612,7 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[8]; unsigned int ov_count; unsigned int kept_count; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[12]; unsigned int ov_count; unsigned int kept_count; };
 static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FParserCfg's side list
 
 // Pass 1 of filter_parser on a device chunk: every record decoded, located, matched and sized (locate / rx /
@@ -607,7 +620,7 @@ static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FP
 // size of record r's output (0: nothing is emitted for it), *n_valid the rows in front of the first decoder
 // error, hm the counters.  The emit pass (or the fused pair's decide + emit) follows.
 // pair mode (filter_grep follows and is evaluated inline): grep's rules for k_parser_rx, keep_len for k_parser_finish
-struct PairCtx { PgInline pg; uint32_t *keep_len; };
+struct PairCtx { PgInline pg; uint32_t *keep_len; const flbgpu_filter *fg; };
 
 static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
                              PairCtx *pair = nullptr) {
@@ -644,6 +657,26 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         else { tab_bytes = 0; if (caps_bytes > lds_cap) caps_bytes = 0; }
     }
     uint32_t lds_bytes = tab_bytes;                          // staged table bytes (0: tables stay in global memory)
+    // single-pass tile kernel (tile_kernels.inc) instead of locate / rx / finish: parser 0 start-anchored with compact
+    // tables; a workgroup's waves share one copy of the tables, every wave owns a record tile + its capture columns
+    const DevFx &fx = f->parsers[0]->dev.fx;
+    bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE");
+    for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
+    uint32_t tile_wave_bytes = 0, tile_pg_room = 0;
+    // two builds of the single pass: value bytes in registers (k_parser_reg, 16 waves per CU: the default) or the
+    // records in an LDS tile (k_parser_tile, FLBGPU_TILE_MODE=tile)
+    const char *tmode = getenv("FLBGPU_TILE_MODE");
+    const bool tile_in_lds = tmode && !strcmp(tmode, "tile");
+    if (use_tile) {
+        tile_wave_bytes = tile_in_lds ? (uint32_t) TILE_BYTES + fx.nslots * 128u : fx.nslots * 128u + 64u * (4 * TBUF_WORDS + 4);
+        if (pair) for (int i = 0; i < pair->pg.nrules; i++) if (tile_pg_room + ((pair->pg.rule_lds_bytes[i] + 15) & ~15u) <= 8192) tile_pg_room += (pair->pg.rule_lds_bytes[i] + 15) & ~15u;
+        int waves = (int) ((lds_cap - 64 - fx.bytes - tile_pg_room) / tile_wave_bytes);
+        const int wmax = tile_in_lds ? 8 : 16;
+        if (waves > wmax) waves = wmax;
+        if (getenv("FLBGPU_TILE_WAVES")) { int w = atoi(getenv("FLBGPU_TILE_WAVES")); if (w >= 1 && w < waves) waves = w; }
+        if (waves < 2) use_tile = false;
+        else { rx_threads = waves * 64; caps_bytes = 1; }
+    }
     int grid = cus;
     uint64_t need_blocks = (n + rx_threads - 1) / rx_threads;
     if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
@@ -678,23 +711,56 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.info = f->d_info.as<uint32_t>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
-    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
+    ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr;
+    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
+    if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
         uint32_t at = (ma.lds_total + 15) & ~15u, used = 0;
         ma.pg_lds_off = at;
+        const uint32_t room = use_tile ? at + tile_pg_room : lds_cap;
         for (int i = 0; i < pair->pg.nrules; i++) {
             const uint32_t blob = pair->pg.rule_lds_bytes[i];
             pair->pg.rule_lds_off[i] = 0xFFFFFFFFu;
-            if (at + used + blob <= lds_cap) { pair->pg.rule_lds_off[i] = used; used += (blob + 15) & ~15u; }
+            if (at + used + ((blob + 15) & ~15u) <= room) { pair->pg.rule_lds_off[i] = used; used += (blob + 15) & ~15u; }
         }
         ma.lds_total = at + used;
         if (!f->d_pg.ensure(sizeof(PgInline))) return false;
         HIPOK(hipMemcpyAsync(f->d_pg.p, &pair->pg, sizeof(PgInline), hipMemcpyHostToDevice, st));
         ma.pg = f->d_pg.as<PgInline>();
         ma.pg_keep_len = pair->keep_len;
+    }
+    {
+        // the parser's and the rules' per-record configuration for the single-pass kernels, by value (dev.hpp TileCfg)
+        TileCfg &tc = ma.tc;
+        memset(&tc, 0, sizeof(tc));
+        const DevParser &d0 = f->parsers[0]->dev;
+        tc.nfields = d0.nfields; tc.skip_empty = d0.skip_empty; tc.time_field = d0.time_field; tc.time_keep = d0.time_keep;
+        tc.nregs_minus1 = d0.nregs_minus1; tc.time_with_tz = d0.time_with_tz; tc.time_offset = d0.time_offset; tc.plain_types = d0.plain_types;
+        tc.plan = d0.plan;
+        for (int q = 0; q < d0.nfields && q < MAX_NAMES; q++) {
+            if (d0.field_is_time[q]) tc.is_time_mask |= 1u << q;
+            const uint32_t nl = (uint32_t) d0.field_name_len[q], cost = (nl < 32 ? 1 : nl < 256 ? 2 : nl < 65536 ? 3 : 5) + nl;
+            tc.name_cost[q] = (uint8_t) cost;
+        }
+        if (pair) {
+            tc.pg_on = 1; tc.pg_nrules = pair->pg.nrules; tc.pg_logical_op = pair->pg.logical_op;
+            tc.pg_static_drop = pair->pg.static_drop; tc.pg_time_fields = pair->pg.time_fields;
+            tc.pg_fast = pair->pg.nrules <= TILE_RULES ? 1 : 0;
+            for (int i = 0; i < pair->pg.nrules; i++) {
+                tc.pg_named |= pair->pg.rule_fmask[i];
+                if (pair->pg.rule_lds_off[i] == 0xFFFFFFFFu) tc.pg_fast = 0;
+                if (i < TILE_RULES) {
+                    const DevDfa &df = pair->fg->rules[(size_t) i].dfa;
+                    TileRule &tr = tc.rule[i];
+                    tr.type = (uint32_t) pair->fg->rules[(size_t) i].type; tr.fmask = pair->pg.rule_fmask[i]; tr.lds_off = pair->pg.rule_lds_off[i];
+                    tr.ncls = (uint32_t) df.ncls; tr.d_init = (uint32_t) df.d_init;
+                    tr.o_dd = (uint32_t) ((const uint8_t *) df.ddelta - df.cls); tr.o_df = (uint32_t) (df.d_final - df.cls);
+                }
+            }
+        }
     }
     // records outside the fast path (UTF-8 input, several parsers / candidate keys, ...): one general kernel
     auto run_generic = [&]() -> bool {
@@ -720,6 +786,28 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             if (f->pcfg.nparsers > 1) { if (!run_generic()) return false; }      // the other parsers of the list get their turn
             else { ProfScope ps(f, st, "k_pjson_size_generic"); launch_pjson_size_generic(ma, st); }
         }
+    }
+    else if (use_tile) {
+        ma.tile_lds_off = (ma.lds_total + 15) & ~15u;
+        ma.lds_total = ma.tile_lds_off + (uint32_t) (rx_threads / 64) * tile_wave_bytes + 64;
+        if (!f->d_args.ensure(sizeof(ParserMatchArgs)) || !f->hp_args.ensure(sizeof(ParserMatchArgs))) return false;
+        ma.self = f->d_args.as<ParserMatchArgs>();
+        memcpy(f->hp_args.p, &ma, sizeof(ma));                   // (page-locked: the copy below is a real asynchronous transfer)
+        HIPOK(hipMemcpyAsync(f->d_args.p, f->hp_args.p, sizeof(ma), hipMemcpyHostToDevice, st));
+        if (tile_in_lds) { ProfScope ps(f, st, "k_parser_tile"); launch_parser_tile(ma, grid, rx_threads, st); }
+        else { ProfScope ps(f, st, "k_parser_reg"); launch_parser_reg(ma, grid, rx_threads, st); }
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when
+        // that is the rule for this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on
+        if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
+        if (hm.counts[8] > 0) {
+            // rows whose time text needs the strptime interpreter, sizes that depend on the record's bytes, ...
+            { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
+            HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+        }
+        if (hm.counts[2] > 0 && !run_generic()) return false;
     }
     else {
         { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ma, cus, st); }
@@ -852,6 +940,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     static thread_local PairCtx pc;                    // (page of host memory the async upload reads from)
     memset(&pc.pg, 0, sizeof(pc.pg));
     pc.keep_len = fp->d_keep.as<uint32_t>();
+    pc.fg = fg;
     pc.pg.rules = fg->d_rules.as<GrepRule>(); pc.pg.nrules = (int) fg->rules.size(); pc.pg.logical_op = fg->logical_op;
     for (int f = 0; f < d0.nfields; f++) {
         if (!d0.field_is_time[f]) continue;

@@ -71,6 +71,9 @@ struct TableBlob {
 
 bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out);
 bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out);
+bool upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out);
+bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out);
+int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool parse_ra(const char *pat, DevKey &k, std::string &why);
 // "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)
@@ -94,6 +97,7 @@ struct flbgpu_filter {
     std::vector<flbgpu_parser *> parsers;
     flbgpu::DevBuf d_parsers;
     uint32_t caps_stride = 0;
+    bool tile_declined = false;       // k_parser_tile sent too many values through its fallback: phase kernels from now on
     // filter_grep (and the rule gate of filter_log_to_metrics)
     std::vector<flbgpu::GrepRule> rules;
     std::vector<flbgpu::TableBlob *> rule_blobs;
@@ -105,9 +109,9 @@ struct flbgpu_filter {
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
-    flbgpu::PinnedBuf hp_misc, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
+    flbgpu::PinnedBuf hp_misc, hp_args, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     flbgpu_indexer *indexer = nullptr;        // device record indexer of the host-level call (large chunks)
     uint64_t last_in = 0, last_out = 0;
@@ -124,7 +128,7 @@ struct flbgpu_filter {
                                  &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
-        hp_misc.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
+        hp_misc.release(); hp_args.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();
         for (auto &e : ev_stage) if (e) (void) hipEventDestroy(e);
         if (ev0) (void) hipEventDestroy(ev0);
         if (ev1) (void) hipEventDestroy(ev1);

@@ -44,88 +44,9 @@ constexpr int LOC_BLOCK = 256;
 constexpr int LOC_TILE = 18432;             // LDS bytes per wave (64 records of 277 B + slack)
 
 
-// per-record part of k_parser_locate; rec may point into LDS (generic pointer)
 DEV uint32_t locate_one(const ParserMatchArgs &a, uint64_t r, const uint8_t *rec, const uint8_t *rec_end, uint32_t &n_dec) {
     RecInfo ri;
-    recinfo_init(ri);
-    // the body map is validated by the candidate search below (it walks every key and value)
-    Event ev = decode_event(rec, rec_end, true);
-    ri.flags = ev.flags;
-    if (ev.flags & RF_BAD) {
-        atomicMin(a.first_bad, (unsigned long long) r);
-        rec_store(a.info, a.n, r, ri);
-        return 0;
-    }
-    if (ev.flags & RF_SKIP) {
-        if (rec != rec_end && mp_skip(ev.body, rec_end, 1) != rec_end) {     // a marker with a broken body is a decoder error too
-            ri.flags = RF_BAD;
-            atomicMin(a.first_bad, (unsigned long long) r);
-        }
-        rec_store(a.info, a.n, r, ri);
-        return 0;
-    }
-    n_dec++;
-    ri.body_off = (uint32_t) (ev.body - rec); ri.body_len = (uint32_t) (ev.body_end - ev.body);
-    if (ev.meta) { ri.meta_off = (uint32_t) (ev.meta - rec); ri.meta_len = (uint32_t) (ev.meta_end - ev.meta); }
-    // candidate values (plugins/filter_parser/filter_parser.c:259-323)
-    uint32_t ncand = 0;
-    bool whole = false, have_canon = false;
-    CountSink canon;                       // canonical size of the body (the record if no parser matches)
-    if (a.cfg.key.is_ra) {
-        const uint8_t *v = ra_resolve(a.cfg.key, ev.body, ev.body_end, &whole);
-        if (v) {
-            Tok t = mp_tok(v, ev.body_end);
-            if (t.type == T_STR || t.type == T_BIN) { ri.val_off = (uint32_t) (t.next - rec); ri.val_len = t.len; ncand = 1; }
-        }
-    }
-    else {
-        // the same walk validates the body, finds the candidates and sizes the canonical re-pack
-        Tok bm = mp_tok(ev.body, ev.body_end);
-        const uint8_t *p = bm.next;
-        pk_map_hdr(canon, bm.len);
-        have_canon = true;
-        for (uint32_t i = 0; i < bm.len; i++) {
-            Tok kt = mp_tok(p, ev.body_end);
-            const uint8_t *kend;
-            if (kt.type == T_ARRAY || kt.type == T_MAP) kend = mp_canon(p, ev.body_end, canon);
-            else { kend = mp_end_of(kt, p, ev.body_end); canon.n += mp_canon_size_scalar(kt); }
-            if (!kend) { p = nullptr; break; }
-            Tok vt = mp_tok(kend, ev.body_end);
-            if (vt.type == T_ARRAY || vt.type == T_MAP) p = mp_canon(kend, ev.body_end, canon);
-            else { p = mp_end_of(vt, kend, ev.body_end); canon.n += mp_canon_size_scalar(vt); }
-            if (!p) break;
-            if ((kt.type == T_STR || kt.type == T_BIN) && kt.len == (uint32_t) a.cfg.key.key_len &&
-                bytes_eq(kt.next, a.cfg.key.key, kt.len) && (vt.type == T_STR || vt.type == T_BIN)) {
-                if (ncand == 0) { ri.val_off = (uint32_t) (vt.next - rec); ri.val_len = vt.len; ri.key_index = i; }
-                ncand++;
-            }
-        }
-        whole = (p == ev.body_end);
-    }
-    if (!whole) {
-        // the body does not decode to exactly the rest of the row: decoder error, the loop stops here
-        n_dec--;
-        recinfo_init(ri);
-        ri.flags = RF_BAD;
-        atomicMin(a.first_bad, (unsigned long long) r);
-        rec_store(a.info, a.n, r, ri);
-        return 0;
-    }
-    if (ncand == 1 && a.caps_in_lds && ri.val_len < 0xFFFF && (ri.val_len / CHK_STEP + 2) <= a.chk_len) ri.flags |= RF_CAND;
-    else if (ncand >= 1) { ri.flags |= RF_GENERIC; atomicAdd(&a.counts[2], 1ull); }
-    // size of the record if no parser matches: 12 + canonical metadata + canonical body; an event
-    // time outside the EventTime range makes the encoder reject the record
-    uint32_t out_len = 0;
-    if (ev.sec < 0 || (uint64_t) ev.sec > 0xffffffffull || ev.nsec < 0 || ev.nsec >= 1000000000LL) ri.flags |= RF_BADTS;
-    else {
-        ri.ts_sec = (uint32_t) ev.sec; ri.ts_nsec = (uint32_t) ev.nsec;
-        CountSink cs;
-        cs.n = 12;
-        if (ev.meta) mp_canon(ev.meta, ev.meta_end, cs); else cs.n += 1;
-        ri.meta_canon = (uint32_t) cs.n - 12;
-        if (have_canon) cs.n += canon.n; else mp_canon(ev.body, ev.body_end, cs, 1);
-        out_len = (uint32_t) cs.n;
-    }
+    const uint32_t out_len = locate_core(a, r, rec, rec_end, n_dec, ri);
     rec_store(a.info, a.n, r, ri);
     return out_len;
 }
@@ -308,6 +229,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const uint64_t n = a.n;
     for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t fl0 = a.info[r];
+        if (fl0 & RF_PARSED) continue;                         // completed by k_parser_tile (nothing else sets the flag before this kernel)
         if (!(fl0 & RF_RXOK) || (fl0 & RF_GENERIC)) {
             if (!(fl0 & RF_GENERIC)) a.null_mask[r] = 0;
             if (a.pg_keep_len) { a.pg_keep_len[r] = PG_UNDECIDED; pg_pending++; }

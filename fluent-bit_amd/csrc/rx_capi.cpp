@@ -5,6 +5,7 @@
 #include <cstring>
 #include <string>
 #include "rx.hpp"
+#include "host_int.hpp"
 
 extern "C" {
 
@@ -44,6 +45,33 @@ void flbgpu_rx_info(void *h, int *info)
 }
 
 void flbgpu_rx_debug_stats(long *out3) { rx::debug_stats(out3); }
+
+/* The compact tables of the single-pass tile kernel (fx.cpp) executed on the host with the kernel's rules.
+ * >= 0: groups, beg/end of the NAMED groups filled (-1 elsewhere), beg[0] = 0, end[0] = end of the match;
+ * -1: the forward walk from boundary 0 does not settle this text (the kernel falls back to the classic walk);
+ * -2: a byte >= 0x80 (UTF-8 tables); -4: the pattern has no compact tables. */
+int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end)
+{
+    auto *p = (rx::Program *) h;
+    int ncap = 0;
+    for (uint8_t c : p->slot2cap) if (c != 0xFF) ncap++;
+    if (ncap == 0) return -4;
+    std::vector<uint8_t> blob;
+    flbgpu::DevFx fx;
+    if (!flbgpu::build_fx(p->ascii, ncap, blob, fx) || !fx.ok) return -4;
+    std::vector<uint16_t> caps(fx.nslots);
+    const int r = flbgpu::simulate_fx(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
+    if (r < 0) return r;
+    for (int g = 0; g <= p->ngroups; g++) { beg[g] = -1; end[g] = -1; }
+    beg[0] = 0; end[0] = r;
+    for (int g = 1; g <= p->ngroups; g++) {
+        const uint8_t cb = p->slot2cap[2 * (size_t) g], ce = p->slot2cap[2 * (size_t) g + 1];
+        if (cb == 0xFF || ce == 0xFF) continue;
+        const uint16_t b = caps[(size_t) cb + 1], e = caps[(size_t) ce + 1];
+        if (b != 0xFFFF && e != 0xFFFF) { beg[g] = b; end[g] = e; }
+    }
+    return p->ngroups;
+}
 
 /* "name=group\n" lines in onig_foreach_name order */
 int flbgpu_rx_names(void *h, char *buf, int cap)

@@ -1,0 +1,138 @@
+"""filter_parser's pass 1 in its three builds -- the single pass with the value in registers (k_parser_reg, the
+default), the single pass over an LDS tile (k_parser_tile), the phase kernels (locate / rx / finish) -- against the CPU
+oracle on inputs chosen for the places where they differ: the end-of-text sentinel (a real 0xFF in the text, empty
+values, values that end on every byte of a group), values longer than the registers hold, lines the forward walk from
+boundary 0 cannot settle, bodies that are not the one-key layout, bad events; alone and as the pair with filter_grep."""
+import os, random
+import pytest
+import oracle_binding as ob
+import synth
+import flbamd_loader
+
+pytestmark = pytest.mark.gpu
+APACHE2 = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$'
+APACHE = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^\"]*?)(?: +\S*)?)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>[^\"]*)")?$'
+TF = "%d/%b/%Y:%H:%M:%S %z"
+MODES = {"reg": {}, "tile": {"FLBGPU_TILE_MODE": "tile"}, "phase": {"FLBGPU_NO_TILE": "1"}}
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def _set_mode(mode):
+    for k in ("FLBGPU_TILE_MODE", "FLBGPU_NO_TILE"):
+        os.environ.pop(k, None)
+    os.environ.update(MODES[mode])
+
+
+def _rec(body, sec=1, nsec=0, meta=None):
+    return synth.v2_record(sec, nsec, body, meta)
+
+
+def _hostile_chunk(seed, n=3000):
+    rng = random.Random(seed)
+    data, off, _ = synth.apache_records(n)
+    blob = bytes(data)
+    lines = [blob[int(off[i]) + 21:int(off[i + 1])] for i in range(n)]
+    out = []
+    for i, ln in enumerate(lines):
+        r = rng.random()
+        m = bytearray(ln)
+        if r < 0.05:
+            m[rng.randrange(len(m))] = 0xFF                          # the sentinel's own byte value inside the text
+        elif r < 0.10:
+            m[rng.randrange(len(m))] = rng.choice(b"\xe9\x80\xc3")   # other bytes >= 0x80
+        elif r < 0.15:
+            m = m[: rng.randrange(len(m))]                           # cut anywhere: most of these do not match
+        elif r < 0.20:
+            k = rng.randrange(len(m)); m[k:k] = b"x" * rng.randrange(1, 600)    # values far beyond 272 bytes
+        elif r < 0.23:
+            m = bytearray(b"")                                       # empty value
+        elif r < 0.26:
+            m = bytearray(ln.replace(b'"GET ', b'"GET  ', 1))
+        elif r < 0.29:
+            m += b"\n" + ln                                          # a second line: ^ / $ are line anchors
+        elif r < 0.32:
+            m = bytearray(b"\n") + m                                 # the match starts behind the first byte
+        elif r < 0.35:
+            m = m[: 250 + rng.randrange(0, 30)]                      # ends around the register windows' edge
+        body = {"log": bytes(m)}
+        r2 = rng.random()
+        if r2 < 0.04:
+            rec = _rec(synth.KV([("stream", "stdout"), ("log", bytes(m)), ("n", i)]))                # not the one-key layout
+        elif r2 < 0.06:
+            rec = _rec(synth.KV([("log", b"first"), ("log", bytes(m))]))                             # two candidates
+        elif r2 < 0.08:
+            rec = synth.legacy_record(1700000000 + i, body)                                          # legacy event
+        elif r2 < 0.09:
+            rec = _rec(body, meta={"k": "v"})                                                        # metadata
+        elif r2 < 0.10:
+            rec = _rec({"log": i})                                                                   # value is not a string
+        elif r2 < 0.105:
+            rec = synth.mp([[synth.ext_ts(0xffffffff, 0), {}], {"g": 1}])                            # group marker
+        else:
+            rec = _rec(body, sec=1700000000 + i, nsec=i % 1000)
+        out.append(rec)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("regex", [APACHE2, APACHE])
+def test_three_builds_against_the_oracle(g, regex):
+    chunk = _hostile_chunk(7 if regex is APACHE2 else 8)
+    bad_tail = chunk + b"\x92\x92\xd7\x00"                          # the decoder stops at a broken last event
+    pargs = dict(regex=regex, time_fmt=TF, time_key="time")
+    rule_sets = [([("regex", r"code ^5\d\d$")], None), ([("exclude", "method GET")], None),
+                 ([("regex", "code ^2"), ("regex", "agent curl")], "AND"), ([("regex", "time 2024")], None),
+                 ([("regex", "log x")], None)]
+    for data in (chunk, bad_tail, chunk[:277 * 5]):
+        po = ob.Parser(**pargs)
+        want_p = ob.FilterParser("log", [po]).filter(data)
+        want_pairs = []
+        for rules, op in rule_sets:
+            # flb_filter_do (src/flb_filter.c:121-325): a NOTOUCH filter hands its input on; MODIFIED with nothing left ends the chain
+            inp = want_p[1] if want_p[0] == ob.MODIFIED else data
+            if want_p[0] == ob.MODIFIED and not inp:
+                want_pairs.append((want_p[0], ob.NOTOUCH, b""))
+                continue
+            r2, o2 = ob.Grep(rules, op).filter(inp)
+            want_pairs.append((want_p[0], r2, o2 if r2 == ob.MODIFIED else inp))
+        for mode in MODES:
+            _set_mode(mode)
+            p = g.Parser(**pargs)
+            fp = g.FilterParser("log", [p])
+            got = fp.filter(data)
+            assert got[0] == want_p[0] and got[1] == want_p[1], (mode, "parser", got[0], want_p[0])
+            for (rules, op), want in zip(rule_sets, want_pairs):
+                fg = g.FilterGrep(rules, op)
+                ch = g.FilterChain([fp, fg])
+                r3, o3 = ch.filter(data)
+                exp_ret = ob.MODIFIED if ob.MODIFIED in (want[0], want[1]) else ob.NOTOUCH
+                assert r3 == exp_ret, (mode, rules, r3, want[0], want[1])
+                if exp_ret == ob.MODIFIED:
+                    assert (o3 or b"") == (want[2] or b""), (mode, rules, len(o3 or b""), len(want[2] or b""))
+                fg.close()
+            fp.close(); p.close()
+    _set_mode("reg")
+
+
+def test_three_builds_with_keep_options(g):
+    """Time_Keep / Reserve_Data / Preserve_Key / Types: k_parser_finish takes these rows over from the single pass"""
+    chunk = _hostile_chunk(9, 800)
+    for extra, reserve, preserve in [(dict(time_keep=True), False, False), (dict(), True, False), (dict(), True, True),
+                                     (dict(types="code:integer size:integer"), False, False),
+                                     (dict(time_fmt="%d/%b/%Y:%H:%M:%S"), False, False)]:
+        pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+        pargs.update(extra)
+        want = ob.FilterParser("log", [ob.Parser(**pargs)], reserve, preserve).filter(chunk)
+        for mode in MODES:
+            _set_mode(mode)
+            p = g.Parser(**pargs)
+            fp = g.FilterParser("log", [p], reserve, preserve)
+            got = fp.filter(chunk)
+            assert got[0] == want[0] and got[1] == want[1], (mode, extra, reserve, preserve)
+            fp.close(); p.close()
+    _set_mode("reg")
