@@ -43,7 +43,7 @@ GREP32_EXCLUDE = [("exclude", r) for r in (
     "path ^/v2", "$svc['name'] ^$", r"path x=\d\d$", "msg [5-6]{3} finished", r"level ^\s", "path items/[1-2]{2}", "msg ok ", "$svc['name'] b$")]
 
 
-PMC_FILE = os.path.join("profiles", "r2_pmc_hbm_bench_10M.json")
+PMC_FILE = os.path.join("profiles", "r2c_pmc_hbm_bench_10M.json")
 
 
 def recorded_traffic(kernel, n):
@@ -71,7 +71,8 @@ def recorded_traffic(kernel, n):
         if os.path.exists(cpath):
             cal = json.load(open(cpath))
         pattern = {"k_parser_locate": "coalesced16", "k_grep_match": "coalesced16", "k_gather": "coalesced16",
-                   "k_parser_rx": "lane_line128", "k_parser_finish": "column4", "k_parser_emit": "lane_line128", "k_pg_emit": "lane_line128"}.get(kernel, "column4")
+                   "k_parser_rx": "lane_line128", "k_parser_finish": "column4", "k_parser_emit": "lane_line128", "k_pg_emit": "lane_line128",
+                   "k_parser_reg": "per_lane16", "k_parser_tile": "coalesced16"}.get(kernel, "column4")
         ff = float(cal.get("fetch_factor", {}).get(pattern, 2.0))
         wf = float(cal.get("write_factor", {}).get("write16", 1.0))
         b = hit[0].get("FETCH_SIZE", 0) * 1024 * ff + hit[0].get("WRITE_SIZE", 0) * 1024 * wf
@@ -467,6 +468,8 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
     value_bytes = in_bytes - 21 * n                      # the `log` values (277 B event = 21 B framing + 256 B line)
     alg_bytes_per_launch = {
+        "k_parser_reg": in_bytes,                        # the single pass: every chunk byte once (header + value)
+        "k_parser_tile": in_bytes,
         "k_parser_locate": in_bytes,                     # reads every chunk byte once
         "k_parser_rx": value_bytes,                      # the capture program consumes each value byte once
         "k_parser_finish": 8 * n,                        # time field + sizes
@@ -506,7 +509,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "filter_parser(conf/parsers.conf apache2, Key_Name log) -> filter_grep(Regex code ^5\\d\\d$) "
-                               "on %d x 256B apache-combined lines per GPU (277B V2 events), flb_filter_do on device, %s" % (n, "fused pair: rules evaluated on the capture spans, only the kept records written" if fused else "unfused"),
+                               "on %d x 256B apache-combined lines per GPU (277B V2 events), flb_filter_do on device, %s" % (n, "fused pair: one pass over the chunk (event decode, capture program, time, rules on the capture spans), only the kept records written" if fused else "unfused"),
                    "records_per_gpu": n, "in_bytes": in_bytes, "parsed_bytes": parsed_bytes, "kept_records": int(kept_records),
                    "row_offsets": "part of the device-resident chunk (every filter's output carries them); finding them from "
                                   "raw bytes is secondary.record_indexer",

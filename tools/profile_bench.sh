@@ -10,10 +10,12 @@ CMD="python $R/bench.py --no-cpu --no-secondary --steps 5 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats_run.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $CMD > /dev/null 2>&1
-# counter calibration: kernels with a known HBM byte count per request shape (csrc/calib.hip)
+# counter calibration: kernels with a known HBM byte count per request shape (csrc/calib.hip); SKIP_CAL=1 leaves it out
+if [ -z "$SKIP_CAL" ]; then
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_fetch -- python3 $R/tools/calib_counters.py run > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_write -- python3 $R/tools/calib_counters.py run > /dev/null 2>&1
 python3 $R/tools/calib_counters.py summarize $(find $O/cal_fetch $O/cal_write -name "*counter_collection.csv") > $O/counter_calibration.json
+fi
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 python - $O <<'PY'
 import csv, sys, collections, json, glob, os
