@@ -169,6 +169,7 @@ enum {
     RF_EXACT = 256,        // a Types float value needs the exact decimal conversion: k_parser_emit_exact rewrites the record
     RF_PGDONE = 512,       // pair [filter_parser, filter_grep]: grep's rules were evaluated on the spans by k_parser_rx ...
     RF_PGKEEP = 1024,      // ... and keep the record
+    RF_DESC = 2048,        // pair mode: the kept record's fields are in its descriptor (PgEmitArgs::desc), not in the columns
 };
 constexpr uint32_t PG_UNDECIDED = 0xFFFFFFFFu;   // keep_len of a row whose rules k_pg_decide still has to evaluate
 
@@ -251,6 +252,11 @@ struct ParserMatchArgs {
     // k_parser_tile: dynamic LDS layout = fx tables | rule DFAs (pg_lds_off) | per wave: record tile + capture columns
     uint32_t tile_lds_off;           // first wave's area
     uint32_t tile_wave_bytes;        // bytes per wave (tile + capture columns)
+    // pair mode: one descriptor of dstride dwords per ROW, written for the rows the single pass keeps -- ONE aligned store
+    // of whole 64-byte sectors instead of 34 column stores of 4 bytes (each of which costs a sector write):
+    //   [0] ts_sec [1] ts_nsec [2] val_off [3] drop_mask [4] meta_off [5] meta_len [6] nkept, then the capture spans as u16 pairs
+    uint32_t *desc;
+    uint32_t dstride;
     TileCfg tc;
     const ParserMatchArgs *self;     // this structure in device memory: what the out-of-line slow paths read (taking the address of a
                                      // kernel argument makes the compiler keep the whole argument block in scratch memory)
@@ -366,6 +372,9 @@ struct PgEmitArgs {
     uint64_t n;
     const uint64_t *out_off;
     uint8_t *out;
+    const uint32_t *desc;            // row descriptors of the single pass (ParserMatchArgs::desc), nullptr: columns only
+    uint32_t dstride;
+    uint64_t bytes;                  // chunk size (bounds the wide tail loads)
 };
 
 // ---- filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c)
@@ -496,7 +505,7 @@ constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_m
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st);
 void launch_parser_emit_exact(const ParserEmitArgs &a, hipStream_t st);
 void launch_pg_decide(const PgDecideArgs &a, int cus, hipStream_t st);
-void launch_pg_emit(const PgEmitArgs &a, int cus, hipStream_t st);
+void launch_pg_emit(const PgEmitArgs &a, int nfields, int cus, hipStream_t st);
 void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);

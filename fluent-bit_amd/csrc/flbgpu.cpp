@@ -620,7 +620,7 @@ static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FP
 // size of record r's output (0: nothing is emitted for it), *n_valid the rows in front of the first decoder
 // error, hm the counters.  The emit pass (or the fused pair's decide + emit) follows.
 // pair mode (filter_grep follows and is evaluated inline): grep's rules for k_parser_rx, keep_len for k_parser_finish
-struct PairCtx { PgInline pg; uint32_t *keep_len; const flbgpu_filter *fg; };
+struct PairCtx { PgInline pg; uint32_t *keep_len; const flbgpu_filter *fg; uint32_t *desc; uint32_t dstride; };
 
 static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
                              PairCtx *pair = nullptr) {
@@ -713,7 +713,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
@@ -731,6 +731,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         HIPOK(hipMemcpyAsync(f->d_pg.p, &pair->pg, sizeof(PgInline), hipMemcpyHostToDevice, st));
         ma.pg = f->d_pg.as<PgInline>();
         ma.pg_keep_len = pair->keep_len;
+        ma.desc = pair->desc; ma.dstride = pair->dstride;
     }
     {
         // the parser's and the rules' per-record configuration for the single-pass kernels, by value (dev.hpp TileCfg)
@@ -941,6 +942,10 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     memset(&pc.pg, 0, sizeof(pc.pg));
     pc.keep_len = fp->d_keep.as<uint32_t>();
     pc.fg = fg;
+    // row descriptors of the kept records (dev.hpp ParserMatchArgs::desc): 7 dwords + the spans as u16 pairs, whole 64-byte sectors
+    pc.dstride = (uint32_t) ((7 + d0.nfields + 15) / 16 * 16);
+    pc.desc = nullptr;
+    if (!getenv("FLBGPU_NO_DESC") && fp->d_desc.ensure(n * (size_t) pc.dstride * sizeof(uint32_t))) pc.desc = fp->d_desc.as<uint32_t>();
     pc.pg.rules = fg->d_rules.as<GrepRule>(); pc.pg.nrules = (int) fg->rules.size(); pc.pg.logical_op = fg->logical_op;
     for (int f = 0; f < d0.nfields; f++) {
         if (!d0.field_is_time[f]) continue;
@@ -1000,7 +1005,8 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     ea.data = da.data; ea.row_off = da.row_off; ea.cfg = fp->pcfg; ea.parsers = fp->d_parsers.as<DevParser>(); ea.n_cols = in->n;
     ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
     ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
-    { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, cus, st); }
+    ea.desc = pc.desc; ea.dstride = pc.dstride; ea.bytes = in->bytes;
+    { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     return 1;
