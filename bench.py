@@ -312,12 +312,47 @@ def measure_cpu(data, off, n, args):
                                            "what": "onig_search with a region, the real Onigmo 6.2.0 compiled from the reference's sources, apache2 pattern, same lines"}
     except Exception as e:
         cpu["reference_onigmo_error"] = repr(e)[:200]
+    ref_ok = False
+    try:
+        # the reference's OWN plugins: cb_filter of filter_parser + filter_grep (plugins/filter_parser/filter_parser.c,
+        # plugins/filter_grep/grep.c and everything under them, oracle/_ref/ref_filters built by oracle/Makefile from the
+        # reference's sources), flb_filter_do's loop over the two, timed inside the driver (clock_gettime around the loop)
+        import ref_filters as rf
+        if rf.available():
+            m = min(ns, 2_000_000)
+            secs, rin, rkept = rf.bench_result(rf.run([rf.bench_pair_case("log", dict(regex=APACHE2, time_fmt=TIME_FMT, time_key="time"), [GREP_RULE],
+                                                                           bytes(data[: int(off[m])]), 1)], timeout=900)[0])
+            assert rin == m, (rin, m)
+            cpu["port"] = {"value": cpu["value"], "sample": cpu["sample"]}
+            cpu.update({"value": round(rin / secs, 1), "kind": "reference", "kept": int(rkept),
+                        "sample": "first %d records of the same seeded workload through the reference's own cb_filter of filter_parser(apache2) and "
+                                  "filter_grep (compiled from its sources: oracle/_ref/ref_filters), single thread (%d host cores present)" % (m, os.cpu_count())})
+            ref_ok = True
+    except Exception as e:
+        cpu["reference_error"] = repr(e)[:200]
     try:
         nproc = os.cpu_count() or 1
         m = min(n, 2_000_000)
-        v = cpu_nproc_leg((bytes(data[: int(off[m])]), np.array(off[: m + 1])), nproc)
-        cpu["nproc"] = {"processes": nproc, "value": round(v, 1), "unit": "records/s",
-                        "note": "%d independent processes, each the oracle pair on its own shard for ~6 s, wall-clock aggregate" % nproc}
+        if ref_ok:
+            import ref_filters as rf
+            from concurrent.futures import ThreadPoolExecutor
+            per = max(2000, m // nproc)
+            shards = [bytes(data[int(off[i * per % max(1, m - per)]): int(off[i * per % max(1, m - per) + per])]) for i in range(nproc)]
+            iters = max(1, int(6.0 * cpu["value"] / per))               # ~6 s of work per process at the single-thread rate
+            def one(sh):
+                return rf.bench_result(rf.run([rf.bench_pair_case("log", dict(regex=APACHE2, time_fmt=TIME_FMT, time_key="time"), [GREP_RULE], sh, iters)], timeout=900)[0])
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=nproc) as ex:
+                res = list(ex.map(one, shards))
+            wall = time.perf_counter() - t0
+            v = sum(r[1] for r in res) * iters / wall
+            cpu["nproc"] = {"processes": nproc, "value": round(v, 1), "unit": "records/s", "kind": "reference",
+                            "note": "%d independent processes of the reference's filter pair, %d records x %d passes each, wall-clock aggregate "
+                                    "(process start-up included)" % (nproc, per, iters)}
+        else:
+            v = cpu_nproc_leg((bytes(data[: int(off[m])]), np.array(off[: m + 1])), nproc)
+            cpu["nproc"] = {"processes": nproc, "value": round(v, 1), "unit": "records/s", "kind": "port",
+                            "note": "%d independent processes, each the oracle pair on its own shard for ~6 s, wall-clock aggregate" % nproc}
     except Exception as e:
         cpu["nproc_error"] = repr(e)[:200]
     return cpu

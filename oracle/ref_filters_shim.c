@@ -1,0 +1,295 @@
+/* ref_filters_shim.c -- TEST INFRASTRUCTURE.  Drives the REAL filter plugins of the reference --
+ * plugins/filter_grep/grep.c (cb_grep_init / cb_grep_filter) and plugins/filter_parser/filter_parser.c
+ * (cb_parser_init / cb_parser_filter) -- compiled from where they lie together with everything under them:
+ * src/flb_parser*.c, flb_regex.c, flb_strptime.c, flb_log_event_decoder.c, flb_log_event_encoder*.c, flb_mp.c, flb_pack.c,
+ * flb_record_accessor.c, flb_ra_key.c, record_accessor/flb_ra_parser.c, flb_config_map.c, flb_kv.c, flb_time.c, flb_sds.c,
+ * flb_utils.c, ..., the real Onigmo and the real msgpack-c (oracle/Makefile, _ref/ref_filters: an executable, because the
+ * objects reference engine parts this path never calls, which the link leaves unresolved).
+ *
+ * What is NOT the reference's: (1) the two files flex / bison generate from src/record_accessor/ra.l / ra.y (neither tool
+ * is in this image): the 40-line grammar -- '$' IDENTIFIER ( '[' STRING ']' | '[' INTEGER ']' )* -- is written out by
+ * hand below with the lexer's exact token rules; (2) the engine around a filter instance: this file builds the
+ * struct flb_filter_instance / struct flb_config the callbacks read (properties list, config map, parser list) the way
+ * src/flb_filter.c does (flb_filter_set_property: flb_kv_item_create; flb_filter_init: flb_config_map_create).
+ *
+ * Protocol (stdin -> stdout, binary, one case after the other):
+ *   u32 kind (1 grep, 2 parser, 3 bench-pair), u32 nprops, nprops x (u32 klen, key, u32 vlen, val),
+ *   u32 nparsers, nparsers x 9 strings (name, format, regex, time_fmt, time_key, time_offset, types, skip_empty "0/1",
+ *   flags "time_keep time_strict"), u64 data_len, data        [kind 3: u32 iterations first]
+ * answer: i32 ret (-100: cb_init failed), u64 out_len, out bytes; kind 3: f64 seconds, u64 records in, u64 records kept */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+#include <fluent-bit/flb_info.h>
+#include <fluent-bit/flb_mem.h>
+#include <fluent-bit/flb_sds.h>
+#include <fluent-bit/flb_kv.h>
+#include <fluent-bit/flb_config.h>
+#include <fluent-bit/flb_config_map.h>
+#include <fluent-bit/flb_filter.h>
+#include <fluent-bit/flb_parser.h>
+#include <fluent-bit/flb_log.h>
+#include <fluent-bit/flb_worker.h>
+#include <fluent-bit/flb_slist.h>
+#include <fluent-bit/flb_mp.h>
+#include <fluent-bit/flb_utils.h>
+#include <fluent-bit/flb_env.h>
+#include <fluent-bit/record_accessor/flb_ra_parser.h>
+
+extern struct flb_filter_plugin filter_grep_plugin;
+extern struct flb_filter_plugin filter_parser_plugin;
+
+/* ---- the logger: the worker context stays NULL and the print hooks do nothing */
+FLB_TLS_DEFINE(struct flb_worker, flb_worker_ctx);
+void flb_log_print(int type, const char *file, int line, const char *fmt, ...) { (void) type; (void) file; (void) line; (void) fmt; }
+int flb_log_is_truncated(int type, const char *file, int line, const char *fmt, ...) { (void) type; (void) file; (void) line; (void) fmt; return 0; }
+int flb_errno_print(int errnum, const char *file, int line) { (void) errnum; (void) file; (void) line; return 0; }
+struct flb_worker *flb_worker_get(void) { return NULL; }
+int flb_worker_log_level(struct flb_worker *worker) { (void) worker; return 0; }
+int flb_log_cache_check_suppress(struct flb_log_cache *cache, char *msg_buf, size_t msg_size) { (void) cache; (void) msg_buf; (void) msg_size; return 0; }
+
+/* ---- src/flb_filter.c:757-775 */
+void flb_filter_set_context(struct flb_filter_instance *ins, void *context) { ins->context = context; }
+const char *flb_filter_get_property(const char *key, struct flb_filter_instance *ins) { return flb_kv_get_key_value((char *) key, &ins->properties); }
+const char *flb_filter_name(struct flb_filter_instance *ins) { return ins->alias ? ins->alias : ins->name; }
+
+/* ---- src/record_accessor/ra.l + ra.y by hand (see the header of this file) */
+typedef void *yyscan_t;
+typedef void *YY_BUFFER_STATE;
+int flb_ra_lex_init(yyscan_t *s) { *s = NULL; return 0; }
+int flb_ra_lex_destroy(yyscan_t s) { (void) s; return 0; }
+YY_BUFFER_STATE flb_ra__scan_string(const char *str, yyscan_t s) { (void) s; return (YY_BUFFER_STATE) str; }
+void flb_ra__delete_buffer(YY_BUFFER_STATE b, yyscan_t s) { (void) b; (void) s; }
+
+static void ra_ws(const char **p) { while (**p == ' ' || **p == '\t' || **p == '\n') (*p)++; }
+static int ra_ident_start(int c) { return c == '_' || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+static int ra_ident_char(int c) { return ra_ident_start(c) || (c >= '0' && c <= '9') || c == '.' || c == '-' || c == '/'; }
+
+int flb_ra_parse(struct flb_ra_parser *rp, const char *str, void *scanner)
+{
+    const char *p = str;
+    void *key;
+    (void) scanner;
+    ra_ws(&p);
+    if (*p != '$') return 1;
+    p++;
+    ra_ws(&p);
+    if (!ra_ident_start((unsigned char) *p)) return 1;
+    {
+        const char *b = p;
+        char *id;
+        while (ra_ident_char((unsigned char) *p)) p++;
+        id = flb_strndup(b, p - b);
+        /* the subkeys are reduced before the key in the grammar (record_subkey is to the right of IDENTIFIER and its
+         * actions run first); flb_ra_parser_key_add only stores the name, so the order does not show */
+        rp->type = FLB_RA_PARSER_KEYMAP;
+        key = flb_ra_parser_key_add(rp, id);
+        if (key) rp->key = key;
+        flb_free(id);
+    }
+    for (;;) {
+        ra_ws(&p);
+        if (*p == '\0') return 0;
+        if (*p != '[') return 1;
+        p++;
+        ra_ws(&p);
+        if (*p == '\'') {
+            /* \'([^']|'{2})*\' with '' -> ' */
+            const char *b = ++p;
+            char *s;
+            size_t n = 0, i;
+            for (;;) {
+                if (*p == '\0') return 1;
+                if (*p == '\'') { if (p[1] == '\'') { p += 2; continue; } break; }
+                p++;
+            }
+            s = flb_malloc((size_t) (p - b) + 1);
+            for (i = 0; b + i < p; i++) { s[n++] = b[i]; if (b[i] == '\'') i++; }
+            s[n] = '\0';
+            p++;
+            flb_ra_parser_subentry_add_string(rp, s);
+            flb_free(s);
+        }
+        else if (*p >= '0' && *p <= '9') {
+            /* [1-9][0-9]*|0 */
+            const char *b = p;
+            if (*p == '0') p++;
+            else while (*p >= '0' && *p <= '9') p++;
+            flb_ra_parser_subentry_add_array_id(rp, atoi(b));
+        }
+        else return 1;
+        ra_ws(&p);
+        if (*p != ']') return 1;
+        p++;
+    }
+}
+
+/* ---- protocol helpers */
+static int rd(void *p, size_t n) { return fread(p, 1, n, stdin) == n; }
+static char *rd_str(void)
+{
+    uint32_t n;
+    char *s;
+    if (!rd(&n, 4)) return NULL;
+    s = malloc((size_t) n + 1);
+    if (n && !rd(s, n)) { free(s); return NULL; }
+    s[n] = '\0';
+    return s;
+}
+
+struct inst {
+    struct flb_config *config;
+    struct flb_filter_instance ins;
+    int ok;
+};
+
+/* one filter instance the way src/flb_filter.c builds it: properties (flb_filter_set_property :383-440), config map
+ * (flb_filter_init :605-640: flb_config_map_create + flb_config_map_properties_check), cb_init */
+static void inst_open(struct inst *it, struct flb_config *config, struct flb_filter_plugin *p, uint32_t nprops, char **keys, char **vals)
+{
+    uint32_t i;
+    memset(&it->ins, 0, sizeof(it->ins));
+    it->config = config;
+    it->ins.p = p;
+    it->ins.config = config;
+    it->ins.log_level = -1;
+    snprintf(it->ins.name, sizeof(it->ins.name), "%s.0", p->name);
+    mk_list_init(&it->ins.properties);
+    for (i = 0; i < nprops; i++) {
+        /* (the engine expands ${ENV} through flb_env_var_translate first: no variables here) */
+        flb_kv_item_create(&it->ins.properties, keys[i], vals[i]);
+    }
+    it->ins.config_map = p->config_map ? flb_config_map_create(config, p->config_map) : NULL;
+    it->ok = p->cb_init(&it->ins, config, NULL) == 0;
+}
+
+static struct flb_config *make_config(void)
+{
+    struct flb_config *c = calloc(1, sizeof(*c));
+    mk_list_init(&c->parsers);
+    mk_list_init(&c->filters);
+    mk_list_init(&c->multiline_parsers);
+    c->env = flb_env_create();                  /* flb_config_init: the (empty) environment the config map translates defaults through */
+    return c;
+}
+
+static void wr_answer(int32_t ret, const void *out, uint64_t n)
+{
+    fwrite(&ret, 4, 1, stdout);
+    fwrite(&n, 8, 1, stdout);
+    if (n) fwrite(out, 1, n, stdout);
+}
+
+/* a call into an engine part that was left unresolved lands on address 0: say where it came from */
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void on_segv(int sig)
+{
+    void *bt[32];
+    int n = backtrace(bt, 32);
+    (void) sig;
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(139);
+}
+
+int main(void)
+{
+    signal(SIGSEGV, on_segv);
+    for (;;) {
+        uint32_t kind, nprops, nparsers, iters = 0, i;
+        char **keys, **vals;
+        struct flb_config *config;
+        uint64_t dlen;
+        char *data;
+        if (!rd(&kind, 4)) break;
+        if (kind == 3 && !rd(&iters, 4)) break;
+        if (!rd(&nprops, 4)) break;
+        keys = calloc(nprops + 1, sizeof(char *)); vals = calloc(nprops + 1, sizeof(char *));
+        for (i = 0; i < nprops; i++) { keys[i] = rd_str(); vals[i] = rd_str(); }
+        if (!rd(&nparsers, 4)) break;
+        config = make_config();
+        for (i = 0; i < nparsers; i++) {
+            char *f[9];
+            int k, time_keep = 0, time_strict = 1;
+            struct flb_parser_types *types = NULL;
+            int types_len = 0;
+            for (k = 0; k < 9; k++) f[k] = rd_str();
+            sscanf(f[8], "%d %d", &time_keep, &time_strict);
+            if (f[6][0]) {
+                /* Types: src/flb_parser.c:1130-1182 (parser_types_create is static there; same split) */
+                struct mk_list *split = flb_utils_split(f[6], ' ', 256);
+                struct mk_list *head;
+                int cnt = mk_list_size(split), q = 0;
+                types = flb_calloc(cnt, sizeof(struct flb_parser_types));
+                mk_list_foreach(head, split) {
+                    struct flb_split_entry *e = mk_list_entry(head, struct flb_split_entry, _head);
+                    char *colon = strchr(e->value, ':');
+                    const char *ty;
+                    if (!colon) continue;
+                    types[q].key = flb_strndup(e->value, colon - e->value);
+                    types[q].key_len = (int) (colon - e->value);
+                    ty = colon + 1;
+                    if (!strcasecmp(ty, "integer")) types[q].type = FLB_PARSER_TYPE_INT;
+                    else if (!strcasecmp(ty, "bool")) types[q].type = FLB_PARSER_TYPE_BOOL;
+                    else if (!strcasecmp(ty, "float")) types[q].type = FLB_PARSER_TYPE_FLOAT;
+                    else if (!strcasecmp(ty, "hex")) types[q].type = FLB_PARSER_TYPE_HEX;
+                    else types[q].type = FLB_PARSER_TYPE_STRING;
+                    q++;
+                }
+                types_len = q;
+                flb_utils_split_free(split);
+            }
+            flb_parser_create(f[0], f[1], f[2][0] ? f[2] : NULL, atoi(f[7]), f[3][0] ? f[3] : NULL, f[4][0] ? f[4] : NULL, f[5][0] ? f[5] : NULL,
+                              time_keep, time_strict, FLB_FALSE, FLB_FALSE, types, types_len, NULL, config);
+        }
+        if (!rd(&dlen, 8)) break;
+        data = malloc(dlen + 1);
+        if (dlen && !rd(data, dlen)) break;
+        if (kind == 1 || kind == 2) {
+            struct inst it;
+            void *out = NULL;
+            size_t out_size = 0;
+            int ret;
+            inst_open(&it, config, kind == 1 ? &filter_grep_plugin : &filter_parser_plugin, nprops, keys, vals);
+            if (!it.ok) { wr_answer(-100, NULL, 0); fflush(stdout); continue; }
+            ret = it.ins.p->cb_filter(data, dlen, "t", 1, &out, &out_size, &it.ins, NULL, it.ins.context, config);
+            wr_answer(ret, out, ret == FLB_FILTER_MODIFIED ? out_size : 0);
+        }
+        else if (kind == 3) {
+            /* parser (the properties up to the first "--") then grep (the rest): flb_filter_do's loop over the two, timed */
+            struct inst ip, ig;
+            uint32_t cut = 0, it_n;
+            struct timespec t0, t1;
+            uint64_t rin = 0, rkept = 0;
+            double secs;
+            while (cut < nprops && strcmp(keys[cut], "--") != 0) cut++;
+            inst_open(&ip, config, &filter_parser_plugin, cut, keys, vals);
+            inst_open(&ig, config, &filter_grep_plugin, nprops - cut - 1, keys + cut + 1, vals + cut + 1);
+            if (!ip.ok || !ig.ok) { wr_answer(-100, NULL, 0); fflush(stdout); continue; }
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (it_n = 0; it_n < iters; it_n++) {
+                void *o1 = NULL, *o2 = NULL;
+                size_t s1 = 0, s2 = 0;
+                int r1 = ip.ins.p->cb_filter(data, dlen, "t", 1, &o1, &s1, &ip.ins, NULL, ip.ins.context, config);
+                const void *d2 = r1 == FLB_FILTER_MODIFIED ? o1 : data;
+                size_t n2 = r1 == FLB_FILTER_MODIFIED ? s1 : dlen;
+                int r2 = ig.ins.p->cb_filter(d2, n2, "t", 1, &o2, &s2, &ig.ins, NULL, ig.ins.context, config);
+                if (it_n == 0) {
+                    rin = (uint64_t) flb_mp_count(data, dlen);
+                    rkept = (uint64_t) flb_mp_count(r2 == FLB_FILTER_MODIFIED ? o2 : d2, r2 == FLB_FILTER_MODIFIED ? s2 : n2);
+                }
+                if (r1 == FLB_FILTER_MODIFIED) flb_free(o1);
+                if (r2 == FLB_FILTER_MODIFIED) flb_free(o2);
+            }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            secs = (double) (t1.tv_sec - t0.tv_sec) + 1e-9 * (double) (t1.tv_nsec - t0.tv_nsec);
+            { int32_t z = 0; uint64_t n = 24; fwrite(&z, 4, 1, stdout); fwrite(&n, 8, 1, stdout); fwrite(&secs, 8, 1, stdout); fwrite(&rin, 8, 1, stdout); fwrite(&rkept, 8, 1, stdout); }
+        }
+        fflush(stdout);
+        free(data);
+    }
+    return 0;
+}

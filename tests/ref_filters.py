@@ -1,0 +1,79 @@
+"""Binding of oracle/_ref/ref_filters: the REAL cb_filter of the reference's filter_grep / filter_parser plugins (built by
+oracle/Makefile from /root/reference, see oracle/ref_filters_shim.c).  Test infrastructure only."""
+import os, struct, subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_filters")
+MODIFIED, NOTOUCH = 1, 2
+
+
+def available():
+    return os.path.exists(EXE)
+
+
+def _s(x):
+    b = x if isinstance(x, bytes) else str(x).encode()
+    return struct.pack("<I", len(b)) + b
+
+
+def _parser_fields(name, p):
+    """p: the keyword arguments of oracle_binding.Parser / flbgpu Parser"""
+    fmt = p.get("format") or "regex"
+    return [name, fmt, p.get("regex") or "", p.get("time_fmt") or "", p.get("time_key") or "", p.get("time_offset") or "", p.get("types") or "",
+            "1" if p.get("skip_empty", True) else "0", "%d %d" % (1 if p.get("time_keep") else 0, 1 if p.get("time_strict", True) else 0)]
+
+
+def _case(kind, props, parsers, data, iters=None):
+    out = struct.pack("<I", kind)
+    if kind == 3:
+        out += struct.pack("<I", iters)
+    out += struct.pack("<I", len(props))
+    for k, v in props:
+        out += _s(k) + _s(v)
+    out += struct.pack("<I", len(parsers))
+    for name, p in parsers:
+        for f in _parser_fields(name, p):
+            out += _s(f)
+    return out + struct.pack("<Q", len(data)) + data
+
+
+def run(cases, timeout=600):
+    """cases: list of bytes built by grep_case / parser_case / bench_case; returns [(ret, out bytes)]"""
+    r = subprocess.run([EXE], input=b"".join(cases), capture_output=True, timeout=timeout)
+    res, o, buf = [], 0, r.stdout
+    while o + 12 <= len(buf):
+        ret, n = struct.unpack_from("<iQ", buf, o)
+        o += 12
+        res.append((ret, buf[o:o + n]))
+        o += n
+    assert len(res) == len(cases), (len(res), len(cases), r.returncode, r.stderr[-400:])
+    return res
+
+
+def grep_case(rules, logical_op, data):
+    props = [(k, v) for k, v in rules]
+    if logical_op:
+        props.append(("logical_op", logical_op))
+    return _case(1, props, [], data)
+
+
+def parser_case(key_name, parsers, data, reserve=False, preserve=False):
+    named = [("p%d" % i, p) for i, p in enumerate(parsers)]
+    props = [("key_name", key_name)] + [("parser", n) for n, _ in named]
+    if reserve:
+        props.append(("reserve_data", "on"))
+    if preserve:
+        props.append(("preserve_key", "on"))
+    return _case(2, props, named, data)
+
+
+def bench_pair_case(key_name, parser, rules, data, iters):
+    props = [("key_name", key_name), ("parser", "p0"), ("--", "")] + [(k, v) for k, v in rules]
+    return _case(3, props, [("p0", parser)], data, iters)
+
+
+def bench_result(res):
+    ret, out = res
+    assert ret == 0 and len(out) == 24, (ret, len(out))
+    secs, rin, rkept = struct.unpack("<dQQ", out)
+    return secs, rin, rkept
