@@ -169,6 +169,7 @@ enum {
     RF_EXACT = 256,        // a Types float value needs the exact decimal conversion: k_parser_emit_exact rewrites the record
     RF_PGDONE = 512,       // pair [filter_parser, filter_grep]: grep's rules were evaluated on the spans by k_parser_rx ...
     RF_PGKEEP = 1024,      // ... and keep the record
+    RF_NEEDLOC = 4096,     // k_parser_reg<false> left the row to the fix-up launch (another layout, the end of the chunk)
     RF_DESC = 2048,        // pair mode: the kept record's fields are in its descriptor (PgEmitArgs::desc), not in the columns
 };
 constexpr uint32_t PG_UNDECIDED = 0xFFFFFFFFu;   // keep_len of a row whose rules k_pg_decide still has to evaluate
@@ -257,6 +258,9 @@ struct ParserMatchArgs {
     //   [0] ts_sec [1] ts_nsec [2] val_off [3] drop_mask [4] meta_off [5] meta_len [6] nkept, then the capture spans as u16 pairs
     uint32_t *desc;
     uint32_t dstride;
+    uint64_t fix_first;              // k_parser_reg<true>: first flagged row
+    const uint8_t *tail_buf;         // the chunk's bytes from tail_start on, followed by 512 zero bytes (wide loads of the last records)
+    uint64_t tail_start;
     TileCfg tc;
     const ParserMatchArgs *self;     // this structure in device memory: what the out-of-line slow paths read (taking the address of a
                                      // kernel argument makes the compiler keep the whole argument block in scratch memory)
@@ -498,7 +502,7 @@ void launch_parser_rx(const ParserMatchArgs &a, int grid, int threads, hipStream
 void launch_parser_finish(const ParserMatchArgs &a, int cus, hipStream_t st);
 constexpr int TILE_BYTES = 17920;         // k_parser_tile: LDS bytes of a wave's record tile (64 records of 277 B + slack)
 void launch_parser_tile(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
-void launch_parser_reg(const ParserMatchArgs &a, int grid, int threads, hipStream_t st);
+void launch_parser_reg(const ParserMatchArgs &a, int grid, int threads, bool fixup, hipStream_t st);
 void launch_parser_generic(const ParserMatchArgs &a, int grid, hipStream_t st);
 void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *out, hipStream_t st);
 constexpr int MATCH_BLOCK = 1024;         // threads per workgroup of k_parser_match

@@ -760,7 +760,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
@@ -838,14 +838,34 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     else if (use_tile) {
         ma.tile_lds_off = (ma.lds_total + 15) & ~15u;
         ma.lds_total = ma.tile_lds_off + (uint32_t) (rx_threads / 64) * tile_wave_bytes + 64;
+        if (!tile_in_lds) {
+            // a zero-padded copy of the chunk's last bytes: the call-free kernel loads 16 bytes at a time without bounds tests
+            const size_t T = 4096, tb = in->bytes < T ? (size_t) in->bytes : T;
+            if (!f->d_tail.ensure(T + 512)) return false;
+            HIPOK(hipMemsetAsync(f->d_tail.p, 0, T + 512, st));
+            if (tb) HIPOK(hipMemcpyAsync(f->d_tail.p, data + (in->bytes - tb), tb, hipMemcpyDeviceToDevice, st));
+            ma.tail_buf = f->d_tail.as<uint8_t>(); ma.tail_start = in->bytes - tb;
+        }
         if (!f->d_args.ensure(sizeof(ParserMatchArgs)) || !f->hp_args.ensure(sizeof(ParserMatchArgs))) return false;
         ma.self = f->d_args.as<ParserMatchArgs>();
         memcpy(f->hp_args.p, &ma, sizeof(ma));                   // (page-locked: the copy below is a real asynchronous transfer)
         HIPOK(hipMemcpyAsync(f->d_args.p, f->hp_args.p, sizeof(ma), hipMemcpyHostToDevice, st));
         if (tile_in_lds) { ProfScope ps(f, st, "k_parser_tile"); launch_parser_tile(ma, grid, rx_threads, st); }
-        else { ProfScope ps(f, st, "k_parser_reg"); launch_parser_reg(ma, grid, rx_threads, st); }
+        else { ProfScope ps(f, st, "k_parser_reg"); launch_parser_reg(ma, grid, rx_threads, false, st); }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
+        if (!tile_in_lds && hm.counts[10] > 0) {
+            // rows the call-free kernel only flagged (another layout, the last records of the chunk): the same pass with the
+            // general locate, guarded loads and the reverse-pass fallback, for those rows
+            ma.fix_first = hm.counts[11] <= n ? n - hm.counts[11] : 0;
+            uint64_t fix_blocks = ((n - (ma.fix_first & ~63ull)) + (uint64_t) rx_threads - 1) / (uint64_t) rx_threads;
+            if (fix_blocks > (uint64_t) grid) fix_blocks = (uint64_t) grid;
+            { ProfScope ps(f, st, "k_parser_reg_fixup"); launch_parser_reg(ma, (int) fix_blocks, rx_threads, true, st); }
+            HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            // when most of the data is of that kind the phase kernels (tiled, general) are the better choice from now on
+            if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
+        }
         // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when
         // that is the rule for this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on
         if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;

@@ -109,7 +109,7 @@ struct flbgpu_filter {
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     flbgpu::PinnedBuf hp_misc, hp_args, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
