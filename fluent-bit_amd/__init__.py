@@ -282,6 +282,48 @@ class JsonFormatter(_Filter):
         return r, out
 
 
+class TailLines:
+    """in_tail's line packing (plugins/in_tail/tail_file.c:689-1040 process_content, the plain path, + :552-604
+    flb_tail_file_pack_line): a file buffer cut at the newlines, every line one log event."""
+
+    def __init__(self, key="log", path_key=None, path="", offset_key=None, skip_empty_lines=True):
+        L = lib()
+        L.flbgpu_tail_create.restype = c_void_p
+        L.flbgpu_tail_create.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_int]
+        L.flbgpu_tail_destroy.argtypes = [c_void_p]
+        L.flbgpu_tail_run.argtypes = [c_void_p, c_void_p, c_size_t, c_uint64, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t),
+                                      POINTER(c_uint64), POINTER(c_uint64)]
+        L.flbgpu_tail_run_dev.argtypes = [c_void_p, c_void_p, c_uint64, c_uint64, ctypes.c_uint32, ctypes.c_uint32, POINTER(DevChunk), POINTER(c_uint64), POINTER(c_uint64)]
+        e = lambda x: None if x is None else _b(x)
+        self.h = L.flbgpu_tail_create(e(key), e(path_key), e(path), e(offset_key), int(bool(skip_empty_lines)))
+        if not self.h:
+            raise ValueError(last_error())
+
+    def process(self, text, stream_offset=0, sec=0, nsec=0):
+        """host buffer -> (lines, records, processed bytes)"""
+        out = c_void_p(); sz = c_size_t(); proc = c_uint64(); lines = c_uint64()
+        r = lib().flbgpu_tail_run(self.h, text, len(text), stream_offset, sec, nsec, byref(out), byref(sz), byref(proc), byref(lines))
+        if r != 0:
+            raise RuntimeError(last_error())
+        b = ctypes.string_at(out, sz.value) if out.value else b""
+        if out.value:
+            _libc.free(out)
+        return int(lines.value), b, int(proc.value)
+
+    def process_dev(self, d_text, nbytes, stream_offset=0, sec=0, nsec=0):
+        """text in HBM -> (lines, DevChunk, processed bytes)"""
+        out = DevChunk(); proc = c_uint64(); lines = c_uint64()
+        r = lib().flbgpu_tail_run_dev(self.h, d_text, nbytes, stream_offset, sec, nsec, byref(out), byref(proc), byref(lines))
+        if r != 0:
+            raise RuntimeError(last_error())
+        return int(lines.value), out, int(proc.value)
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_tail_destroy(self.h)
+            self.h = None
+
+
 def msgpack_to_json_format(data, json_format, date_format, date_key, escape_unicode=1, nan_to_null=0):
     """the one-shot C entry with the reference's argument list"""
     out = c_void_p(); sz = c_size_t()

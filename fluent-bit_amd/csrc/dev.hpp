@@ -471,6 +471,30 @@ struct JsonArgs {
 };
 
 
+// ---- in_tail's line packing (tail_kernels.inc)
+struct TailArgs {
+    const uint8_t *text;
+    uint64_t bytes;
+    const unsigned long long *lead;  // leading NUL bytes
+    const uint64_t *nl_pos;          // [nl] positions of the newlines
+    uint64_t nl;
+    uint32_t *out_len;               // [nl]
+    const uint64_t *out_off;         // [nl + 1]
+    uint8_t *out;
+    unsigned long long *lines;       // records produced
+    uint64_t stream_offset;
+    uint32_t ts_sec, ts_nsec;
+    int skip_empty_lines;
+    uint32_t la, lb, lc;             // bytes of [path_key path], [offset_key], [key] in pre[]
+    uint8_t pre[1024];               // the packed strings every record carries
+};
+void launch_tl_lead(const uint8_t *text, uint64_t bytes, unsigned long long *lead, hipStream_t st);
+size_t tl_tiles(uint64_t bytes);
+void launch_tl_count(const uint8_t *text, uint64_t bytes, uint64_t *masks, uint32_t *tile_cnt, hipStream_t st);
+void launch_tl_fill(const uint64_t *masks, uint64_t bytes, const uint64_t *tile_off, uint64_t *nl_pos, hipStream_t st);
+void launch_tl_size(const TailArgs &a, hipStream_t st);
+void launch_tl_emit(const TailArgs &a, int cus, hipStream_t st);
+
 struct GatherArgs {
     const uint8_t *data;
     const uint64_t *row_off;

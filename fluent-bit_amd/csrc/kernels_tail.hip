@@ -1,0 +1,15 @@
+// kernels_tail.hip -- in_tail's line packing (shares kdev.inc with the other kernel units)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <type_traits>
+#include "dev.hpp"
+#include "numconv.hpp"
+
+namespace flbgpu {
+
+#include "kdev.inc"
+
+#include "tail_kernels.inc"
+
+}  // namespace flbgpu

@@ -233,6 +233,21 @@ int flbgpu_json_run_dev(flbgpu_json *j, const flbgpu_dev_chunk *text_rows, int e
 int flbgpu_json_row_info(flbgpu_json *j, uint64_t first, uint64_t count, uint32_t *records, uint32_t *consumed,
                          uint8_t *root_type, uint8_t *status);
 void flbgpu_json_stats(flbgpu_json *j, uint64_t *out3);   /* rows sent to the generic kernels, values, error rows */
+/* ---- in_tail: a file buffer cut into lines, every line one log event ------------------------------------------------
+ * plugins/in_tail/tail_file.c:689-1040 (process_content: leading NULs skipped, lines end at '\n', Skip_Empty_Lines, the CR of
+ * a CR LF dropped, what follows the last newline stays in the buffer) + :552-604 (flb_tail_file_pack_line: Path_Key, Offset_Key
+ * = stream offset of the line, Key = the line; records in the begin_record / append_body_values layout with map32 headers).
+ * The plain path: no multiline, parser, docker mode, truncate_long_lines, encoding conversion.  The reference stamps every
+ * record with flb_time_get(); the caller passes the timestamp of the call.  *processed = bytes consumed. */
+typedef struct flbgpu_tail flbgpu_tail;
+flbgpu_tail *flbgpu_tail_create(const char *key, const char *path_key, const char *path, const char *offset_key, int skip_empty_lines);
+void flbgpu_tail_destroy(flbgpu_tail *t);
+int flbgpu_tail_run(flbgpu_tail *t, const void *text, size_t bytes, uint64_t stream_offset, uint32_t ts_sec, uint32_t ts_nsec,
+                    void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *lines);
+/* text already in HBM -> a device chunk (one row per newline, skipped lines as empty rows) the filters take as it is */
+int flbgpu_tail_run_dev(flbgpu_tail *t, const void *d_text, uint64_t bytes, uint64_t stream_offset, uint32_t ts_sec, uint32_t ts_nsec,
+                        flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *lines);
+
 /* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
 int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);
 

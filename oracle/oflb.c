@@ -1674,3 +1674,47 @@ int oflb_time_lookup(oflb_parser *p, const char *s, size_t len, int64_t now, int
     if (r == 0) *sec = (int64_t) tm2time(&tm);
     return r;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * in_tail: the buffer of a tailed file cut into lines, every line one log event
+ * plugins/in_tail/tail_file.c:689-1040 (process_content, the plain path: no multiline, no parser, no docker mode, no
+ * truncate_long_lines, no encoding conversion) + :552-604 (flb_tail_file_pack_line) + the encoder's layout for a record built
+ * with begin_record / append_body_values (src/flb_log_event_encoder.c:195-217, src/flb_mp.c:591-640: map32 headers for metadata
+ * and body).  The reference stamps every record with "now" (flb_time_get); here the time is a parameter.
+ * Returns the number of lines; *processed = bytes consumed (what stays in the file's buffer starts there). */
+int oflb_tail_process(const char *buf, size_t len, const char *key, const char *path_key, const char *path, const char *offset_key,
+                      uint64_t stream_offset, int skip_empty_lines, uint32_t sec, uint32_t nsec, char **out, size_t *out_size, uint64_t *processed_out)
+{
+    omp_buf b;
+    const char *d = buf, *end = buf + len, *nl;
+    uint64_t processed = 0;
+    int lines = 0;
+    uint32_t nbody = 1u + (path_key ? 1u : 0u) + (offset_key ? 1u : 0u);
+    omp_buf_init(&b);
+    while (d < end && *d == '\0') { d++; processed++; }                                  /* :783-786 */
+    while (d < end && (nl = memchr(d, '\n', (size_t) (end - d)))) {                       /* :840 */
+        size_t ll = (size_t) (nl - d), line_len;
+        int crlf = 0;
+        uint8_t h[22];
+        if (skip_empty_lines) {                                                          /* :863-874 */
+            if (ll == 0) { d++; processed++; continue; }
+            else if (ll == 1 && d[0] == '\r') { d += 2; processed += 2; continue; }
+        }
+        if (ll >= 2) crlf = (d[ll - 1] == '\r');                                         /* :877-884 */
+        line_len = ll - (size_t) crlf;
+        /* 92 92 d7 00 <sec> <nsec> | df 00 00 00 00 | df 00 00 00 nn */
+        h[0] = 0x92; h[1] = 0x92; h[2] = 0xd7; h[3] = 0x00;
+        h[4] = (uint8_t) (sec >> 24); h[5] = (uint8_t) (sec >> 16); h[6] = (uint8_t) (sec >> 8); h[7] = (uint8_t) sec;
+        h[8] = (uint8_t) (nsec >> 24); h[9] = (uint8_t) (nsec >> 16); h[10] = (uint8_t) (nsec >> 8); h[11] = (uint8_t) nsec;
+        h[12] = 0xdf; h[13] = h[14] = h[15] = h[16] = 0;
+        h[17] = 0xdf; h[18] = h[19] = h[20] = 0; h[21] = (uint8_t) nbody;
+        omp_buf_write(&b, h, 22);
+        if (path_key) { omp_pack_str_with_body(&b, path_key, strlen(path_key)); omp_pack_str_with_body(&b, path, strlen(path)); }      /* :565-573 */
+        if (offset_key) { omp_pack_str_with_body(&b, offset_key, strlen(offset_key)); omp_pack_uint64(&b, stream_offset + processed); }  /* :576-587 */
+        omp_pack_str_with_body(&b, key, strlen(key));                                   /* :589-595 */
+        omp_pack_str_with_body(&b, d, line_len);
+        d += ll + 1; processed += ll + 1; lines++;                                      /* :985-992 */
+    }
+    *out = b.data; *out_size = b.size; *processed_out = processed;
+    return lines;
+}

@@ -16,6 +16,9 @@
  *   u32 kind (1 grep, 2 parser, 3 bench-pair), u32 nprops, nprops x (u32 klen, key, u32 vlen, val),
  *   u32 nparsers, nparsers x 9 strings (name, format, regex, time_fmt, time_key, time_offset, types, skip_empty "0/1",
  *   flags "time_keep time_strict"), u64 data_len, data        [kind 3: u32 iterations first]
+ *   kind 4 (in_tail's line packing): props = key, path_key, path, offset_key, stream_offset, skip_empty_lines, sec, nsec; data = text:
+ *   the loop of process_content (plugins/in_tail/tail_file.c:783-786,840-1000, plain path) restated here, every line packed by the
+ *   REAL encoder through flb_tail_file_pack_line's call sequence (:552-604); answer ret = lines, out = records, then u64 processed
  * answer: i32 ret (-100: cb_init failed), u64 out_len, out bytes; kind 3: f64 seconds, u64 records in, u64 records kept */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,6 +39,8 @@
 #include <fluent-bit/flb_mp.h>
 #include <fluent-bit/flb_utils.h>
 #include <fluent-bit/flb_env.h>
+#include <fluent-bit/flb_time.h>
+#include <fluent-bit/flb_log_event_encoder.h>
 #include <fluent-bit/record_accessor/flb_ra_parser.h>
 
 extern struct flb_filter_plugin filter_grep_plugin;
@@ -257,6 +262,52 @@ int main(void)
             if (!it.ok) { wr_answer(-100, NULL, 0); fflush(stdout); continue; }
             ret = it.ins.p->cb_filter(data, dlen, "t", 1, &out, &out_size, &it.ins, NULL, it.ins.context, config);
             wr_answer(ret, out, ret == FLB_FILTER_MODIFIED ? out_size : 0);
+        }
+        else if (kind == 4) {
+            const char *key = "log", *path_key = NULL, *path = "", *offset_key = NULL;
+            uint64_t stream_offset = 0, processed = 0;
+            int skip_empty = 1, lines = 0;
+            struct flb_time tm;
+            struct flb_log_event_encoder *enc = flb_log_event_encoder_create(FLB_LOG_EVENT_FORMAT_DEFAULT);
+            const char *d = data, *end = data + dlen, *nl;
+            tm.tm.tv_sec = 0; tm.tm.tv_nsec = 0;
+            for (i = 0; i < nprops; i++) {
+                if (!strcmp(keys[i], "key")) key = vals[i];
+                else if (!strcmp(keys[i], "path_key")) path_key = vals[i];
+                else if (!strcmp(keys[i], "path")) path = vals[i];
+                else if (!strcmp(keys[i], "offset_key")) offset_key = vals[i];
+                else if (!strcmp(keys[i], "stream_offset")) stream_offset = strtoull(vals[i], NULL, 10);
+                else if (!strcmp(keys[i], "skip_empty_lines")) skip_empty = atoi(vals[i]);
+                else if (!strcmp(keys[i], "sec")) tm.tm.tv_sec = (time_t) strtoull(vals[i], NULL, 10);
+                else if (!strcmp(keys[i], "nsec")) tm.tm.tv_nsec = (long) strtoull(vals[i], NULL, 10);
+            }
+            while (d < end && *d == '\0') { d++; processed++; }                     /* :783-786 flb_skip_leading_zeros_simd */
+            while (d < end && (nl = memchr(d, '\n', end - d))) {                    /* :840 */
+                size_t len = nl - d, line_len;
+                int crlf = 0, r;
+                if (skip_empty) {                                                   /* :863-874 */
+                    if (len == 0) { d++; processed++; continue; }
+                    else if (len == 1 && d[0] == '\r') { d += 2; processed += 2; continue; }
+                }
+                if (len >= 2) crlf = (d[len - 1] == '\r');                          /* :877-884 */
+                line_len = len - crlf;
+                /* flb_tail_file_pack_line (:552-604), with the timestamp given instead of "now" */
+                r = flb_log_event_encoder_begin_record(enc);
+                if (r == FLB_EVENT_ENCODER_SUCCESS) r = flb_log_event_encoder_set_timestamp(enc, &tm);
+                if (path_key && r == FLB_EVENT_ENCODER_SUCCESS)
+                    r = flb_log_event_encoder_append_body_values(enc, FLB_LOG_EVENT_CSTRING_VALUE(path_key), FLB_LOG_EVENT_STRING_VALUE(path, strlen(path)));
+                if (offset_key) {
+                    if (r == FLB_EVENT_ENCODER_SUCCESS) r = flb_log_event_encoder_append_body_values(enc, FLB_LOG_EVENT_CSTRING_VALUE(offset_key));
+                    if (r == FLB_EVENT_ENCODER_SUCCESS) r = flb_log_event_encoder_append_body_uint64(enc, (uint64_t) (stream_offset + processed));
+                }
+                if (r == FLB_EVENT_ENCODER_SUCCESS)
+                    r = flb_log_event_encoder_append_body_values(enc, FLB_LOG_EVENT_CSTRING_VALUE(key), FLB_LOG_EVENT_STRING_VALUE(d, line_len));
+                if (r == FLB_EVENT_ENCODER_SUCCESS) r = flb_log_event_encoder_commit_record(enc);
+                d += len + 1; processed += len + 1; lines++;                        /* go_next :985-992 */
+            }
+            { int32_t ret = lines; uint64_t n = enc->output_length + 8; fwrite(&ret, 4, 1, stdout); fwrite(&n, 8, 1, stdout);
+              if (enc->output_length) fwrite(enc->output_buffer, 1, enc->output_length, stdout); fwrite(&processed, 8, 1, stdout); }
+            flb_log_event_encoder_destroy(enc);
         }
         else if (kind == 3) {
             /* parser (the properties up to the first "--") then grep (the rest): flb_filter_do's loop over the two, timed */

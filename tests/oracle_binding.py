@@ -180,3 +180,15 @@ class L2M:
             out.append(dict(labels=tuple(lib().oflb_l2m_series_label(self.h, s, i) for i in range(lc.value)),
                             value=v.value, buckets=list(bk), count=cnt.value, sum=sm.value))
         return keys, list(bounds[: nb.value]), out
+
+
+def tail_process(text, key="log", path_key=None, path="", offset_key=None, stream_offset=0, skip_empty_lines=True, sec=0, nsec=0):
+    """in_tail's process_content (plain path) + flb_tail_file_pack_line: (lines, records, processed bytes)"""
+    L = lib()
+    L.oflb_tail_process.argtypes = [c_char_p, c_size_t, c_char_p, c_char_p, c_char_p, c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                    ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), ctypes.POINTER(ctypes.c_uint64)]
+    out = c_void_p(); sz = c_size_t(); proc = ctypes.c_uint64()
+    enc = lambda x: None if x is None else (x if isinstance(x, bytes) else x.encode())
+    n = L.oflb_tail_process(text, len(text), enc(key), enc(path_key), enc(path), enc(offset_key), stream_offset, 1 if skip_empty_lines else 0, sec, nsec,
+                            byref(out), byref(sz), byref(proc))
+    return n, _take(out, sz), int(proc.value)

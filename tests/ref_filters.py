@@ -77,3 +77,18 @@ def bench_result(res):
     assert ret == 0 and len(out) == 24, (ret, len(out))
     secs, rin, rkept = struct.unpack("<dQQ", out)
     return secs, rin, rkept
+
+
+def tail_case(text, key="log", path_key=None, path="", offset_key=None, stream_offset=0, skip_empty_lines=True, sec=0, nsec=0):
+    props = [("key", key), ("skip_empty_lines", "1" if skip_empty_lines else "0"), ("sec", sec), ("nsec", nsec), ("stream_offset", stream_offset), ("path", path)]
+    if path_key is not None:
+        props.append(("path_key", path_key))
+    if offset_key is not None:
+        props.append(("offset_key", offset_key))
+    return _case(4, props, [], text)
+
+
+def tail_result(res):
+    lines, out = res
+    (processed,) = struct.unpack("<Q", out[-8:])
+    return lines, out[:-8], processed
