@@ -267,6 +267,42 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         r = o(sample)
         cdt = time.perf_counter() - t0
         out["ndjson_to_events"]["cpu_port_lines_per_s"] = round(r[3] / cdt, 1)
+    # -- in_tail in front of the path: a file buffer (the same apache lines, '\n' terminated) cut into log events on the device
+    #    (process_content + flb_tail_file_pack_line), and the headline pair run on THAT chunk (in_tail's 32-bit map headers)
+    try:
+        import numpy as np
+        m = min(n, 4_000_000)
+        # the `log` values of the first m events (277 B = 21 B framing + 256 B line) with a newline behind each
+        ev = np.zeros((m, 277), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(ev.ctypes.data, raw_chunk.data, m * 277)
+        txt = np.empty((m, 257), dtype=np.uint8)
+        txt[:, :256] = ev[:, 21:]; txt[:, 256] = 10
+        d_txt = L.flbgpu_dev_alloc(txt.nbytes); L.flbgpu_memcpy_h2d(d_txt, txt.ctypes.data, txt.nbytes)
+        tl = g.TailLines()
+        lines_, tchunk, proc_ = tl.process_dev(d_txt, txt.nbytes, sec=1700000000, nsec=0)
+        assert lines_ == m and proc_ == txt.nbytes, (lines_, proc_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tl.process_dev(d_txt, txt.nbytes, sec=1700000000, nsec=0)
+        dt_t = (time.perf_counter() - t0) / steps
+        lines_, tchunk, proc_ = tl.process_dev(d_txt, txt.nbytes, sec=1700000000, nsec=0)
+        p2 = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+        f2 = g.FilterParser("log", [p2]); g2 = g.FilterGrep([GREP_RULE])
+        ch2 = g.FilterChain([f2, g2])
+        ch2.filter_dev(tchunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r_, o_ = ch2.filter_dev(tchunk)
+        dt_c = (time.perf_counter() - t0) / steps
+        out["tail_lines"] = {"lines_per_s_per_gpu": round(m / dt_t, 1), "ms_per_step": round(dt_t * 1e3, 3), "text_bytes": int(txt.nbytes),
+                             "event_bytes": int(tchunk.bytes), "GBps_in_plus_out": round((txt.nbytes + int(tchunk.bytes)) / dt_t / 1e9, 1),
+                             "then_parser_grep": {"records_per_s_per_gpu": round(m / dt_c, 1), "ms_per_step": round(dt_c * 1e3, 3), "kept": int(ch2.last_stats()[1]["out_records"]),
+                                                  "layout": "in_tail's records: map32 metadata / body headers (299 B events)"}}
+        f2.close(); g2.close(); tl.close(); L.flbgpu_dev_free(d_txt)
+    except Exception as e:
+        out["tail_lines"] = {"error": repr(e)[:300]}
     fg1.close(); fg2.close(); pk.close()
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
     if "rccl" in out:

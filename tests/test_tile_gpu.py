@@ -33,7 +33,7 @@ def _rec(body, sec=1, nsec=0, meta=None):
     return synth.v2_record(sec, nsec, body, meta)
 
 
-def _hostile_chunk(seed, n=3000):
+def _hostile_chunk(seed, n=3000, map32_first=False):
     rng = random.Random(seed)
     data, off, _ = synth.apache_records(n)
     blob = bytes(data)
@@ -74,6 +74,11 @@ def _hostile_chunk(seed, n=3000):
             rec = _rec({"log": i})                                                                   # value is not a string
         elif r2 < 0.105:
             rec = synth.mp([[synth.ext_ts(0xffffffff, 0), {}], {"g": 1}])                            # group marker
+        elif r2 < (0.16 if not map32_first else 0.9):
+            # in_tail's layout (begin_record + append_body_values: 32-bit map headers, tail_file.c:552-604)
+            v = bytes(m)
+            sh = bytes([0xa0 | len(v)]) if len(v) < 32 else b"\xd9" + bytes([len(v)]) if len(v) < 256 else b"\xda" + len(v).to_bytes(2, "big") if len(v) < 65536 else b"\xdb" + len(v).to_bytes(4, "big")
+            rec = b"\x92\x92\xd7\x00" + (1700000000 + i).to_bytes(4, "big") + (i % 1000).to_bytes(4, "big") + b"\xdf\x00\x00\x00\x00\xdf\x00\x00\x00\x01\xa3log" + sh + v
         else:
             rec = _rec(body, sec=1700000000 + i, nsec=i % 1000)
         out.append(rec)
@@ -83,12 +88,13 @@ def _hostile_chunk(seed, n=3000):
 @pytest.mark.parametrize("regex", [APACHE2, APACHE])
 def test_three_builds_against_the_oracle(g, regex):
     chunk = _hostile_chunk(7 if regex is APACHE2 else 8)
+    tailish = _hostile_chunk(17, 1500, map32_first=True)               # mostly in_tail's layout, the first record too
     bad_tail = chunk + b"\x92\x92\xd7\x00"                          # the decoder stops at a broken last event
     pargs = dict(regex=regex, time_fmt=TF, time_key="time")
     rule_sets = [([("regex", r"code ^5\d\d$")], None), ([("exclude", "method GET")], None),
                  ([("regex", "code ^2"), ("regex", "agent curl")], "AND"), ([("regex", "time 2024")], None),
                  ([("regex", "log x")], None)]
-    for data in (chunk, bad_tail, chunk[:277 * 5]):
+    for data in (chunk, bad_tail, chunk[:277 * 5], tailish):
         po = ob.Parser(**pargs)
         want_p = ob.FilterParser("log", [po]).filter(data)
         want_pairs = []
