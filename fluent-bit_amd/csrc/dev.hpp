@@ -266,6 +266,16 @@ struct ParserMatchArgs {
                                      // kernel argument makes the compiler keep the whole argument block in scratch memory)
 };
 
+// What the record writer reads per field of parser 0, by value in the kernel arguments (scalar loads; through the DevParser
+// pointer each is a dependent vector load per field per record).  ok: parser 0 is a regex parser without Types casts and the
+// filter neither reserves nor preserves keys -- the plain "parsed fields only" record.
+struct EmitCfg {
+    int ok, nfields, nregs_minus1;
+    uint8_t kw_off[MAX_NAMES];           // first dword of field f's packed key in keywords[]
+    uint8_t kw_bytes[MAX_NAMES];         // str header + name bytes
+    uint32_t keywords[96];
+};
+
 struct ParserEmitArgs {
     const uint8_t *data;
     const uint64_t *row_off;
@@ -281,6 +291,7 @@ struct ParserEmitArgs {
     const uint64_t *out_off;    // exclusive scan of out_len, [n+1]
     uint8_t *out;
     uint64_t bytes;             // chunk size (bounds the wide tail loads)
+    EmitCfg ec;
 };
 
 // ---- filter_grep (plugins/filter_grep/grep.c)
@@ -379,6 +390,7 @@ struct PgEmitArgs {
     const uint32_t *desc;            // row descriptors of the single pass (ParserMatchArgs::desc), nullptr: columns only
     uint32_t dstride;
     uint64_t bytes;                  // chunk size (bounds the wide tail loads)
+    EmitCfg ec;
 };
 
 // ---- filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c)

@@ -890,6 +890,20 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     return true;
 }
 
+// the record writer's per-field configuration for the kernel arguments (dev.hpp EmitCfg)
+static void fill_emit_cfg(const flbgpu_filter *f, EmitCfg &ec) {
+    memset(&ec, 0, sizeof(ec));
+    const DevParser &d = f->parsers[0]->dev;
+    if (d.is_json || d.kv_format || !d.plain_types || f->pcfg.reserve_data || f->pcfg.preserve_key || d.nfields > MAX_NAMES) return;
+    for (int q = 0; q < d.nfields; q++) {
+        const int end = d.kw_off[q] + (d.kw_bytes[q] + 3) / 4;
+        if (d.kw_off[q] > 255 || d.kw_bytes[q] > 255 || end > (int) (sizeof(ec.keywords) / 4)) return;
+        ec.kw_off[q] = (uint8_t) d.kw_off[q]; ec.kw_bytes[q] = (uint8_t) d.kw_bytes[q];
+        memcpy(ec.keywords + d.kw_off[q], d.keywords + d.kw_off[q], (size_t) (end - d.kw_off[q]) * 4);
+    }
+    ec.nfields = d.nfields; ec.nregs_minus1 = d.nregs_minus1; ec.ok = 1;
+}
+
 static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret) {
     uint64_t n = in->n;
     *ret = FLBGPU_FILTER_NOTOUCH;
@@ -921,6 +935,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ea.n_cols = in->n; ea.info = f->d_info.as<uint32_t>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
     ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes;
+    fill_emit_cfg(f, ea.ec);
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
     if (hm.counts[3] > 0) { ProfScope ps(f, st, "k_parser_emit_exact"); launch_parser_emit_exact(ea, st); }
     HIPOK(hipStreamSynchronize(st));
@@ -1073,6 +1088,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
     ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
     ea.desc = pc.desc; ea.dstride = pc.dstride; ea.bytes = in->bytes;
+    fill_emit_cfg(fp, ea.ec);
     { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;

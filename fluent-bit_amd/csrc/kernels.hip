@@ -501,8 +501,9 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
                 s.limit = s.p + (uint32_t) (o1 - o0);
                 CapsView cv;
                 cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
-                write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], rec_load(a.info, a.n_cols, r),
-                             cv, a.null_mask[r]);
+                const RecInfo ri = rec_load(a.info, a.n_cols, r);
+                if (a.ec.ok && (ri.flags & RF_PARSED) && ri.parser_idx == 0) write_record_plain(s, a.ec, a.data + a.row_off[r], ri, cv);
+                else write_record(s, a.cfg, a.parsers, a.data + a.row_off[r], a.data + a.row_off[r + 1], ri, cv, a.null_mask[r]);
             }
             uint32_t total = (uint32_t) (__shfl(o1, (int) (lo + m - 1), 64) - batch_base);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // staged bytes visible to the wave
