@@ -43,7 +43,7 @@ GREP32_EXCLUDE = [("exclude", r) for r in (
     "path ^/v2", "$svc['name'] ^$", r"path x=\d\d$", "msg [5-6]{3} finished", r"level ^\s", "path items/[1-2]{2}", "msg ok ", "$svc['name'] b$")]
 
 
-PMC_FILE = os.path.join("profiles", "r2c_pmc_hbm_bench_10M.json")
+PMC_FILE = os.path.join("profiles", "r2e_pmc_hbm_bench_10M.json")
 
 
 def recorded_traffic(kernel, n):
