@@ -1432,7 +1432,7 @@ struct CopyPool {
         if (n < (1u << 20) || getenv("FLBGPU_COPY_THREADS_OFF")) { memcpy(d, s, n); return; }
         std::unique_lock<std::mutex> lk(mu);
         if (!started) { for (int i = 0; i < HELPERS; i++) th[i] = std::thread(&CopyPool::worker, this, i); started = true; }
-        dst = (uint8_t *) d; src = (const uint8_t *) s; total = n; part = ((n / (HELPERS + 1)) + 63) & ~(size_t) 63;
+        dst = (uint8_t *) d; src = (const uint8_t *) s; total = n; part = (((n + HELPERS) / (HELPERS + 1)) + 63) & ~(size_t) 63;      // (rounded UP: the four shares cover n)
         pending = HELPERS; gen++;
         lk.unlock();
         cv_go.notify_all();
