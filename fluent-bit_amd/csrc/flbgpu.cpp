@@ -1449,6 +1449,9 @@ struct CopyPool {
 CopyPool g_copy;
 }  // namespace
 
+// (diagnostics: the slab copy of the host-level calls, for the CPU-only unit test)
+extern "C" void flbgpu_diag_copy(void *dst, const void *src, size_t n) { g_copy.copy(dst, src, n); }
+
 int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off) {
     hipStream_t st = f->stream;
     if (!stage_init(f) || !f->h_in_data.ensure(bytes + 16)) return -1;

@@ -95,3 +95,18 @@ def test_reference_side_binding_type_checks_against_reference_headers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([os.path.join(root, "fluent-bit_amd", "plugin", "check_syntax.sh")], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_threaded_slab_copy(g):
+    """the pageable <-> pinned copy of the host-level calls is split over helper threads above 1 MB: every byte arrives"""
+    import random
+    L = g.lib()
+    L.flbgpu_diag_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rng = random.Random(3)
+    src = bytes(rng.getrandbits(8) for _ in range(1 << 16)) * 40
+    for n in [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1834560 * 4 + 2, 2621441, len(src) - 71] + [rng.randrange(1 << 20, len(src) - 64) for _ in range(20)]:
+        off = rng.randrange(0, 64)
+        dst = ctypes.create_string_buffer(n + 16)
+        sbuf = ctypes.create_string_buffer(src, len(src))
+        L.flbgpu_diag_copy(ctypes.addressof(dst) + 3, ctypes.addressof(sbuf) + off, n)
+        assert dst.raw[3:3 + n] == src[off:off + n] and dst.raw[:3] == b"\0\0\0" and dst.raw[3 + n:3 + n + 8] == b"\0" * 8, n
