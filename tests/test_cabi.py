@@ -103,7 +103,7 @@ def test_threaded_slab_copy(g):
     L = g.lib()
     L.flbgpu_diag_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     rng = random.Random(3)
-    src = bytes(rng.getrandbits(8) for _ in range(1 << 16)) * 40
+    src = bytes(rng.getrandbits(8) for _ in range(1 << 16)) * 160
     for n in [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, 1834560 * 4 + 2, 2621441, len(src) - 71] + [rng.randrange(1 << 20, len(src) - 64) for _ in range(20)]:
         off = rng.randrange(0, 64)
         dst = ctypes.create_string_buffer(n + 16)
