@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r2c_bench_10M.json, written by `python bench.py` on an MI355X) keeps
+"""The committed bench line (profiles/r2e_bench_10M.json, written by `python bench.py` on an MI355X) keeps
 the driver's contract: one JSON object with the metric / config / roofline / cpu_baseline fields, and numbers
 that are consistent with each other."""
 import json
@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(HERE, "..", "profiles", "r2c_bench_10M.json")))
+    d = json.load(open(os.path.join(HERE, "..", "profiles", "r2e_bench_10M.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
