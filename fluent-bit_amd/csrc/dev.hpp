@@ -318,6 +318,10 @@ struct GrepArgs {
     uint32_t *status;           // [n] RF_* flags
     unsigned long long *first_bad;
     unsigned long long *counts; // [0] = decoded (non-skipped) records, [1] = kept records
+    // the rules' match-only DFA blobs (cls | ddelta | d_final: upload_dfa) staged behind the record tiles in LDS: two dependent
+    // table reads per byte of a tested value, ~100 cycles from LDS against ~400 through L2
+    uint32_t rule_lds_off[MAX_RULES], rule_lds_bytes[MAX_RULES];   // offset 0xFFFFFFFF: not staged
+    uint32_t rules_lds_total;
 };
 
 

@@ -971,6 +971,18 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     ga.data = (const uint8_t *) in->data; ga.row_off = in->row_off; ga.n = n; ga.bytes = in->bytes; ga.rules = f->d_rules.as<GrepRule>();
     ga.nrules = (int) f->rules.size(); ga.logical_op = f->logical_op; ga.keep_len = f->d_len.as<uint32_t>();
     ga.status = f->d_status.as<uint32_t>(); ga.first_bad = &dm->first_bad; ga.counts = dm->counts;
+    {
+        // rule DFA blobs into what the two resident workgroups leave of the LDS (8 KB each: 160 KB - 2 x 4 x 18 KB of tiles)
+        uint32_t used = 0;
+        const uint32_t room = getenv("FLBGPU_GREP_NO_LDS_RULES") ? 0 : 8192 - 64;
+        for (size_t i = 0; i < f->rules.size() && i < (size_t) MAX_RULES; i++) {
+            const DevDfa &df = f->rules[i].dfa;
+            const uint32_t blob = (uint32_t) ((df.d_final + df.nD) - df.cls);
+            ga.rule_lds_off[i] = 0xFFFFFFFFu; ga.rule_lds_bytes[i] = blob;
+            if (used + ((blob + 15) & ~15u) <= room) { ga.rule_lds_off[i] = used; used += (blob + 15) & ~15u; }
+        }
+        ga.rules_lds_total = used;
+    }
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     total = 0;

@@ -552,6 +552,16 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
     const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
     const uint8_t *data_end = a.data + a.bytes;
     uint32_t n_dec = 0, n_keep = 0;
+    // the rules' DFA blobs behind the tiles (one copy per workgroup)
+    LDS_AS uint8_t *lds_rules = (LDS_AS uint8_t *) g_lds + (size_t) (GREP_BLOCK / 64) * GREP_TILE;
+    if (a.rules_lds_total) {
+        for (int i = 0; i < a.nrules; i++) {
+            if (a.rule_lds_off[i] == 0xFFFFFFFFu) continue;
+            const uint8_t *src = a.rules[i].dfa.cls;
+            for (uint32_t k = threadIdx.x; k < a.rule_lds_bytes[i]; k += blockDim.x) lds_rules[a.rule_lds_off[i] + k] = src[k];
+        }
+        __syncthreads();
+    }
     for (uint64_t base = wave_id * 64; base < a.n; base += nwaves * 64) {
         const uint64_t r = base + lane;
         const uint32_t cnt = (uint32_t) ((a.n - base) < 64 ? (a.n - base) : 64);
@@ -597,7 +607,7 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
                 bool keep = false;
                 if (!(ev.flags & (RF_BAD | RF_SKIP))) {
                     bool valid = false;
-                    keep = grep_decide(a, ev, &valid);
+                    keep = grep_decide(a, ev, &valid, a.rules_lds_total ? (LDS_AS const uint8_t *) lds_rules : (LDS_AS const uint8_t *) nullptr);
                     if (!valid) valid = mp_skip(ev.body, rec_end, 1) == rec_end;  // no rule walked the map
                     if (!valid) ev.flags = RF_BAD;
                 }
@@ -813,7 +823,7 @@ void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
     static bool attr_set = false;
-    const size_t lds = (size_t) (GREP_BLOCK / 64) * GREP_TILE;
+    const size_t lds = (size_t) (GREP_BLOCK / 64) * GREP_TILE + a.rules_lds_total;
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_grep_match, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
