@@ -52,6 +52,11 @@ int mk_event_timeout_create(struct mk_event_loop *loop, time_t sec, long nsec, v
 int mk_event_timeout_destroy(struct mk_event_loop *loop, void *data) { (void) loop; (void) data; return 0; }
 int mk_event_closesocket(int fd) { (void) fd; return 0; }
 
+/* ---- CREATE STREAM: the in_stream_processor instance the result would be appended to is the engine's; the packaged bytes are
+ * what this driver returns (task->stream stays NULL) */
+int flb_sp_stream_create(const char *name, struct flb_sp_task *task, struct flb_sp *sp) { (void) name; (void) task; (void) sp; return 0; }
+void flb_sp_stream_destroy(struct flb_sp_stream *stream, struct flb_sp *sp) { (void) stream; (void) sp; }
+
 /* ---- the clock of package_results */
 static struct flb_time g_now;
 int __wrap_flb_time_get(struct flb_time *tm) { *tm = g_now; return 0; }
