@@ -324,6 +324,88 @@ class TailLines:
             self.h = None
 
 
+class StreamTask:
+    """one task of the stream processor (src/stream_processor/flb_sp.c: flb_sp_task_create :433, flb_sp_do :2007, the window
+    timer of flb_sp_fd_event :2101) for aggregate queries: GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING."""
+
+    def __init__(self, sql, str_conv=True):
+        L = lib()
+        L.flbgpu_sp_create.restype = c_void_p
+        L.flbgpu_sp_create.argtypes = [c_char_p, c_int]
+        L.flbgpu_sp_destroy.argtypes = [c_void_p]
+        L.flbgpu_sp_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int64), POINTER(c_int), POINTER(c_char_p), POINTER(c_char_p)]
+        L.flbgpu_sp_stream_prop.restype = c_char_p
+        L.flbgpu_sp_stream_prop.argtypes = [c_void_p, c_char_p]
+        L.flbgpu_sp_key_count.argtypes = [c_void_p]
+        L.flbgpu_sp_key_name.restype = c_char_p
+        L.flbgpu_sp_key_name.argtypes = [c_void_p, c_int]
+        L.flbgpu_sp_do.argtypes = [c_void_p, c_char_p, c_size_t, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int64)]
+        L.flbgpu_sp_do_dev.argtypes = [c_void_p, POINTER(DevChunk), c_void_p, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t),
+                                       POINTER(c_int64)]
+        L.flbgpu_sp_timer.argtypes = [c_void_p, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t)]
+        L.flbgpu_sp_set_index_base.argtypes = [c_void_p, c_uint64]
+        L.flbgpu_sp_profile.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_uint64)]
+        self.h = L.flbgpu_sp_create(_b(sql), int(bool(str_conv)))
+        if not self.h:
+            raise ValueError(last_error())
+        wt = c_int(); ws = c_int64(); st = c_int(); src = c_char_p(); name = c_char_p()
+        L.flbgpu_sp_info(self.h, byref(wt), byref(ws), byref(st), byref(src), byref(name))
+        self.window = "tumbling" if wt.value == 1 else "default"
+        self.window_size = int(ws.value)
+        self.source_type = "tag" if st.value == 1 else "stream"
+        self.source = src.value.decode()
+        self.stream_name = name.value.decode() if name.value else None
+        self.key_names = [L.flbgpu_sp_key_name(self.h, i).decode() for i in range(L.flbgpu_sp_key_count(self.h))]
+
+    def stream_prop(self, key):
+        v = lib().flbgpu_sp_stream_prop(self.h, _b(key))
+        return None if v is None else v.decode()
+
+    @staticmethod
+    def _take(out, sz):
+        b = ctypes.string_at(out, sz.value) if out.value else b""
+        if out.value:
+            _libc.free(out)
+        return b
+
+    def do(self, chunk, now=(1, 0)):
+        """one appended chunk in host memory -> (records in the window, packaged records when the query has no WINDOW)"""
+        out = c_void_p(); sz = c_size_t(); rec = c_int64()
+        r = lib().flbgpu_sp_do(self.h, bytes(chunk), len(chunk), now[0], now[1], byref(out), byref(sz), byref(rec))
+        if r != 0:
+            raise RuntimeError(last_error())
+        return int(rec.value), self._take(out, sz)
+
+    def do_dev(self, chunk, now=(1, 0)):
+        """the same for a chunk resident in HBM (DevChunk)"""
+        out = c_void_p(); sz = c_size_t(); rec = c_int64()
+        r = lib().flbgpu_sp_do_dev(self.h, byref(chunk), None, now[0], now[1], byref(out), byref(sz), byref(rec))
+        if r != 0:
+            raise RuntimeError(last_error())
+        return int(rec.value), self._take(out, sz)
+
+    def timer(self, now=(1, 0)):
+        """the window's timer fires: packaged records of the window, which is then pruned"""
+        out = c_void_p(); sz = c_size_t()
+        r = lib().flbgpu_sp_timer(self.h, now[0], now[1], byref(out), byref(sz))
+        if r != 0:
+            raise RuntimeError(last_error())
+        return self._take(out, sz)
+
+    def set_index_base(self, base):
+        lib().flbgpu_sp_set_index_base(self.h, base)
+
+    def profile(self, enable=True):
+        ms = (c_double * 2)(); n = (c_uint64 * 2)()
+        lib().flbgpu_sp_profile(self.h, int(bool(enable)), ms, n)
+        return {"k_sp_extract": (ms[0], int(n[0])), "k_sp_aggregate": (ms[1], int(n[1]))}
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_sp_destroy(self.h)
+            self.h = None
+
+
 def msgpack_to_json_format(data, json_format, date_format, date_key, escape_unicode=1, nan_to_null=0):
     """the one-shot C entry with the reference's argument list"""
     out = c_void_p(); sz = c_size_t()

@@ -468,6 +468,69 @@ struct L2mAggArgs {
     const unsigned int *n_series;
 };
 
+// ---- stream processor: GROUP BY aggregation (src/stream_processor/flb_sp.c:1280-1601), sp_kernels.inc / sp.cpp
+constexpr int SP_MAX_KEYS = 12;       // distinct key references: GROUP BY columns, aggregated keys, WHERE operands
+constexpr int SP_MAX_GB = 4;
+constexpr int SP_MAX_SRC = 6;         // distinct aggregated keys
+constexpr int SP_MAX_SUB = 3;
+constexpr int SP_MAX_LEAF = 20;
+constexpr int SP_MAX_OPS = 24;
+constexpr int SP_BLOB = 448;
+struct SpKeyRef { uint16_t name_off, name_len, nsub, pad; uint16_t sub_off[SP_MAX_SUB], sub_len[SP_MAX_SUB]; };
+enum { SPL_KEY = 0, SPL_INT, SPL_FLOAT, SPL_STR, SPL_BOOL, SPL_NULL, SPL_TIME, SPL_CONTAINS, SPL_NONE };
+struct SpLeaf { uint8_t kind, key; uint16_t str_off, str_len, pad; uint64_t v; };
+enum { SPO_EQ = 0, SPO_LT, SPO_LTE, SPO_GT, SPO_GTE, SPO_TRUTH, SPO_NOT, SPO_AND, SPO_OR };
+struct SpOp { uint8_t op, l, r, pad; };
+struct SpPlan {
+    int nkeys, ngb, nsrc, nleaf, nops, str_conv;
+    SpKeyRef keys[SP_MAX_KEYS];
+    uint8_t gb_key[SP_MAX_GB], src_key[SP_MAX_SRC];
+    SpLeaf leaf[SP_MAX_LEAF];
+    SpOp ops[SP_MAX_OPS];          // postfix; the bool stack is a bit mask
+    char blob[SP_BLOB];            // key names, sub-key names, string constants
+};
+// One row of 64-bit words per group; like the log_to_metrics rows every word merges with max or add, so the state does
+// not depend on the order records (or GPUs) are visited in:
+//   [0]                      max of ~(global index of the record that created the group)  -> first-seen order of package_results
+//   [1 + 4 s + 0..3]         max: ~ord(min int), ord(max int), ~ord(min float), ord(max float) of aggregated key s
+//   [A] (A = 1 + 4 nsrc)     add: records of the group (aggr_node->records)
+//   [A + 1 + s SP_SRC_ADD +] add: ints seen, non-zero floats seen, wrapping int64 sum, NaN / +Inf / -Inf counts, then the
+//                            exact fixed-point sum digits of every value (L2M_NLIMB words, digit j has weight 2^(32 j - 1074))
+constexpr int SP_SRC_MAX = 4;
+constexpr int SP_A_NINT = 0, SP_A_NFLT = 1, SP_A_ISUM = 2, SP_A_NAN = 3, SP_A_PINF = 4, SP_A_NINF = 5, SP_A_LIMB = 6;
+constexpr int SP_SRC_ADD = SP_A_LIMB + 68;
+inline int sp_row_words(int nsrc) { return 1 + SP_SRC_MAX * nsrc + 1 + SP_SRC_ADD * nsrc; }
+constexpr uint32_t SP_GID_NONE = 0xFFFFFFFFu;
+// status bits (SpArgs::flags): inputs the reference itself does not treat in an order-independent way -> the call fails
+enum { SPF_BAD_RECORD = 1, SPF_KEY_NUL = 2, SPF_KEY_NAN = 4, SPF_FLOAT_RANGE = 8 };
+struct SpArgs {
+    const uint8_t *data;
+    const uint64_t *row_off;
+    uint64_t n, bytes;
+    const SpPlan *plan;             // in device memory (its blob is read through pointers)
+    L2mTable t;
+    uint32_t *gid_col;               // [n]
+    uint64_t *val_col;               // [nsrc][n] int64 / binary64 bits
+    uint8_t *vt_col;                 // [nsrc][n] class (0 none, 1 int, 2 float) | occurrences << 2
+    unsigned long long *first_bad;
+    unsigned long long *counts;      // [0] records that entered a group
+    unsigned int *col_class;         // [SP_MAX_GB] OR of (1 << class) seen in each GROUP BY column (1 int, 2 float, 4 string)
+    unsigned int *flags;
+};
+struct SpAggArgs {
+    const uint32_t *gid_col;
+    const uint64_t *val_col;
+    const uint8_t *vt_col;
+    uint64_t n;
+    const unsigned long long *first_bad;
+    unsigned long long *rows;
+    int W, nsrc;
+    uint64_t idx_base;
+    const unsigned int *n_series;
+};
+void launch_sp_extract(const SpArgs &a, int cus, hipStream_t st);
+void launch_sp_aggregate(const SpAggArgs &a, int cus, hipStream_t st);
+
 // ---- JSON text -> msgpack (src/flb_pack.c:389-508)
 struct JsonArgs {
     const uint8_t *text;

@@ -81,8 +81,32 @@ bool compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r,
 
 }  // namespace flbgpu
 
-struct L2mState;
+// series / group dictionary + rows in HBM (l2m.cpp; the stream processor's groups reuse the table part: sp.cpp)
+struct L2mCtr { unsigned long long arena_used; unsigned int n_series; unsigned int overflow; };
+
+struct L2mState {
+    int mode = 0, discard_logs = 0, nb = 0, W = 0;
+    std::vector<double> bounds;
+    std::vector<std::string> label_keys;
+    std::vector<flbgpu::DevKey> labels;
+    flbgpu::DevKey value_key;
+    flbgpu::DevBuf d_labels, d_value_key, d_bounds;
+    // series dictionary + rows
+    uint64_t cap = 0, arena_cap = 0;
+    uint32_t max_series = 0;
+    flbgpu::DevBuf d_slot_hash, d_slot_sid, d_arena, d_key_off, d_key_len, d_series_hash, d_rows, d_ctr;
+    // per-call columns
+    flbgpu::DevBuf d_sid, d_val, d_tmp, d_misc;
+    uint64_t idx_base = 0;
+    uint64_t last_obs = 0, last_deferred = 0, last_stale = 0, grows = 0;
+};
+
 void l2m_state_destroy(L2mState *);
+flbgpu::L2mTable l2m_table_of(L2mState *s);
+bool l2m_table_init(L2mState *s);
+bool l2m_table_grow(L2mState *s, hipStream_t st);
+// fixed-point sum digits (L2M_NLIMB words, carries not yet propagated) + special counts -> binary64 bits, rounded once
+uint64_t l2m_limbs_bits(const uint64_t *limbs, uint64_t n_nan, uint64_t n_pinf, uint64_t n_ninf);
 
 struct KernelProf { const char *name; double ms = 0; uint64_t launches = 0; };
 struct ProfPending { const char *name; hipEvent_t e0, e1; };

@@ -12,4 +12,6 @@ namespace flbgpu {
 
 #include "l2m_kernels.inc"
 
+#include "sp_kernels.inc"
+
 }  // namespace flbgpu

@@ -18,25 +18,7 @@
 
 using namespace flbgpu;
 
-struct L2mCtr { unsigned long long arena_used; unsigned int n_series; unsigned int overflow; };
 struct L2mMisc { unsigned long long first_bad; unsigned long long counts[3]; };
-
-struct L2mState {
-    int mode = 0, discard_logs = 0, nb = 0, W = 0;
-    std::vector<double> bounds;
-    std::vector<std::string> label_keys;
-    std::vector<DevKey> labels;
-    DevKey value_key;
-    DevBuf d_labels, d_value_key, d_bounds;
-    // series dictionary + rows
-    uint64_t cap = 0, arena_cap = 0;
-    uint32_t max_series = 0;
-    DevBuf d_slot_hash, d_slot_sid, d_arena, d_key_off, d_key_len, d_series_hash, d_rows, d_ctr;
-    // per-call columns
-    DevBuf d_sid, d_val, d_tmp, d_misc;
-    uint64_t idx_base = 0;
-    uint64_t last_obs = 0, last_deferred = 0, last_stale = 0, grows = 0;
-};
 
 void l2m_state_destroy(L2mState *s) {
     if (!s) return;
@@ -91,7 +73,7 @@ static bool grow_keep(DevBuf &b, size_t new_bytes, size_t keep) {
     return true;
 }
 
-static L2mTable table_of(L2mState *s) {
+L2mTable l2m_table_of(L2mState *s) {
     L2mTable t;
     L2mCtr *c = s->d_ctr.as<L2mCtr>();
     t.slot_hash = s->d_slot_hash.as<unsigned long long>();
@@ -109,7 +91,7 @@ static L2mTable table_of(L2mState *s) {
     return t;
 }
 
-static bool table_init(L2mState *s) {
+bool l2m_table_init(L2mState *s) {
     uint64_t cap = 1u << 16;
     if (const char *e = getenv("FLBGPU_L2M_INIT_CAP")) {
         uint64_t v = strtoull(e, nullptr, 10);
@@ -127,7 +109,7 @@ static bool table_init(L2mState *s) {
 }
 
 // doubles whatever ran out (series capacity and/or arena) and rebuilds the slot array
-static bool table_grow(L2mState *s, hipStream_t st) {
+bool l2m_table_grow(L2mState *s, hipStream_t st) {
     L2mCtr c;
     HIPOK(hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost));
     const uint32_t ns = c.n_series;
@@ -144,7 +126,7 @@ static bool table_grow(L2mState *s, hipStream_t st) {
             !grow_keep(s->d_key_len, (size_t) s->max_series * 4, (size_t) old_max * 4) ||
             !grow_keep(s->d_series_hash, (size_t) s->max_series * 8, (size_t) old_max * 8) ||
             !grow_keep(s->d_rows, (size_t) s->max_series * s->W * 8, (size_t) old_max * s->W * 8)) return false;
-        L2mTable t = table_of(s);
+        L2mTable t = l2m_table_of(s);
         launch_l2m_rehash(t, ns, st);
         HIPOK(hipStreamSynchronize(st));
     }
@@ -244,7 +226,7 @@ extern "C" flbgpu_filter *flbgpu_filter_l2m_create(const char *metric_mode, int 
     if (!filter_common_init(f)) { delete f; return nullptr; }
     bool ok = f->d_rules.ensure(std::max<size_t>(1, f->rules.size()) * sizeof(GrepRule)) &&
               s->d_labels.ensure(std::max<size_t>(1, s->labels.size()) * sizeof(DevKey)) && s->d_value_key.ensure(sizeof(DevKey)) &&
-              s->d_bounds.ensure(std::max<size_t>(1, s->bounds.size()) * sizeof(double)) && table_init(s);
+              s->d_bounds.ensure(std::max<size_t>(1, s->bounds.size()) * sizeof(double)) && l2m_table_init(s);
     if (ok && !f->rules.empty()) ok = hipMemcpy(f->d_rules.p, f->rules.data(), f->rules.size() * sizeof(GrepRule), hipMemcpyHostToDevice) == hipSuccess;
     if (ok && !s->labels.empty()) ok = hipMemcpy(s->d_labels.p, s->labels.data(), s->labels.size() * sizeof(DevKey), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok = hipMemcpy(s->d_value_key.p, &s->value_key, sizeof(DevKey), hipMemcpyHostToDevice) == hipSuccess;
@@ -275,7 +257,7 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
         a.rules = f->d_rules.as<GrepRule>(); a.nrules = (int) f->rules.size();
         a.labels = s->d_labels.as<DevKey>(); a.nlabels = (int) s->labels.size();
         a.value_key = s->d_value_key.as<DevKey>(); a.mode = s->mode;
-        a.t = table_of(s);
+        a.t = l2m_table_of(s);
         a.sid_col = s->d_sid.as<uint32_t>(); a.val_col = s->d_val.as<uint64_t>();
         a.first_bad = &s->d_misc.as<L2mMisc>()->first_bad; a.counts = s->d_misc.as<L2mMisc>()->counts;
         { ProfScope ps(f, st, "k_l2m_extract"); launch_l2m_extract(a, cus, st); }
@@ -289,7 +271,7 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
             HIPOK(hipStreamSynchronize(st));
         }
         if (!hc.overflow) break;
-        if (!table_grow(s, st)) return false;          // nothing was aggregated yet: the pass simply runs again
+        if (!l2m_table_grow(s, st)) return false;          // nothing was aggregated yet: the pass simply runs again
     }
     s->last_obs = hm.counts[0]; s->last_deferred = hm.counts[1]; s->last_stale = hm.counts[2];
     if (hm.counts[2] > 0) {
@@ -377,23 +359,8 @@ extern "C" int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint
     return (int64_t) live.size();
 }
 
-// one merged row -> the numbers cmetrics would hold.  Pure host arithmetic on integers.
-extern "C" int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
-                                       double *sum) {
-    *value = 0; *count = 0; *sum = 0;
-    if (mode == L2M_COUNTER) {
-        // cmt_counter_inc adds 1.0 to an f64 (lib/cmetrics/src/cmt_counter.c:100-116): exact up to 2^53, stuck there after
-        uint64_t c = row[L2M_W_COUNT];
-        if (c > (1ull << 53)) c = 1ull << 53;
-        *value = (double) c;
-        return 0;
-    }
-    if (mode == L2M_GAUGE) { memcpy(value, &row[L2M_W_LASTVAL], 8); return 0; }
-    // histogram: cumulative buckets (lib/cmetrics/src/cmt_histogram.c:344-356)
-    uint64_t run = 0;
-    for (int b = 0; b <= nbuckets; b++) { run += row[L2M_W_BUCKET + b]; buckets[b] = run; }
-    *count = run;
-    const uint64_t n_nan = row[L2M_W_SPECIAL], n_pinf = row[L2M_W_SPECIAL + 1], n_ninf = row[L2M_W_SPECIAL + 2];
+// the exact sum held as fixed-point digits -> the binary64 nearest to it (ties to even); NaN / infinities by their counts
+uint64_t l2m_limbs_bits(const uint64_t *limbs, uint64_t n_nan, uint64_t n_pinf, uint64_t n_ninf) {
     uint64_t bits;
     if (n_nan || (n_pinf && n_ninf)) bits = nc::DBL_NAN_BITS;
     else if (n_pinf) bits = nc::DBL_INF_BITS;
@@ -403,12 +370,12 @@ extern "C" int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *r
         uint64_t d[L2M_NLIMB];
         long long carry = 0;
         for (int j = 0; j < L2M_NLIMB - 1; j++) {
-            long long t = (long long) row[L2M_W_LIMB + j] + carry;
+            long long t = (long long) limbs[j] + carry;
             long long lo = t & 0xFFFFFFFFll;
             carry = (t - lo) >> 32;
             d[j] = (uint64_t) lo;
         }
-        long long top = (long long) row[L2M_W_LIMB + L2M_NLIMB - 1] + carry;
+        long long top = (long long) limbs[L2M_NLIMB - 1] + carry;
         bool neg = top < 0;
         uint64_t utop = (uint64_t) top;
         if (neg) {
@@ -449,6 +416,26 @@ extern "C" int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *r
             bits = nc::make_double_bits(m, low_pos - 1074, sticky) | (neg ? nc::DBL_SIGN : 0);
         }
     }
+    return bits;
+}
+
+// one merged row -> the numbers cmetrics would hold.  Pure host arithmetic on integers.
+extern "C" int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
+                                       double *sum) {
+    *value = 0; *count = 0; *sum = 0;
+    if (mode == L2M_COUNTER) {
+        // cmt_counter_inc adds 1.0 to an f64 (lib/cmetrics/src/cmt_counter.c:100-116): exact up to 2^53, stuck there after
+        uint64_t c = row[L2M_W_COUNT];
+        if (c > (1ull << 53)) c = 1ull << 53;
+        *value = (double) c;
+        return 0;
+    }
+    if (mode == L2M_GAUGE) { memcpy(value, &row[L2M_W_LASTVAL], 8); return 0; }
+    // histogram: cumulative buckets (lib/cmetrics/src/cmt_histogram.c:344-356)
+    uint64_t run = 0;
+    for (int b = 0; b <= nbuckets; b++) { run += row[L2M_W_BUCKET + b]; buckets[b] = run; }
+    *count = run;
+    const uint64_t bits = l2m_limbs_bits(row + L2M_W_LIMB, row[L2M_W_SPECIAL], row[L2M_W_SPECIAL + 1], row[L2M_W_SPECIAL + 2]);
     memcpy(sum, &bits, 8);
     return 0;
 }

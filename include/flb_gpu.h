@@ -251,6 +251,47 @@ int flbgpu_tail_run_dev(flbgpu_tail *t, const void *d_text, uint64_t bytes, uint
 /* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
 int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);
 
+/* ---- stream processor, aggregate queries: replaces flb_sp_task_create / flb_sp_do / the window timer of flb_sp_fd_event -------
+ * src/stream_processor/flb_sp.c:433-560 (task), :2007-2097 -> sp_process_data_aggr :1435-1601 (one appended chunk),
+ * :2101-2160 -> package_results :1161-1278 + flb_sp_window_prune (timer).  `sql` is the task's Exec string, parsed with the
+ * token rules of parser/sql.l and the grammar of parser/sql.y:
+ *   [CREATE STREAM name [WITH (k='v', ...)] AS] SELECT key | COUNT(*) | COUNT|SUM|AVG|MIN|MAX(key) [AS alias], ...
+ *   FROM STREAM:name | TAG:'pattern' [WINDOW TUMBLING (n SECOND|MINUTE|HOUR)] [WHERE condition] [GROUP BY key, ...];
+ * keys may carry sub-keys (k['a']['b']); conditions: key|@record.time()|@record.contains(key) =,!=,<>,<,<=,>,>= constant,
+ * key IS [NOT] NULL, NOT / AND / OR / parentheses with the reference's (precedence-less, right-associative) binding.
+ * str_conv = the engine's stream_processor_str_conv (src/flb_config.c:482, default on): numeric strings count as numbers.
+ * NULL (flbgpu_last_error says why) for what flb_sp_task_create rejects and for what this path does not take: HOPPING
+ * windows, TIMESERIES_FORECAST, time / record functions as select keys, snapshots, SELECTs without an aggregate.
+ * State lives in HBM as order-independent integer words per group (counts, wrapping int64 sums, exact fixed-point sums,
+ * min / max): chunks and GPUs can be visited in any order; float SUM / AVG are the exact sum rounded once where the
+ * reference adds sequentially (both leave as float32: msgpack_pack_float). */
+typedef struct flbgpu_sp flbgpu_sp;
+flbgpu_sp *flbgpu_sp_create(const char *sql, int str_conv);
+void flbgpu_sp_destroy(flbgpu_sp *t);
+/* window_type 0 none (results are packaged per chunk) / 1 tumbling (the caller's timer calls flbgpu_sp_timer every
+ * window_sec seconds); source_type 0 STREAM: / 1 TAG:; stream_name NULL unless CREATE STREAM */
+int flbgpu_sp_info(const flbgpu_sp *t, int *window_type, int64_t *window_sec, int *source_type, const char **source, const char **stream_name);
+const char *flbgpu_sp_stream_prop(const flbgpu_sp *t, const char *key);        /* WITH (tag='...') */
+int flbgpu_sp_key_count(const flbgpu_sp *t);
+const char *flbgpu_sp_key_name(const flbgpu_sp *t, int i);                     /* output name: alias, "AVG(k)", "k['a']" */
+/* flb_sp_do for one chunk (host memory / device resident).  *records = task->window.records after the chunk.  Without a
+ * WINDOW the result records -- one [now, {key: value, ...}] per group in first-seen order -- come back in *out_buf
+ * (malloc()'d, release with free(); NULL when no group exists) and the window is pruned; with one they wait for the timer.
+ * 0 ok, -1 error: device failure, or input on which the reference's own answer depends on arrival order / tree shape
+ * (a GROUP BY column mixing ints, floats and strings inside one window, NaN group keys, NaN under MIN / MAX). */
+int flbgpu_sp_do(flbgpu_sp *t, const void *data, size_t bytes, uint32_t now_sec, uint32_t now_nsec, void **out_buf, size_t *out_size,
+                 int64_t *records);
+int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
+                     size_t *out_size, int64_t *records);
+/* the window's timer fired: package (if the window saw records) and prune */
+int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf, size_t *out_size);
+/* the SQL front end alone (needs no device): 0 and a canonical text of the plan in desc, -1 when the query is refused */
+int flbgpu_sp_parse_check(const char *sql, char *desc, size_t cap);
+/* global index of the next record (first-seen order of groups across shards) */
+void flbgpu_sp_set_index_base(flbgpu_sp *t, uint64_t base);
+/* event-timed kernel milliseconds / launches since the last call: [0] k_sp_extract, [1] k_sp_aggregate (+ normalize) */
+void flbgpu_sp_profile(flbgpu_sp *t, int enable, double *ms2, uint64_t *launches2);
+
 /* ---- record boundary discovery (flb_log_event_decoder_next loop, src/flb_log_event_decoder.c:342) --
  * Walks concatenated msgpack objects in host memory; fills row_off[0..n] (capacity cap entries).
  * Returns n; *consumed is the offset where decoding stopped (== bytes for a clean chunk). */

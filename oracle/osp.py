@@ -21,6 +21,7 @@ non-aggregate SELECTs; a GROUP BY column whose values mix number / string classe
 comparator is not an order there: flb_sp_groupby.c:77 "Sides have different types -> -1", and it rewrites nodes in place :37-44).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file."""
+import decimal
 import math
 import re
 import struct
@@ -382,6 +383,8 @@ def time_to_double(ts):
 
 _DEC = re.compile(rb"[ \t\n\v\f\r]*([+-]?)(?:(0[xX](?:[0-9a-fA-F]+\.?[0-9a-fA-F]*|\.[0-9a-fA-F]+)(?:[pP][+-]?[0-9]+)?)"
                   rb"|((?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)|([iI][nN][fF](?:[iI][nN][iI][tT][yY])?)|([nN][aA][nN]))")
+_LDBL_MAX = decimal.Decimal("1.18973149535723176502e4932")
+_LDBL_MIN = decimal.Decimal("3.36210314311209350626e-4932")
 _INT = re.compile(rb"[ \t\n\v\f\r]*([+-]?[0-9]+)")
 
 
@@ -407,14 +410,11 @@ def string_to_number(s):
             except OverflowError:
                 return None
         elif m.group(3):
-            try:
-                d = float(m.group(3))
-            except OverflowError:
+            # strtold: ERANGE only outside the x87 long double range; inside it a value binary64 cannot hold narrows to inf / 0
+            dec = decimal.Decimal(m.group(3).decode())
+            if dec != 0 and not (_LDBL_MIN <= dec <= _LDBL_MAX):
                 return None
-            if d == math.inf:
-                return None                     # ERANGE
-            if d == 0.0 and any(c in b"123456789" for c in m.group(3).split(b"e")[0].split(b"E")[0]):
-                return None                     # underflow to zero: ERANGE
+            d = float(m.group(3))
         elif m.group(4):
             d = math.inf
         else:

@@ -1,0 +1,214 @@
+"""the stream processor's aggregate queries on the device (flbgpu_sp_* through the C ABI) against the reference:
+committed answers of the reference's own flb_sp (tests/golden/sp_cases.json), the oracle restatement (oracle/osp.py) on seeded
+hostile chunks, and -- at the bench size -- the reference binary itself (oracle/_ref/ref_sp) plus size-independent properties.
+
+Bar: byte-identical records (group order, key names, value types, integers) -- except float32 fields fed by float SUM / AVG,
+where the reference adds in arrival order and the device rounds the exact sum once: those may differ by one float32 ULP
+(the tolerance north_star states for the sums)."""
+import json
+import os
+import random
+import struct
+import sys
+
+import msgpack
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import flbamd_loader
+import osp
+import ref_sp
+import sp_synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def _rows(buf):
+    u = msgpack.Unpacker(raw=True, strict_map_key=False)
+    u.feed(buf)
+    return list(u)
+
+
+def _f32_ulps(a, b):
+    ia, ib = struct.unpack("<i", struct.pack("<f", a))[0], struct.unpack("<i", struct.pack("<f", b))[0]
+    ia = ia if ia >= 0 else -(ia & 0x7FFFFFFF)
+    ib = ib if ib >= 0 else -(ib & 0x7FFFFFFF)
+    return abs(ia - ib)
+
+
+def assert_same_records(got, want, ctx):
+    """identical bytes, or identical structure with float32 values within one ULP"""
+    if got == want:
+        return 0
+    a, b = _rows(got), _rows(want)
+    assert len(a) == len(b), ctx
+    soft = 0
+    for ra, rb in zip(a, b):
+        assert ra[0] == rb[0], ctx
+        assert list(ra[1].keys()) == list(rb[1].keys()), ctx
+        for k in ra[1]:
+            va, vb = ra[1][k], rb[1][k]
+            assert type(va) is type(vb), (ctx, k, va, vb)
+            if isinstance(va, float) and va != vb:
+                if va != va and vb != vb:
+                    continue
+                assert _f32_ulps(va, vb) <= 1, (ctx, k, va, vb)
+                soft += 1
+            else:
+                assert va == vb, (ctx, k, va, vb)
+    return soft
+
+
+def test_reference_answers(g):
+    with open(os.path.join(HERE, "golden", "sp_cases.json")) as f:
+        cases = json.load(f)
+    exact = refused = 0
+    for c in cases:
+        try:
+            osp_ok = True
+            o = osp.Task(c["sql"], str_conv=c["str_conv"])
+            for ch in c["chunks"]:
+                o.do(bytes.fromhex(ch))
+        except osp.Unsupported:
+            osp_ok = False
+        t = g.StreamTask(c["sql"], str_conv=c["str_conv"])
+        try:
+            for ch, (ret, out) in zip(c["chunks"], c["do"]):
+                rec, got = t.do(bytes.fromhex(ch))
+                assert rec == ret, c["sql"]
+                assert_same_records(got, bytes.fromhex(out), c["sql"])
+            assert_same_records(t.timer(), bytes.fromhex(c["timer"]), c["sql"])
+            assert osp_ok, "the device answered a case the oracle refuses: " + c["sql"]
+            exact += 1
+        except RuntimeError:
+            assert not osp_ok and not c["clean"], (c["sql"], g.last_error())
+            refused += 1
+        finally:
+            t.close()
+    assert exact >= 24, (exact, refused)
+
+
+def test_hostile_chunks_against_the_oracle(g):
+    rng = random.Random(0xBEE)
+    compared = soft = 0
+    for q in sp_synth.QUERIES:
+        for rep in range(4):
+            clean = rep < 2
+            conv = rep != 3
+            chunks = [sp_synth.chunk(rng, rng.choice([1, 65, 3000]), clean) for _ in range(rng.choice([1, 3]))]
+            o = osp.Task(q, str_conv=conv)
+            t = g.StreamTask(q, str_conv=conv)
+            try:
+                want = []
+                try:
+                    for c in chunks:
+                        want.append(o.do(c))
+                    want_timer = o.timer()
+                except osp.Unsupported:
+                    assert not clean
+                    with pytest.raises(RuntimeError):
+                        for c in chunks:
+                            t.do(c)
+                        t.timer()
+                    continue
+                for c, (ret, out) in zip(chunks, want):
+                    rec, got = t.do(c)
+                    assert rec == ret, q
+                    soft += assert_same_records(got, out, q)
+                soft += assert_same_records(t.timer(), want_timer, q)
+                compared += 1
+            finally:
+                t.close()
+    assert compared >= 20
+    print("float32 fields off by one ULP:", soft)
+
+
+def test_window_life_cycle(g):
+    """records accumulate over chunks until the timer; an idle timer packages nothing; the next window starts empty"""
+    rng = random.Random(5)
+    q = "SELECT host, COUNT(*), SUM(bytes) FROM STREAM:x WINDOW TUMBLING (5 SECOND) GROUP BY host;"
+    t = g.StreamTask(q)
+    o = osp.Task(q)
+    assert t.window == "tumbling" and t.window_size == 5 and t.key_names == ["host", "COUNT(*)", "SUM(bytes)"]
+    assert t.timer() == b"" == o.timer()
+    for rnd in range(3):
+        for _ in range(rnd + 1):
+            c = sp_synth.chunk(rng, 500, clean=True)
+            assert t.do(c) == o.do(c)
+        assert t.timer(now=(77, 5)) == o.timer(now=(77, 5))
+        assert t.timer() == b""
+    t.close()
+    s = g.StreamTask("CREATE STREAM agg WITH (tag='agg.out') AS SELECT COUNT(*) FROM TAG:'app.*';")
+    assert s.stream_name == "agg" and s.stream_prop("tag") == "agg.out" and s.source_type == "tag" and s.source == "app.*" and s.window == "default"
+    s.close()
+
+
+def test_refusals(g):
+    for bad in ["SELECT id, MIN(id) FROM STREAM:FLB;", "SELECT * FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 1 SECOND);"]:
+        with pytest.raises(ValueError):
+            g.StreamTask(bad)
+    # a GROUP BY column that mixes strings and numbers inside one window: the reference's tree comparator is not an order
+    t = g.StreamTask("SELECT k, COUNT(*) FROM STREAM:s GROUP BY k;")
+    rec = lambda v: b"\x92\xd7\x00" + struct.pack(">II", 1, 0) + msgpack.packb({"k": v})
+    with pytest.raises(RuntimeError):
+        t.do(rec(1) + rec("abc"))
+    t.close()
+    t = g.StreamTask("SELECT k, COUNT(*) FROM STREAM:s GROUP BY k;", str_conv=True)
+    ret, out = t.do(rec(7) + rec("7") + rec(" 7") + rec(True))
+    assert [r[1] for r in _rows(out)] == [{b"k": 7, b"COUNT(*)": 3}, {b"k": 1, b"COUNT(*)": 1}]
+    t.close()
+
+
+def test_truncated_chunk_stops_at_the_first_bad_record(g):
+    q = "SELECT COUNT(*), SUM(bytes) FROM STREAM:x;"
+    rng = random.Random(9)
+    c = sp_synth.chunk(rng, 50, clean=True)
+    cut = c[:len(c) - 7]
+    t, o = g.StreamTask(q), osp.Task(q)
+    assert t.do(cut) == o.do(cut)
+    t.close()
+
+
+@pytest.mark.skipif(not ref_sp.available(), reason="oracle/_ref/ref_sp not built")
+def test_bench_size_against_the_reference_binary(g):
+    """BASELINE configs[4]: GROUP BY status, AVG(latency) over a tumbling window -- 1 M records in 4 chunks, the reference's own
+    flb_sp on the same bytes; plus properties that do not need it (counts add up, merging is chunk-order independent)"""
+    rng = random.Random(0xC0FFEE)
+    statuses = [200] * 7 + [301, 404, 500]
+    chunks = []
+    for ci in range(4):
+        out = bytearray()
+        for i in range(250_000):
+            body = {"status": rng.choice(statuses), "latency": rng.random() * 250.0, "bytes": rng.randrange(1 << 20), "host": "h%d" % rng.randrange(64)}
+            out += b"\x92\x92\xd7\x00" + struct.pack(">II", 1700000000 + i, 0) + b"\x80" + msgpack.packb(body)
+        chunks.append(bytes(out))
+    q = "SELECT status, host, COUNT(*), AVG(latency), SUM(bytes), MIN(latency), MAX(bytes) FROM STREAM:x WINDOW TUMBLING (60 SECOND) WHERE status < 500 GROUP BY status, host;"
+    r = ref_sp.RefSp(q)
+    t = g.StreamTask(q)
+    for c in chunks:
+        ret_r, _ = r.do(c)
+        ret_t, _ = t.do(c)
+        assert ret_r == ret_t
+    want, got = r.timer(), t.timer()
+    r.close()
+    soft = assert_same_records(got, want, q)
+    rows = _rows(got)
+    assert len(rows) == 3 * 64 and sum(x[1][b"COUNT(*)"] for x in rows) == ret_t
+    # chunk order does not matter to the aggregate state: same groups, same numbers (first-seen order aside)
+    t2 = g.StreamTask(q)
+    for c in reversed(chunks):
+        t2.do(c)
+    rows2 = _rows(t2.timer())
+    key = lambda x: (x[1][b"status"], x[1][b"host"])
+    assert sorted(rows, key=key) == sorted(rows2, key=key)
+    t.close(); t2.close()
+    print("float32 fields off by one ULP vs the reference:", soft, "of", 2 * len(rows))
