@@ -501,6 +501,7 @@ constexpr int SP_A_NINT = 0, SP_A_NFLT = 1, SP_A_ISUM = 2, SP_A_NAN = 3, SP_A_PI
 constexpr int SP_SRC_ADD = SP_A_LIMB + 68;
 inline int sp_row_words(int nsrc) { return 1 + SP_SRC_MAX * nsrc + 1 + SP_SRC_ADD * nsrc; }
 constexpr uint32_t SP_GID_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SP_GID_DEFER = 0xFFFFFFFEu;     // needs k_sp_generic (decimal string -> binary64)
 // status bits (SpArgs::flags): inputs the reference itself does not treat in an order-independent way -> the call fails
 enum { SPF_BAD_RECORD = 1, SPF_KEY_NUL = 2, SPF_KEY_NAN = 4, SPF_FLOAT_RANGE = 8 };
 struct SpArgs {
@@ -513,7 +514,7 @@ struct SpArgs {
     uint64_t *val_col;               // [nsrc][n] int64 / binary64 bits
     uint8_t *vt_col;                 // [nsrc][n] class (0 none, 1 int, 2 float) | occurrences << 2
     unsigned long long *first_bad;
-    unsigned long long *counts;      // [0] records that entered a group
+    unsigned long long *counts;      // [0] records that entered a group, [1] records deferred to k_sp_generic
     unsigned int *col_class;         // [SP_MAX_GB] OR of (1 << class) seen in each GROUP BY column (1 int, 2 float, 4 string)
     unsigned int *flags;
 };
@@ -529,6 +530,7 @@ struct SpAggArgs {
     const unsigned int *n_series;
 };
 void launch_sp_extract(const SpArgs &a, int cus, hipStream_t st);
+void launch_sp_generic(const SpArgs &a, hipStream_t st);
 void launch_sp_aggregate(const SpAggArgs &a, int cus, hipStream_t st);
 
 // ---- JSON text -> msgpack (src/flb_pack.c:389-508)

@@ -680,6 +680,12 @@ bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
         HIPOK(hipMemcpyAsync(&hm, t->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipMemcpyAsync(&hc, s.d_ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
+        if (!hc.overflow && hm.counts[1] > 0) {
+            launch_sp_generic(a, st);
+            HIPOK(hipMemcpyAsync(&hm, t->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipMemcpyAsync(&hc, s.d_ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+        }
         if (!hc.overflow) break;
         if (!l2m_table_grow(&s, st)) return false;          // nothing was aggregated yet: the pass runs again
     }

@@ -50,3 +50,36 @@ def chunk(rng, n, clean=False):
         ts = b"\xd7\x00" + struct.pack(">II", 1700000000 + i, rng.randrange(10 ** 9))
         out += b"\x92\x92" + ts + b"\x80" + body
     return bytes(out)
+
+
+def config4_chunk(n, seed=0x5ca1e, base_sec=1700000000):
+    """BASELINE configs[4]'s shape, vectorised: n fixed-layout V2 records
+    [[ts, {}], {"status": u16, "latency": f64, "bytes": u32, "host": "hNN"}] (status 70 % 200, the rest 301 / 404 / 500)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    head = b"\x92\x92\xd7\x00" + b"\0" * 8 + b"\x80\x84"
+    parts = [head, b"\xa6status\xcd", b"\0\0", b"\xa7latency\xcb", b"\0" * 8, b"\xa5bytes\xce", b"\0" * 4, b"\xa4host\xa3h00"]
+    tmpl = b"".join(parts)
+    L = len(tmpl)
+    a = np.tile(np.frombuffer(tmpl, dtype=np.uint8), (n, 1))
+    o_ts = 4
+    o_status = len(parts[0]) + len(parts[1])
+    o_lat = o_status + 2 + len(parts[3])
+    o_bytes = o_lat + 8 + len(parts[5])
+    o_host = o_bytes + 4 + len(parts[7]) - 2
+    sec = (base_sec + np.arange(n) // 1000).astype(">u4")
+    a[:, o_ts:o_ts + 4] = sec.view(np.uint8).reshape(n, 4)
+    st = rng.choice(np.array([200, 200, 200, 200, 200, 200, 200, 301, 404, 500], dtype=">u2"), n)
+    a[:, o_status:o_status + 2] = st.view(np.uint8).reshape(n, 2)
+    lat = (rng.random(n) * 250.0).astype(">f8")
+    a[:, o_lat:o_lat + 8] = lat.view(np.uint8).reshape(n, 8)
+    by = rng.integers(0, 1 << 20, n).astype(">u4")
+    a[:, o_bytes:o_bytes + 4] = by.view(np.uint8).reshape(n, 4)
+    h = rng.integers(0, 64, n)
+    a[:, o_host] = 48 + h // 10
+    a[:, o_host + 1] = 48 + h % 10
+    off = (np.arange(n + 1, dtype=np.uint64) * L)
+    return a.reshape(-1), off
+
+
+CONFIG4_SQL = "SELECT status, COUNT(*), AVG(latency) FROM STREAM:x WINDOW TUMBLING (60 SECOND) GROUP BY status;"
