@@ -303,6 +303,64 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         f2.close(); g2.close(); tl.close(); L.flbgpu_dev_free(d_txt)
     except Exception as e:
         out["tail_lines"] = {"error": repr(e)[:300]}
+    # -- flb_sp (BASELINE configs[4] shape): GROUP BY status, AVG(latency) over a tumbling window; the chunk is resident in HBM, the
+    #    window's partial aggregates are exchanged over RCCL when N > 1 (one all-gather of KB-sized group states per timer)
+    try:
+        import sp_synth
+        m = min(n, 4_000_000)
+        sdata, soff = sp_synth.config4_chunk(m, seed=0x5ca1e + rank)
+        d_sd = L.flbgpu_dev_alloc(sdata.nbytes + 16); d_so = L.flbgpu_dev_alloc(soff.nbytes)
+        L.flbgpu_memcpy_h2d(d_sd, sdata.ctypes.data, sdata.nbytes); L.flbgpu_memcpy_h2d(d_so, soff.ctypes.data, soff.nbytes)
+        sch = g.DevChunk(d_sd, d_so, m, sdata.nbytes)
+        st_ = g.StreamTask(sp_synth.CONFIG4_SQL)
+        st_.set_index_base(rank << 40)
+        st_.do_dev(sch); st_.timer()
+        st_.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st_.do_dev(sch)
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / steps
+        prof_s = st_.profile(False)
+        e = {"records_per_s_per_gpu": round(m / dt_s, 1), "ms_per_step": round(dt_s * 1e3, 3), "query": sp_synth.CONFIG4_SQL,
+             "chunk_bytes": int(sdata.nbytes), "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in prof_s.items()}}
+        ke_ = e["kernel_ms"].get("k_sp_extract") or 0
+        if ke_:
+            a_ = sdata.nbytes / (ke_ / 1e3) / 1e9
+            e["roofline"] = {"kernel": "k_sp_extract", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(a_, 1),
+                             "frac": round(a_ / HBM_PEAK_GBS, 4), "note": "61 B records: the kernel is bound by per-record work, not by bytes"}
+        if dist is not None and "rccl" in out:
+            t0 = time.perf_counter()
+            merged = st_.timer_all_reduce(out["rccl"])
+            e["all_reduce_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            e["rccl_ranks"] = world
+        else:
+            merged = st_.timer()
+        import msgpack as _mp
+        u_ = _mp.Unpacker(raw=True, strict_map_key=False)
+        u_.feed(merged)
+        rows_ = [r_[1] for r_ in u_]
+        e["groups"] = len(rows_)
+        e["window_records"] = int(sum(r_[b"COUNT(*)"] for r_ in rows_))
+        if rank == 0:
+            import ref_sp
+            if ref_sp.available():
+                k_ = min(m, 1_000_000)
+                sample = sdata[: int(soff[k_])].tobytes()
+                rr = ref_sp.RefSp(sp_synth.CONFIG4_SQL)
+                t0 = time.perf_counter()
+                rr.do(sample); want_ = rr.timer()
+                dt_r = time.perf_counter() - t0
+                rr.close()
+                t2_ = g.StreamTask(sp_synth.CONFIG4_SQL)
+                t2_.do(sample); got_ = t2_.timer(); t2_.close()
+                e["cpu_baseline"] = {"value": round(k_ / dt_r, 1), "unit": "records/s", "cores": 1, "kind": "reference",
+                                     "sample": "%d records through the reference's own flb_sp (oracle/_ref/ref_sp)" % k_, "identical_output": got_ == want_}
+        out["flb_sp_group_by"] = e
+        st_.close(); L.flbgpu_dev_free(d_sd); L.flbgpu_dev_free(d_so)
+    except Exception as e:
+        out["flb_sp_group_by"] = {"error": repr(e)[:300]}
     fg1.close(); fg2.close(); pk.close()
     L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
     if "rccl" in out:

@@ -395,6 +395,43 @@ class StreamTask:
     def set_index_base(self, base):
         lib().flbgpu_sp_set_index_base(self.h, base)
 
+    def export(self):
+        """this shard's window state (opaque bytes: typed key tuples + order-independent row words)"""
+        L = lib()
+        L.flbgpu_sp_export.restype = c_int64
+        L.flbgpu_sp_export.argtypes = [c_void_p, c_void_p, c_size_t]
+        n = L.flbgpu_sp_export(self.h, None, 0)
+        if n < 0:
+            raise RuntimeError(last_error())
+        buf = ctypes.create_string_buffer(int(n))
+        if L.flbgpu_sp_export(self.h, buf, n) != n:
+            raise RuntimeError(last_error())
+        return buf.raw
+
+    def package_merged(self, snapshots, now=(1, 0)):
+        """package_results over the merge of shard states (flbgpu_sp_package_merged): the records a single task fed
+        with all the shards' chunks would package"""
+        L = lib()
+        L.flbgpu_sp_package_merged.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_size_t), c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                               POINTER(c_void_p), POINTER(c_size_t)]
+        n = len(snapshots)
+        keep = [ctypes.create_string_buffer(b, len(b)) for b in snapshots]
+        ptrs = (c_void_p * max(n, 1))(*[ctypes.cast(k, c_void_p) for k in keep])
+        sizes = (c_size_t * max(n, 1))(*[len(b) for b in snapshots])
+        out = c_void_p(); sz = c_size_t()
+        if L.flbgpu_sp_package_merged(self.h, ptrs, sizes, n, now[0], now[1], byref(out), byref(sz)) != 0:
+            raise RuntimeError(last_error())
+        return self._take(out, sz)
+
+    def timer_all_reduce(self, comm, now=(1, 0)):
+        """the timer of a window sharded over ranks: exchange over RCCL, merged records on every rank, window pruned"""
+        L = lib()
+        L.flbgpu_sp_timer_all_reduce.argtypes = [c_void_p, c_void_p, c_void_p, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t)]
+        out = c_void_p(); sz = c_size_t()
+        if L.flbgpu_sp_timer_all_reduce(self.h, comm.h, None, now[0], now[1], byref(out), byref(sz)) != 0:
+            raise RuntimeError(last_error())
+        return self._take(out, sz)
+
     def profile(self, enable=True):
         ms = (c_double * 2)(); n = (c_uint64 * 2)()
         lib().flbgpu_sp_profile(self.h, int(bool(enable)), ms, n)

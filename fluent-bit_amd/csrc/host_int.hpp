@@ -105,6 +105,8 @@ void l2m_state_destroy(L2mState *);
 flbgpu::L2mTable l2m_table_of(L2mState *s);
 bool l2m_table_init(L2mState *s);
 bool l2m_table_grow(L2mState *s, hipStream_t st);
+// variable-size all-gather over RCCL through device staging buffers (l2m.cpp): all[r] = rank r's bytes
+bool rccl_all_gather_bytes(void *rccl_comm, hipStream_t st, const void *mine, size_t bytes, std::vector<std::vector<uint8_t>> &all);
 // fixed-point sum digits (L2M_NLIMB words, carries not yet propagated) + special counts -> binary64 bits, rounded once
 uint64_t l2m_limbs_bits(const uint64_t *limbs, uint64_t n_nan, uint64_t n_pinf, uint64_t n_ninf);
 

@@ -508,6 +508,33 @@ bool rccl_load() {
     } while (0)
 }  // namespace
 
+// variable-size all-gather over RCCL (sizes first, then the blobs padded to the largest): every rank ends with every rank's
+// bytes, in rank order.  Staged through device buffers: RCCL moves HBM over xGMI.
+bool rccl_all_gather_bytes(void *rccl_comm, hipStream_t st, const void *mine, size_t bytes, std::vector<std::vector<uint8_t>> &all) {
+    if (!rccl_load()) return false;
+    int world = 0;
+    if (g_rccl.comm_count(rccl_comm, &world) != 0 || world <= 0) { set_err("rccl: ncclCommCount failed"); return false; }
+    DevBuf d_a, d_b;
+    uint64_t mysize = bytes;
+    std::vector<uint64_t> sizes((size_t) world);
+    bool ok = d_a.ensure(8) && d_b.ensure(8 * (size_t) world) && hipMemcpyAsync(d_a.p, &mysize, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+              g_rccl.all_gather(d_a.p, d_b.p, 1, NCCL_UINT64, rccl_comm, st) == 0 &&
+              hipMemcpyAsync(sizes.data(), d_b.p, 8 * (size_t) world, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    size_t mx = 8;
+    if (ok) for (int r = 0; r < world; r++) mx = std::max<size_t>(mx, (size_t) sizes[r]);
+    mx = (mx + 7) & ~(size_t) 7;
+    std::vector<uint8_t> pad(mx, 0), flat(ok ? mx * (size_t) world : 0);
+    if (bytes) memcpy(pad.data(), mine, bytes);
+    ok = ok && d_a.ensure(mx) && d_b.ensure(mx * (size_t) world) && hipMemcpyAsync(d_a.p, pad.data(), mx, hipMemcpyHostToDevice, st) == hipSuccess &&
+         g_rccl.all_gather(d_a.p, d_b.p, mx, NCCL_UINT8, rccl_comm, st) == 0 &&
+         hipMemcpyAsync(flat.data(), d_b.p, mx * (size_t) world, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    d_a.release(); d_b.release();
+    if (!ok) { if (!*flbgpu_last_error()) set_err("rccl: all-gather failed"); return false; }
+    all.clear();
+    for (int r = 0; r < world; r++) all.emplace_back(flat.begin() + (size_t) r * mx, flat.begin() + (size_t) r * mx + (size_t) sizes[r]);
+    return true;
+}
+
 extern "C" int flbgpu_rccl_unique_id(void *id128) { if (!rccl_load()) return -1; NCCLOK(g_rccl.get_id(id128)); return 0; }
 extern "C" int flbgpu_rccl_comm_init(void **comm, int nranks, const void *id128, int rank) {
     if (!rccl_load()) return -1;

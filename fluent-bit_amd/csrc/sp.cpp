@@ -563,8 +563,17 @@ double bits_double(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
 int64_t unord_i(uint64_t o) { return (int64_t) (o ^ 0x8000000000000000ull); }
 uint64_t unord_f(uint64_t o) { return (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o; }
 
-// package_results (flb_sp.c:1161-1278) over the group rows
-bool package(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, std::string &out) {
+// ---- the window's state on the host: live groups (typed key tuple as stored in the arena + the row words), the record count
+// and the class mask of every GROUP BY column.  Snapshots of shards merge word by word (max / add), which is what the
+// multi-GPU exchange ships.
+struct Group { std::string key; std::vector<uint64_t> row; };
+struct Snapshot {
+    uint64_t records = 0;
+    unsigned int col_class[SP_MAX_GB] = {0, 0, 0, 0};
+    std::vector<Group> groups;
+};
+
+bool snapshot(flbgpu_sp *t, Snapshot &sn) {
     L2mState &s = t->tab;
     const SpPlan &pl = t->plan;
     L2mCtr c;
@@ -583,19 +592,92 @@ bool package(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, std::string &out
             if (!arena.empty()) HIPOK(hipMemcpy(arena.data(), s.d_arena.p, arena.size(), hipMemcpyDeviceToHost));
         }
     }
-    std::vector<uint32_t> live;
-    for (uint32_t g = 0; g < ng; g++) if (rows[g * W] != 0) live.push_back(g);
-    std::sort(live.begin(), live.end(), [&](uint32_t a, uint32_t b) { return ~rows[a * W] < ~rows[b * W]; });
+    sn.records = t->records;
+    memcpy(sn.col_class, t->col_class, sizeof(sn.col_class));
+    sn.groups.clear();
+    for (uint32_t g = 0; g < ng; g++) {
+        if (rows[g * W] == 0) continue;                 // a dictionary entry no counted record stands behind
+        Group gr;
+        if (pl.ngb) gr.key.assign((const char *) arena.data() + koff[g], klen[g]);
+        gr.row.assign(rows.begin() + g * W, rows.begin() + (g + 1) * W);
+        sn.groups.push_back(std::move(gr));
+    }
+    return true;
+}
+
+// word-wise merge: max for the first 1 + 4 nsrc words, add for the rest
+void merge_into(Snapshot &dst, const Snapshot &src, int nsrc) {
+    const size_t nmax = 1 + (size_t) SP_SRC_MAX * nsrc;
+    dst.records += src.records;
+    for (int g = 0; g < SP_MAX_GB; g++) dst.col_class[g] |= src.col_class[g];
+    for (const Group &g : src.groups) {
+        Group *hit = nullptr;
+        for (Group &d : dst.groups) if (d.key == g.key) { hit = &d; break; }
+        if (!hit) { dst.groups.push_back(g); continue; }
+        for (size_t w = 0; w < g.row.size(); w++) {
+            if (w < nmax) hit->row[w] = std::max(hit->row[w], g.row[w]);
+            else hit->row[w] += g.row[w];
+        }
+    }
+}
+
+void put_u64(std::string &o, uint64_t v) { o.append((const char *) &v, 8); }
+std::string serialize(const Snapshot &sn, int W) {
+    std::string o;
+    put_u64(o, 0x5350534e41503031ull);                  // "SPSNAP01"
+    put_u64(o, sn.records);
+    for (int g = 0; g < SP_MAX_GB; g++) put_u64(o, sn.col_class[g]);
+    put_u64(o, sn.groups.size());
+    put_u64(o, (uint64_t) W);
+    for (const Group &g : sn.groups) {
+        put_u64(o, g.key.size());
+        o.append(g.key);
+        o.append((8 - g.key.size() % 8) % 8, '\0');
+        o.append((const char *) g.row.data(), g.row.size() * 8);
+    }
+    return o;
+}
+bool deserialize(const uint8_t *p, size_t n, int W, Snapshot &sn) {
+    auto get = [&](uint64_t &v) -> bool { if (n < 8) return false; memcpy(&v, p, 8); p += 8; n -= 8; return true; };
+    uint64_t magic, ng, w, cc;
+    if (!get(magic) || magic != 0x5350534e41503031ull || !get(sn.records)) return false;
+    for (int g = 0; g < SP_MAX_GB; g++) { if (!get(cc)) return false; sn.col_class[g] = (unsigned int) cc; }
+    if (!get(ng) || !get(w) || w != (uint64_t) W) return false;
+    sn.groups.clear();
+    for (uint64_t i = 0; i < ng; i++) {
+        uint64_t kl;
+        if (!get(kl)) return false;
+        const size_t padded = (size_t) ((kl + 7) & ~7ull);
+        if (n < padded + (size_t) W * 8) return false;
+        Group g;
+        g.key.assign((const char *) p, (size_t) kl);
+        p += padded; n -= padded;
+        g.row.resize((size_t) W);
+        memcpy(g.row.data(), p, (size_t) W * 8);
+        p += (size_t) W * 8; n -= (size_t) W * 8;
+        sn.groups.push_back(std::move(g));
+    }
+    return true;
+}
+
+// package_results (flb_sp.c:1161-1278) over a window's groups
+bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, std::string &out) {
+    const SpPlan &pl = t->plan;
+    for (int g = 0; g < pl.ngb; g++) {
+        const unsigned int m = sn.col_class[g];
+        if (m & (m - 1)) { set_err("stream processor: GROUP BY column %d mixes value classes across the shards of one window", g); return false; }
+    }
+    std::stable_sort(sn.groups.begin(), sn.groups.end(), [](const Group &a, const Group &b) { return ~a.row[0] < ~b.row[0]; });
     const size_t A = 1 + (size_t) SP_SRC_MAX * pl.nsrc;
-    for (uint32_t g : live) {
-        const uint64_t *row = &rows[g * W];
+    for (const Group &grp : sn.groups) {
+        const uint64_t *row = grp.row.data();
         // the group's typed key values
         int gcls[SP_MAX_GB] = {0, 0, 0, 0};
         uint64_t gu[SP_MAX_GB] = {0, 0, 0, 0};
         const char *gs[SP_MAX_GB] = {nullptr, nullptr, nullptr, nullptr};
         size_t gl[SP_MAX_GB] = {0, 0, 0, 0};
         if (pl.ngb) {
-            const uint8_t *p = arena.data() + koff[g], *e = p + klen[g];
+            const uint8_t *p = (const uint8_t *) grp.key.data(), *e = p + grp.key.size();
             for (int k = 0; k < pl.ngb && p < e; k++) {
                 gcls[k] = *p++;
                 if (gcls[k] == 's') { gs[k] = (const char *) p; gl[k] = strnlen((const char *) p, (size_t) (e - p)); p += gl[k] + 1; }
@@ -723,7 +805,8 @@ int finish_do(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
     if (t->q.window == 0) {
         // no WINDOW: packaged per appended chunk (flb_sp.c:2051-2054), then pruned (only a window that saw records is)
         std::string out;
-        if (!package(t, now_sec, now_nsec, out)) return -1;
+        Snapshot sn;
+        if (!snapshot(t, sn) || !package(t, sn, now_sec, now_nsec, out)) return -1;
         if (t->records > 0) reset_window(t);
         if (out_buf && out_size && !out.empty()) {
             *out_buf = malloc(out.size());
@@ -884,7 +967,8 @@ extern "C" int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec
     if (out_size) *out_size = 0;
     if (t->records > 0) {
         std::string out;
-        if (!package(t, now_sec, now_nsec, out)) return -1;
+        Snapshot sn;
+        if (!snapshot(t, sn) || !package(t, sn, now_sec, now_nsec, out)) return -1;
         reset_window(t);
         if (out_buf && out_size && !out.empty()) {
             *out_buf = malloc(out.size());
@@ -894,6 +978,63 @@ extern "C" int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec
         }
     }
     return 0;
+}
+
+// ---- multi-GPU: the shards of one window.  Every rank runs flbgpu_sp_do on its own records (flbgpu_sp_set_index_base gives the
+// ranks disjoint record index ranges: first-seen order across shards); when the window's timer fires the ranks exchange their
+// group states and every rank packages the same merged result.
+extern "C" int64_t flbgpu_sp_export(flbgpu_sp *t, void *buf, size_t cap) {
+    if (!t) { set_err("stream processor: null argument"); return -1; }
+    Snapshot sn;
+    if (!snapshot(t, sn)) return -1;
+    const std::string o = serialize(sn, t->tab.W);
+    if (buf && cap >= o.size()) memcpy(buf, o.data(), o.size());
+    return (int64_t) o.size();
+}
+
+static int package_snaps(flbgpu_sp *t, const void *const *snaps, const size_t *sizes, int n, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
+                         size_t *out_size) {
+    if (out_buf) *out_buf = nullptr;
+    if (out_size) *out_size = 0;
+    Snapshot total;
+    for (int i = 0; i < n; i++) {
+        Snapshot sn;
+        if (!deserialize((const uint8_t *) snaps[i], sizes[i], t->tab.W, sn)) { set_err("stream processor: snapshot %d does not belong to this query", i); return -1; }
+        merge_into(total, sn, t->plan.nsrc);
+    }
+    if (total.records == 0) return 0;
+    std::string out;
+    if (!package(t, total, now_sec, now_nsec, out)) return -1;
+    if (out_buf && out_size && !out.empty()) {
+        *out_buf = malloc(out.size());
+        if (!*out_buf) { set_err("out of memory"); return -1; }
+        memcpy(*out_buf, out.data(), out.size());
+        *out_size = out.size();
+    }
+    return 0;
+}
+
+extern "C" int flbgpu_sp_package_merged(flbgpu_sp *t, const void *const *snaps, const size_t *sizes, int n, uint32_t now_sec, uint32_t now_nsec,
+                                        void **out_buf, size_t *out_size) {
+    if (!t || (n > 0 && (!snaps || !sizes))) { set_err("stream processor: null argument"); return -1; }
+    return package_snaps(t, snaps, sizes, n, now_sec, now_nsec, out_buf, out_size);
+}
+
+extern "C" int flbgpu_sp_timer_all_reduce(flbgpu_sp *t, void *rccl_comm, void *stream, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
+                                          size_t *out_size) {
+    if (!t || !rccl_comm) { set_err("stream processor: null argument"); return -1; }
+    hipStream_t st = stream ? (hipStream_t) stream : t->stream;
+    Snapshot sn;
+    if (!snapshot(t, sn)) return -1;
+    const std::string mine = serialize(sn, t->tab.W);
+    std::vector<std::vector<uint8_t>> all;
+    if (!rccl_all_gather_bytes(rccl_comm, st, mine.data(), mine.size(), all)) return -1;
+    std::vector<const void *> ptrs;
+    std::vector<size_t> sizes;
+    for (auto &b : all) { ptrs.push_back(b.data()); sizes.push_back(b.size()); }
+    const int r = package_snaps(t, ptrs.data(), sizes.data(), (int) ptrs.size(), now_sec, now_nsec, out_buf, out_size);
+    if (r == 0) reset_window(t);
+    return r;
 }
 
 // kernel times since the last call (ms, launches) for k_sp_extract, k_sp_aggregate; enable != 0 switches the event timing on

@@ -289,6 +289,17 @@ int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **ou
 int flbgpu_sp_parse_check(const char *sql, char *desc, size_t cap);
 /* global index of the next record (first-seen order of groups across shards) */
 void flbgpu_sp_set_index_base(flbgpu_sp *t, uint64_t base);
+/* ---- multi-GPU: one window sharded over ranks (one process per GPU, records sharded by batch; no exchange on the data path).
+ * flbgpu_sp_export: this rank's window state -- per group the typed key tuple and the order-independent row words -- as an
+ * opaque blob (returns its size; written when cap suffices).  flbgpu_sp_package_merged: package_results over the word-wise
+ * merge (max / add) of such blobs, a pure host function.  flbgpu_sp_timer_all_reduce: the timer of a sharded window --
+ * all-gather of the blobs over RCCL (rccl_comm: an ncclComm_t, see flbgpu_rccl_comm_init), the same merged records on every
+ * rank, window pruned.  The merged result does not depend on the number of ranks or on which rank saw which record. */
+int64_t flbgpu_sp_export(flbgpu_sp *t, void *buf, size_t cap);
+int flbgpu_sp_package_merged(flbgpu_sp *t, const void *const *snaps, const size_t *sizes, int n, uint32_t now_sec, uint32_t now_nsec,
+                             void **out_buf, size_t *out_size);
+int flbgpu_sp_timer_all_reduce(flbgpu_sp *t, void *rccl_comm, void *stream, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
+                               size_t *out_size);
 /* event-timed kernel milliseconds / launches since the last call: [0] k_sp_extract, [1] k_sp_aggregate (+ normalize) */
 void flbgpu_sp_profile(flbgpu_sp *t, int enable, double *ms2, uint64_t *launches2);
 

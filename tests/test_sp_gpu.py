@@ -212,3 +212,44 @@ def test_bench_size_against_the_reference_binary(g):
     assert sorted(rows, key=key) == sorted(rows2, key=key)
     t.close(); t2.close()
     print("float32 fields off by one ULP vs the reference:", soft, "of", 2 * len(rows))
+
+
+def test_shards_merge_like_one_task(g):
+    """one window sharded over ranks: every shard runs on its own records with a disjoint index base; the merge of the exported
+    states packages what a single task (and the reference) packages for all the records -- whatever the shard count"""
+    rng = random.Random(0x5AD)
+    q = "SELECT host, status, COUNT(*), AVG(latency), SUM(bytes), MIN(bytes), MAX(latency) FROM STREAM:x WINDOW TUMBLING (10 SECOND) WHERE status <> 404 GROUP BY host, status;"
+    chunks = [sp_synth.chunk(rng, 2000, clean=True) for _ in range(6)]
+    o = osp.Task(q)
+    for c in chunks:
+        o.do(c)
+    want = o.timer()
+    for nshards in (1, 2, 3):
+        tasks = [g.StreamTask(q) for _ in range(nshards)]
+        for ci, c in enumerate(chunks):
+            t = tasks[ci % nshards]
+            t.set_index_base(ci * 2000)
+            t.do(c)
+        snaps = [t.export() for t in tasks]
+        got = tasks[0].package_merged(snaps)
+        assert_same_records(got, want, (q, nshards))
+        # the order the states arrive in does not matter
+        assert tasks[-1].package_merged(snaps[::-1]) == got
+        for t in tasks:
+            t.close()
+
+
+def test_rccl_timer_single_rank(g):
+    """flbgpu_sp_timer_all_reduce over a real RCCL communicator (one rank: the exchange is the identity)"""
+    rng = random.Random(0xCC1)
+    q = "SELECT host, COUNT(*), AVG(latency) FROM STREAM:x WINDOW TUMBLING (5 SECOND) GROUP BY host;"
+    c = sp_synth.chunk(rng, 3000, clean=True)
+    t, o = g.StreamTask(q), osp.Task(q)
+    t.do(c); o.do(c)
+    comm = g.RcclComm(1, 0)
+    try:
+        assert_same_records(t.timer_all_reduce(comm), o.timer(), q)
+        assert t.timer() == b""                                     # pruned
+    finally:
+        comm.close()
+        t.close()
