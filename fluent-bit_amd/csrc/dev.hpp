@@ -8,7 +8,7 @@ namespace flbgpu {
 struct DevCap {
     // hot tables (touched once per input byte); stored back to back so that a workgroup can
     // stage them into LDS with one coalesced copy: [hot_base, hot_base + hot_bytes)
-    const uint16_t *rdelta;        // [nR + 1][1 << cls_shift]; bit15 = a match may start here
+    const uint16_t *rdelta;        // [nR + 1][1 << cls_shift]; bit15 = a match may start here (`wide`: see below)
     const uint32_t *ft;            // [nX * NKp][1 << wsh] forward table (encoding: rx.hpp)
     const uint32_t *ft2;           // [nmulti][1 << fc_shift] one-byte-lookahead rows
     const uint8_t *cls;            // [256] byte -> class
@@ -22,6 +22,8 @@ struct DevCap {
     const uint32_t *tag_off;
     const uint8_t *tag_data;
     int ncls, nR, r_init, VW, nX, NK, NKp, kind_edge, ascii_only, cls_shift, fc_shift, wsh, col_eot;
+    int wide;                      // utf8 set only (rx.hpp `wide`): rdelta points at 32-bit entries, bit31 = a match may
+                                   // start here; walked from HBM by the generic kernels, never staged
     const uint8_t *hot_base;
     uint32_t hot_bytes;
     uint32_t off_rdelta, off_ft, off_ft2, off_cls, off_col;   // byte offsets inside the hot block

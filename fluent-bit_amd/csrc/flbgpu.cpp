@@ -77,7 +77,7 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint32_t> ftd(t.ft.size()), ft2d(t.ft2.size());
     for (size_t i = 0; i < t.ft.size(); i++) ftd[i] = dev_entry(t.ft[i]);
     for (size_t i = 0; i < t.ft2.size(); i++) ft2d[i] = dev_entry(t.ft2[i]);
-    size_t o_rd = put(b, t.rdelta_p), o_ft = put(b, ftd), o_f2 = put(b, ft2d), o_cls = put(b, cls), o_col = put(b, t.col);
+    size_t o_rd = t.wide ? put(b, t.rdelta32_p) : put(b, t.rdelta_p), o_ft = put(b, ftd), o_f2 = put(b, ft2d), o_cls = put(b, cls), o_col = put(b, t.col);
     size_t hot_end = (b.size() + 15) & ~(size_t) 15;
     b.resize(hot_end);
     size_t o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
@@ -93,7 +93,7 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     out.list_ent = (const uint32_t *) (d + o_le); out.tag_off = (const uint32_t *) (d + o_to); out.tag_data = d + o_td;
     out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK; out.NKp = t.NKp;
     out.kind_edge = t.kind_edge; out.ascii_only = t.ascii_only ? 1 : 0; out.cls_shift = t.cls_shift; out.fc_shift = t.fc_shift;
-    out.wsh = t.wsh; out.col_eot = t.col_eot;
+    out.wsh = t.wsh; out.col_eot = t.col_eot; out.wide = t.wide ? 1 : 0;
     out.hot_base = d; out.hot_bytes = (uint32_t) hot_end;
     out.off_rdelta = (uint32_t) o_rd; out.off_ft = (uint32_t) o_ft; out.off_ft2 = (uint32_t) o_f2;
     out.off_cls = (uint32_t) o_cls; out.off_col = (uint32_t) o_col;

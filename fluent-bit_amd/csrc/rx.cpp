@@ -12,6 +12,7 @@
 #include "rx.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -1060,6 +1061,7 @@ inline bool bit(const std::vector<uint64_t> &v, int i) { return (v[i >> 6] >> (i
 inline void setbit(std::vector<uint64_t> &v, int i) { v[i >> 6] |= 1ull << (i & 63); }
 
 constexpr int MAX_DFA_STATES = 20000;
+constexpr int MAX_WIDE_STATES = 200000;    // utf8 set's reverse automaton with 32-bit entries (rx.hpp: `wide`)
 
 }  // namespace
 
@@ -1232,23 +1234,33 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     std::vector<uint64_t> k0(WP, 0);
     k0[WP - 1] = (uint64_t) kinv[kmap[K_EDGE]];
     out.r_init = intern(k0);
+    // transitions are collected as 32-bit entries (id | start << 31) and narrowed below when the ids fit 15 bits
+    std::vector<uint32_t> rd32;
+    const int state_cap = ascii_only ? 0x7FF0 : MAX_WIDE_STATES;
     for (size_t si = 0; si < states.size(); si++) {
-        if ((int) states.size() > MAX_DFA_STATES) { err = "capture automaton exceeds the state budget"; return false; }
+        if ((int) states.size() > state_cap) { err = "capture automaton exceeds the state budget"; return false; }
         std::vector<uint64_t> S = states[si];
         int nk = (int) S[WP - 1];
-        out.rdelta.resize((si + 1) * out.ncls);
+        rd32.resize((si + 1) * out.ncls);
         for (int c = 0; c < out.ncls; c++) {
-            if (c == out.high_cls) { out.rdelta[si * out.ncls + c] = R_POISON; continue; }
+            if (c == out.high_cls) { rd32[si * out.ncls + c] = R_POISON; continue; }
             int pk = kind_cls[c];
             std::vector<uint64_t> N(WP, 0);
             for (int p : pos_of_cls[c]) if (ok(p, pk, nk, S)) setbit(N, p);
             N[WP - 1] = (uint64_t) kinv[kmap[kind_cls[c]]];
             bool startok = ok(START, pk, nk, S);
             int id = intern(N);
-            if (id >= 0x7FF0) { err = "capture automaton exceeds the state budget"; return false; }
-            out.rdelta[si * out.ncls + c] = (uint16_t) (id | (startok ? 0x8000 : 0));
+            rd32[si * out.ncls + c] = (uint32_t) id | (startok ? 0x80000000u : 0u);
         }
         out.r_info.push_back((uint8_t) (kmap[nk] | (ok(START, K_EDGE, nk, S) ? 0x80 : 0)));
+    }
+    if ((int) states.size() > state_cap) { err = "capture automaton exceeds the state budget"; return false; }
+    out.wide = (int) states.size() > 0x7FF0 || (!ascii_only && std::getenv("FLBGPU_RX_FORCE_WIDE") != nullptr);
+    if (out.wide) out.rdelta32.swap(rd32);
+    else {
+        out.rdelta.resize(rd32.size());
+        for (size_t i = 0; i < rd32.size(); i++)
+            out.rdelta[i] = rd32[i] == R_POISON ? R_POISON : (uint16_t) ((rd32[i] & 0x7FFF) | ((rd32[i] >> 31) ? 0x8000 : 0));
     }
     out.nR = (int) states.size();
     out.P = P;
@@ -1372,12 +1384,20 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
         const size_t rc = (size_t) 1 << out.cls_shift;
         // row nR is an absorbing POISON state (entered on a byte >= 0x80 in the ASCII set), so
         // the kernels can test for it once per unrolled group and never index out of the table
-        out.rdelta_p.assign((size_t) (out.nR + 1) * rc, (uint16_t) out.nR);
-        for (int r = 0; r < out.nR; r++)
-            for (int c = 0; c < out.ncls; c++) {
-                uint16_t e = out.rdelta[(size_t) r * out.ncls + c];
-                out.rdelta_p[(size_t) r * rc + c] = (e & 0x7FFF) == R_POISON ? (uint16_t) out.nR : e;
-            }
+        if (out.wide) {
+            // (no POISON in the utf8 set; row nR is kept so both layouts have nR + 1 rows)
+            out.rdelta32_p.assign((size_t) (out.nR + 1) * rc, (uint32_t) out.nR);
+            for (int r = 0; r < out.nR; r++)
+                for (int c = 0; c < out.ncls; c++) out.rdelta32_p[(size_t) r * rc + c] = out.rdelta32[(size_t) r * out.ncls + c];
+        }
+        else {
+            out.rdelta_p.assign((size_t) (out.nR + 1) * rc, (uint16_t) out.nR);
+            for (int r = 0; r < out.nR; r++)
+                for (int c = 0; c < out.ncls; c++) {
+                    uint16_t e = out.rdelta[(size_t) r * out.ncls + c];
+                    out.rdelta_p[(size_t) r * rc + c] = (e & 0x7FFF) == R_POISON ? (uint16_t) out.nR : e;
+                }
+        }
         out.ck.resize(256);
         for (int b = 0; b < 256; b++) out.ck[b] = (uint8_t) (out.cls[b] | (out.kind_of_cls[out.cls[b]] << 6));
     }
@@ -1460,7 +1480,14 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
                 f++;
             }
     }
-    if (!build_tables(root.get(), true, true, want_captures, out.slot2cap, out.ascii, err)) return false;
+    if (!build_tables(root.get(), true, true, want_captures, out.slot2cap, out.ascii, err)) {
+        // a parser only walks the capture program: the match-only DFA (forward subset construction) may be left out
+        // when it alone is over the budget (stock parser `ambassador`); grep rules (no captures) still need it
+        if (!want_captures || err != "match DFA exceeds the state budget") return false;
+        err.clear();
+        out.ascii = TableSet();
+        if (!build_tables(root.get(), true, false, true, out.slot2cap, out.ascii, err)) return false;
+    }
     if (!build_tables(root.get(), false, false, true, out.slot2cap, out.utf8, err)) return false;
     return true;
 }
@@ -1534,19 +1561,36 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int olen, int 
     // the utf8 set walks symbols over a possibly shortened text (see utf8_walk_len)
     const int len = t.ascii_only ? olen : utf8_walk_len(s, olen);
     auto sym = [&](int i, int *L) -> int { if (t.ascii_only) { if (L) *L = 1; return s[i]; } return utf8_symbol(t.xl, s, i, olen, L); };
+    // the wide layout mirrors the kernels too: 32-bit entries, a checkpoint every 32 boundaries kept as two
+    // 16-bit halves in the slots the narrow layout would use for boundaries 32k and 32k + 16
+    const int CHKW = t.wide ? 2 * CHK : CHK;
     std::vector<uint16_t> chk(len / CHK + 2);
+    auto chk_put = [&](int tt, int R) {
+        if (!t.wide) chk[tt / CHK] = (uint16_t) R;
+        else { chk[(tt / CHKW) * 2] = (uint16_t) (R & 0xFFFF); chk[(tt / CHKW) * 2 + 1] = (uint16_t) ((uint32_t) R >> 16); }
+    };
+    auto chk_get = [&](int tt) -> int {
+        return !t.wide ? (int) chk[tt / CHK] : (int) ((uint32_t) chk[(tt / CHKW) * 2] | ((uint32_t) chk[(tt / CHKW) * 2 + 1] << 16));
+    };
     int R = t.r_init, best = -1;
     int h1 = -1, h2 = -1;                     // best as it was 1/2 boundaries to the right
-    chk[0] = (uint16_t) R;
+    chk_put(0, R);
     for (int i = len - 1; i >= 0; i--) {
         int L = 1;
-        uint16_t e = t.rdelta[(size_t) R * t.ncls + t.cls[sym(i, &L)]];
-        if ((e & 0x7FFF) == R_POISON) return -3;
+        bool st;
+        if (t.wide) {
+            uint32_t e = t.rdelta32[(size_t) R * t.ncls + t.cls[sym(i, &L)]];
+            st = (e >> 31) != 0; R = (int) (e & 0x7FFFFFFFu);
+        }
+        else {
+            uint16_t e = t.rdelta[(size_t) R * t.ncls + t.cls[sym(i, &L)]];
+            if ((e & 0x7FFF) == R_POISON) return -3;
+            st = (e & 0x8000) != 0; R = e & 0x7FFF;
+        }
         int before = best;
-        if (e & 0x8000) best = i + 1;
-        R = e & 0x7FFF;
+        if (st) best = i + 1;
         int tt = len - i;                     // distance of boundary i from the end
-        if (tt % CHK == 0) chk[tt / CHK] = (uint16_t) R;
+        if (tt % CHKW == 0) chk_put(tt, R);
         if (!t.ascii_only) {
             // a match may only start on a character boundary (onig_search advances by enclen):
             // boundaries strictly inside the well-formed sequence that starts here are not start candidates
@@ -1591,9 +1635,11 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int olen, int 
         }
         else {
             g_stat_multi++;
-            int t0 = ((len - j) / CHK) * CHK, b0 = len - t0;
-            int r = chk[t0 / CHK];
-            for (int i = b0 - 1; i >= j; i--) r = t.rdelta_p[((size_t) r << t.cls_shift) + t.cls[sym(i, nullptr)]] & 0x7FFF;   // never poisoned here
+            int t0 = ((len - j) / CHKW) * CHKW, b0 = len - t0;
+            int r = chk_get(t0);
+            for (int i = b0 - 1; i >= j; i--)                                   // never poisoned here
+                r = t.wide ? (int) (t.rdelta32_p[((size_t) r << t.cls_shift) + t.cls[sym(i, nullptr)]] & 0x7FFFFFFFu)
+                           : (int) (t.rdelta_p[((size_t) r << t.cls_shift) + t.cls[sym(i, nullptr)]] & 0x7FFF);
             for (uint32_t k = t.list_off[li]; k < t.list_off[li + 1]; k++) {
                 uint32_t ent = t.list_ent[k];
                 uint32_t tg = ent & 0xFFFF;
@@ -1625,6 +1671,11 @@ void debug_stats(long *out) { out[0] = g_stat_fast; out[1] = g_stat_look; out[2]
 
 int simulate_match(const Program &p, const uint8_t *s, int len) {
     const TableSet &t = p.ascii;
+    if (t.nD == 0) {                          // no match-only DFA (see compile): the capture program answers
+        std::vector<int> b(p.ngroups + 1), e(p.ngroups + 1);
+        int r = simulate_capture(p, s, len, b.data(), e.data());
+        return r >= 0 ? 1 : r == -1 ? 0 : r;
+    }
     int st = t.d_init;
     for (int i = 0; i < len; i++) {
         uint16_t n = t.ddelta[(size_t) st * t.ncls + t.cls[s[i]]];

@@ -91,6 +91,14 @@ struct TableSet {
     //             holds FC_LOOK | m and fast2[m][class of byte j+1] is consulted (same encoding)
     int cls_shift = 0, fc_shift = 0;
     std::vector<uint16_t> rdelta_p;           // [nR + 1][1 << cls_shift]
+    // WIDE reverse automaton (utf8 set only: the ASCII set is what the hot kernels step and stays narrow).
+    // A capture automaton of more than 0x7FF0 states (stock parsers `envoy`, `ambassador`: 33 k / 96 k states
+    // once every class is spelled out in UTF-8 sequences) keeps its transitions as 32-bit entries, bit 31 = a
+    // match may start here, no POISON row in use.  rdelta / rdelta_p are empty then; the generic kernels walk
+    // rdelta32_p straight from HBM and keep a checkpoint every 32 boundaries in two 16-bit halves.
+    bool wide = false;
+    std::vector<uint32_t> rdelta32;           // [nR][ncls]
+    std::vector<uint32_t> rdelta32_p;         // [nR + 1][1 << cls_shift]
     std::vector<uint8_t> ck;                  // [256]
     std::vector<uint32_t> fast2;              // [nmulti][1 << fc_shift]
     // ---- what the kernels step through (derived from fastc/fast2 by encode_kernel_tables):

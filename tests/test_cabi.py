@@ -75,6 +75,73 @@ def test_regex_tables_against_golden(g):
     assert checked > 15000
 
 
+def _sim(L, h, s):
+    beg = (ctypes.c_int * 40)(); end = (ctypes.c_int * 40)()
+    n = L.flbgpu_rx_simulate_capture(h, s, len(s), beg, end)
+    return None if n == -1 else [(beg[i], end[i]) for i in range(n)]
+
+
+def test_wide_reverse_tables_stock_parsers(g):
+    """`envoy` and `ambassador` (conf/parsers.conf:102, conf/parsers_ambassador.conf:4) compile since round 2: the
+    UTF-8 capture automaton keeps 32-bit transitions (33 k / 96 k states), ambassador's match-only DFA is left out.
+    The tables executed on the host against the real Onigmo (the oracle's engine where the reference is absent)."""
+    import rxdiff, stock_wide
+    L = g.lib()
+    ref = rxdiff.load_ref()
+    orx = rxdiff.load_orx()
+    for pat, prefix in ((stock_wide.ENVOY, b""), (stock_wide.AMBASSADOR, b"ACCESS ")):
+        pat = pat.encode()
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        assert h, err.value
+        info = (ctypes.c_int * 16)()
+        L.flbgpu_rx_info(h, info)
+        assert info[2] <= 0x7FF0 < info[7], list(info)               # ascii narrow, utf8 wide
+        eng = rxdiff.RefRegex(ref, pat) if ref else rxdiff.OrxRegex(orx, pat)
+        assert eng.ok
+        hit = 0
+        for s in stock_wide.lines(1500, 11, prefix):
+            want = eng.search(s)
+            assert _sim(L, h, s) == want, (pat[:20], s)
+            assert L.flbgpu_rx_simulate_match(h, s, len(s)) == (0 if want is None else 1)
+            hit += want is not None
+        assert 600 < hit < 1500, hit
+        L.flbgpu_rx_free(h)
+    # still over every budget: fails loudly at create
+    with pytest.raises(ValueError):
+        g.Parser(stock_wide.ENVOY.replace("(?<code>", "(?<response_code>").replace('"(?<upstream_host>[^ ]*)"',
+                 '"(?<upstream_host>[^ ]*)" ' + " ".join("(?<f%d>[^ ]*)" % i for i in range(6)) + "$"))
+
+
+def test_wide_reverse_tables_forced_on_golden(g, monkeypatch):
+    """FLBGPU_RX_FORCE_WIDE makes every utf8 table set wide: the golden answers with bytes >= 0x80 through the 32-bit
+    tables and the two-half checkpoints."""
+    monkeypatch.setenv("FLBGPU_RX_FORCE_WIDE", "1")
+    L = g.lib()
+    kat = json.load(open(os.path.join(HERE, "golden", "regex_kat.json")))
+    checked = 0
+    for ent in kat:
+        pat = base64.b64decode(ent["pattern"])
+        if not ent["compiles"] or any(t in pat for t in (rb'[:', rb'\b', rb'\B')):
+            continue
+        cases = [(base64.b64decode(a), w) for a, w in ent["cases"]]
+        cases = [c for c in cases if any(b >= 0x80 for b in c[0])]
+        if not cases:
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        if not h:
+            continue
+        info = (ctypes.c_int * 16)()
+        L.flbgpu_rx_info(h, info)
+        for s, want in cases:
+            got = _sim(L, h, s)
+            assert got == (None if want is None else [tuple(x) for x in want]), (pat, s)
+            checked += 1
+        L.flbgpu_rx_free(h)
+    assert checked > 4000, checked
+
+
 def test_index_host(g):
     import synth
     data, off, ep = synth.apache_records(100)

@@ -257,3 +257,37 @@ def test_illformed_utf8_through_stock_patterns(g):
     for rules in ([("regex", r"agent [^ ]+ \S+"), ("exclude", "user .")], [("regex", "log \u00e9"), ("regex", 'log "[^"]*\u20ac')]):
         a, b = both_grep(g, blob, rules, "OR" if len(rules) == 2 and rules[0][0] == rules[1][0] else None)
         assert a == b, (rules, first_diff(a[1], b[1]))
+
+
+def test_wide_reverse_tables_on_device(g, monkeypatch):
+    """Stock parsers `envoy` / `ambassador` (conf/parsers.conf:102, conf/parsers_ambassador.conf:4): their UTF-8 capture
+    automaton has more than 0x7FF0 states and is walked from 32-bit tables in HBM (rx.hpp `wide`; kdev.inc
+    rx_reverse<wide>, rx_resolve_multi).  Lines with ill-formed UTF-8 go that way; byte-identical to the oracle.  Then
+    the same walkers under every utf8 set of the apache case (FLBGPU_RX_FORCE_WIDE)."""
+    import stock_wide
+    from test_gpu_parity import both_parser, both_grep, APACHE2, TF
+    for pat, prefix, tkey in ((stock_wide.ENVOY, b"", "start_time"), (stock_wide.AMBASSADOR, b"ACCESS ", None)):
+        blob = b"".join(_rec({"log": s}, 100 + i, i) for i, s in enumerate(stock_wide.lines(4000, 23, prefix)))
+        pa = dict(regex=pat)
+        if tkey:
+            pa.update(time_fmt=stock_wide.ENVOY_TIME_FMT, time_key=tkey)
+        o, q = both_parser(g, blob, "log", [pa], reserve=True)
+        assert o == q, first_diff(o[1], q[1])
+        assert ob.count_records(o[1]) == 4000
+    monkeypatch.setenv("FLBGPU_RX_FORCE_WIDE", "1")
+    import random
+    rng = random.Random(9)
+    data, off, ep = synth.apache_records(2000)
+    recs = []
+    for i in range(2000):
+        m = bytearray(data[int(off[i]) + 21:int(off[i + 1])])
+        for _ in range(rng.randint(1, 3)):
+            k = rng.randrange(len(m) + 1)
+            m[k:k] = rng.choice(stock_wide.FRAG[:12])
+        recs.append(_rec({"log": bytes(m)}, i, i))
+    blob = b"".join(recs)
+    o, q = both_parser(g, blob, "log", [dict(regex=APACHE2, time_fmt=TF, time_key="time")])
+    assert o == q, first_diff(o[1], q[1])
+    for rules in ([("regex", "log é"), ("regex", 'log "[^"]*€')], [("exclude", "log [à-ÿ]{1,2} ")]):
+        a, b = both_grep(g, blob, rules, "OR" if len(rules) == 2 else None)
+        assert a == b, (rules, first_diff(a[1], b[1]))
