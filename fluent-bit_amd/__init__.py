@@ -344,14 +344,18 @@ class StreamTask:
                                        POINTER(c_int64)]
         L.flbgpu_sp_timer.argtypes = [c_void_p, ctypes.c_uint32, ctypes.c_uint32, POINTER(c_void_p), POINTER(c_size_t)]
         L.flbgpu_sp_set_index_base.argtypes = [c_void_p, c_uint64]
+        L.flbgpu_sp_hop.argtypes = [c_void_p]
+        L.flbgpu_sp_window_advance.restype = c_int64
+        L.flbgpu_sp_window_advance.argtypes = [c_void_p]
         L.flbgpu_sp_profile.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_uint64)]
         self.h = L.flbgpu_sp_create(_b(sql), int(bool(str_conv)))
         if not self.h:
             raise ValueError(last_error())
         wt = c_int(); ws = c_int64(); st = c_int(); src = c_char_p(); name = c_char_p()
         L.flbgpu_sp_info(self.h, byref(wt), byref(ws), byref(st), byref(src), byref(name))
-        self.window = "tumbling" if wt.value == 1 else "default"
+        self.window = "hopping" if wt.value == 2 else "tumbling" if wt.value == 1 else "default"
         self.window_size = int(ws.value)
+        self.window_advance = int(L.flbgpu_sp_window_advance(self.h))
         self.source_type = "tag" if st.value == 1 else "stream"
         self.source = src.value.decode()
         self.stream_name = name.value.decode() if name.value else None
@@ -391,6 +395,12 @@ class StreamTask:
         if r != 0:
             raise RuntimeError(last_error())
         return self._take(out, sz)
+
+    def hop(self):
+        """the hop timer of a HOPPING window fires (every window_advance seconds): a slot is closed"""
+        if lib().flbgpu_sp_hop(self.h) != 0:
+            raise RuntimeError(last_error())
+        return 0
 
     def set_index_base(self, base):
         lib().flbgpu_sp_set_index_base(self.h, base)

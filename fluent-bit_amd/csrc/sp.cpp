@@ -1,13 +1,14 @@
 // sp.cpp -- the stream processor's aggregate queries behind the C ABI (include/flb_gpu.h, flbgpu_sp_*):
-//   SELECT keys / COUNT SUM AVG MIN MAX FROM STREAM:x | TAG:'m' [WINDOW TUMBLING (n SECOND|MINUTE|HOUR)] [WHERE cond] [GROUP BY keys];
+//   SELECT keys / COUNT SUM AVG MIN MAX FROM STREAM:x | TAG:'m' [WINDOW TUMBLING (n unit) | HOPPING (n unit, ADVANCE BY m unit)]
+//   [WHERE cond] [GROUP BY keys];
 // replaces, for those queries, flb_sp_task_create (src/stream_processor/flb_sp.c:433-560), flb_sp_do's aggregate branch
 // (:2007-2097 -> sp_process_data_aggr :1435-1601) and the window timer of flb_sp_fd_event (:2101-2160 -> package_results
-// :1161-1278, flb_sp_window_prune flb_sp_window.c:26-50).
+// :1161-1278, flb_sp_window_prune flb_sp_window.c:26-104) and, for HOPPING windows, its hop timer (sp_process_hopping_slot :1852-2004).
 //
 // Host side: the SQL front end (the token rules of parser/sql.l and the grammar of parser/sql.y, restated -- flex / bison
 // resolve the precedence-less AND / OR / NOT rules by shifting: right-associative, NOT takes everything after it), the plan
 // the kernels interpret, and package_results over the order-independent group rows the kernels maintain (dev.hpp, SpArgs).
-// Queries outside that set (HOPPING, TIMESERIES_FORECAST, snapshots, plain SELECTs) are refused at create time; inputs on
+// Queries outside that set (TIMESERIES_FORECAST, snapshots, plain SELECTs) are refused at create time; inputs on
 // which the reference's own result depends on the rb-tree's shape (a GROUP BY column mixing numbers and strings, NaN keys)
 // make the call fail instead of answering something else.
 #include <hip/hip_runtime.h>
@@ -16,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <deque>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/flb_gpu.h"
@@ -135,8 +138,8 @@ struct Query {
     std::vector<KeyName> gb;
     std::vector<Node> nodes;
     int cond = -1;
-    int window = 0;             // 0 default, 1 tumbling
-    int64_t window_sec = 0;
+    int window = 0;             // 0 default, 1 tumbling, 2 hopping
+    int64_t window_sec = 0, advance_sec = 0;
     int source_type = 0;        // 0 stream, 1 tag
     std::string source, stream_name;
     std::vector<std::pair<std::string, std::string>> props;
@@ -310,13 +313,27 @@ struct Parser {
         }
         else return fail("STREAM: or TAG: expected");
         if (eat(TK_KW, "WINDOW")) {
-            if (eat(TK_KW, "HOPPING")) return fail("HOPPING windows are not supported");
-            if (!need(TK_KW, "TUMBLING") || !need(TK_CH, "(")) return false;
+            // sql.y:269-278: TUMBLING '(' INTEGER time ')' | HOPPING '(' INTEGER time ',' ADVANCE_BY INTEGER time ')'
+            const bool hopping = eat(TK_KW, "HOPPING");
+            if (!hopping && !need(TK_KW, "TUMBLING")) return false;
+            if (!need(TK_CH, "(")) return false;
             if (!is(TK_INT)) return fail("window size expected");
             int64_t n = cur().i, m = 1;
             i++;
-            if (!time_unit(m) || !need(TK_CH, ")")) return false;
+            if (!time_unit(m)) return false;
             q.window = 1; q.window_sec = n * m;
+            if (hopping) {
+                if (!need(TK_CH, ",") || !need(TK_KW, "ADVANCE BY")) return false;
+                if (!is(TK_INT)) return fail("ADVANCE BY size expected");
+                int64_t an = cur().i, am = 1;
+                i++;
+                if (!time_unit(am)) return false;
+                q.window = 2; q.advance_sec = an * am;
+                // flb_sp_cmd_window returns -1 for this (parser/flb_sp_parser.c:552) but the grammar action drops the result and the
+                // task would run with a window that never prunes
+                if (q.advance_sec >= q.window_sec) return fail("HOPPING window that advances by its size or more");
+            }
+            if (!need(TK_CH, ")")) return false;
         }
         if (eat(TK_KW, "WHERE")) { q.cond = condition(); if (q.cond < 0) return fail("condition expected"); }
         if (eat(TK_KW, "GROUP BY")) {
@@ -380,6 +397,14 @@ struct flbgpu_sp {
     uint64_t idx_base = 0;
     uint64_t records = 0;               // task->window.records
     unsigned int col_class[SP_MAX_GB] = {0, 0, 0, 0};
+    // HOPPING (flb_sp.c:1852-2004 sp_process_hopping_slot, flb_sp_window.c:57-104): the device rows hold what a group gained
+    // since its node was created; what the pruned slots took away again lives here, and the slots themselves
+    struct HopNum { bool f = false; int64_t i64 = 0; double f64 = 0; };       // aggregate_num of a SUM / AVG key: type, i64, f64
+    struct HopNode { int64_t records = 0; std::vector<HopNum> src; };
+    struct HopSlot { std::map<std::string, HopNode> nodes; int64_t records = 0; };
+    struct HopLife { int64_t rm_records = 0; std::vector<int64_t> rm_i; std::vector<double> rm_f; };
+    std::deque<HopSlot> hop_slots;                                            // task->window.hopping_slot, oldest first
+    std::map<std::string, HopLife> hop_life;
     KernelProf kp[2] = {{"k_sp_extract"}, {"k_sp_aggregate"}};
     bool prof = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -566,7 +591,7 @@ uint64_t unord_f(uint64_t o) { return (o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : 
 // ---- the window's state on the host: live groups (typed key tuple as stored in the arena + the row words), the record count
 // and the class mask of every GROUP BY column.  Snapshots of shards merge word by word (max / add), which is what the
 // multi-GPU exchange ships.
-struct Group { std::string key; std::vector<uint64_t> row; };
+struct Group { std::string key; std::vector<uint64_t> row; uint32_t idx = 0; };
 struct Snapshot {
     uint64_t records = 0;
     unsigned int col_class[SP_MAX_GB] = {0, 0, 0, 0};
@@ -600,6 +625,7 @@ bool snapshot(flbgpu_sp *t, Snapshot &sn) {
         Group gr;
         if (pl.ngb) gr.key.assign((const char *) arena.data() + koff[g], klen[g]);
         gr.row.assign(rows.begin() + g * W, rows.begin() + (g + 1) * W);
+        gr.idx = g;
         sn.groups.push_back(std::move(gr));
     }
     return true;
@@ -684,7 +710,10 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
                 else { memcpy(&gu[k], p, 8); p += 8; }
             }
         }
-        const uint64_t records = row[A];
+        // HOPPING: minus what the pruned slots took from this node (aggregate_func_remove_sum; MIN / MAX / the type stay)
+        const flbgpu_sp::HopLife *lf = nullptr;
+        if (t->q.window == 2) { auto it = t->hop_life.find(grp.key); if (it != t->hop_life.end()) lf = &it->second; }
+        const uint64_t records = row[A] - (lf ? (uint64_t) lf->rm_records : 0);
         out.push_back((char) 0x92);
         out.push_back((char) 0xd7); out.push_back((char) 0x00);
         pk_be(out, now_sec, 4); pk_be(out, now_nsec, 4);
@@ -710,6 +739,10 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
                 double dsum = 0;
                 int64_t isum = (int64_t) ad[SP_A_ISUM];
                 if (is_f64) dsum = bits_double(l2m_limbs_bits(ad + SP_A_LIMB, ad[SP_A_NAN], ad[SP_A_PINF], ad[SP_A_NINF]));
+                if (lf) {
+                    if (is_f64) dsum = dsum - (double) lf->rm_i[src] - lf->rm_f[src];
+                    else isum = (int64_t) ((uint64_t) isum - (uint64_t) lf->rm_i[src]);
+                }
                 if (k.func == F_SUM) { if (is_f64) pk_float(out, dsum); else pk_int64(out, isum); }
                 else pk_float(out, (is_f64 ? dsum : (double) isum) / (double) (int64_t) records);
                 continue;
@@ -784,6 +817,11 @@ bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
                     "rb-tree comparator is not an order there, flb_sp_groupby.c:77)", g);
             return false;
         }
+        if (t->q.window == 2 && (m & 4)) {
+            set_err("stream processor: string GROUP BY value in a HOPPING window (a slot's nodes share the key's string with the window's "
+                    "node and both free it, flb_sp.c:1985: the reference dies with a double free)");
+            return false;
+        }
         t->col_class[g] = m;
     }
     SpAggArgs g;
@@ -795,6 +833,103 @@ bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
     HIPOK(hipStreamSynchronize(st));
     t->idx_base += n;
     t->records += hm.counts[0];
+    return true;
+}
+
+// ---- HOPPING windows on the host.  The view of a live node: the device row (everything since the node was created) minus
+// what flb_sp_window_prune took away again.  aggregate_num is a struct, not a union: an I64-typed num has f64 == 0.0, and the
+// i64 of an F64-typed one is stale (its value when the first non-zero float arrived) -- the one thing the rows cannot give.
+// It is only read when an I64-typed node meets an F64-typed slot of an earlier life of the same group: refused.
+flbgpu_sp::HopNode hop_view(flbgpu_sp *t, const Group &grp) {
+    const SpPlan &pl = t->plan;
+    const size_t A = 1 + (size_t) SP_SRC_MAX * pl.nsrc;
+    const uint64_t *row = grp.row.data();
+    const flbgpu_sp::HopLife *lf = nullptr;
+    auto it = t->hop_life.find(grp.key);
+    if (it != t->hop_life.end()) lf = &it->second;
+    flbgpu_sp::HopNode n;
+    n.records = (int64_t) row[A] - (lf ? lf->rm_records : 0);
+    n.src.resize((size_t) pl.nsrc);
+    for (int s = 0; s < pl.nsrc; s++) {
+        const uint64_t *ad = row + A + 1 + (size_t) SP_SRC_ADD * s;
+        flbgpu_sp::HopNum &x = n.src[(size_t) s];
+        x.f = ad[SP_A_NFLT] > 0;
+        const int64_t rmi = lf ? lf->rm_i[(size_t) s] : 0;
+        if (x.f) x.f64 = bits_double(l2m_limbs_bits(ad + SP_A_LIMB, ad[SP_A_NAN], ad[SP_A_PINF], ad[SP_A_NINF])) - (double) rmi - (lf ? lf->rm_f[(size_t) s] : 0.0);
+        else x.i64 = (int64_t) (ad[SP_A_ISUM] - (uint64_t) rmi);
+    }
+    return n;
+}
+
+// the sources a SUM / AVG key reads (aggregate_func_remove_sum runs for those keys only)
+std::vector<char> hop_sum_sources(const flbgpu_sp *t) {
+    std::vector<char> u((size_t) std::max(t->plan.nsrc, 1), 0);
+    for (size_t ki = 0; ki < t->q.keys.size(); ki++)
+        if ((t->q.keys[ki].func == F_SUM || t->q.keys[ki].func == F_AVG) && t->key_src[ki] >= 0) u[(size_t) t->key_src[ki]] = 1;
+    return u;
+}
+
+bool hop_stale(const char *where) {
+    set_err("stream processor: HOPPING window, %s: an int-typed node meets a float-typed slot of an earlier life of the same group "
+            "(the reference subtracts the slot's stale i64, which depends on arrival order)", where);
+    return false;
+}
+
+// sp_process_hopping_slot: the slot = a clone of every live node minus the slots still in the list
+bool hop_slot(flbgpu_sp *t) {
+    Snapshot sn;
+    if (!snapshot(t, sn)) return false;
+    const std::vector<char> used = hop_sum_sources(t);
+    flbgpu_sp::HopSlot hs;
+    for (const Group &grp : sn.groups) {
+        flbgpu_sp::HopNode c = hop_view(t, grp);
+        for (const flbgpu_sp::HopSlot &prev : t->hop_slots) {
+            auto it = prev.nodes.find(grp.key);
+            if (it == prev.nodes.end()) continue;
+            c.records -= it->second.records;
+            for (size_t s = 0; s < c.src.size(); s++) {
+                if (!used[s]) continue;
+                const flbgpu_sp::HopNum &p = it->second.src[s];
+                if (!c.src[s].f) { if (p.f) return hop_stale("closing a slot"); c.src[s].i64 = (int64_t) ((uint64_t) c.src[s].i64 - (uint64_t) p.i64); }
+                else c.src[s].f64 -= p.f64;
+            }
+        }
+        if (c.records > 0) hs.nodes.emplace(grp.key, std::move(c));
+    }
+    hs.records = (int64_t) t->records;
+    for (const flbgpu_sp::HopSlot &prev : t->hop_slots) hs.records -= prev.records;
+    t->hop_slots.push_back(std::move(hs));
+    return true;
+}
+
+// flb_sp_window_prune, FLB_SP_WINDOW_HOPPING: the oldest slot leaves the window
+bool hop_prune(flbgpu_sp *t, const Snapshot &sn) {
+    if (t->hop_slots.empty()) return true;
+    const flbgpu_sp::HopSlot &hs = t->hop_slots.front();
+    const std::vector<char> used = hop_sum_sources(t);
+    L2mState &st = t->tab;
+    for (const Group &grp : sn.groups) {
+        auto it = hs.nodes.find(grp.key);
+        if (it == hs.nodes.end()) continue;
+        const flbgpu_sp::HopNode node = hop_view(t, grp);
+        if (it->second.records == node.records) {
+            // the node is destroyed: its row starts over (a later record creates a new node at the end of the list)
+            HIPOK(hipMemset((uint8_t *) st.d_rows.p + (size_t) grp.idx * st.W * 8, 0, (size_t) st.W * 8));
+            t->hop_life.erase(grp.key);
+            continue;
+        }
+        flbgpu_sp::HopLife &lf = t->hop_life[grp.key];
+        if (lf.rm_i.empty()) { lf.rm_i.assign(node.src.size(), 0); lf.rm_f.assign(node.src.size(), 0.0); }
+        lf.rm_records += it->second.records;
+        for (size_t s = 0; s < node.src.size(); s++) {
+            if (!used[s]) continue;
+            const flbgpu_sp::HopNum &p = it->second.src[s];
+            if (!node.src[s].f) { if (p.f) return hop_stale("pruning"); lf.rm_i[s] = (int64_t) ((uint64_t) lf.rm_i[s] + (uint64_t) p.i64); }
+            else lf.rm_f[s] += p.f64;
+        }
+    }
+    t->records -= (uint64_t) hs.records;
+    t->hop_slots.pop_front();
     return true;
 }
 
@@ -884,6 +1019,7 @@ extern "C" int flbgpu_sp_parse_check(const char *sql, char *desc, size_t cap) {
     o += ";gb=";
     for (int g = 0; g < pl.ngb; g++) o += (g ? "|" : "") + keyname(pl.gb_key[g]);
     o += ";window=" + std::to_string(t.q.window) + ":" + std::to_string((long long) t.q.window_sec);
+    if (t.q.window == 2) o += ":" + std::to_string((long long) t.q.advance_sec);
     o += ";source=" + std::to_string(t.q.source_type) + ":" + t.q.source + ";stream=" + t.q.stream_name + ";where=";
     static const char *OPN[] = {"EQ", "LT", "LTE", "GT", "GTE", "TRUTH", "NOT", "AND", "OR"};
     for (int i = 0; i < pl.nops; i++) {
@@ -965,6 +1101,21 @@ extern "C" int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec
     if (!t) { set_err("stream processor: null argument"); return -1; }
     if (out_buf) *out_buf = nullptr;
     if (out_size) *out_size = 0;
+    if (t->q.window == 2) {
+        // flb_sp_fd_event, the window.fd branch: package when the window holds records, then the oldest slot leaves
+        std::string out;
+        Snapshot sn;
+        if (!snapshot(t, sn)) return -1;
+        if (t->records > 0 && !package(t, sn, now_sec, now_nsec, out)) return -1;
+        if (!hop_prune(t, sn)) return -1;
+        if (out_buf && out_size && !out.empty()) {
+            *out_buf = malloc(out.size());
+            if (!*out_buf) { set_err("out of memory"); return -1; }
+            memcpy(*out_buf, out.data(), out.size());
+            *out_size = out.size();
+        }
+        return 0;
+    }
     if (t->records > 0) {
         std::string out;
         Snapshot sn;
@@ -980,11 +1131,20 @@ extern "C" int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec
     return 0;
 }
 
+// the hop timer of a HOPPING window (flb_sp_fd_event, the window.fd_hop branch): fires every ADVANCE BY seconds
+extern "C" int flbgpu_sp_hop(flbgpu_sp *t) {
+    if (!t) { set_err("stream processor: null argument"); return -1; }
+    if (t->q.window != 2) { set_err("stream processor: not a HOPPING window"); return -1; }
+    return hop_slot(t) ? 0 : -1;
+}
+extern "C" int64_t flbgpu_sp_window_advance(const flbgpu_sp *t) { return t ? t->q.advance_sec : -1; }
+
 // ---- multi-GPU: the shards of one window.  Every rank runs flbgpu_sp_do on its own records (flbgpu_sp_set_index_base gives the
 // ranks disjoint record index ranges: first-seen order across shards); when the window's timer fires the ranks exchange their
 // group states and every rank packages the same merged result.
 extern "C" int64_t flbgpu_sp_export(flbgpu_sp *t, void *buf, size_t cap) {
     if (!t) { set_err("stream processor: null argument"); return -1; }
+    if (t->q.window == 2) { set_err("stream processor: HOPPING windows are not sharded (their slots live on the host of one task)"); return -1; }
     Snapshot sn;
     if (!snapshot(t, sn)) return -1;
     const std::string o = serialize(sn, t->tab.W);

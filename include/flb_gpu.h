@@ -260,8 +260,9 @@ int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_of
  * keys may carry sub-keys (k['a']['b']); conditions: key|@record.time()|@record.contains(key) =,!=,<>,<,<=,>,>= constant,
  * key IS [NOT] NULL, NOT / AND / OR / parentheses with the reference's (precedence-less, right-associative) binding.
  * str_conv = the engine's stream_processor_str_conv (src/flb_config.c:482, default on): numeric strings count as numbers.
- * NULL (flbgpu_last_error says why) for what flb_sp_task_create rejects and for what this path does not take: HOPPING
- * windows, TIMESERIES_FORECAST, time / record functions as select keys, snapshots, SELECTs without an aggregate.
+ * NULL (flbgpu_last_error says why) for what flb_sp_task_create rejects and for what this path does not take:
+ * TIMESERIES_FORECAST, time / record functions as select keys, snapshots, SELECTs without an aggregate, a HOPPING window that
+ * advances by its size or more.
  * State lives in HBM as order-independent integer words per group (counts, wrapping int64 sums, exact fixed-point sums,
  * min / max): chunks and GPUs can be visited in any order; float SUM / AVG are the exact sum rounded once where the
  * reference adds sequentially (both leave as float32: msgpack_pack_float). */
@@ -269,7 +270,7 @@ typedef struct flbgpu_sp flbgpu_sp;
 flbgpu_sp *flbgpu_sp_create(const char *sql, int str_conv);
 void flbgpu_sp_destroy(flbgpu_sp *t);
 /* window_type 0 none (results are packaged per chunk) / 1 tumbling (the caller's timer calls flbgpu_sp_timer every
- * window_sec seconds); source_type 0 STREAM: / 1 TAG:; stream_name NULL unless CREATE STREAM */
+ * window_sec seconds) / 2 hopping (see flbgpu_sp_hop); source_type 0 STREAM: / 1 TAG:; stream_name NULL unless CREATE STREAM */
 int flbgpu_sp_info(const flbgpu_sp *t, int *window_type, int64_t *window_sec, int *source_type, const char **source, const char **stream_name);
 const char *flbgpu_sp_stream_prop(const flbgpu_sp *t, const char *key);        /* WITH (tag='...') */
 int flbgpu_sp_key_count(const flbgpu_sp *t);
@@ -285,6 +286,16 @@ int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uin
                      size_t *out_size, int64_t *records);
 /* the window's timer fired: package (if the window saw records) and prune */
 int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf, size_t *out_size);
+/* WINDOW HOPPING (n unit, ADVANCE BY m unit) -- replaces flb_sp_fd_event's window.fd_hop branch (src/stream_processor/flb_sp.c:2170-2185
+ * -> sp_process_hopping_slot :1852-2004) and flb_sp_window_prune's HOPPING branch (flb_sp_window.c:57-104).  The caller arms the
+ * two timers the reference arms (flb_sp.c:517-545, :2119-2140): flbgpu_sp_hop every flbgpu_sp_window_advance() seconds, and
+ * flbgpu_sp_timer first after window_sec seconds, then every advance seconds.  The hop closes a slot (what the window gained
+ * since the previous one); the timer packages the window and drops its oldest slot: counts and SUM / AVG lose the slot's
+ * share, MIN / MAX and the int / float type of a sum stay as long as the group's node lives -- as in the reference.
+ * -1: a string GROUP BY value (the reference frees the key twice and dies), or an int-typed node that meets a float-typed slot
+ * of an earlier life of its group (the reference's answer then depends on arrival order). */
+int flbgpu_sp_hop(flbgpu_sp *t);
+int64_t flbgpu_sp_window_advance(const flbgpu_sp *t);
 /* the SQL front end alone (needs no device): 0 and a canonical text of the plan in desc, -1 when the query is refused */
 int flbgpu_sp_parse_check(const char *sql, char *desc, size_t cap);
 /* global index of the next record (first-seen order of groups across shards) */

@@ -16,7 +16,7 @@ the I64 -> F64 switch of a sum at the first non-zero float):
 Pinned on the reference itself: tests/test_sp_oracle.py runs the same queries over the same chunks through
 oracle/_ref/ref_sp (the reference's own sources compiled in place) and wants identical bytes.
 
-Not restated (Unsupported is raised, the product refuses the same queries): HOPPING windows, TIMESERIES_FORECAST, snapshots,
+Not restated (Unsupported is raised, the product refuses the same queries): TIMESERIES_FORECAST, snapshots,
 non-aggregate SELECTs; a GROUP BY column whose values mix number / string classes in one window (the reference's rb-tree
 comparator is not an order there: flb_sp_groupby.c:77 "Sides have different types -> -1", and it rewrites nodes in place :37-44).
 
@@ -119,7 +119,7 @@ class Cond:
 class Query:
     def __init__(self):
         self.keys, self.gb_keys, self.cond = [], [], None
-        self.window, self.window_size = "default", 0
+        self.window, self.window_size, self.advance_by = "default", 0, 0
         self.source_type, self.source, self.stream_name, self.props, self.limit = None, None, None, [], 0
 
     def finish(self):
@@ -309,7 +309,18 @@ class _P:
                 q.window, q.window_size = "tumbling", n * self.time_unit()
                 self.need("ch", ")")
             elif self.eat("kw", "HOPPING"):
-                raise Unsupported("HOPPING window")
+                # sql.y:275-278: HOPPING '(' INTEGER time ',' ADVANCE_BY INTEGER time ')'; flb_sp_cmd_window's -1 for
+                # advance_by >= size is not looked at by the grammar action (the product refuses those queries)
+                self.need("ch", "(")
+                n = self.need("int")
+                size = n * self.time_unit()
+                self.need("ch", ",")
+                self.need("kw", "ADVANCE BY")
+                a = self.need("int")
+                q.window, q.window_size, q.advance_by = "hopping", size, a * self.time_unit()
+                self.need("ch", ")")
+                if q.advance_by >= q.window_size:
+                    raise Unsupported("HOPPING window that advances by its size or more")
             else:
                 raise ParseError("window")
         if self.eat("kw", "WHERE"):
@@ -603,12 +614,13 @@ class Task:
         self.order = []
         self.records = 0
         self.col_class = [None] * len(self.q.gb_keys)
+        self.slots = []           # HOPPING: task->window.hopping_slot, oldest first
 
     def _group(self, m):
         q = self.q
         if not q.gb_keys:
             if not self.order:
-                node = {"records": 1, "nums": [_Num() for _ in q.keys], "gb": None}
+                node = {"records": 1, "nums": [_Num() for _ in q.keys], "gb": None, "canon": ()}
                 self.order.append(node)
             else:
                 node = self.order[0]
@@ -649,10 +661,14 @@ class Task:
             canon.append((cls, g.string if cls == "s" else g.i64 if cls == "i" else (g.f64 + 0.0)))
             if cls == "s" and b"\0" in g.string:
                 raise Unsupported("NUL in a string group key (strcmp)")
+            if cls == "s" and self.q.window == "hopping":
+                # a slot's nodes share the sds of a string key with the window's node (memcpy of groupby_nums / nums,
+                # flb_sp.c:1900,1985) and both destroy it: the reference binary dies with a double free
+                raise Unsupported("string GROUP BY key in a HOPPING window (the reference frees the key twice)")
         canon = tuple(canon)
         node = self.groups.get(canon)
         if node is None:
-            node = {"records": 1, "nums": [_Num() for _ in q.keys], "gb": gb}
+            node = {"records": 1, "nums": [_Num() for _ in q.keys], "gb": gb, "canon": canon}
             self.groups[canon] = node
             self.order.append(node)
         else:
@@ -700,6 +716,9 @@ class Task:
                         elif isinstance(v, float):
                             num.type, num.f64 = "f", v
                         elif isinstance(v, str):
+                            if q.window == "hopping":
+                                # (also when str_conv turns the value into a number for the GROUP BY column: nums[] keeps the sds)
+                                raise Unsupported("string value under a plain select key in a HOPPING window (the reference frees it twice)")
                             num.type = "s"
                             if num.string is None:
                                 num.string = _b(v)
@@ -764,7 +783,57 @@ class Task:
             out.append(bytes(rec))
         return b"".join(out)
 
+    def _remove_sums(self, node_nums, prev_nums):
+        """aggregate_func_remove[] (flb_sp_aggregate_func.c:207-221,348-355): AVG / SUM subtract by the type of the node that
+        loses the values (aggregate_num is a struct: an I64-typed slot holds f64 == 0.0), COUNT / MIN / MAX are no-ops"""
+        for ki, ck in enumerate(self.q.keys):
+            if ck.func in (FLB_SP_AVG, FLB_SP_SUM):
+                a, b = node_nums[ki], prev_nums[ki]
+                if a.type == "i":
+                    a.i64 = _wrap(a.i64 - b.i64)
+                elif a.type == "f":
+                    a.f64 -= b.f64
+
+    def hop(self):
+        """sp_process_hopping_slot (flb_sp.c:1852-2004): the hop timer (every ADVANCE BY) closes a slot = what the window
+        gained since the previous slot, as a clone of every live node minus the slots still in the list"""
+        hs = {"nodes": {}, "records": 0}
+        for node in self.order:
+            c = {"records": node["records"], "nums": []}
+            for n in node["nums"]:
+                m = _Num()
+                m.type, m.ops, m.i64, m.f64, m.boolean, m.string = n.type, n.ops, n.i64, n.f64, n.boolean, n.string
+                c["nums"].append(m)
+            for prev in self.slots:
+                pn = prev["nodes"].get(node["canon"])
+                if pn is not None:
+                    c["records"] -= pn["records"]
+                    self._remove_sums(c["nums"], pn["nums"])
+            if c["records"] > 0:
+                hs["nodes"][node["canon"]] = c
+        hs["records"] = self.records - sum(p["records"] for p in self.slots)
+        self.slots.append(hs)
+        return 0
+
     def _prune(self):
+        if self.q.window == "hopping":
+            # flb_sp_window_prune, FLB_SP_WINDOW_HOPPING (flb_sp_window.c:57-104): the oldest slot leaves the window
+            if not self.slots:
+                return
+            hs = self.slots[0]
+            for node in list(self.order):
+                pn = hs["nodes"].get(node["canon"])
+                if pn is None:
+                    continue
+                if pn["records"] == node["records"]:
+                    self.order.remove(node)
+                    self.groups.pop(node["canon"], None)
+                else:
+                    node["records"] -= pn["records"]
+                    self._remove_sums(node["nums"], pn["nums"])
+            self.records -= hs["records"]
+            self.slots.pop(0)
+            return
         if self.records > 0:
             self._reset()
 

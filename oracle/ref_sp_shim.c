@@ -16,7 +16,9 @@
  *   op 1: u32 str_conv, u32 sec, u32 nsec, str sql      -> i32 0 / -1 (task not created)
  *   op 2: u64 len, chunk bytes                         -> i32 ret (window.records), u64 out_len, out (DEFAULT window: packaged now)
  *   op 3: (timer of the window fires)                  -> i32 0, u64 out_len, out
- *   op 4: destroy the task                             -> i32 0 */
+ *   op 4: destroy the task                             -> i32 0
+ *   op 5: (the hop timer of a HOPPING window fires)    -> i32 ret of sp_process_hopping_slot (flb_sp_fd_event, the window.fd_hop
+ *         branch, src/stream_processor/flb_sp.c:2170-2185) */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -474,6 +476,7 @@ static void wr_answer(int32_t ret, const void *out, uint64_t n)
 int sp_process_data_aggr(const char *buf_data, size_t buf_size, const char *tag, int tag_len, struct flb_sp_task *task, struct flb_sp *sp,
                          int convert_str_to_num);
 void package_results(const char *tag, int tag_len, char **out_buf, size_t *out_size, struct flb_sp_task *task);
+int sp_process_hopping_slot(const char *tag, int tag_len, struct flb_sp_task *task);
 
 int main(void)
 {
@@ -533,6 +536,9 @@ int main(void)
         else if (op == 4) {
             if (task) { flb_sp_task_destroy(task); task = NULL; }
             wr_answer(0, NULL, 0);
+        }
+        else if (op == 5) {
+            wr_answer(task && task->window.type == FLB_SP_WINDOW_HOPPING ? sp_process_hopping_slot("t", 1, task) : -1, NULL, 0);
         }
         else break;
     }

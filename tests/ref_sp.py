@@ -42,6 +42,12 @@ class RefSp:
         self.p.stdin.flush()
         return self._answer()[1]
 
+    def hop(self):
+        """the hop timer of a HOPPING window fires (sp_process_hopping_slot)"""
+        self.p.stdin.write(struct.pack("<I", 5))
+        self.p.stdin.flush()
+        return self._answer()[0]
+
     def close(self):
         if self.p:
             try:

@@ -17,6 +17,28 @@ QUERIES = [
 ]
 
 
+# HOPPING windows (sql.y:275-278): the hop timer closes a slot every ADVANCE BY, the window timer packages and drops the oldest.
+# Number GROUP BY keys only: a slot's nodes share the string of a string key with the window's node (memcpy of groupby_nums,
+# flb_sp.c:1985) and both free it -- the reference binary dies with "double free" on such queries.
+HOPPING_QUERIES = [
+    "SELECT COUNT(*), AVG(latency), SUM(latency), MIN(latency), MAX(latency) FROM STREAM:x WINDOW HOPPING (5 SECOND, ADVANCE BY 1 SECOND);",
+    "SELECT code, COUNT(*), AVG(latency), SUM(bytes), MIN(latency), MAX(bytes) FROM STREAM:x WINDOW HOPPING (1 MINUTE, ADVANCE BY 20 SECOND) GROUP BY code;",
+    "SELECT status, COUNT(*) AS n, SUM(bytes) AS b, AVG(bytes) FROM TAG:'app.*' WINDOW HOPPING (10 SECOND, ADVANCE BY 5 SECOND) WHERE status >= 200 GROUP BY status;",
+    "SELECT code, svc['n'], COUNT(latency), SUM(latency), AVG(status) FROM STREAM:x WINDOW HOPPING (1 HOUR, ADVANCE BY 1 MINUTE) WHERE latency IS NOT NULL GROUP BY code, svc['n'];",
+]
+
+
+def hopping_schedule(rng, steps):
+    """a timer schedule as the engine produces it (flb_sp_fd_event): 'c' = a chunk arrives, 'h' = the hop timer, 't' = the
+    window timer; a hop timer precedes every window timer but the order of the two at one instant is the event loop's"""
+    ev = []
+    for _ in range(steps):
+        ev += ["c"] * rng.choice([0, 1, 1, 2])
+        r = rng.random()
+        ev += ["h"] if r < 0.45 else ["h", "t"] if r < 0.8 else ["t", "h"] if r < 0.9 else ["t"]
+    return ev
+
+
 def chunk(rng, n, clean=False):
     """n V2 records [[ts, {}], body]; clean = one value class per GROUP BY column and finite sums"""
     out = bytearray()

@@ -49,10 +49,14 @@ LOGFMT_TEXTS = [b'str="text" int=100 double=1.23 bool=true', b'str="text" int=10
                 b"time=garbage a=1", b"time=2020-01-02T03:04:05.0", b"time= a=1", b"time=20x a=1", b'time="2022-10-31T12:00:01.123" q="w"',
                 b'level=info msg="request done" path=/v1/x?y=1 dur=12ms ok', b"x" * 300 + b"=" + b"y" * 70000, b'a="' + b"\\n" * 200 + b'"']
 LOGFMT_TEXTS += [b'k="' + e + b'" tail=1' for e in ESC_CASES]
+# one `struct flb_tm` per walk (src/flb_parser_logfmt.c:70, src/flb_parser_ltsv.c:88): under Time_Strict Off a later value that
+# parses only partially keeps the fields the earlier value set
+LOGFMT_TEXTS += [b"time=2020-01-02T03:04:05.5 a=1 time=2021-03x", b"time=2019-12-31T23:59:58.25 time=2021 b=2 time=x", b"time=2020-05-06T07:08 time=2021-01-02T03:04:05.5 time=1999-"]
 LTSV_TEXTS = [b"str:text\tint:100\tdouble:1.23\tbool:true", b"str:text\ttime:2022-10-31T12:00:01.123\tz:1", b"", b"nolabel", b":v\ta:1",
               b"a:\tb:x y:z", b"a:1\t\tb:2", b"a:1\nb:2", b"a:1\r\nb:2", b"a b:1", b"a:1\tb", b"a:x\x00y\tb:2", b"time:garbage\ta:1",
               b"time:2020-01-02T03:04:05.5", b"host:10.0.0.1\tident:-\tuser:bob\treq:GET /x HTTP/1.1\tstatus:200\tsize:512",
-              b'json_str:{"str":"text", "int":100}', b"l-a.b_c:" + b"v" * 40000]
+              b'json_str:{"str":"text", "int":100}', b"l-a.b_c:" + b"v" * 40000,
+              b"time:2020-01-02T03:04:05.5\ta:1\ttime:2021-03x", b"time:2019-12-31T23:59:58.25\ttime:2021\tb:2\ttime:x", b"time:2020-05-06T07:08\ttime:2021-01-02T03:04:05.5\ttime:1999-"]
 
 
 @pytest.mark.parametrize("fmt,texts", [("logfmt", LOGFMT_TEXTS), ("ltsv", LTSV_TEXTS)])

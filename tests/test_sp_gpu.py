@@ -153,7 +153,7 @@ def test_window_life_cycle(g):
 
 
 def test_refusals(g):
-    for bad in ["SELECT id, MIN(id) FROM STREAM:FLB;", "SELECT * FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 1 SECOND);"]:
+    for bad in ["SELECT id, MIN(id) FROM STREAM:FLB;", "SELECT * FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);"]:
         with pytest.raises(ValueError):
             g.StreamTask(bad)
     # a GROUP BY column that mixes strings and numbers inside one window: the reference's tree comparator is not an order
@@ -253,3 +253,58 @@ def test_rccl_timer_single_rank(g):
     finally:
         comm.close()
         t.close()
+
+
+def assert_same_hopping_records(got, want, ctx):
+    """as assert_same_records; a float32 field fed by a float SUM / AVG may also differ by 1e-6 absolute: both sides subtract
+    f64 slot sums from f64 window sums and keep the rounding residue of their own order of additions"""
+    if got == want:
+        return
+    a, b = _rows(got), _rows(want)
+    assert len(a) == len(b), ctx
+    for ra, rb in zip(a, b):
+        assert ra[0] == rb[0] and list(ra[1].keys()) == list(rb[1].keys()), ctx
+        for k in ra[1]:
+            va, vb = ra[1][k], rb[1][k]
+            assert type(va) is type(vb), (ctx, k, va, vb)
+            if isinstance(va, float) and va != vb:
+                assert _f32_ulps(va, vb) <= 1 or abs(va - vb) <= 1e-6, (ctx, k, va, vb)
+            else:
+                assert va == vb, (ctx, k, va, vb)
+
+
+def test_hopping_windows(g):
+    """WINDOW HOPPING (n, ADVANCE BY m): chunks, hop timers (flbgpu_sp_hop) and window timers interleaved as the engine's
+    event loop would; every packaged record and every window.records equal to the oracle's, which
+    tests/test_sp_oracle.py::test_hopping_windows_against_the_reference pins on the reference binary"""
+    rng = random.Random(0x40B)
+    packaged = 0
+    for q in sp_synth.HOPPING_QUERIES:
+        for rep in range(4):
+            t = g.StreamTask(q)
+            o = osp.Task(q)
+            assert t.window == "hopping" and (t.window_size, t.window_advance) == (o.q.window_size, o.q.advance_by)
+            log = []
+            for ev in sp_synth.hopping_schedule(rng, 12):
+                log.append(ev)
+                if ev == "c":
+                    c = sp_synth.chunk(rng, rng.choice([1, 8, 60, 300]), clean=True)
+                    assert t.do(c)[0] == o.do(c)[0], (q, "".join(log))
+                elif ev == "h":
+                    assert t.hop() == 0 == o.hop()
+                else:
+                    a, b = t.timer(now=(9, rep)), o.timer(now=(9, rep))
+                    assert_same_hopping_records(a, b, (q, "".join(log)))
+                    packaged += len(a) > 0
+            t.close()
+    assert packaged > 40
+    # a string GROUP BY value: the reference frees the key twice and dies; refused
+    t = g.StreamTask("SELECT host, COUNT(*) FROM STREAM:x WINDOW HOPPING (5 SECOND, ADVANCE BY 1 SECOND) GROUP BY host;")
+    with pytest.raises(RuntimeError):
+        t.do(sp_synth.chunk(rng, 50, clean=True))
+    t.close()
+    # shards of a hopping window are not exchanged
+    t = g.StreamTask(sp_synth.HOPPING_QUERIES[0])
+    with pytest.raises(RuntimeError):
+        t.export()
+    t.close()

@@ -76,8 +76,10 @@ def test_parser_follows_the_grammar():
         osp.parse("SELECT a, COUNT(*) FROM STREAM:s;")                 # a plain key that is not a GROUP BY key
     with pytest.raises(osp.ParseError):
         osp.parse("SELECT COUNT(*) FROM STREAM:s WHERE time > 3;")      # TIME is a keyword of the lexer
+    q = osp.parse("SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 MINUTE, ADVANCE BY 10 SECOND);")
+    assert (q.window, q.window_size, q.advance_by) == ("hopping", 300, 10)
     with pytest.raises(osp.Unsupported):
-        osp.parse("SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 1 SECOND);")
+        osp.parse("SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);")
 
 
 @pytest.mark.skipif(not ref_sp.available(), reason="oracle/_ref/ref_sp not built")
@@ -102,6 +104,40 @@ def test_live_fuzz_against_the_reference():
             finally:
                 r.close()
     assert compared >= 30
+
+
+@pytest.mark.skipif(not ref_sp.available(), reason="oracle/_ref/ref_sp not built")
+def test_hopping_windows_against_the_reference():
+    """sp_process_hopping_slot / flb_sp_window_prune's HOPPING branch: chunks, hop timers and window timers interleaved;
+    every packaged byte and every record count equal to the reference binary's"""
+    rng = random.Random(0x40B)
+    compared = packaged = 0
+    for q in sp_synth.HOPPING_QUERIES:
+        for rep in range(8):
+            clean = rep < 6
+            r = ref_sp.RefSp(q, str_conv=rep != 7)
+            assert r.ok, q
+            t = osp.Task(q, str_conv=rep != 7)
+            try:
+                for ev in sp_synth.hopping_schedule(rng, 14):
+                    # (the oracle first: it raises Unsupported where the reference binary would die)
+                    if ev == "c":
+                        c = sp_synth.chunk(rng, rng.choice([1, 8, 60]), clean)
+                        b = t.do(c)
+                        assert r.do(c) == b, q
+                    elif ev == "h":
+                        assert t.hop() == 0 and r.hop() == 0
+                    else:
+                        b = t.timer()
+                        a = r.timer()
+                        assert a == b, q
+                        packaged += len(a) > 0
+                compared += 1
+            except osp.Unsupported:
+                assert not clean
+            finally:
+                r.close()
+    assert compared >= 24 and packaged > 100
 
 
 @pytest.mark.skipif(not ref_sp.available(), reason="oracle/_ref/ref_sp not built")
