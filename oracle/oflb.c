@@ -107,7 +107,16 @@ typedef struct oflb_parser {
     int time_with_tz;
     struct ptype *types;
     int types_len;
+    struct odec *decs;       /* Decode_Field / Decode_Field_As (src/flb_parser_decoder.c), one entry per key */
+    int ndecs;
 } oflb_parser;
+
+/* include/fluent-bit/flb_parser_decoder.h:28-59 */
+enum { DEC_DEFAULT = 0, DEC_AS = 1 };
+enum { DEC_JSON = 0, DEC_ESCAPED = 1, DEC_ESCAPED_UTF8 = 2, DEC_MYSQL_QUOTED = 3 };
+enum { ACT_NONE = 0, ACT_TRY_NEXT = 1, ACT_DO_NEXT = 2 };
+struct odec_rule { int type, backend, action; };
+struct odec { char *key; size_t key_len; int add_extra_keys; struct odec_rule *rules; int nrules; };
 
 /* src/flb_parser.c:1806-1870 flb_parser_tzone_offset */
 static int tzone_offset(const char *str, int len, int *tmdiff)
@@ -241,7 +250,42 @@ void oflb_parser_destroy(oflb_parser *p)
     free(p->time_fmt); free(p->time_fmt_year); free(p->time_key);
     for (i = 0; i < p->types_len; i++) free(p->types[i].key);
     free(p->types);
+    for (i = 0; i < p->ndecs; i++) { free(p->decs[i].key); free(p->decs[i].rules); }
+    free(p->decs);
     free(p);
+}
+
+/* One `Decode_Field[_As] <backend> <field> [action]` line, in configuration order: flb_parser_decoder_list_create
+ * (src/flb_parser_decoder.c:603-745) with get_decoder_key_context (:555-601).  -1: unknown backend. */
+int oflb_parser_add_decoder(oflb_parser *p, int as, const char *backend, const char *field, const char *action)
+{
+    struct odec *d = NULL;
+    struct odec_rule r;
+    int i;
+    if (!strcasecmp(backend, "json")) r.backend = DEC_JSON;
+    else if (!strcasecmp(backend, "escaped")) r.backend = DEC_ESCAPED;
+    else if (!strcasecmp(backend, "escaped_utf8")) r.backend = DEC_ESCAPED_UTF8;
+    else if (!strcasecmp(backend, "mysql_quoted")) r.backend = DEC_MYSQL_QUOTED;
+    else return -1;
+    r.type = as ? DEC_AS : DEC_DEFAULT;
+    r.action = ACT_NONE;
+    if (action && action[0]) {
+        if (!strcasecmp(action, "try_next")) r.action = ACT_TRY_NEXT;
+        else if (!strcasecmp(action, "do_next")) r.action = ACT_DO_NEXT;
+    }
+    for (i = 0; i < p->ndecs; i++)
+        if (p->decs[i].key_len == strlen(field) && memcmp(p->decs[i].key, field, p->decs[i].key_len) == 0) { d = &p->decs[i]; break; }
+    if (!d) {
+        p->decs = realloc(p->decs, sizeof(*p->decs) * (size_t) (p->ndecs + 1));
+        d = &p->decs[p->ndecs++];
+        memset(d, 0, sizeof(*d));
+        d->key = strdup(field);
+        d->key_len = strlen(field);
+    }
+    if (r.type == DEC_DEFAULT) d->add_extra_keys = 1;
+    d->rules = realloc(d->rules, sizeof(*d->rules) * (size_t) (d->nrules + 1));
+    d->rules[d->nrules++] = r;
+    return 0;
 }
 
 /* src/flb_parser.c:1876-1897 */
@@ -392,6 +436,7 @@ int ojson_pack(const char *js, size_t len, char **buffer, size_t *size, int *roo
  * left whole and the time is 0 (+ whatever fraction was parsed).  Decoders are not restated.
  * Returns the bytes consumed or -1.
  */
+static int decoder_do(oflb_parser *parser, const char *in_buf, size_t in_size, char **out_buf, size_t *out_size);
 static int oflb_parser_json_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
                                int64_t *out_sec, int64_t *out_nsec)
 {
@@ -415,6 +460,19 @@ static int oflb_parser_json_do(oflb_parser *parser, const char *buf, size_t leng
     if (omp_unpack_next(&arena, &map, mp, mp_size, &off) != OMP_UNPACK_SUCCESS || map.type != OMP_MAP) {
         free(mp); omp_arena_free(&arena);
         return -1;
+    }
+    if (parser->ndecs > 0) {
+        /* src/flb_parser_json.c:100-114: the decoders see the map before the time key is looked up in it */
+        char *d = NULL;
+        size_t dn = 0;
+        if (decoder_do(parser, mp, mp_size, &d, &dn) == 0) {
+            free(mp);
+            mp = d; mp_size = dn;
+            omp_arena_free(&arena);
+            omp_arena_init(&arena);
+            off = 0;
+            omp_unpack_next(&arena, &map, mp, mp_size, &off);
+        }
     }
     *out = mp; *out_size = mp_size;
     if (!parser->time_fmt) { omp_arena_free(&arena); return (int) consumed; }
@@ -723,8 +781,216 @@ static int oflb_parser_kv_do(oflb_parser *parser, const char *buf, size_t length
     return last;
 }
 
+/* ------------------------------------------------------------------ Decode_Field / Decode_Field_As
+ * src/flb_parser_decoder.c.  The string backends: flb_unescape_string (src/flb_unescape.c:278-335), flb_unescape_string_utf8
+ * (above), flb_mysql_unquote_string (:338-388); the json backend: decode_json (:39-83) over flb_pack_json_recs. */
+static int unescape_plain(const char *buf, int buf_len, char *p)
+{
+    int i = 0, j = 0;
+    while (i < buf_len) {
+        if (buf[i] == '\\') {
+            if (i + 1 < buf_len) {
+                char n = buf[i + 1];
+                if (n == 'n') { p[j++] = '\n'; i++; }
+                else if (n == 'a') { p[j++] = '\a'; i++; }
+                else if (n == 'b') { p[j++] = '\b'; i++; }
+                else if (n == 't') { p[j++] = '\t'; i++; }
+                else if (n == 'v') { p[j++] = '\v'; i++; }
+                else if (n == 'f') { p[j++] = '\f'; i++; }
+                else if (n == 'r') { p[j++] = '\r'; i++; }
+                else if (n == '\\') { p[j++] = '\\'; i++; }
+                i++;
+                continue;
+            }
+            else i++;                    /* (a trailing backslash: the byte behind the text is copied -- the NUL of the sds) */
+        }
+        p[j++] = buf[i++];
+    }
+    p[j] = '\0';
+    return j;
+}
+static int mysql_unquote(const char *buf, int buf_len, char *p)
+{
+    int i = 0, j = 0;
+    char n;
+    while (i < buf_len) {
+        if ((n = buf[i++]) != '\\') p[j++] = n;
+        else if (i >= buf_len) p[j++] = n;
+        else {
+            n = buf[i++];
+            switch (n) {
+            case 'n': p[j++] = '\n'; break;
+            case 'r': p[j++] = '\r'; break;
+            case 't': p[j++] = '\t'; break;
+            case '\\': p[j++] = '\\'; break;
+            case '\'': p[j++] = '\''; break;
+            case '\"': p[j++] = '\"'; break;
+            case '0': p[j++] = 0; break;
+            case 'Z': p[j++] = 0x1a; break;
+            default: p[j++] = '\\'; p[j++] = n; break;
+            }
+        }
+    }
+    p[j] = '\0';
+    return j;
+}
+/* exported for the pin against the reference's own flb_unescape.c (oracle/_ref/libunescape_ref.so) */
+int oflb_unescape_plain(const char *in_buf, int sz, char *out_buf) { return unescape_plain(in_buf, sz, out_buf); }
+int oflb_mysql_unquote(const char *in_buf, int sz, char *out_buf) { return mysql_unquote(in_buf, sz, out_buf); }
+
+/* one backend on `in` (NUL-terminated copy of the current content); 0 and *o / *on / *otype (0 string, 1 object), or -1 */
+static int dec_backend(int backend, const char *in, size_t in_size, char **o, size_t *on, int *otype)
+{
+    char *b;
+    if (backend == DEC_JSON) {
+        const char *p = in;
+        int root_type = 0, records = 0;
+        size_t consumed = 0, size = 0;
+        char *mp = NULL;
+        while (*p == ' ') p++;
+        if (p[0] != '{' && p[0] != '[') return -1;
+        if (ojson_pack(p, in_size - (size_t) (p - in), &mp, &size, &root_type, &records, &consumed) != 0) return -1;
+        if (records != 1) { free(mp); return -1; }
+        if (root_type != 1 /* JSMN_OBJECT */) { free(mp); return -1; }
+        *o = mp; *on = size; *otype = 1;
+        return 0;
+    }
+    b = malloc(in_size * 2 + 16);
+    *otype = 0;
+    if (backend == DEC_ESCAPED) *on = (size_t) unescape_plain(in, (int) in_size, b);
+    else if (backend == DEC_ESCAPED_UTF8) *on = (size_t) kv_unescape_utf8(in, (int) in_size, b);
+    else {
+        /* decode_mysql_quoted (:114-147) */
+        if (in_size < 2) { b[0] = in[0]; b[1] = 0; *on = in_size; }
+        else if ((in[0] == '\'' && in[in_size - 1] == '\'') || (in[0] == '"' && in[in_size - 1] == '"'))
+            *on = (size_t) mysql_unquote(in + 1, (int) in_size - 2, b);
+        else { memcpy(b, in, in_size); b[in_size] = 0; *on = in_size; }
+    }
+    *o = b;
+    return 0;
+}
+
+/* flb_parser_decoder_do (src/flb_parser_decoder.c:215-550) + merge_record_and_extra_keys (:149-209) */
+static int decoder_do(oflb_parser *parser, const char *in_buf, size_t in_size, char **out_buf, size_t *out_size)
+{
+    omp_arena arena;
+    omp_obj map;
+    size_t off = 0;
+    int matched = -1, extra_keys = 0, q;
+    uint32_t i;
+    omp_buf pck, extra;
+    char *in_sds = NULL, *out_sds = NULL, *data = NULL;
+    size_t in_len = 0, out_len = 0, data_len = 0;
+    omp_arena_init(&arena);
+    if (omp_unpack_next(&arena, &map, in_buf, in_size, &off) != OMP_UNPACK_SUCCESS || map.type != OMP_MAP) { omp_arena_free(&arena); return -1; }
+    for (i = 0; i < map.via.map.size && matched < 0; i++) {
+        const omp_obj *k = &map.via.map.ptr[i].key;
+        if (k->type != OMP_STR) continue;
+        for (q = 0; q < parser->ndecs; q++)
+            if (parser->decs[q].key_len == k->via.str.size && memcmp(parser->decs[q].key, k->via.str.ptr, k->via.str.size) == 0) { matched = (int) i; break; }
+    }
+    if (matched == -1) { omp_arena_free(&arena); return -1; }
+    omp_buf_init(&pck);
+    memset(&extra, 0, sizeof(extra));
+    omp_pack_map(&pck, map.via.map.size);
+    for (i = 0; i < map.via.map.size; i++) {
+        const omp_obj *k = &map.via.map.ptr[i].key, *v = &map.via.map.ptr[i].val;
+        struct odec *dec = NULL;
+        int is_decoded = 0, is_decoded_as = 0, in_type = 0, out_type = 0, ri;
+        if ((int) i < matched || k->type != OMP_STR || v->type != OMP_STR) { omp_pack_object(&pck, k); omp_pack_object(&pck, v); continue; }
+        for (q = 0; q < parser->ndecs; q++)
+            if (parser->decs[q].key_len == k->via.str.size && memcmp(parser->decs[q].key, k->via.str.ptr, k->via.str.size) == 0) { dec = &parser->decs[q]; break; }
+        if (!dec) { omp_pack_object(&pck, k); omp_pack_object(&pck, v); continue; }
+        free(data);
+        data = malloc(v->via.str.size + 1);
+        memcpy(data, v->via.str.ptr, v->via.str.size);
+        data[v->via.str.size] = 0;
+        data_len = v->via.str.size;
+        if (dec->add_extra_keys) {
+            if (extra_keys) free(extra.data);
+            extra_keys = 1;
+            omp_buf_init(&extra);
+        }
+        for (ri = 0; ri < dec->nrules; ri++) {
+            const struct odec_rule *rule = &dec->rules[ri];
+            char *dbuf = NULL;
+            size_t dsize = 0;
+            int dtype = 0;
+            if (rule->type == DEC_DEFAULT && rule->action == ACT_DO_NEXT && is_decoded) continue;
+            if (is_decoded_as && in_type != 0) continue;
+            if (dec_backend(rule->backend, data, data_len, &dbuf, &dsize, &dtype) == -1) {
+                if (rule->action == ACT_TRY_NEXT || rule->action == ACT_DO_NEXT) continue;
+                break;
+            }
+            if (rule->type == DEC_AS) {
+                free(in_sds);
+                in_sds = malloc(dsize + 1); memcpy(in_sds, dbuf, dsize); in_len = dsize;
+                free(data);
+                data = malloc(dsize + 1); memcpy(data, dbuf, dsize); data[dsize] = 0; data_len = dsize;
+                in_type = dtype;
+                is_decoded_as = 1;
+            }
+            else {
+                free(out_sds);
+                out_sds = malloc(dsize + 1); memcpy(out_sds, dbuf, dsize); out_len = dsize;
+                out_type = dtype;
+                is_decoded = 1;
+            }
+            free(dbuf);
+            if (rule->action == ACT_DO_NEXT) continue;
+            break;
+        }
+        omp_pack_object(&pck, k);
+        if (is_decoded_as) {
+            if (in_type == 0) omp_pack_str_with_body(&pck, in_sds, in_len);
+            else omp_buf_write(&pck, in_sds, in_len);
+        }
+        else omp_pack_object(&pck, v);
+        if (is_decoded && out_type == 1) omp_buf_write(&extra, out_sds, out_len);     /* (a string: "not allowed", logged only) */
+    }
+    free(in_sds); free(out_sds); free(data);
+    *out_buf = pck.data; *out_size = pck.size;
+    if (extra_keys) {
+        omp_arena a2;
+        omp_obj in_map, ex_map;
+        size_t o1 = 0, o2 = 0;
+        omp_arena_init(&a2);
+        if (omp_unpack_next(&a2, &ex_map, extra.data, extra.size, &o2) == OMP_UNPACK_SUCCESS &&
+            omp_unpack_next(&a2, &in_map, pck.data, pck.size, &o1) == OMP_UNPACK_SUCCESS) {
+            omp_buf m;
+            omp_buf_init(&m);
+            omp_pack_map(&m, (size_t) in_map.via.map.size + ex_map.via.map.size);
+            for (i = 0; i < in_map.via.map.size; i++) { omp_pack_object(&m, &in_map.via.map.ptr[i].key); omp_pack_object(&m, &in_map.via.map.ptr[i].val); }
+            for (i = 0; i < ex_map.via.map.size; i++) { omp_pack_object(&m, &ex_map.via.map.ptr[i].key); omp_pack_object(&m, &ex_map.via.map.ptr[i].val); }
+            free(pck.data);
+            *out_buf = m.data; *out_size = m.size;
+        }
+        omp_arena_free(&a2);
+        free(extra.data);
+    }
+    omp_arena_free(&arena);
+    return 0;
+}
+
+static int parser_do_inner(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
+                           int64_t *out_sec, int64_t *out_nsec);
+
+/* the decoders run on the map a regex / logfmt / ltsv parser packed, after its time was taken (src/flb_parser_regex.c:210-221,
+ * flb_parser_logfmt.c:314-324, flb_parser_ltsv.c:257-267); Format json applies them before its time lookup (oflb_parser_json_do) */
 int oflb_parser_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
                    int64_t *out_sec, int64_t *out_nsec)
+{
+    int ret = parser_do_inner(parser, buf, length, out, out_size, out_sec, out_nsec);
+    if (ret >= 0 && parser->ndecs > 0 && !parser->is_json) {
+        char *d = NULL;
+        size_t dn = 0;
+        if (decoder_do(parser, *out, *out_size, &d, &dn) == 0) { free(*out); *out = d; *out_size = dn; }
+    }
+    return ret;
+}
+
+static int parser_do_inner(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size,
+                           int64_t *out_sec, int64_t *out_nsec)
 {
     if (parser->kv_format) return oflb_parser_kv_do(parser, buf, length, out, out_size, out_sec, out_nsec);
     if (parser->is_json) return oflb_parser_json_do(parser, buf, length, out, out_size, out_sec, out_nsec);

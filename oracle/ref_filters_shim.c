@@ -15,7 +15,7 @@
  * Protocol (stdin -> stdout, binary, one case after the other):
  *   u32 kind (1 grep, 2 parser, 3 bench-pair), u32 nprops, nprops x (u32 klen, key, u32 vlen, val),
  *   u32 nparsers, nparsers x 9 strings (name, format, regex, time_fmt, time_key, time_offset, types, skip_empty "0/1",
- *   flags "time_keep time_strict"), u64 data_len, data        [kind 3: u32 iterations first]
+ *   flags "time_keep time_strict[|decode_field[_as] backend field [action]]..."), u64 data_len, data        [kind 3: u32 iterations first]
  *   kind 4 (in_tail's line packing): props = key, path_key, path, offset_key, stream_offset, skip_empty_lines, sec, nsec; data = text:
  *   the loop of process_content (plugins/in_tail/tail_file.c:783-786,840-1000, plain path) restated here, every line packed by the
  *   REAL encoder through flb_tail_file_pack_line's call sequence (:552-604); answer ret = lines, out = records, then u64 processed
@@ -33,6 +33,7 @@
 #include <fluent-bit/flb_config_map.h>
 #include <fluent-bit/flb_filter.h>
 #include <fluent-bit/flb_parser.h>
+#include <fluent-bit/flb_parser_decoder.h>
 #include <fluent-bit/flb_log.h>
 #include <fluent-bit/flb_worker.h>
 #include <fluent-bit/flb_slist.h>
@@ -200,6 +201,63 @@ static void on_segv(int sig)
     _exit(139);
 }
 
+/* parser.decoders from "|<decode_field|decode_field_as> <backend> <field> [action]" entries behind the flags: the list
+ * flb_parser_decoder_list_create (src/flb_parser_decoder.c:603-745) builds from a [PARSER] section -- same split (' ', 3), same
+ * backend / action names, one flb_parser_dec per field (get_decoder_key_context :555-601), rules in configuration order.  That
+ * function reads a struct flb_cf_section (the config-format library, not linked here); everything the list is USED by --
+ * flb_parser_decoder_do -- is the reference's own object. */
+static struct mk_list *make_decoders(const char *spec)
+{
+    struct mk_list *list = NULL;
+    while (spec && *spec == '|') {
+        const char *e = strchr(spec + 1, '|');
+        size_t n = e ? (size_t) (e - spec - 1) : strlen(spec + 1);
+        char *line = flb_strndup(spec + 1, n), *sp = strchr(line, ' ');
+        struct mk_list *split, *head;
+        struct flb_split_entry *ent[3] = {NULL, NULL, NULL};
+        struct flb_parser_dec *dec = NULL;
+        struct flb_parser_dec_rule *rule;
+        int type, backend, cnt = 0;
+        spec = e;
+        if (!sp) { flb_free(line); continue; }
+        *sp = 0;
+        type = !strcasecmp(line, "decode_field_as") ? FLB_PARSER_DEC_AS : FLB_PARSER_DEC_DEFAULT;
+        split = flb_utils_split(sp + 1, ' ', 3);
+        mk_list_foreach(head, split) { if (cnt < 3) ent[cnt] = mk_list_entry(head, struct flb_split_entry, _head); cnt++; }
+        if (cnt < 2) { flb_utils_split_free(split); flb_free(line); continue; }
+        if (!strcasecmp(ent[0]->value, "json")) backend = FLB_PARSER_DEC_JSON;
+        else if (!strcasecmp(ent[0]->value, "escaped")) backend = FLB_PARSER_DEC_ESCAPED;
+        else if (!strcasecmp(ent[0]->value, "escaped_utf8")) backend = FLB_PARSER_DEC_ESCAPED_UTF8;
+        else backend = FLB_PARSER_DEC_MYSQL_QUOTED;
+        if (!list) { list = flb_malloc(sizeof(struct mk_list)); mk_list_init(list); }
+        mk_list_foreach(head, list) {
+            struct flb_parser_dec *d = mk_list_entry(head, struct flb_parser_dec, _head);
+            if (flb_sds_cmp(d->key, ent[1]->value, strlen(ent[1]->value)) == 0) { dec = d; break; }
+        }
+        if (!dec) {
+            dec = flb_malloc(sizeof(struct flb_parser_dec));
+            dec->key = flb_sds_create_len(ent[1]->value, strlen(ent[1]->value));
+            dec->buffer = flb_sds_create_size(FLB_PARSER_DEC_BUF_SIZE);
+            dec->add_extra_keys = FLB_FALSE;
+            mk_list_init(&dec->rules);
+            mk_list_add(&dec->_head, list);
+        }
+        rule = flb_calloc(1, sizeof(struct flb_parser_dec_rule));
+        if (type == FLB_PARSER_DEC_DEFAULT) dec->add_extra_keys = FLB_TRUE;
+        rule->type = type;
+        rule->backend = backend;
+        if (cnt >= 3 && ent[2]) {
+            if (!strcasecmp(ent[2]->value, "try_next")) rule->action = FLB_PARSER_ACT_TRY_NEXT;
+            else if (!strcasecmp(ent[2]->value, "do_next")) rule->action = FLB_PARSER_ACT_DO_NEXT;
+            else rule->action = FLB_PARSER_ACT_NONE;
+        }
+        mk_list_add(&rule->_head, &dec->rules);
+        flb_utils_split_free(split);
+        flb_free(line);
+    }
+    return list;
+}
+
 int main(void)
 {
     signal(SIGSEGV, on_segv);
@@ -220,6 +278,7 @@ int main(void)
             char *f[9];
             int k, time_keep = 0, time_strict = 1;
             struct flb_parser_types *types = NULL;
+            struct mk_list *decoders = NULL;
             int types_len = 0;
             for (k = 0; k < 9; k++) f[k] = rd_str();
             sscanf(f[8], "%d %d", &time_keep, &time_strict);
@@ -247,8 +306,9 @@ int main(void)
                 types_len = q;
                 flb_utils_split_free(split);
             }
+            decoders = make_decoders(strchr(f[8], '|'));
             flb_parser_create(f[0], f[1], f[2][0] ? f[2] : NULL, atoi(f[7]), f[3][0] ? f[3] : NULL, f[4][0] ? f[4] : NULL, f[5][0] ? f[5] : NULL,
-                              time_keep, time_strict, FLB_FALSE, FLB_FALSE, types, types_len, NULL, config);
+                              time_keep, time_strict, FLB_FALSE, FLB_FALSE, types, types_len, decoders, config);
         }
         if (!rd(&dlen, 8)) break;
         data = malloc(dlen + 1);

@@ -68,7 +68,7 @@ class Parser:
     time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.
     Defaults are the conf-file defaults (src/flb_parser.c:1277-1304)."""
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, format="regex", no_bare_keys=False):
+                 time_strict=True, skip_empty=True, types=None, format="regex", no_bare_keys=False, decoders=None):
         e = lambda s: s.encode() if isinstance(s, str) else s
         if format == "json":
             regex = None                      # Format json (src/flb_parser_json.c)
@@ -82,6 +82,11 @@ class Parser:
                                               int(time_keep), int(time_strict), e(types))
         if not self.h:
             raise ValueError("oracle: parser create failed")
+        # decoders: [(as: bool, backend, field[, action])] = the parser's Decode_Field / Decode_Field_As lines in order
+        lib().oflb_parser_add_decoder.argtypes = [c_void_p, c_int, c_char_p, c_char_p, c_char_p]
+        for d in decoders or []:
+            if lib().oflb_parser_add_decoder(self.h, int(bool(d[0])), e(d[1]), e(d[2]), e(d[3]) if len(d) > 3 and d[3] else None) != 0:
+                raise ValueError("oracle: unknown decoder backend")
     def do(self, buf):
         out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()
         r = lib().oflb_parser_do(self.h, buf, len(buf), byref(out), byref(sz), byref(sec), byref(nsec))
