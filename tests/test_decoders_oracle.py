@@ -122,3 +122,17 @@ def test_decoders_against_the_real_parser_decoder():
         plain.setdefault(key, ob.FilterParser("msg", [ob.Parser(**PARSERS[key[0]])], bool(key[1]), bool(key[1])).filter(data)[1])
         changed += out != plain[key]
     assert changed > len(got) * 0.6              # the decoders did something in most configurations
+
+
+def test_decoders_golden_digests():
+    """the reference's answers, committed (tests/golden/gen_decoders_kat.py): the check that travels"""
+    import hashlib, json
+    kat = json.load(open(os.path.join(HERE, "golden", "decoders_kat.json")))
+    data = _chunks()
+    assert hashlib.sha256(data).hexdigest() == kat["chunk_sha256"]
+    assert len(kat["cases"]) == len(DECODER_SETS) * len(PARSERS) * 2
+    for c in kat["cases"]:
+        di, pi, rp = c["case"]
+        p = dict(PARSERS[pi], decoders=DECODER_SETS[di])
+        ret, out = ob.FilterParser("msg", [ob.Parser(**p)], bool(rp), bool(rp)).filter(data)
+        assert ret == c["ret"] and hashlib.sha256(out or b"").hexdigest() == c["sha256"], (DECODER_SETS[di], PARSERS[pi], rp)
