@@ -15,9 +15,10 @@ def g():
 
 
 def test_exports_match_header(g):
-    hdr = open(os.path.join(ROOT, "include", "flb_gpu.h")).read()
+    import glob
+    hdr = "".join(open(h).read() for h in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     names = sorted(set(re.findall(r"\b(flbgpu_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(names) >= 25
+    assert len(names) >= 25 and "flbgpu_dec_simulate" in names and "flbgpu_sp_hop" in names
     L = g.lib()
     for n in names:
         assert hasattr(L, n), "libflbgpu.so does not export %s" % n

@@ -136,3 +136,33 @@ def test_decoders_golden_digests():
         p = dict(PARSERS[pi], decoders=DECODER_SETS[di])
         ret, out = ob.FilterParser("msg", [ob.Parser(**p)], bool(rp), bool(rp)).filter(data)
         assert ret == c["ret"] and hashlib.sha256(out or b"").hexdigest() == c["sha256"], (DECODER_SETS[di], PARSERS[pi], rp)
+
+
+def test_device_ready_string_backends_match_the_oracle():
+    """csrc/dec.hpp (the decoders' string backends as the kernels will run them: one template for host and device) executed on
+    the host through flbgpu_dec_simulate, against the oracle functions the test above pins on the reference's flb_unescape.c;
+    the size-only call (what a size pass does) agrees with the writing call"""
+    import flbamd_loader
+    G = flbamd_loader.load().lib()
+    G.flbgpu_dec_simulate.restype = ctypes.c_int64
+    G.flbgpu_dec_simulate.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    L = ob.lib()
+    for f in (L.oflb_unescape_plain, L.oflb_mysql_unquote):
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+
+    def oracle_mysql_quoted(s):                      # decode_mysql_quoted (src/flb_parser_decoder.c:114-147) over the pinned unquote
+        if len(s) >= 2 and ((s[:1] == b"'" and s[-1:] == b"'") or (s[:1] == b'"' and s[-1:] == b'"')):
+            return _call(L.oflb_mysql_unquote, s[1:-1])
+        return s
+    rng = random.Random(29)
+    cases = list(STR_CASES) + [b"'a\\nb'", b'"q\\"', b"'", b"''", b'"x', b"'\\'"]
+    alphabet = [b"\\", b"n", b"t", b"a", b"b", b"v", b"f", b"r", b"0", b"Z", b"'", b'"', b"x", b" ", b"\xc3\xa9", b"q", b"\x00"]
+    for _ in range(5000):
+        cases.append(b"".join(rng.choice(alphabet) for _ in range(rng.randrange(0, 16))))
+    for s in cases:
+        for backend, want in ((1, _call(L.oflb_unescape_plain, s)), (3, oracle_mysql_quoted(s))):
+            out = ctypes.create_string_buffer(2 * len(s) + 16)
+            n = G.flbgpu_dec_simulate(backend, s, len(s), out, len(out))
+            assert n == len(want) and out.raw[:n] == want, (backend, s)
+            assert G.flbgpu_dec_simulate(backend, s, len(s), None, 0) == n
+    assert G.flbgpu_dec_simulate(0, b"{}", 2, None, 0) == -1 and G.flbgpu_dec_simulate(2, b"x", 1, None, 0) == -1
