@@ -25,7 +25,9 @@ extern "C" int64_t flbgpu_dec_simulate(int backend, const void *in, size_t n, vo
     switch (backend) {
     case flbgpu::dec::BK_ESCAPED: r = flbgpu::dec::unescape_plain(s, (uint32_t) n, k); break;
     case flbgpu::dec::BK_MYSQL_QUOTED: r = flbgpu::dec::mysql_quoted(s, (uint32_t) n, k); break;
-    default: return -1;                                    // json / escaped_utf8: not in dec.hpp (json_dev.inc, pkv_dev.inc)
+    case flbgpu::dec::BK_ESCAPED_UTF8: r = flbgpu::dec::unescape_utf8<false>(s, (uint32_t) n, k); break;
+    case 102: r = flbgpu::dec::unescape_utf8<true>(s, (uint32_t) n, k); break;      // logfmt's use of it (strlen of the result)
+    default: return -1;                                    // json: json_dev.inc
     }
     return r == k.len ? (int64_t) r : -1;
 }

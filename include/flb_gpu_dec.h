@@ -2,7 +2,9 @@
  * /root/reference/src/flb_parser_decoder.c:85-147).  The product does not take parsers with decoders yet (round 2): this runs
  * the device-ready string backends (csrc/dec.hpp) on the HOST, for unit tests only.
  *
- * flbgpu_dec_simulate: backend 1 = escaped (replaces flb_unescape_string, src/flb_unescape.c:278-335, as decode_escaped calls
+ * flbgpu_dec_simulate: backend 2 = escaped_utf8 (flb_unescape_string_utf8, src/flb_unescape.c:186-277, as decode_escaped_utf8
+ * calls it, src/flb_parser_decoder.c:100-112; 102 = the same followed by logfmt's strlen(), src/flb_parser_logfmt.c:186-196),
+ * 1 = escaped (replaces flb_unescape_string, src/flb_unescape.c:278-335, as decode_escaped calls
  * it, src/flb_parser_decoder.c:85-98), 3 = mysql_quoted (decode_mysql_quoted :114-147 over flb_mysql_unquote_string,
  * src/flb_unescape.c:338-388).  Writes at most cap bytes to out (NULL: size only) and returns the decoded length; -1 for any
  * other backend. */

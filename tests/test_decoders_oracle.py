@@ -165,4 +165,16 @@ def test_device_ready_string_backends_match_the_oracle():
             n = G.flbgpu_dec_simulate(backend, s, len(s), out, len(out))
             assert n == len(want) and out.raw[:n] == want, (backend, s)
             assert G.flbgpu_dec_simulate(backend, s, len(s), None, 0) == n
-    assert G.flbgpu_dec_simulate(0, b"{}", 2, None, 0) == -1 and G.flbgpu_dec_simulate(2, b"x", 1, None, 0) == -1
+    assert G.flbgpu_dec_simulate(0, b"{}", 2, None, 0) == -1
+    # escaped_utf8 on the 6 k answers of the real flb_unescape.c (tests/golden/unescape_kat.json) and the corner list
+    import json
+    from test_kv_oracle import ESC_CASES
+    L.oflb_unescape_utf8.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    kat = [(bytes.fromhex(c["in"]), bytes.fromhex(c["out"])) for c in json.load(open(os.path.join(HERE, "golden", "unescape_kat.json")))["cases"]]
+    kat += [(s, _call(L.oflb_unescape_utf8, s)) for s in ESC_CASES]
+    for s, want in kat:
+        out = ctypes.create_string_buffer(2 * len(s) + 16)
+        n = G.flbgpu_dec_simulate(2, s, len(s), out, len(out))
+        assert n == len(want) and out.raw[:n] == want, s
+        n2 = G.flbgpu_dec_simulate(102, s, len(s), out, len(out))
+        assert out.raw[:n2] == want.split(b"\x00")[0], s
