@@ -61,15 +61,28 @@ def gen(rng, depth, names):
     return p
 
 
-def run(seed, npat, nsub, force_wide=False):
+MORE_ATOMS = [rb"\b", rb"\B", rb"[[:alpha:]]", rb"[[:digit:][:punct:]]", rb"[^[:space:]]", rb"\h", rb"\H", rb"$", rb"^", rb"\A", rb"\z", rb"\Z", rb"\n", rb"A", rb"K",
+              rb"[A-Z]", rb"\x41", rb"\t"]
+
+
+def run(seed, npat, nsub, more=False):
+    global ATOMS
     ref = rxdiff.load_ref()
     L = flbamd_loader.load().lib()
     rng = random.Random(seed)
     tried = accepted = compared = 0
+    base = ATOMS
     for _ in range(npat):
         names = []
-        pat = gen(rng, 2, names)
-        if any(n for n in names) and b"(" in pat.replace(b"(?<", b"").replace(b"(?:", b""):
+        ATOMS = base + MORE_ATOMS if more else base
+        try:
+            pat = gen(rng, 2, names)
+        finally:
+            ATOMS = base
+        if more:
+            o = rng.random()
+            pat = b"(?i)" + pat if o < 0.2 else b"(?m)" + pat if o < 0.3 else pat
+        if any(n for n in names) and b"(" in pat.replace(b"(?<", b"").replace(b"(?:", b"").replace(b"(?i)", b"").replace(b"(?m)", b""):
             continue                               # named and numbered groups together: ONIG_OPTION_CAPTURE_GROUP off -> plain groups do not capture
         eng = rxdiff.RefRegex(ref, pat)
         if not eng.ok:
@@ -81,8 +94,10 @@ def run(seed, npat, nsub, force_wide=False):
             continue                               # refused loudly (budget / unsupported construct): not a wrong answer
         accepted += 1
         for k in range(nsub):
-            s = rxdiff.rand_input(rng, pat, 20, utf8=(k % 3 == 1)) if k % 3 != 2 else rxdiff.rand_input_illformed(rng, pat, 16)
-            if b"^" in pat and STRAY_AFTER_NL.search(s):
+            # \b, POSIX brackets and (?i) are documented deviations next to non-ASCII characters: ASCII subjects for those
+            ascii_only = any(t in pat for t in (rb"\b", rb"\B", b"[:", b"(?i)"))
+            s = rxdiff.rand_input(rng, pat, 20, utf8=(k % 3 == 1 and not ascii_only)) if (k % 3 != 2 or ascii_only) else rxdiff.rand_input_illformed(rng, pat, 16)
+            if (b"^" in pat or b"(?m)" in pat) and STRAY_AFTER_NL.search(s):
                 continue                           # documented deviation: `^` behind "\n" + stray continuation bytes
             want = eng.search(s)
             beg = (ctypes.c_int * 40)(); end = (ctypes.c_int * 40)()
@@ -101,6 +116,12 @@ def test_random_patterns_against_the_real_engine():
 
 
 @pytest.mark.skipif(rxdiff.load_ref() is None, reason="oracle/_ref/libonig_ref.so not built (needs /root/reference)")
+def test_random_patterns_with_anchors_options_and_posix_brackets():
+    tried, accepted, compared = run(0xA2C4, 1500, 9, more=True)
+    assert accepted > 0.4 * tried and compared > 4000, (tried, accepted, compared)
+
+
+@pytest.mark.skipif(rxdiff.load_ref() is None, reason="oracle/_ref/libonig_ref.so not built (needs /root/reference)")
 def test_random_patterns_wide_layout(monkeypatch):
     monkeypatch.setenv("FLBGPU_RX_FORCE_WIDE", "1")
     tried, accepted, compared = run(0x71DE, 300, 9)
@@ -113,7 +134,7 @@ if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     total = [0, 0, 0]
     while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 60:
-        r = run(seed, 500, 9)
+        r = run(seed, 500, 9, more=seed % 2 == 1)
         total = [a + b for a, b in zip(total, r)]
         seed += 1
     print("seeds up to", seed, "tried / accepted / compared", total)
