@@ -178,3 +178,29 @@ def test_device_ready_string_backends_match_the_oracle():
         assert n == len(want) and out.raw[:n] == want, s
         n2 = G.flbgpu_dec_simulate(102, s, len(s), out, len(out))
         assert out.raw[:n2] == want.split(b"\x00")[0], s
+
+
+@pytest.mark.skipif(not rf.available(), reason="oracle/_ref/ref_filters not built (no reference tree)")
+def test_random_decoder_sets_against_the_real_parser_decoder():
+    """random rule lists (1-4 rules over four keys, every backend, both rule types, try_next / do_next / an unknown action word)
+    on random parser formats: the rule bookkeeping of flb_parser_decoder_do beyond the hand-written sets (a run of 300
+    configurations of the same loop: no difference)"""
+    data = _chunks()
+    rng = random.Random(77)
+    cases, want, meta = [], [], []
+    for _ in range(60):
+        rules = []
+        for _ in range(rng.randint(1, 4)):
+            r = [rng.random() < 0.6, rng.choice(["json", "escaped", "escaped_utf8", "mysql_quoted"]), rng.choice(["log", "log", "other", "nokey", "n"])]
+            a = rng.choice([None, None, "try_next", "do_next", "bogus"])
+            if a:
+                r.append(a)
+            rules.append(tuple(r))
+        pa = rng.choice(PARSERS)
+        rp = rng.random() < 0.5
+        p = dict(pa, decoders=rules)
+        cases.append(rf.parser_case("msg", [p], data, rp, rp))
+        want.append(ob.FilterParser("msg", [ob.Parser(**p)], rp, rp).filter(data))
+        meta.append((rules, pa, rp))
+    for (ret, out), (wret, wout), m in zip(rf.run(cases), want, meta):
+        assert ret == wret and out == (wout or b""), m
