@@ -1,6 +1,7 @@
 // dev.hpp -- structures shared by the host side (flbgpu.cpp) and the HIP kernels (kernels.hip).
 #pragma once
 #include <cstdint>
+#include <atomic>
 
 namespace flbgpu {
 
@@ -223,6 +224,9 @@ struct TileCfg {
     TileRule rule[TILE_RULES];
 };
 
+constexpr uint32_t STAGE_MAXK = 20;              // 1 KiB pieces of a staging buffer (ParserMatchArgs::stage_bytes <= 20 KiB)
+constexpr uint32_t STAGE_SLACK = 48;             // bytes behind a buffer that the lanes' 16-byte reads may touch
+
 struct ParserMatchArgs {
     const uint8_t *data;
     const uint64_t *row_off;
@@ -261,6 +265,10 @@ struct ParserMatchArgs {
     uint32_t *desc;
     uint32_t dstride;
     uint64_t fix_first;              // k_parser_reg<true>: first flagged row
+    // k_parser_reg, staged ingest: a workgroup's waves share stage_nbuf LDS buffers of stage_bytes (+ 32 of slack) each at
+    // stage_lds_off; a wave takes one, copies its 64 records (one contiguous range of the chunk) into it with coalesced
+    // 16 B / lane loads, every lane pulls header + value into registers, and the buffer goes back (0 buffers: per-lane loads)
+    uint32_t stage_lds_off, stage_bytes, stage_nbuf;
     const uint8_t *tail_buf;         // the chunk's bytes from tail_start on, followed by 512 zero bytes (wide loads of the last records)
     uint64_t tail_start;
     TileCfg tc;

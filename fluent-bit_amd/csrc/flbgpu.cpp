@@ -9,6 +9,7 @@
 // host exactly once; per-record work happens only in kernels.hip.  There is no CPU data path.
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include "host_int.hpp"
@@ -763,7 +764,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
@@ -841,6 +842,17 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     else if (use_tile) {
         ma.tile_lds_off = (ma.lds_total + 15) & ~15u;
         ma.lds_total = ma.tile_lds_off + (uint32_t) (rx_threads / 64) * tile_wave_bytes + 64;
+        if (!tile_in_lds) {
+            // staged ingest (tile_kernels.inc): what is left of the LDS becomes the workgroup's ring of staging buffers
+            uint32_t skb = 20, want = 4;
+            if (getenv("FLBGPU_STAGE_KB")) { int v = atoi(getenv("FLBGPU_STAGE_KB")); if (v >= 1 && v <= (int) STAGE_MAXK) skb = (uint32_t) v; }
+            if (getenv("FLBGPU_STAGE_NBUF")) { int v = atoi(getenv("FLBGPU_STAGE_NBUF")); if (v >= 0 && v <= 8) want = (uint32_t) v; }
+            const uint32_t at = (ma.lds_total + 15) & ~15u, per = skb * 1024u + STAGE_SLACK;
+            uint32_t nb = at + 16 < lds_cap ? (lds_cap - at - 16) / per : 0;
+            if (nb > want) nb = want;
+            if (((uintptr_t) data & 15) != 0) nb = 0;                 // (the coalesced loads are aligned 16-byte loads)
+            if (nb) { ma.stage_lds_off = at; ma.stage_bytes = skb * 1024u; ma.stage_nbuf = nb; ma.lds_total = at + 16 + nb * per; }
+        }
         if (!tile_in_lds) {
             // a zero-padded copy of the chunk's last bytes: the call-free kernel loads 16 bytes at a time without bounds tests
             const size_t T = 4096, tb = in->bytes < T ? (size_t) in->bytes : T;
@@ -1027,6 +1039,9 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
 }
 
 // 1: ran fused (*out / stats set), 0: this chunk needs the unfused kernels, -1: failure
+static std::atomic<uint64_t> g_fused_failures{0};          // fused passes that failed on the device (flbgpu_diag_fused_failures)
+extern "C" uint64_t flbgpu_diag_fused_failures(void) { return g_fused_failures.load(); }
+
 static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, flbgpu_chain_stat *stats2) {
     hipStream_t st = fp->stream;
     uint64_t n = in->n;
@@ -1263,6 +1278,13 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
                 }
                 continue;
             }
+            if (fr < 0) {
+                // a device / allocation failure inside the single pass (0 = "not fusable for this chunk"): the reference's
+                // filter would log and hand the data on untouched (SURVEY 8b "Errors"); the error text stays in flbgpu_last_error
+                g_fused_failures.fetch_add(1, std::memory_order_relaxed);
+                *out = *in;
+                return FLBGPU_FILTER_NOTOUCH;
+            }
         }
         int ret = run_any_dev(filters[i], &cur, &o, filters[i]->stream, garbage && !modified);
         if (stats) {
@@ -1440,8 +1462,11 @@ struct CopyPool {
             if (--pending == 0) cv_done.notify_one();
         }
     }
+    std::mutex user;               // ONE job slot: a second caller (another filter's thread) copies by itself instead of queueing
     void copy(void *d, const void *s, size_t n) {
         if (n < (1u << 20) || getenv("FLBGPU_COPY_THREADS_OFF")) { memcpy(d, s, n); return; }
+        std::unique_lock<std::mutex> own(user, std::try_to_lock);
+        if (!own.owns_lock()) { memcpy(d, s, n); return; }
         std::unique_lock<std::mutex> lk(mu);
         if (!started) { for (int i = 0; i < HELPERS; i++) th[i] = std::thread(&CopyPool::worker, this, i); started = true; }
         dst = (uint8_t *) d; src = (const uint8_t *) s; total = n; part = (((n + HELPERS) / (HELPERS + 1)) + 63) & ~(size_t) 63;      // (rounded UP: the four shares cover n)

@@ -44,6 +44,13 @@ struct DevBuf {
     void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *) p; }
 };
+// a function-local device buffer: released on every return path (DevBuf itself is a plain member type that its owner releases)
+struct ScopedDevBuf : DevBuf {
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf &) = delete;
+    ScopedDevBuf &operator=(const ScopedDevBuf &) = delete;
+    ~ScopedDevBuf() { release(); }
+};
 
 // page-locked host memory (staging slabs and the record-offset column of the host-level call)
 struct PinnedBuf {

@@ -772,7 +772,7 @@ __global__ void k_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long
 bool upload_time_tables() { return true; }
 
 void launch_parser_locate(const ParserMatchArgs &a, int cus, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t lds = (size_t) (LOC_BLOCK / 64) * LOC_TILE;
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_parser_locate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -784,7 +784,7 @@ void launch_parser_locate(const ParserMatchArgs &a, int cus, hipStream_t st) {
     hipLaunchKernelGGL(k_parser_locate, dim3((unsigned) blocks), dim3(LOC_BLOCK), lds, st, a);
 }
 void launch_parser_rx(const ParserMatchArgs &a, int grid, int threads, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_parser_rx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void) hipFuncSetAttribute((const void *) k_parser_rx<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -809,7 +809,7 @@ void launch_count_nonzero(const uint32_t *len, uint64_t n, unsigned long long *o
 }
 void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t lds = (size_t) (EMIT_BLOCK / 64) * EMIT_STG;
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_parser_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -822,7 +822,7 @@ void launch_parser_emit(const ParserEmitArgs &a, int cus, hipStream_t st) {
 }
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t lds = (size_t) (GREP_BLOCK / 64) * GREP_TILE + a.rules_lds_total;
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_grep_match, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

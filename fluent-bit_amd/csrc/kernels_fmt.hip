@@ -244,7 +244,7 @@ void launch_fmt_emit(const JsonFmtArgs &a, int cus, hipStream_t st) {
     if (a.n == 0) return;
     uint64_t blocks = (a.n + 255) / 256, cap = (uint64_t) cus * 8;
     if (blocks > cap) blocks = cap;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_fmt_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;

@@ -514,7 +514,7 @@ bool rccl_all_gather_bytes(void *rccl_comm, hipStream_t st, const void *mine, si
     if (!rccl_load()) return false;
     int world = 0;
     if (g_rccl.comm_count(rccl_comm, &world) != 0 || world <= 0) { set_err("rccl: ncclCommCount failed"); return false; }
-    DevBuf d_a, d_b;
+    ScopedDevBuf d_a, d_b;                      // (released on every return path)
     uint64_t mysize = bytes;
     std::vector<uint64_t> sizes((size_t) world);
     bool ok = d_a.ensure(8) && d_b.ensure(8 * (size_t) world) && hipMemcpyAsync(d_a.p, &mysize, 8, hipMemcpyHostToDevice, st) == hipSuccess &&
@@ -574,7 +574,7 @@ extern "C" int64_t flbgpu_l2m_all_reduce(flbgpu_filter *f, void *rccl_comm, void
         cap = (uint64_t) (-ln - 2) + 16;
     }
     // ---- all-gather of the label tuples: sizes, then the blobs padded to the largest
-    DevBuf d_a, d_b;
+    ScopedDevBuf d_a, d_b;                      // (released on every return path)
     const size_t hdr = 2 * sizeof(uint64_t);
     uint64_t mine[2] = {(uint64_t) ln, (uint64_t) loff[ln]};
     std::vector<uint64_t> sizes((size_t) world * 2);

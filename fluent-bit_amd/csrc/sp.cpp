@@ -669,10 +669,12 @@ bool deserialize(const uint8_t *p, size_t n, int W, Snapshot &sn) {
     if (!get(magic) || magic != 0x5350534e41503031ull || !get(sn.records)) return false;
     for (int g = 0; g < SP_MAX_GB; g++) { if (!get(cc)) return false; sn.col_class[g] = (unsigned int) cc; }
     if (!get(ng) || !get(w) || w != (uint64_t) W) return false;
+    if (ng > n / 8) return false;                             // (every group takes at least its length word: a corrupt count ends here)
     sn.groups.clear();
     for (uint64_t i = 0; i < ng; i++) {
         uint64_t kl;
         if (!get(kl)) return false;
+        if (kl > n) return false;                             // (before the rounding below can wrap)
         const size_t padded = (size_t) ((kl + 7) & ~7ull);
         if (n < padded + (size_t) W * 8) return false;
         Group g;

@@ -362,54 +362,134 @@ struct flb_filter_plugin filter_parser_gpu_plugin = {
  * released with flb_free, *out_time the parsed time or zero).  The GPU twin of a struct flb_parser is created on
  * first use and kept in a small table keyed by the parser's address. */
 #include <fluent-bit/flb_time.h>
+#include <pthread.h>
+/*
+ * The twins are keyed by the parser's CONFIGURATION (name, regex, time settings, types), not by the address of the
+ * struct flb_parser: after a hot reload a new parser may live where a destroyed one did.  The table is guarded by a
+ * mutex, every twin by its own (flb_parser_do is re-entrant in the reference; a flbgpu_parser owns one stream and one
+ * set of device buffers), and a full table evicts its least recently used idle entry instead of failing.
+ */
 #define MAX_TWINS 64
-static struct { struct flb_parser *p; flbgpu_parser *g; } twins[MAX_TWINS];
+struct parser_twin {
+    char *sig;
+    flbgpu_parser *g;
+    pthread_mutex_t lock;
+    unsigned long stamp;
+    int users;
+};
+static struct parser_twin twins[MAX_TWINS];
 static int n_twins = 0;
+static unsigned long twin_clock = 0;
+static pthread_mutex_t twins_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static char *twin_signature(struct flb_parser *parser, const char *types)
+{
+    size_t len;
+    char *sig;
+
+    len = 96 + (parser->name ? strlen(parser->name) : 0) + (parser->p_regex ? strlen(parser->p_regex) : 0) +
+          (parser->time_fmt_full ? strlen(parser->time_fmt_full) : 0) + (parser->time_key ? strlen(parser->time_key) : 0) +
+          (types ? strlen(types) : 0);
+    sig = flb_malloc(len);
+    if (!sig) {
+        return NULL;
+    }
+    snprintf(sig, len, "%s\x01%s\x01%d\x01%s\x01%s\x01%d\x01%d\x01%d\x01%s",
+             parser->name ? parser->name : "", parser->p_regex ? parser->p_regex : "", parser->skip_empty,
+             parser->time_fmt_full ? parser->time_fmt_full : "\x02", parser->time_key ? parser->time_key : "\x02",
+             parser->time_offset, parser->time_keep, parser->time_strict, types ? types : "");
+    return sig;
+}
 
 int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
                       void **out_buf, size_t *out_size, struct flb_time *out_time)
 {
     int i;
     int ret;
+    int slot = -1;
     int64_t sec = 0;
     int64_t nsec = 0;
     char off[16];
     char *types;
+    char *sig;
     flbgpu_parser *g = NULL;
 
+    if (parser->type != FLB_PARSER_REGEX || parser->decoders != NULL || parser->time_zone != NULL ||
+        parser->time_system_timezone) {
+        return -1;
+    }
+    types = types_to_str(parser);
+    sig = twin_signature(parser, types);
+    if (!sig) {
+        flb_free(types);
+        return -1;
+    }
+    pthread_mutex_lock(&twins_mu);
     for (i = 0; i < n_twins; i++) {
-        if (twins[i].p == parser) {
-            g = twins[i].g;
+        if (twins[i].sig && strcmp(twins[i].sig, sig) == 0) {
+            slot = i;
             break;
         }
     }
-    if (!g) {
-        if (n_twins >= MAX_TWINS || flbgpu_init(0) != 0) {
-            return -1;
+    if (slot < 0) {
+        if (flbgpu_init(0) != 0) {
+            goto fail_locked;
         }
-        if (parser->type != FLB_PARSER_REGEX || parser->decoders != NULL || parser->time_zone != NULL ||
-            parser->time_system_timezone) {
-            return -1;
-        }
-        types = types_to_str(parser);
         snprintf(off, sizeof(off), "%c%02d%02d", parser->time_offset < 0 ? '-' : '+',
                  abs(parser->time_offset) / 3600, (abs(parser->time_offset) / 60) % 60);
         g = flbgpu_parser_create(parser->name, parser->p_regex, parser->skip_empty, parser->time_fmt_full,
                                  parser->time_key, parser->time_offset ? off : NULL, parser->time_keep,
                                  parser->time_strict, types);
-        flb_free(types);
         if (!g) {
-            return -1;
+            goto fail_locked;
         }
-        twins[n_twins].p = parser;
-        twins[n_twins].g = g;
-        n_twins++;
+        if (n_twins < MAX_TWINS) {
+            slot = n_twins++;
+            pthread_mutex_init(&twins[slot].lock, NULL);
+        }
+        else {
+            /* the least recently used twin nobody is inside of */
+            for (i = 0; i < MAX_TWINS; i++) {
+                if (twins[i].users == 0 && (slot < 0 || twins[i].stamp < twins[slot].stamp)) {
+                    slot = i;
+                }
+            }
+            if (slot < 0) {
+                flbgpu_parser_destroy(g);
+                goto fail_locked;
+            }
+            flbgpu_parser_destroy(twins[slot].g);
+            flb_free(twins[slot].sig);
+        }
+        twins[slot].g = g;
+        twins[slot].sig = sig;
+        twins[slot].users = 0;
+        sig = NULL;
     }
+    twins[slot].users++;
+    twins[slot].stamp = ++twin_clock;
+    g = twins[slot].g;
+    pthread_mutex_unlock(&twins_mu);
+    flb_free(types);
+    flb_free(sig);
+
+    pthread_mutex_lock(&twins[slot].lock);
     ret = flbgpu_parser_do(g, buf, length, out_buf, out_size, &sec, &nsec);
+    pthread_mutex_unlock(&twins[slot].lock);
+
+    pthread_mutex_lock(&twins_mu);
+    twins[slot].users--;
+    pthread_mutex_unlock(&twins_mu);
     if (ret >= 0 && out_time) {
         flb_time_set(out_time, (time_t) sec, (long) nsec);
     }
     return ret;
+
+fail_locked:
+    pthread_mutex_unlock(&twins_mu);
+    flb_free(types);
+    flb_free(sig);
+    return -1;
 }
 #endif /* FLBGPU_WITH_PARSER */
 

@@ -356,6 +356,7 @@ int flbgpu_rx_simulate_match(void *h, const char *s, int len);
 void flbgpu_rx_info(void *h, int *info12);
 int flbgpu_rx_names(void *h, char *buf, int cap);
 void flbgpu_diag_copy(void *dst, const void *src, size_t n);   /* the threaded slab copy of the host-level calls (unit test) */
+uint64_t flbgpu_diag_fused_failures(void);                       /* single passes over a [parser, grep] pair that failed on the device (the chain then answers NOTOUCH) */
 int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end);   /* compact tables of the tile kernel, host execution */
 void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call: fast, lookahead, slow */
 

@@ -178,3 +178,30 @@ def test_threaded_slab_copy(g):
         sbuf = ctypes.create_string_buffer(src, len(src))
         L.flbgpu_diag_copy(ctypes.addressof(dst) + 3, ctypes.addressof(sbuf) + off, n)
         assert dst.raw[3:3 + n] == src[off:off + n] and dst.raw[:3] == b"\0\0\0" and dst.raw[3 + n:3 + n + 8] == b"\0" * 8, n
+
+
+def test_threaded_slab_copy_two_callers(g):
+    """two threads in the slab copy at once (every filter has its own stream: concurrent host-level calls are intended):
+    the pool has ONE job slot, the second caller copies by itself -- every byte of both arrives"""
+    import random, threading
+    L = g.lib()
+    L.flbgpu_diag_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rng = random.Random(11)
+    srcs = [bytes(rng.getrandbits(8) for _ in range(1 << 14)) * 200 for _ in range(2)]
+    bad = []
+
+    def work(i):
+        r = random.Random(100 + i)
+        sbuf = ctypes.create_string_buffer(srcs[i], len(srcs[i]))
+        for _ in range(40):
+            n = r.randrange(1 << 20, len(srcs[i]) - 64)
+            off = r.randrange(0, 64)
+            dst = ctypes.create_string_buffer(n + 16)
+            L.flbgpu_diag_copy(ctypes.addressof(dst) + 5, ctypes.addressof(sbuf) + off, n)
+            if not (dst.raw[5:5 + n] == srcs[i][off:off + n] and dst.raw[5 + n:5 + n + 8] == b"\0" * 8):
+                bad.append((i, n))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad, bad[:4]
