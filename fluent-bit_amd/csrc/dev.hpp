@@ -269,6 +269,9 @@ struct ParserMatchArgs {
     // stage_lds_off; a wave takes one, copies its 64 records (one contiguous range of the chunk) into it with coalesced
     // 16 B / lane loads, every lane pulls header + value into registers, and the buffer goes back (0 buffers: per-lane loads)
     uint32_t stage_lds_off, stage_bytes, stage_nbuf;
+    // diagnostics (FLBGPU_TRACE=<iterations>): s_memtime stamps of the phases of a wave's first iterations, [wave][iteration][8]
+    unsigned long long *trace;
+    uint32_t trace_iters;
     const uint8_t *tail_buf;         // the chunk's bytes from tail_start on, followed by 512 zero bytes (wide loads of the last records)
     uint64_t tail_start;
     TileCfg tc;

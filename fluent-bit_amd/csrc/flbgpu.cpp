@@ -764,7 +764,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
@@ -865,8 +865,31 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         ma.self = f->d_args.as<ParserMatchArgs>();
         memcpy(f->hp_args.p, &ma, sizeof(ma));                   // (page-locked: the copy below is a real asynchronous transfer)
         HIPOK(hipMemcpyAsync(f->d_args.p, f->hp_args.p, sizeof(ma), hipMemcpyHostToDevice, st));
+        // diagnostics: FLBGPU_TRACE=<iterations> FLBGPU_TRACE_FILE=<path> -- phase time stamps of every wave's first iterations
+        void *d_trace = nullptr;
+        size_t trace_bytes = 0;
+        if (!tile_in_lds && getenv("FLBGPU_TRACE") && getenv("FLBGPU_TRACE_FILE")) {
+            const int iters = atoi(getenv("FLBGPU_TRACE"));
+            if (iters > 0 && iters <= 4096) {
+                trace_bytes = (size_t) grid * (rx_threads / 64) * (size_t) iters * 8 * sizeof(unsigned long long);
+                if (hipMalloc(&d_trace, trace_bytes) == hipSuccess && hipMemsetAsync(d_trace, 0, trace_bytes, st) == hipSuccess) {
+                    ma.trace = (unsigned long long *) d_trace; ma.trace_iters = (uint32_t) iters;
+                }
+            }
+        }
         if (tile_in_lds) { ProfScope ps(f, st, "k_parser_tile"); launch_parser_tile(ma, grid, rx_threads, st); }
         else { ProfScope ps(f, st, "k_parser_reg"); launch_parser_reg(ma, grid, rx_threads, false, st); }
+        if (d_trace) {
+            std::vector<unsigned long long> ht(trace_bytes / sizeof(unsigned long long));
+            if (hipMemcpyAsync(ht.data(), d_trace, trace_bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                if (FILE *tf = fopen(getenv("FLBGPU_TRACE_FILE"), "wb")) {
+                    const uint32_t hdr[4] = {(uint32_t) grid, (uint32_t) (rx_threads / 64), ma.trace_iters, 8};
+                    fwrite(hdr, sizeof(hdr), 1, tf); fwrite(ht.data(), 1, trace_bytes, tf); fclose(tf);
+                }
+            }
+            (void) hipFree(d_trace);
+            ma.trace = nullptr; ma.trace_iters = 0;
+        }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
         if (!tile_in_lds && hm.counts[10] > 0) {

@@ -51,6 +51,19 @@ int refcmt_update(void *h, uint64_t ts, double val, int nlabels, char **label_va
     return cmt_histogram_observe(r->h, ts, val, nlabels, label_vals);
 }
 
+/* n observations in record order, ONE label each: label_idx[i] picks its value from the table (bench.py's measured
+ * ULP distance of the device's once-rounded histogram sums to the real cmetrics' sequential f64 sums) */
+int refcmt_update_many(void *h, uint64_t n, const double *vals, const int32_t *label_idx, char **label_table)
+{
+    uint64_t i;
+    int ret = 0;
+    for (i = 0; i < n && ret == 0; i++) {
+        char *lv[1] = { label_table[label_idx[i]] };
+        ret = refcmt_update(h, (uint64_t) (i + 1), vals[i], 1, lv);
+    }
+    return ret;
+}
+
 static struct cmt_map *map_of(struct refcmt *r) { return r->mode == 0 ? r->c->map : r->mode == 1 ? r->g->map : r->h->map; }
 
 int refcmt_nbuckets(void *h) { return ((struct refcmt *) h)->nbuckets; }
