@@ -12,8 +12,8 @@ struct DevCap {
     const uint16_t *rdelta;        // [nR + 1][1 << cls_shift]; bit15 = a match may start here (`wide`: see below)
     const uint32_t *ft;            // [nX * NKp][1 << wsh] forward table (encoding: rx.hpp)
     const uint32_t *ft2;           // [nmulti][1 << fc_shift] one-byte-lookahead rows
-    const uint8_t *cls;            // [256] byte -> class
-    const uint8_t *col;            // [256] byte -> kind << fc_shift | class
+    const uint8_t *cls;            // [512] symbol -> class (symbols 256 + b: rx.hpp TableSet::cls, word variants)
+    const uint8_t *col;            // [512] symbol -> kind << fc_shift | class
     const uint8_t *xl;             // [512] utf8 set: symbol of a stray byte / of a truncated sequence's lead (rx.cpp SymbolMap)
     // cold tables (only when several candidates remain for a byte)
     const uint8_t *r_info;         // [nR]
@@ -23,6 +23,9 @@ struct DevCap {
     const uint32_t *tag_off;
     const uint8_t *tag_data;
     int ncls, nR, r_init, VW, nX, NK, NKp, kind_edge, ascii_only, cls_shift, fc_shift, wsh, col_eot;
+    int word_variants;             // utf8 set of a pattern with \b / \B: a byte of a well-formed multi-byte WORD character is symbol 256 + b
+    const uint32_t *wr;            // the Unicode word ranges {lo, hi} the walkers decide that with (rx::unicode_word_ranges), nwr pairs
+    int nwr;
     int wide;                      // utf8 set only (rx.hpp `wide`): rdelta points at 32-bit entries, bit31 = a match may
                                    // start here; walked from HBM by the generic kernels, never staged
     const uint8_t *hot_base;

@@ -65,7 +65,7 @@ template <class T> static size_t put(std::vector<uint8_t> &blob, const std::vect
 
 bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint8_t> b;
-    std::vector<uint8_t> cls(t.cls, t.cls + 256);
+    std::vector<uint8_t> cls(t.cls, t.cls + 512);
     // hot block first (staged into LDS as one piece): rdelta | ft | ft2 | cls | col
     // device encoding of the forward tables: a plain entry carries the dword index of the next
     // ROW (row << wsh, 19 bits: rx.cpp caps the table at 2 MiB) so that a step's address is one add
@@ -84,6 +84,11 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     size_t o_ri = put(b, t.r_info), o_vm = put(b, t.vmask);
     size_t o_lo = put(b, t.list_off), o_le = put(b, t.list_ent), o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
     size_t o_xl = put(b, std::vector<uint8_t>(t.xl, t.xl + 512));
+    int nwr = 0;
+    const unsigned int (*wr)[2] = rx::unicode_word_ranges(&nwr);
+    std::vector<uint32_t> wrv;
+    if (t.word_variants) for (int i = 0; i < nwr; i++) { wrv.push_back(wr[i][0]); wrv.push_back(wr[i][1]); }
+    size_t o_wr = put(b, wrv);
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     const uint8_t *d = (const uint8_t *) blob.dev;
@@ -95,6 +100,7 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     out.ncls = t.ncls; out.nR = t.nR; out.r_init = t.r_init; out.VW = t.VW; out.nX = t.nX; out.NK = t.NK; out.NKp = t.NKp;
     out.kind_edge = t.kind_edge; out.ascii_only = t.ascii_only ? 1 : 0; out.cls_shift = t.cls_shift; out.fc_shift = t.fc_shift;
     out.wsh = t.wsh; out.col_eot = t.col_eot; out.wide = t.wide ? 1 : 0;
+    out.word_variants = t.word_variants ? 1 : 0; out.wr = (const uint32_t *) (d + o_wr); out.nwr = t.word_variants ? nwr : 0;
     out.hot_base = d; out.hot_bytes = (uint32_t) hot_end;
     out.off_rdelta = (uint32_t) o_rd; out.off_ft = (uint32_t) o_ft; out.off_ft2 = (uint32_t) o_f2;
     out.off_cls = (uint32_t) o_cls; out.off_col = (uint32_t) o_col;
@@ -844,7 +850,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         ma.lds_total = ma.tile_lds_off + (uint32_t) (rx_threads / 64) * tile_wave_bytes + 64;
         if (!tile_in_lds) {
             // staged ingest (tile_kernels.inc): what is left of the LDS becomes the workgroup's ring of staging buffers
-            uint32_t skb = 20, want = 4;
+            uint32_t skb = 20, want = 0;                                  // (off unless asked for: the per-lane burst is faster)
             if (getenv("FLBGPU_STAGE_KB")) { int v = atoi(getenv("FLBGPU_STAGE_KB")); if (v >= 1 && v <= (int) STAGE_MAXK) skb = (uint32_t) v; }
             if (getenv("FLBGPU_STAGE_NBUF")) { int v = atoi(getenv("FLBGPU_STAGE_NBUF")); if (v >= 0 && v <= 8) want = (uint32_t) v; }
             const uint32_t at = (ma.lds_total + 15) & ~15u, per = skb * 1024u + STAGE_SLACK;

@@ -16,7 +16,12 @@ using namespace flbgpu;
 bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out) {
     memset(&out, 0, sizeof(out));
     if (!t.has_capture || !t.ascii_only || t.ft.empty()) return true;
-    const uint32_t stride = (uint32_t) t.ncls + 1, rowb = stride * 4;
+    // a row holds an ODD number of dwords: lanes that read the same column of different rows -- the common case, the lanes of a
+    // wave sit in different states over similar bytes -- then fall on different LDS banks (rows aligned to a power of two put
+    // a column of every row on ONE bank: measured 3.5x the bank conflicts and a 25 % slower kernel)
+    const uint32_t stride = (uint32_t) t.ncls + 1;
+    const uint32_t rstride = stride | 1u;                                // dwords between rows
+    const uint32_t rowb = rstride * 4;
     const uint32_t nrows = (uint32_t) t.nX * (uint32_t) t.NKp;          // + absorb + poison
     const size_t W = (size_t) 1 << t.wsh, ncols2 = (size_t) 1 << t.fc_shift, nm = t.ft2.size() / ncols2;
     const uint32_t ft_at = 1024, ft2_at = ft_at + (nrows + 2) * rowb;
@@ -26,7 +31,7 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
     if (nslots > 63 || p2_at64 > 60000) return true;
     const uint32_t S_END_EOT = (uint32_t) ncap + FXS_END_EOT, S_END_MID = (uint32_t) ncap + FXS_END_MID,
                    S_DEAD_EOT = (uint32_t) ncap + FXS_DEAD_EOT, S_FAIL = (uint32_t) ncap + FXS_FAIL;
-    std::vector<uint32_t> ft((size_t) (nrows + 2) * stride), ft2(nm * stride), p2;
+    std::vector<uint32_t> ft((size_t) (nrows + 2) * rstride), ft2(nm * rstride), p2;
     auto plain = [&](uint32_t next_at, uint32_t slot) -> uint32_t { return next_at | ((slot * 128u) << FX_SLOT_SHIFT); };
     auto pair = [&](uint32_t next_at, uint32_t a, uint32_t b) -> uint32_t {
         p2.push_back(plain(next_at, a)); p2.push_back(b * 128u);
@@ -59,9 +64,9 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
             const bool eot = c == (uint32_t) t.ncls;
             const uint32_t kind = eot ? (uint32_t) t.kind_edge : t.kind_of_cls[c];
             const size_t colc = ((size_t) kind << t.fc_shift) | c;
-            ft[(size_t) r * stride + c] = (!eot && (int) c == t.high_cls) ? plain(poison, 0) : conv(t.ft[(size_t) r * W + colc], eot);
+            ft[(size_t) r * rstride + c] = (!eot && (int) c == t.high_cls) ? plain(poison, 0) : conv(t.ft[(size_t) r * W + colc], eot);
         }
-    for (uint32_t c = 0; c < stride; c++) { ft[(size_t) nrows * stride + c] = plain(absorb, 0); ft[(size_t) (nrows + 1) * stride + c] = plain(poison, 0); }
+    for (uint32_t c = 0; c < stride; c++) { ft[(size_t) nrows * rstride + c] = plain(absorb, 0); ft[(size_t) (nrows + 1) * rstride + c] = plain(poison, 0); }
     // ft2 rows: resolved entries of a LOOK cell, indexed by the class of the NEXT byte; the cell itself is never in the
     // end-of-text column (nothing follows it), so a MATCH here ends in front of the end of the text
     for (size_t m = 0; m < nm; m++)
@@ -70,7 +75,7 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
             if (c < (uint32_t) t.ncls && (int) c == t.high_cls) v = plain(absorb, S_FAIL);   // a byte >= 0x80 follows: the UTF-8 tables decide
             else v = conv(t.ft2[m * ncols2 + c], false);
             if ((v & FX_PAIR) == FX_LOOK) v = plain(absorb, S_FAIL);
-            ft2[m * stride + c] = v;
+            ft2[m * rstride + c] = v;
         }
     if (!fits) return true;
     std::vector<uint32_t> cls(256);

@@ -111,10 +111,9 @@ struct CC {
     enum Kind { CLASS, ANY, WORD, LIT } kind = CLASS;
     ByteSet bs;
     CodeSet mb;
-    // what the automaton is BUILT from for well-formed multi-byte characters: equal to mb except that the
-    // non-ASCII members of a POSIX bracket are left out ([[:alpha:]] accepts no non-ASCII letter here, the
-    // reference accepts the Unicode ones -- DESIGN.md "known deviations": the byte-class budget of the tables
-    // cannot hold the Unicode categories).  mb itself stays exact: it decides how ill-formed bytes are treated.
+    // what the automaton is BUILT from for well-formed multi-byte characters.  Equal to mb since round 3 (the Unicode members
+    // of a POSIX bracket are in: [[:alpha:]] accepts U+00E9 as the reference does; a pattern whose UTF-8 tables then need
+    // more byte classes than the tables hold is refused at create).
     CodeSet mbx;
     bool neg = false;
     uint32_t lit = 0;                 // LIT: the code point (matched as its exact byte sequence)
@@ -200,6 +199,21 @@ struct CC {
 
 #include "posix_ranges.inc"
 
+}  // namespace
+bool unicode_word(uint32_t cp) {
+    if (cp < 0x80) return (cp >= '0' && cp <= '9') || (cp >= 'A' && cp <= 'Z') || (cp >= 'a' && cp <= 'z') || cp == '_';
+    int lo = 0, hi = posix_u_word_n - 1;
+    while (lo <= hi) {
+        const int m = (lo + hi) / 2;
+        if (cp < posix_u_word[m][0]) hi = m - 1;
+        else if (cp > posix_u_word[m][1]) lo = m + 1;
+        else return true;
+    }
+    return false;
+}
+const unsigned int (*unicode_word_ranges(int *n))[2] { *n = posix_u_word_n; return posix_u_word; }
+namespace {
+
 // \d \s \w \h inside or outside brackets: ASCII-range under Ruby syntax (ONIG_OPTION_ASCII_RANGE).  The
 // positive form has no code-range part; the negated form is "ASCII complement + every code point >= 0x80"
 // (regparse.c add_ctype_to_cc with ascii_range)
@@ -247,12 +261,12 @@ bool add_posix(CC &cc, const std::string &n, bool negated) {
 #undef PX
     CodeSet m;
     for (int i = 0; i < un; i++) m.add(u[i][0], u[i][1]);
-    if (!negated) { cc.bs.merge(a); cc.mb.merge(m); }
+    if (!negated) { cc.bs.merge(a); cc.mb.merge(m); cc.mbx.merge(m); }
     else {
         for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
         CodeSet c = mb_complement(m);
         cc.mb.merge(c);
-        cc.mbx.add(0x80, LASTCP);
+        cc.mbx.merge(c);
     }
     cc.mb.norm(); cc.mbx.norm();
     return true;
@@ -291,6 +305,7 @@ struct Ast {
     int min = 0, max = 0;       // max < 0: unbounded
     bool greedy = true;
     AnchorKind anchor = A_BOL;
+    uint32_t ilit = 0;          // SET made from a literal LETTER under (?i): the letter, lower case (multi-character folds, below)
 };
 using AstP = std::unique_ptr<Ast>;
 
@@ -479,6 +494,7 @@ struct Syntax {
             a->cc.kind = CC::CLASS;
             a->cc.bs.set((int) c);
             fold_case(a->cc);
+            a->ilit = c | 32;
             return a;
         }
         a->cc.kind = CC::LIT;
@@ -655,6 +671,69 @@ struct Syntax {
         return a;
     }
 
+    // ---- (?i): the multi-character case folds that reach ASCII letters.  The reference folds with
+    // INTERNAL_ONIGENC_CASE_FOLD_MULTI_CHAR on (ONIGENC_CASE_FOLD_DEFAULT): inside ONE literal string of the pattern,
+    // "ss" also matches U+00DF / U+1E9E, "st" U+FB05 / U+FB06, "ff" "fi" "fl" "ffi" "ffl" U+FB00 .. U+FB04
+    // (lib/onigmo/regcomp.c:3575 expand_case_fold_string, enc/unicode.c onigenc_unicode_get_case_fold_codes_by_str:
+    // alternatives per position, the rest of the string compared case-folded at run time -- every way of cutting the run
+    // into letters and ligatures).  A string is a run of literal characters that no quantifier, group or class
+    // interrupts (a quantifier takes the last character out of the run: regparse.c parse_exp).
+    static AstP clone_set(const Ast *a) { AstP c = mk(Ast::SET); c->cc = a->cc; c->ilit = a->ilit; return c; }
+    static AstP cp_class(std::initializer_list<uint32_t> cps) {
+        AstP a = mk(Ast::SET);
+        a->cc.kind = CC::CLASS;
+        for (uint32_t c : cps) a->cc.add_cp(c, c);
+        a->cc.mb.norm(); a->cc.mbx.norm();
+        return a;
+    }
+    int fold_budget = 0;
+    AstP fold_run(const std::vector<AstP> &run, size_t i) {
+        if (i >= run.size()) return mk(Ast::EMPTY);
+        if (++fold_budget > 4000) { fail("pattern too large for the GPU tables (case folds)"); return mk(Ast::EMPTY); }
+        auto at = [&](size_t k, uint32_t c) { return k < run.size() && run[k]->ilit == c; };
+        std::vector<AstP> alts;
+        auto add = [&](AstP head, size_t used) {
+            AstP c = mk(Ast::CAT);
+            c->kids.push_back(std::move(head));
+            c->kids.push_back(fold_run(run, i + used));
+            alts.push_back(std::move(c));
+        };
+        add(clone_set(run[i].get()), 1);
+        if (at(i, 's') && at(i + 1, 's')) add(cp_class({0xDF, 0x1E9E}), 2);
+        if (at(i, 's') && at(i + 1, 't')) add(cp_class({0xFB05, 0xFB06}), 2);
+        if (at(i, 'f') && at(i + 1, 'f')) {
+            add(cp_class({0xFB00}), 2);
+            if (at(i + 2, 'i')) add(cp_class({0xFB03}), 3);
+            if (at(i + 2, 'l')) add(cp_class({0xFB04}), 3);
+        }
+        if (at(i, 'f') && at(i + 1, 'i')) add(cp_class({0xFB01}), 2);
+        if (at(i, 'f') && at(i + 1, 'l')) add(cp_class({0xFB02}), 2);
+        if (alts.size() == 1) return std::move(alts[0]);
+        AstP alt = mk(Ast::ALT);
+        for (auto &x : alts) alt->kids.push_back(std::move(x));
+        return alt;
+    }
+    void fold_strings(Ast *cat) {
+        std::vector<AstP> out;
+        size_t i = 0;
+        auto &k = cat->kids;
+        while (i < k.size()) {
+            size_t j = i;
+            while (j < k.size() && k[j]->t == Ast::SET && k[j]->ilit) j++;
+            bool hit = false;
+            for (size_t q = i; q + 1 < j && !hit; q++) {
+                const uint32_t a = k[q]->ilit, b = k[q + 1]->ilit;
+                hit = (a == 's' && (b == 's' || b == 't')) || (a == 'f' && (b == 'f' || b == 'i' || b == 'l'));
+            }
+            if (!hit) { for (size_t q = i; q < (j > i ? j : i + 1); q++) out.push_back(std::move(k[q])); i = j > i ? j : i + 1; continue; }
+            std::vector<AstP> run;
+            for (size_t q = i; q < j; q++) run.push_back(std::move(k[q]));
+            out.push_back(fold_run(run, 0));
+            i = j;
+        }
+        k = std::move(out);
+    }
+
     AstP concat(unsigned &opts, int depth) {
         AstP cat = mk(Ast::CAT);
         for (;;) {
@@ -665,6 +744,7 @@ struct Syntax {
             cat->kids.push_back(std::move(r));
             if (tail) break;
         }
+        fold_strings(cat.get());
         return cat;
     }
 };
@@ -777,9 +857,19 @@ struct SymbolMap {
     uint8_t xl[512];                                   // [b]: stray byte b, [256 + b]: truncated sequence with lead b
     SymbolMap() { for (int b = 0; b < 256; b++) { xl[b] = (uint8_t) b; xl[256 + b] = (uint8_t) b; } }
     std::map<const Ast *, ByteSet> accepts;            // per character node: the symbols it accepts
+    bool sym_word[11] = {false, false, false, false, false, false, false, false, false, false, false};   // uses_word: the symbol's byte is a word character
+    static bool has_word_anchor(const Ast *a) {
+        if (a->t == Ast::ANCHOR && (a->anchor == A_WORDB || a->anchor == A_NWORDB)) return true;
+        for (auto &k : a->kids) if (has_word_anchor(k.get())) return true;
+        return false;
+    }
     bool build(const Ast *root, std::string &err) {
         std::vector<const Ast *> atoms;
         collect(root, atoms);
+        // \b / \B: a stray byte b (a character of its own whose code is b) and the lead of a cut sequence (code = the lead) are
+        // word characters when U+00xx is one (regexec.c OP_WORD_BOUND: ONIGENC_IS_MBC_WORD on the decoded character): the kind
+        // is part of what tells symbols apart
+        const bool uses_word = has_word_anchor(root);
         std::map<std::vector<bool>, int> ids;
         std::vector<std::vector<bool>> sigs;
         auto sym_of = [&](const std::vector<bool> &sig) -> int {
@@ -793,16 +883,20 @@ struct SymbolMap {
         memset(xl, 0, sizeof(xl));
         for (int b = 0; b < 256; b++) { xl[b] = (uint8_t) b; xl[256 + b] = (uint8_t) b; }
         for (int b = 0x80; b < 256; b++) {
-            std::vector<bool> sig(atoms.size());
+            const bool w = uses_word && b < 0xfe && unicode_word((uint32_t) b);     // (0xFE / 0xFF decode to the engine's INVALID_CODE_*: no word)
+            std::vector<bool> sig(atoms.size() + 1);
             for (size_t i = 0; i < atoms.size(); i++) sig[i] = atoms[i]->cc.invalid_byte(b);
+            sig[atoms.size()] = w;
             int id = sym_of(sig);
             if (id >= 11) { err = "too many kinds of ill-formed UTF-8 bytes for the GPU tables"; return false; }
             xl[b] = SPARE_BYTES[id];
+            sym_word[id] = w;
             if (b >= 0xc2 && b <= 0xf4) {
                 for (size_t i = 0; i < atoms.size(); i++) sig[i] = atoms[i]->cc.truncated(b);
                 id = sym_of(sig);
                 if (id >= 11) { err = "too many kinds of ill-formed UTF-8 bytes for the GPU tables"; return false; }
                 xl[256 + b] = SPARE_BYTES[id];
+                sym_word[id] = w;
             }
             else xl[256 + b] = xl[b];
         }
@@ -1127,10 +1221,19 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     }
     int kinv[NKIND];                         // compact index -> a canonical kind
     for (int k = NKIND - 1; k >= 0; k--) kinv[kmap[k]] = k;
-    auto kind_of_byte = [&](int b) -> int {
+    // kind of a SYMBOL (rx.hpp TableSet::cls): an ASCII byte by itself; utf8 set with \b / \B: a stray byte / the lead of a cut
+    // sequence by the code it stands for (SymbolMap::sym_word), a byte of a well-formed multi-byte character by the half of
+    // the symbol space the walker found it in (256 + b: the character is a word character)
+    const int NSYM = (!ascii_only && nfa.uses_word) ? 512 : 256;
+    out.word_variants = NSYM == 512;
+    auto kind_of_byte = [&](int sym) -> int {
+        const int b = sym & 255;
         if (nfa.uses_nl && b == '\n') return K_NL;
-        if (nfa.uses_word && ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_')) return K_WORD;
-        return K_OTHER;
+        if (!nfa.uses_word) return K_OTHER;
+        if (b < 0x80) return ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_') ? K_WORD : K_OTHER;
+        if (ascii_only) return K_OTHER;
+        for (int k = 0; k < 11; k++) if (SPARE_BYTES[k] == b) return syms.sym_word[k] ? K_WORD : K_OTHER;
+        return sym >= 256 ? K_WORD : K_OTHER;
     };
 
     Tables tb(nfa);
@@ -1138,27 +1241,29 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     {
         std::map<std::vector<uint64_t>, int> sig2cls;
         std::vector<uint64_t> sig((P + 63) / 64 + 1);
-        for (int b = 0; b < 256; b++) {
+        for (int sy = 0; sy < NSYM; sy++) {
+            const int b = sy & 255;
             std::fill(sig.begin(), sig.end(), 0);
             for (int p = 0; p < P; p++) if (nfa.n[tb.pos_node[p]].set.has(b)) setbit(sig, p);
-            sig.back() = (uint64_t) kind_of_byte(b) | ((ascii_only && b >= 0x80) ? 16u : 0u);
+            sig.back() = (uint64_t) kind_of_byte(sy) | ((ascii_only && b >= 0x80) ? 16u : 0u);
             auto it = sig2cls.find(sig);
             int id;
             if (it == sig2cls.end()) { id = (int) sig2cls.size(); sig2cls[sig] = id; }
             else id = it->second;
-            out.cls[b] = (uint8_t) id;
+            out.cls[sy] = (uint8_t) id;
             if (ascii_only && b >= 0x80) out.high_cls = id;
         }
+        if (NSYM == 256) for (int sy = 256; sy < 512; sy++) out.cls[sy] = out.cls[sy - 256];
         out.ncls = (int) sig2cls.size();
         if (out.ncls > 63) { err = "too many byte classes for the GPU tables"; return false; }
     }
-    std::vector<int> rep(out.ncls, -1);
-    for (int b = 255; b >= 0; b--) rep[out.cls[b]] = b;
+    std::vector<int> rep(out.ncls, -1), rsym(out.ncls, -1);      // a byte of the class / a symbol of the class
+    for (int sy = NSYM - 1; sy >= 0; sy--) { rsym[out.cls[sy]] = sy; rep[out.cls[sy]] = sy & 255; }
     std::vector<std::vector<int>> pos_of_cls(out.ncls);
     for (int c = 0; c < out.ncls; c++)
         for (int p = 0; p < P; p++) if (nfa.n[tb.pos_node[p]].set.has(rep[c])) pos_of_cls[c].push_back(p);
     std::vector<int> kind_cls(out.ncls);     // canonical kinds
-    for (int c = 0; c < out.ncls; c++) kind_cls[c] = kind_of_byte(rep[c]);
+    for (int c = 0; c < out.ncls; c++) kind_cls[c] = kind_of_byte(rsym[c]);
 
     const int X = tb.ncores(), START = tb.start_core();
     const int W = (X + 63) / 64;
@@ -1398,8 +1503,8 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
                     out.rdelta_p[(size_t) r * rc + c] = (e & 0x7FFF) == R_POISON ? (uint16_t) out.nR : e;
                 }
         }
-        out.ck.resize(256);
-        for (int b = 0; b < 256; b++) out.ck[b] = (uint8_t) (out.cls[b] | (out.kind_of_cls[out.cls[b]] << 6));
+        out.ck.resize(512);
+        for (int b = 0; b < 512; b++) out.ck[b] = (uint8_t) (out.cls[b] | (out.kind_of_cls[out.cls[b]] << 6));
     }
     // kernel encoding of the fast tables
     {
@@ -1409,8 +1514,8 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
         const size_t W = (size_t) 1 << out.wsh;
         if ((size_t) X * out.NKp >= 4096 || out.NKp * ncols > 256) { err = "pattern too large for the GPU fast tables"; return false; }
         if ((((size_t) X * out.NKp + 1) << out.wsh) > (1u << 19)) { err = "pattern too large for the GPU fast tables (forward table over 2 MiB)"; return false; }
-        out.col.resize(256);
-        for (int b = 0; b < 256; b++) out.col[b] = (uint8_t) ((out.kind_of_cls[out.cls[b]] << out.fc_shift) | out.cls[b]);
+        out.col.resize(512);
+        for (int b = 0; b < 512; b++) out.col[b] = (uint8_t) ((out.kind_of_cls[out.cls[b]] << out.fc_shift) | out.cls[b]);
         out.col_eot = (out.kind_edge << out.fc_shift) | out.ncls;
         auto enc = [&](uint32_t e, int nk) -> uint32_t {
             if (e == FC_DEAD) return FT_SPECIAL | (FT_DEAD << 28);
@@ -1521,7 +1626,13 @@ int utf8_walk_len(const uint8_t *s, int len) {
     return len;
 }
 // ... and the symbol at position i (i < walk length; len = the real length)
-int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen) {
+// (word_variants: + 256 for a byte of a well-formed multi-byte character that is a word character)
+static int utf8_word_half(const uint8_t *s, int lead, int L) {
+    uint32_t cp = L == 2 ? (uint32_t) (s[lead] & 0x1f) : L == 3 ? (uint32_t) (s[lead] & 0x0f) : (uint32_t) (s[lead] & 0x07);
+    for (int k = 1; k < L; k++) cp = (cp << 6) | (uint32_t) (s[lead + k] & 0x3f);
+    return unicode_word(cp) ? 256 : 0;
+}
+int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen, bool word_variants) {
     int b = s[i];
     if (seqlen) *seqlen = 1;
     if (b < 0x80) return b;
@@ -1530,7 +1641,7 @@ int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen
         if (L == 1) return xl[b];                          // the sequence breaks off: a character of its own
         if (i + L > len) return len - i >= 2 ? xl[256 + b] : xl[b];      // cut by the end of the text
         if (seqlen) *seqlen = L;
-        return b;
+        return b + (word_variants ? utf8_word_half(s, i, L) : 0);
     }
     if (b <= 0xbf) {
         // a continuation byte belongs to the sequence whose lead is the nearest non-continuation byte
@@ -1540,7 +1651,7 @@ int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen
             if (c >= 0x80 && c <= 0xbf) continue;
             if (c >= 0xc2 && c <= 0xf4) {
                 int L = utf8_seq_len(s, i - d, len);
-                if (L > d && i - d + L <= len) return b;
+                if (L > d && i - d + L <= len) return b + (word_variants ? utf8_word_half(s, i - d, L) : 0);
             }
             break;
         }
@@ -1560,7 +1671,7 @@ thread_local long g_stat_fast = 0, g_stat_look = 0, g_stat_multi = 0;
 int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int olen, int *beg, int *end) {
     // the utf8 set walks symbols over a possibly shortened text (see utf8_walk_len)
     const int len = t.ascii_only ? olen : utf8_walk_len(s, olen);
-    auto sym = [&](int i, int *L) -> int { if (t.ascii_only) { if (L) *L = 1; return s[i]; } return utf8_symbol(t.xl, s, i, olen, L); };
+    auto sym = [&](int i, int *L) -> int { if (t.ascii_only) { if (L) *L = 1; return s[i]; } return utf8_symbol(t.xl, s, i, olen, L, t.word_variants); };
     // the wide layout mirrors the kernels too: 32-bit entries, a checkpoint every 32 boundaries kept as two
     // 16-bit halves in the slots the narrow layout would use for boundaries 32k and 32k + 16
     const int CHKW = t.wide ? 2 * CHK : CHK;

@@ -44,7 +44,13 @@ constexpr uint16_t F_MATCH = 0xFFFF;      // forward list entry: low half == MAT
 // small enough to be staged in LDS.
 struct TableSet {
     bool ascii_only = false;
-    uint8_t cls[256];
+    // [symbol] -> class.  Symbols 0 .. 255 are bytes (utf8 set: after the SymbolMap translation); the utf8 set of a pattern
+    // with \b / \B has a second half, 256 + b: byte b of a well-formed multi-byte character that IS a word character
+    // (the reference's \b is Unicode-aware, ONIG_OPTION_WORD_BOUND_ALL_RANGE: every byte of such a character carries the
+    // character's kind, so a class comes in a word and a non-word variant and the walkers pick the column by decoding the
+    // character -- `word_variants`, rx.cpp utf8_symbol)
+    uint8_t cls[512];
+    bool word_variants = false;
     int ncls = 0;
     int high_cls = -1;
     // utf8 set only: symbol of a byte >= 0x80 that is a character of its own ([b]) / of the lead of a
@@ -157,7 +163,11 @@ int simulate_match(const Program &p, const uint8_t *s, int len);
 int utf8_seq_len(const uint8_t *s, int i, int len);
 // what the utf8 table set steps on: the length of the walked text and the symbol at position i
 int utf8_walk_len(const uint8_t *s, int len);
-int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen);
+int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen, bool word_variants = false);
+// Unicode word character (ONIGENC_CTYPE_WORD of the reference's UTF-8 encoding: posix_ranges.inc, probed from the real engine)
+bool unicode_word(uint32_t cp);
+// the ranges behind unicode_word for code points >= 0x80: {lo, hi} pairs, ascending (uploaded for the device walkers)
+const unsigned int (*unicode_word_ranges(int *n))[2];
 // forward-walk step counters of simulate_capture since the last call: {fast, lookahead, slow}
 void debug_stats(long *out);
 

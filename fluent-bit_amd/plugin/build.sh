@@ -23,5 +23,12 @@ for x in grep parser log_to_metrics; do
       -L$CS -lflbgpu -Wl,-rpath,'$ORIGIN/../../csrc'
   i=$((i+1))
 done
-gcc -O2 -Wall -rdynamic $INC -o $B/plugin_host $HERE/plugin_host.c -ldl
+# the host exports the engine symbols the plugins import; with the reference's real cmetrics at hand (oracle/_ref, built by
+# oracle/Makefile) also the ones filter_log_to_metrics_gpu needs
+CMT=$HERE/../../oracle/_ref
+if [ -f $CMT/libcmetrics_ref.so ]; then
+  gcc -O2 -Wall -rdynamic -DHOST_WITH_CMT $INC -I$CMT/stub3 -o $B/plugin_host $HERE/plugin_host.c -L$CMT -lcmetrics_ref -lm -Wl,-rpath,'$ORIGIN/../../../oracle/_ref' -ldl
+else
+  gcc -O2 -Wall -rdynamic $INC -o $B/plugin_host $HERE/plugin_host.c -ldl
+fi
 echo "built: $(ls $B | grep -v stub | tr '\n' ' ')"

@@ -14,8 +14,12 @@
  *     the parsers file would give them (conf/parsers.conf);
  *   - the cb_init / cb_filter / cb_exit call sequence of flb_filter_init_all / flb_filter_do
  *     (src/flb_filter.c:121-325,620-720).
- * Everything else the engine offers is absent: this host exports exactly the symbols the grep and parser
- * plugins import.  Built against the reference's headers by plugin/build.sh (in the build container); the
+ * Everything else the engine offers is absent: this host exports exactly the symbols the plugins import.  For
+ * filter_log_to_metrics_gpu (HOST_WITH_CMT: built when oracle/_ref/libcmetrics_ref.so, the reference's real cmetrics, is
+ * there to link against) that is also the hidden emitter input and the scheduler timer the plugin creates in cb_init
+ * (plugins/filter_log_to_metrics/log_to_metrics.c:852-966) -- stubbed: the emitter's flb_input_metrics_append PRINTS the
+ * struct cmt it is handed (series in map order, label values, values / buckets / sum / count with %.17g), which is what the
+ * test compares with the oracle; the timer callback is kept and fired by hand after cb_filter when a flush interval is set.  Built against the reference's headers by plugin/build.sh (in the build container); the
  * binary travels to the GPU box with the plugin objects.
  *
  * usage: plugin_host <plugin.so> <symbol> inspect
@@ -33,6 +37,16 @@
 #include <fluent-bit/flb_parser.h>
 #include <fluent-bit/flb_sds.h>
 #include <fluent-bit/flb_time.h>
+#ifdef HOST_WITH_CMT
+#include <fluent-bit/flb_input.h>
+#include <fluent-bit/flb_scheduler.h>
+#include <cmetrics/cmetrics.h>
+#include <cmetrics/cmt_map.h>
+#include <cmetrics/cmt_metric.h>
+#include <cmetrics/cmt_counter.h>
+#include <cmetrics/cmt_gauge.h>
+#include <cmetrics/cmt_histogram.h>
+#endif
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -148,6 +162,93 @@ static void add_parser(char *spec)
     registry[n_registry++] = p;
 }
 
+#ifdef HOST_WITH_CMT
+/* ---- what filter_log_to_metrics_gpu imports beyond the above: the emitter input, the scheduler, the metrics hand-off ---- */
+static void (*host_timer_cb)(struct flb_config *, void *) = NULL;
+static void *host_timer_data = NULL;
+static int host_appends = 0;
+
+int flb_input_name_exists(const char *name, struct flb_config *config) { (void) name; (void) config; return FLB_FALSE; }
+struct flb_input_instance *flb_input_new(struct flb_config *config, const char *input, void *data, int public_only)
+{
+    (void) config; (void) data; (void) public_only;
+    if (strcmp(input, "emitter") != 0) return NULL;
+    return calloc(1, sizeof(struct flb_input_instance));
+}
+int flb_input_set_property(struct flb_input_instance *ins, const char *k, const char *v)
+{
+    (void) ins;
+    printf("emitter property %s=%s\n", k, v);
+    return 0;
+}
+int flb_input_instance_init(struct flb_input_instance *ins, struct flb_config *config) { (void) ins; (void) config; return 0; }
+int flb_storage_input_create(struct cio_ctx *cio, struct flb_input_instance *in) { (void) cio; (void) in; return 0; }
+struct flb_sched *flb_sched_ctx_get(void) { static long dummy; return (struct flb_sched *) &dummy; }
+int flb_sched_timer_cb_create(struct flb_sched *sched, int type, int ms, void (*cb)(struct flb_config *, void *), void *data,
+                              struct flb_sched_timer **out_timer)
+{
+    (void) sched; (void) type;
+    printf("timer created ms=%d\n", ms);
+    host_timer_cb = cb; host_timer_data = data;
+    if (out_timer) *out_timer = (struct flb_sched_timer *) &host_timer_cb;
+    return 0;
+}
+int flb_sched_timer_cb_destroy(struct flb_sched_timer *timer) { (void) timer; host_timer_cb = NULL; return 0; }
+
+static void dump_map(const char *kind, struct cmt_map *map, int nbuckets, struct cmt_histogram_buckets *hb)
+{
+    struct cfl_list *head, *lh;
+    int b;
+    printf("%s %s_%s_%s labels=%d\n", kind, map->opts->ns, map->opts->subsystem, map->opts->name, map->label_count);
+    if (map->metric_static_set) {
+        struct cmt_metric *m = &map->metric;
+        printf("  series");
+        if (hb) {
+            for (b = 0; b <= nbuckets; b++) printf(" b%d=%llu", b, (unsigned long long) cmt_metric_hist_get_value(m, b));
+            printf(" count=%llu sum=%.17g\n", (unsigned long long) cmt_metric_hist_get_count_value(m), cmt_metric_hist_get_sum_value(m));
+        }
+        else printf(" value=%.17g\n", cmt_metric_get_value(m));
+    }
+    cfl_list_foreach(head, &map->metrics) {
+        struct cmt_metric *m = cfl_list_entry(head, struct cmt_metric, _head);
+        printf("  series");
+        cfl_list_foreach(lh, &m->labels) {
+            struct cmt_map_label *l = cfl_list_entry(lh, struct cmt_map_label, _head);
+            printf(" [%s]", l->name);
+        }
+        if (hb) {
+            for (b = 0; b <= nbuckets; b++) printf(" b%d=%llu", b, (unsigned long long) cmt_metric_hist_get_value(m, b));
+            printf(" count=%llu sum=%.17g\n", (unsigned long long) cmt_metric_hist_get_count_value(m), cmt_metric_hist_get_sum_value(m));
+        }
+        else printf(" value=%.17g\n", cmt_metric_get_value(m));
+    }
+}
+/* the emitter's entry (src/flb_input_metric.c): here the hand-off point -- print the context the plugin filled */
+int flb_input_metrics_append(struct flb_input_instance *ins, const char *tag, size_t tag_len, struct cmt *cmt)
+{
+    struct cfl_list *head;
+    (void) ins;
+    printf("metrics_append %d tag=%.*s\n", ++host_appends, (int) tag_len, tag);
+    cfl_list_foreach(head, &cmt->counters) {
+        struct cmt_counter *c = cfl_list_entry(head, struct cmt_counter, _head);
+        dump_map("counter", c->map, 0, NULL);
+    }
+    cfl_list_foreach(head, &cmt->gauges) {
+        struct cmt_gauge *g = cfl_list_entry(head, struct cmt_gauge, _head);
+        dump_map("gauge", g->map, 0, NULL);
+    }
+    cfl_list_foreach(head, &cmt->histograms) {
+        struct cmt_histogram *h = cfl_list_entry(head, struct cmt_histogram, _head);
+        size_t i;
+        printf("bounds");
+        for (i = 0; i < h->buckets->count; i++) printf(" %.17g", h->buckets->upper_bounds[i]);
+        printf("\n");
+        dump_map("histogram", h->map, (int) h->buckets->count, h->buckets);
+    }
+    return 0;
+}
+#endif /* HOST_WITH_CMT */
+
 /* ---- the engine's side of the plugin contract ---------------------------------------------------- */
 int main(int argc, char **argv)
 {
@@ -229,6 +330,12 @@ int main(int argc, char **argv)
     fclose(fp);
     ret = p->cb_filter(in, bytes, "test", 4, &out, &out_size, ins, NULL, ins->context, config);   /* src/flb_filter.c:194-211 */
     printf("cb_filter=%d out_size=%zu\n", ret, out_size);
+#ifdef HOST_WITH_CMT
+    if (host_timer_cb) {                                                   /* the flush timer fires (log_to_metrics.c:947-966) */
+        host_timer_cb(config, host_timer_data);
+        host_timer_cb(config, host_timer_data);                            /* a second tick without new data appends nothing */
+    }
+#endif
     fp = fopen(argv[5], "wb");
     if (ret == FLB_FILTER_MODIFIED && out_size) fwrite(out, 1, out_size, fp);
     fclose(fp);

@@ -105,3 +105,62 @@ def test_plugins_run_through_the_host_match_the_oracle():
         m = re.search(r"flb_parser_do=(-?\d+) out_size=(\d+) sec=(\d+) nsec=(\d+)", r.stdout)
         assert m, r.stdout + r.stderr
         assert (int(m.group(1)), int(m.group(3)), int(m.group(4))) == (ret, tm[0], tm[1]) and open(fout, "rb").read() == out
+
+
+@pytest.mark.gpu
+def test_log_to_metrics_plugin_runs_through_the_host():
+    """flb-filter_log_to_metrics_gpu.so executed: cb_init (cmetrics context, the hidden emitter, the flush timer), cb_filter,
+    l2m_gpu_publish -> the struct cmt handed to the emitter's flb_input_metrics_append (the host prints it: the real cmetrics,
+    oracle/_ref/libcmetrics_ref.so, holds the series) is the oracle's state; timer mode publishes on the tick, once."""
+    import oracle_binding as ob
+    import synth
+    if not os.path.exists(HOST) or "timer created" not in open(HOST, "rb").read().decode("latin1"):
+        pytest.skip("plugin_host built without cmetrics (oracle/_ref/libcmetrics_ref.so was absent at build time)")
+    data, off, ep = synth.apache_records(3000)
+    po = ob.Parser(APACHE2, time_fmt=TF, time_key="time")
+    q, parsed = ob.FilterParser("log", [po]).filter(bytes(data))
+    so = os.path.join(B, "flb-filter_log_to_metrics_gpu.so")
+
+    def series(text, want_appends):
+        blocks = text.split("metrics_append ")[1:]
+        assert len(blocks) == want_appends, text
+        out = []
+        for ln in blocks[-1].splitlines():
+            m = re.match(r"\s+series((?: \[[^\]]*\])*)(.*)$", ln)
+            if m:
+                labels = tuple(x.encode() for x in re.findall(r"\[([^\]]*)\]", m.group(1)))
+                kv = dict(p.split("=") for p in m.group(2).split())
+                out.append((labels, kv))
+        return out
+
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.mp"), os.path.join(d, "out.mp")
+        open(fin, "wb").write(parsed)
+        # counter, two labels, published after the call (no flush interval)
+        r = _host(so, "filter_log_to_metrics_gpu_plugin", "run", fin, fout, "metric_mode=counter", "metric_name=requests", "metric_description=n",
+                  "tag=metrics", "label_field=method", "label_field=code")
+        assert r.returncode == 0 and "cb_init=0" in r.stdout and "cb_filter=2" in r.stdout and "cb_exit=0" in r.stdout, r.stdout + r.stderr
+        assert "emitter property alias=emitter_for_log_to_metrics_gpu.0" in r.stdout and "tag=metrics" in r.stdout
+        assert "counter log_metric_counter_requests labels=2" in r.stdout
+        o = ob.L2M("counter", [("label_field", "method"), ("label_field", "code")])
+        assert o.filter(parsed) == ob.NOTOUCH
+        want = o.snapshot()[2]
+        got = series(r.stdout, 1)
+        assert [g[0] for g in got] == [w["labels"] for w in want]
+        assert [float(g[1]["value"]) for g in got] == [w["value"] for w in want]
+        # histogram of `size` with explicit buckets, timer mode: nothing at cb_filter, one append on the first tick, none on the second
+        props = ["metric_mode=histogram", "metric_name=size", "metric_description=b", "tag=m2", "value_field=size", "label_field=code",
+                 "bucket=100", "bucket=10000", "bucket=1000000", "flush_interval_sec=1"]
+        r = _host(so, "filter_log_to_metrics_gpu_plugin", "run", fin, fout, *props)
+        assert r.returncode == 0 and "timer created ms=1000" in r.stdout and "cb_filter=2" in r.stdout, r.stdout + r.stderr
+        assert "bounds 100 10000 1000000" in r.stdout
+        o = ob.L2M("histogram", [("label_field", "code"), ("bucket", "100"), ("bucket", "10000"), ("bucket", "1000000")], value_field="size")
+        o.filter(parsed)
+        want = o.snapshot()[2]
+        got = series(r.stdout, 1)
+        assert [g[0] for g in got] == [w["labels"] for w in want]
+        for g, w in zip(got, want):
+            assert [int(g[1]["b%d" % b]) for b in range(4)] == list(w["buckets"]) and int(g[1]["count"]) == w["count"] and float(g[1]["sum"]) == w["sum"]
+        # discard_logs: MODIFIED with an empty output (log_to_metrics.c:1143-1150)
+        r = _host(so, "filter_log_to_metrics_gpu_plugin", "run", fin, fout, "metric_mode=counter", "metric_name=n", "metric_description=n", "tag=t", "discard_logs=true")
+        assert r.returncode == 0 and "cb_filter=1 out_size=0" in r.stdout, r.stdout + r.stderr
