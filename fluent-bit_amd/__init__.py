@@ -54,6 +54,7 @@ def lib():
     L.flbgpu_parser_create_kv.restype = c_void_p
     L.flbgpu_parser_create_kv.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int, c_char_p]
     L.flbgpu_parser_destroy.argtypes = [c_void_p]
+    L.flbgpu_parser_add_decoder.argtypes = [c_void_p, c_int, c_char_p, c_char_p, c_char_p]
     L.flbgpu_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int64), POINTER(c_int64)]
     L.flbgpu_filter_parser_create.restype = c_void_p
     L.flbgpu_filter_parser_create.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]
@@ -154,7 +155,7 @@ class Parser:
     flb_parser_create.  Defaults are the parsers-file defaults (src/flb_parser.c:1277-1304)."""
 
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex", no_bare_keys=False):
+                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex", no_bare_keys=False, decoders=None):
         if format in ("logfmt", "ltsv"):
             self.h = lib().flbgpu_parser_create_kv(_b(name), _b(format), _b(time_fmt), _b(time_key), _b(time_offset), int(time_keep),
                                                    int(time_strict), int(no_bare_keys), _b(types))
@@ -166,6 +167,10 @@ class Parser:
                                                 _b(time_offset), int(time_keep), int(time_strict), _b(types))
         if not self.h:
             raise ValueError("flbgpu_parser_create: " + last_error())
+        # decoders: [(as: bool, backend, field[, action])] = the parser's Decode_Field / Decode_Field_As lines in order
+        for d in decoders or []:
+            if lib().flbgpu_parser_add_decoder(self.h, int(bool(d[0])), _b(d[1]), _b(d[2]), _b(d[3] if len(d) > 3 else None)) != 0:
+                raise ValueError("flbgpu_parser_add_decoder: " + last_error())
 
     def do(self, buf):
         out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()

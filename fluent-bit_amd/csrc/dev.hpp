@@ -86,6 +86,22 @@ struct TimePlan {
     uint8_t lo[32];                      // NUM2: lower limit
 };
 
+// ---- Decode_Field / Decode_Field_As of a parser (src/flb_parser_decoder.c; include/fluent-bit/flb_parser_decoder.h:27-43): one
+// entry per key with its rules in configuration order (get_decoder_key_context :556-591)
+enum { DEC_T_DEFAULT = 0, DEC_T_AS = 1 };                    // FLB_PARSER_DEC_DEFAULT (Decode_Field) / _AS (Decode_Field_As)
+enum { DEC_A_NONE = 0, DEC_A_TRY_NEXT = 1, DEC_A_DO_NEXT = 2 };
+constexpr int MAX_DEC_KEYS = 8, MAX_DEC_RULES = 8;
+struct DevDecRule { uint8_t type, backend, action, pad; };   // backend: dec::BK_* (csrc/dec.hpp)
+struct DevDecoder {
+    uint8_t key[64];
+    uint32_t key_len;
+    uint32_t add_extra_keys;                                 // a Decode_Field rule exists for the key: its decoded object's pairs are appended
+    uint32_t nrules;
+    DevDecRule rules[MAX_DEC_RULES];
+};
+struct DevDecoders { uint32_t n; DevDecoder d[MAX_DEC_KEYS]; };
+constexpr uint32_t DEC_REGIONS = 6;                          // scratch regions per lane of k_parser_dec (dec_dev.inc)
+
 // ---- one regex parser (struct flb_parser, include/fluent-bit/flb_parser.h:41-70)
 struct DevParser {
     DevCap ascii, utf8;
@@ -130,6 +146,7 @@ struct DevParser {
     int nkvtypes;
     int kvtype_off[MAX_NAMES], kvtype_len[MAX_NAMES], kvtype_kind[MAX_NAMES];
     DevFx fx;                            // compact forward tables of the tile kernel (ok == 0: none)
+    const DevDecoders *decs;             // Decode_Field / Decode_Field_As rules (device memory; nullptr: none) -- dec_dev.inc
 };
 
 // ---- record accessor / key
@@ -176,6 +193,7 @@ enum {
     RF_PGDONE = 512,       // pair [filter_parser, filter_grep]: grep's rules were evaluated on the spans by k_parser_rx ...
     RF_PGKEEP = 1024,      // ... and keep the record
     RF_NEEDLOC = 4096,     // k_parser_reg<false> left the row to the fix-up launch (another layout, the end of the chunk)
+    RF_DEC = 8192,         // the winning parser has decoders: sized and written by k_parser_dec (dec_dev.inc), skipped by k_parser_emit
     RF_DESC = 2048,        // pair mode: the kept record's fields are in its descriptor (PgEmitArgs::desc), not in the columns
 };
 constexpr uint32_t PG_UNDECIDED = 0xFFFFFFFFu;   // keep_len of a row whose rules k_pg_decide still has to evaluate
@@ -309,6 +327,20 @@ struct ParserEmitArgs {
     uint64_t bytes;             // chunk size (bounds the wide tail loads)
     EmitCfg ec;
 };
+
+// k_parser_dec: the rows whose winning parser has decoders (dec_dev.inc).  mode 0 = size pass (out_len, flags, timestamps are
+// rewritten), 1 = emit pass (the record at out_off).  scratch: lanes x DEC_REGIONS x cap bytes, one slab per launched lane.
+struct DecArgs {
+    ParserEmitArgs e;
+    uint32_t *info_w;           // = e.info, writable (size pass)
+    uint32_t *out_len_w;        // = e.out_len, writable (size pass)
+    uint8_t *scratch;
+    uint32_t cap;               // bytes per region
+    int mode;
+    unsigned long long *err;    // rows whose scratch overflowed (the call fails)
+    unsigned long long *ndec;   // rows handled (size pass)
+};
+void launch_parser_dec(const DecArgs &a, int blocks, hipStream_t st);
 
 // ---- filter_grep (plugins/filter_grep/grep.c)
 constexpr int MAX_RULES = 64;

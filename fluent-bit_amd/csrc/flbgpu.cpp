@@ -136,7 +136,47 @@ struct flbgpu_parser {
     TableBlob blob_ascii, blob_utf8, blob_fx;
     DevParser dev;                 // host copy (device pointers inside)
     flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
+    DevDecoders decs;              // Decode_Field / Decode_Field_As (flbgpu_parser_add_decoder), uploaded when a filter takes the parser
+    void *d_decs = nullptr;
+    flbgpu_parser() { memset(&decs, 0, sizeof(decs)); }
+    ~flbgpu_parser() { if (d_decs) (void) hipFree(d_decs); }
 };
+
+// One rule of a parser's decoder list: "Decode_Field[_As] <backend> <key> [try_next|do_next]" (conf/parsers.conf, parsed by
+// src/flb_parser_decoder.c:593-776 flb_parser_decoder_list_create): rules of one key are kept together in configuration order,
+// a key with a Decode_Field rule appends the decoded object's pairs to the record (add_extra_keys :701-703).
+extern "C" int flbgpu_parser_add_decoder(flbgpu_parser *p, int as, const char *backend, const char *key, const char *action) {
+    if (!p || !backend || !key) { set_err("parser decoder: missing argument"); return -1; }
+    int bk;
+    if (!strcasecmp(backend, "json")) bk = 0;
+    else if (!strcasecmp(backend, "escaped")) bk = 1;
+    else if (!strcasecmp(backend, "escaped_utf8")) bk = 2;
+    else if (!strcasecmp(backend, "mysql_quoted")) bk = 3;
+    else { set_err("parser '%s': field decoder '%s' not found", p->name.c_str(), backend); return -1; }
+    int act = DEC_A_NONE;
+    if (action && *action) {
+        if (!strcasecmp(action, "try_next")) act = DEC_A_TRY_NEXT;
+        else if (!strcasecmp(action, "do_next")) act = DEC_A_DO_NEXT;
+        else { set_err("parser '%s': unknown decoder action '%s'", p->name.c_str(), action); return -1; }
+    }
+    const size_t kl = strlen(key);
+    if (kl == 0 || kl > sizeof(p->decs.d[0].key)) { set_err("parser '%s': decoder key too long", p->name.c_str()); return -1; }
+    DevDecoder *d = nullptr;
+    for (uint32_t i = 0; i < p->decs.n; i++) if (p->decs.d[i].key_len == kl && !memcmp(p->decs.d[i].key, key, kl)) d = &p->decs.d[i];
+    if (!d) {
+        if (p->decs.n >= MAX_DEC_KEYS) { set_err("parser '%s': more than %d keys with decoders", p->name.c_str(), MAX_DEC_KEYS); return -1; }
+        d = &p->decs.d[p->decs.n++];
+        memcpy(d->key, key, kl);
+        d->key_len = (uint32_t) kl;
+    }
+    if (d->nrules >= MAX_DEC_RULES) { set_err("parser '%s': more than %d decoder rules for one key", p->name.c_str(), MAX_DEC_RULES); return -1; }
+    DevDecRule &r = d->rules[d->nrules++];
+    r.type = as ? DEC_T_AS : DEC_T_DEFAULT; r.backend = (uint8_t) bk; r.action = (uint8_t) act; r.pad = 0;
+    if (!as) d->add_extra_keys = 1;
+    if (p->d_decs) { (void) hipFree(p->d_decs); p->d_decs = nullptr; }       // (uploaded again by the next filter that takes the parser)
+    if (p->self_filter) { delete p->self_filter; p->self_filter = nullptr; }
+    return 0;
+}
 
 // src/flb_parser.c:1806-1870 flb_parser_tzone_offset
 static int tzone_offset(const char *str, int len, int *tmdiff) {
@@ -538,6 +578,16 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
     std::vector<DevParser> dp;
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
+        parsers[i]->dev.decs = nullptr;
+        if (parsers[i]->decs.n > 0) {
+            if (!parsers[i]->d_decs &&
+                (hipMalloc(&parsers[i]->d_decs, sizeof(DevDecoders)) != hipSuccess ||
+                 hipMemcpy(parsers[i]->d_decs, &parsers[i]->decs, sizeof(DevDecoders), hipMemcpyHostToDevice) != hipSuccess)) {
+                set_err("filter_parser: uploading the decoders failed"); delete f; return nullptr;
+            }
+            parsers[i]->dev.decs = (const DevDecoders *) parsers[i]->d_decs;
+            f->has_decoders = true;
+        }
         dp.push_back(parsers[i]->dev);
         if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
     }
@@ -717,7 +767,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     // single-pass tile kernel (tile_kernels.inc) instead of locate / rx / finish: parser 0 start-anchored with compact
     // tables; a workgroup's waves share one copy of the tables, every wave owns a record tile + its capture columns
     const DevFx &fx = f->parsers[0]->dev.fx;
-    bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE");
+    bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
     for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
     uint32_t tile_wave_bytes = 0, tile_pg_room = 0;
     // two builds of the single pass: value bytes in registers (k_parser_reg, 16 waves per CU: the default) or the
@@ -961,6 +1011,30 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     const uint8_t *data = (const uint8_t *) in->data;
     const int cus = g_cus > 0 ? g_cus : 256;
     if (n == 0) return true;
+    // rows whose winning parser has Decode_Field rules: sized again with the decoders applied (dec_dev.inc)
+    DecArgs dca;
+    int dec_blocks = 0;
+    memset((void *) &dca, 0, sizeof(dca));
+    if (f->has_decoders) {
+        launch_max_row_len(row_off, n, &dm->max_row, st);
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        // a region holds a packed map or a decoded text: 3 x the longest record + room for the field names is never reached
+        const uint64_t cap = (uint64_t) hm.max_row * 3 + 4096;
+        uint64_t lanes = (n + 63) / 64 * 64;
+        const uint64_t budget = (uint64_t) 1 << 31;
+        while (lanes > 64 && lanes * DEC_REGIONS * cap > budget) lanes = (lanes / 2 + 63) / 64 * 64;
+        if (lanes > 64 * 4096) lanes = 64 * 4096;
+        if (cap > 0xFFFFFFF0ull || !f->d_dec.ensure(lanes * DEC_REGIONS * cap)) { set_err("filter_parser: no memory for the decoders' scratch"); return false; }
+        dec_blocks = (int) (lanes / 64);
+        dca.e.data = data; dca.e.row_off = row_off; dca.e.n = n; dca.e.cfg = f->pcfg; dca.e.parsers = f->d_parsers.as<DevParser>();
+        dca.e.n_cols = in->n; dca.e.info = f->d_info.as<uint32_t>(); dca.e.caps = f->d_caps.as<uint32_t>(); dca.e.caps_stride = f->caps_stride;
+        dca.e.null_mask = f->d_null.as<uint64_t>(); dca.e.out_len = f->d_len.as<uint32_t>(); dca.e.out_off = nullptr; dca.e.out = nullptr; dca.e.bytes = in->bytes;
+        dca.info_w = f->d_info.as<uint32_t>(); dca.out_len_w = f->d_len.as<uint32_t>(); dca.scratch = f->d_dec.as<uint8_t>(); dca.cap = (uint32_t) cap;
+        dca.mode = 0; dca.err = &dm->counts[10]; dca.ndec = &dm->counts[11];
+        HIPOK(hipMemsetAsync(&dm->counts[10], 0, 2 * sizeof(unsigned long long), st));
+        { ProfScope ps(f, st, "k_parser_dec_size"); launch_parser_dec(dca, dec_blocks, st); }
+    }
     // write offsets + the number of emitted records (what flb_mp_count_log_records would report) in one pass
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st, &dm->counts[1]); }
     total = 0;
@@ -982,7 +1056,13 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     fill_emit_cfg(f, ea.ec);
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
     if (hm.counts[3] > 0) { ProfScope ps(f, st, "k_parser_emit_exact"); launch_parser_emit_exact(ea, st); }
+    if (f->has_decoders && hm.counts[11] > 0) {
+        dca.e.out_off = ea.out_off; dca.e.out = ea.out; dca.mode = 1;
+        { ProfScope ps(f, st, "k_parser_dec_emit"); launch_parser_dec(dca, dec_blocks, st); }
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+    }
     HIPOK(hipStreamSynchronize(st));
+    if (f->has_decoders && hm.counts[10] > 0) { set_err("filter_parser: a decoded field outgrew the decoders' scratch (%llu records)", hm.counts[10]); return false; }
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     f->last_out = hm.counts[1];   // rows with length 0 (dropped/skipped) remain as empty rows
     *ret = FLBGPU_FILTER_MODIFIED;
@@ -1060,6 +1140,7 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
 static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     if (getenv("FLBGPU_NO_FUSE")) return false;
     if (fp->kind != F_PARSER || fg->kind != F_GREP) return false;
+    if (fp->has_decoders) return false;
     if (fp->pcfg.nparsers != 1 || fp->pcfg.key.is_ra || fp->pcfg.reserve_data || fp->pcfg.preserve_key) return false;
     const DevParser &d = fp->parsers[0]->dev;
     if (d.is_json || !d.plain_types || d.nfields > 32 || d.nfields == 0 || d.nregs_minus1 <= 0) return false;

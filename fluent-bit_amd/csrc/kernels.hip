@@ -23,10 +23,12 @@
 #include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
+#include "dec.hpp"
 
 namespace flbgpu {
 
 #include "kdev.inc"
+#include "dec_dev.inc"
 
 // ------------------------------------------------------------------------------------------
 // filter_parser pass 1 is split into phase kernels so that every wave of a launch runs the same
@@ -485,7 +487,7 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
             if (m > cnt - lo) m = cnt - lo;
             if (m == 0) {
                 // one record larger than the staging area: straight to global memory
-                if (lane == lo && o1 > o0) {
+                if (lane == lo && o1 > o0 && !(a.info[r] & RF_DEC)) {
                     ByteSink s(a.out + o0);
                     CapsView cv;
                     cv.base = a.caps; cv.n = a.n_cols; cv.r = r;
@@ -495,7 +497,7 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
                 lo += 1;
                 continue;
             }
-            if (lane >= lo && lane < lo + m && o1 > o0) {
+            if (lane >= lo && lane < lo + m && o1 > o0 && !(a.info[r] & RF_DEC)) {      // (RF_DEC: k_parser_dec writes the row afterwards)
                 LdsSink s(stg + align + (uint32_t) (o0 - batch_base));
                 s.src_end = a.data + a.bytes;
                 s.limit = s.p + (uint32_t) (o1 - o0);
@@ -523,6 +525,42 @@ __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
             lo += m;
         }
     }
+}
+
+// rows whose winning parser has decoders (dec_dev.inc): one row per lane, straight from / to global memory
+__global__ void __launch_bounds__(64) k_parser_dec(DecArgs a) {
+    const uint64_t tid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t) gridDim.x * blockDim.x;
+    uint8_t *rg = a.scratch + tid * (uint64_t) DEC_REGIONS * a.cap;
+    for (uint64_t r = tid; r < a.e.n; r += nthreads) {
+        const uint32_t fl = a.e.info[r];
+        if (!(fl & RF_PARSED) || (fl & RF_BADTS)) continue;
+        if (a.mode == 1 && (!(fl & RF_DEC) || a.e.out_off[r + 1] == a.e.out_off[r])) continue;
+        RecInfo ri = rec_load(a.e.info, a.e.n_cols, r);
+        if (!a.e.parsers[ri.parser_idx].decs) continue;
+        CapsView cv;
+        cv.base = a.e.caps; cv.n = a.e.n_cols; cv.r = r;
+        const uint8_t *rec = a.e.data + a.e.row_off[r], *rec_end = a.e.data + a.e.row_off[r + 1];
+        int64_t sec = ri.ts_sec, nsec = ri.ts_nsec;
+        bool badts = false, ok;
+        if (a.mode == 0) {
+            CountSink cs;
+            ok = dec_record(cs, a.e.cfg, a.e.parsers, rec, rec_end, ri, cv, a.e.null_mask[r], rg, a.cap, &sec, &nsec, &badts);
+            if (!ok) { atomicAdd(a.err, 1ull); continue; }
+            atomicAdd(a.ndec, 1ull);
+            if (badts) { a.info_w[r] = fl | RF_BADTS; a.out_len_w[r] = 0; continue; }
+            a.info_w[r] = fl | RF_DEC;
+            a.info_w[4 * a.e.n_cols + r] = (uint32_t) sec; a.info_w[5 * a.e.n_cols + r] = (uint32_t) nsec;
+            a.out_len_w[r] = (uint32_t) cs.n;
+        }
+        else {
+            ByteSink s(a.e.out + a.e.out_off[r]);
+            ok = dec_record(s, a.e.cfg, a.e.parsers, rec, rec_end, ri, cv, a.e.null_mask[r], rg, a.cap, &sec, &nsec, &badts);
+            if (!ok) atomicAdd(a.err, 1ull);
+        }
+    }
+}
+void launch_parser_dec(const DecArgs &a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_parser_dec, dim3((unsigned) blocks), dim3(64), 0, st, a);
 }
 
 // records whose Types float literal is a hard rounding case (RF_EXACT): rewritten in place with the

@@ -116,6 +116,11 @@ struct CC {
     // more byte classes than the tables hold is refused at create).
     CodeSet mbx;
     bool neg = false;
+    // (?i): the ASCII members that came in as characters, ranges, \d \s \h or POSIX brackets other than [:word:] / [:ascii:] --
+    // NOT through \w.  The reference keeps this shadow class (regparse.c parse_char_class `asc_cc`, :4739-4748, :4316-4328)
+    // and lets a case fold cross the ASCII boundary (k -> U+212A, s -> U+017F) only for members of it (i_apply_case_fold :5543-5553):
+    // (?i)[a-z] accepts the Kelvin sign, (?i)[\w.-] does not.
+    ByteSet asc;
     uint32_t lit = 0;                 // LIT: the code point (matched as its exact byte sequence)
     bool any_nl = false;              // ANY: also matches \n  ((?m))
 
@@ -125,6 +130,9 @@ struct CC {
         ByteSet b2 = o.bs;
         if (o.neg) b2.invert();
         bs.merge(b2);
+        ByteSet a2 = o.asc;
+        if (o.neg) { a2.invert(); for (int b = 0x80; b < 256; b++) a2.clear(b); }
+        asc.merge(a2);
         if (o.neg) { CodeSet c = mb_complement(o.mb); mb.merge(c); CodeSet cx = mb_complement(o.mbx); mbx.merge(cx); }
         else { mb.merge(o.mb); mbx.merge(o.mbx); }
         mb.norm(); mbx.norm();
@@ -132,8 +140,8 @@ struct CC {
     void add_cp(uint32_t lo, uint32_t hi) {
         // regparse.c next_state_val: single-byte values go to the bit set, code points to the range part; a
         // range that starts single-byte and ends above sets the bits up to min(end, 0xff) AND the whole range
-        if (hi < 0x80) { bs.set_range((int) lo, (int) hi); return; }
-        if (lo < 0x80) bs.set_range((int) lo, (int) std::min<uint32_t>(hi, 0xff));
+        if (hi < 0x80) { bs.set_range((int) lo, (int) hi); asc.set_range((int) lo, (int) hi); return; }
+        if (lo < 0x80) { bs.set_range((int) lo, (int) std::min<uint32_t>(hi, 0xff)); asc.set_range((int) lo, 0x7f); }
         mb.add(lo, hi);
         mbx.add(lo, hi);
     }
@@ -200,8 +208,13 @@ struct CC {
 #include "posix_ranges.inc"
 
 }  // namespace
+// what \b / \B ask of a character (regexec.c OP_WORD_BOUND: ONIGENC_IS_MBC_WORD -> onigenc_unicode_is_code_ctype): below U+0100
+// the encoding's Latin-1 table decides (enc/unicode.c EncUNICODE_ISO_8859_1_CtypeTable: superscripts and vulgar fractions
+// U+00B2 B3 B9 BC BD BE are word characters THERE, though [[:word:]] -- built from the CR_Word ranges -- rejects them), the code
+// ranges from U+0100 on
 bool unicode_word(uint32_t cp) {
     if (cp < 0x80) return (cp >= '0' && cp <= '9') || (cp >= 'A' && cp <= 'Z') || (cp >= 'a' && cp <= 'z') || cp == '_';
+    if (cp == 0xb2 || cp == 0xb3 || cp == 0xb9 || cp == 0xbc || cp == 0xbd || cp == 0xbe) return true;
     int lo = 0, hi = posix_u_word_n - 1;
     while (lo <= hi) {
         const int m = (lo + hi) / 2;
@@ -228,6 +241,7 @@ void ctype_ascii(ByteSet &bs, char t) {
 void add_ctype(CC &cc, char t, bool negated) {
     ByteSet a;
     ctype_ascii(a, t);
+    if (t != 'w') { for (int b = 0; b < 0x80; b++) if (a.has(b) != negated) cc.asc.set(b); }
     if (!negated) { cc.bs.merge(a); return; }
     for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
     cc.mb.add(0x80, LASTCP);
@@ -261,6 +275,7 @@ bool add_posix(CC &cc, const std::string &n, bool negated) {
 #undef PX
     CodeSet m;
     for (int i = 0; i < un; i++) m.add(u[i][0], u[i][1]);
+    if (n != "word" && n != "ascii") { for (int b = 0; b < 0x80; b++) if (a.has(b) != negated) cc.asc.set(b); }
     if (!negated) { cc.bs.merge(a); cc.mb.merge(m); cc.mbx.merge(m); }
     else {
         for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
@@ -276,6 +291,7 @@ bool add_posix(CC &cc, const std::string &n, bool negated) {
 // with U+212A KELVIN SIGN / U+017F LONG S (the only single-character folds that reach an ASCII letter);
 // a class that holds part of the non-ASCII range would need the full fold tables: refused.
 bool fold_case(CC &cc) {
+    const bool had_k = cc.bs.has('k'), had_K = cc.bs.has('K'), had_s = cc.bs.has('s'), had_S = cc.bs.has('S');
     for (int c = 'a'; c <= 'z'; c++) {
         if (cc.bs.has(c) || cc.bs.has(c - 32)) { cc.bs.set(c); cc.bs.set(c - 32); }
     }
@@ -288,8 +304,13 @@ bool fold_case(CC &cc) {
             if (x.first != x.second || (x.first != 0x212a && x.first != 0x17f)) return false;
         }
     }
-    if (cc.bs.has('k') || cc.mb.has(0x212a)) { cc.bs.set('k'); cc.bs.set('K'); cc.mb.add(0x212a, 0x212a); cc.mbx.add(0x212a, 0x212a); }
-    if (cc.bs.has('s') || cc.mb.has(0x17f)) { cc.bs.set('s'); cc.bs.set('S'); cc.mb.add(0x17f, 0x17f); cc.mbx.add(0x17f, 0x17f); }
+    // (the letters were closed under ASCII case above, from the members as they were: the shadow class decides for each of the two)
+    const bool kx = cc.mb.has(0x212a) || (had_k && cc.asc.has('k')) || (had_K && cc.asc.has('K'));
+    const bool sx = cc.mb.has(0x17f) || (had_s && cc.asc.has('s')) || (had_S && cc.asc.has('S'));
+    if (cc.mb.has(0x212a)) { cc.bs.set('k'); cc.bs.set('K'); }
+    if (cc.mb.has(0x17f)) { cc.bs.set('s'); cc.bs.set('S'); }
+    if (kx) { cc.mb.add(0x212a, 0x212a); cc.mbx.add(0x212a, 0x212a); }
+    if (sx) { cc.mb.add(0x17f, 0x17f); cc.mbx.add(0x17f, 0x17f); }
     cc.mb.norm(); cc.mbx.norm();
     return true;
 }
@@ -493,6 +514,7 @@ struct Syntax {
             // a folded letter is a small class (both cases; k and s also reach U+212A / U+017F)
             a->cc.kind = CC::CLASS;
             a->cc.bs.set((int) c);
+            a->cc.asc.set((int) c);
             fold_case(a->cc);
             a->ilit = c | 32;
             return a;

@@ -221,6 +221,37 @@ static char *types_to_str(struct flb_parser *p)
     return out;
 }
 
+/* the parser's Decode_Field / Decode_Field_As rules (struct flb_parser.decoders: one struct flb_parser_dec per key with its rules
+ * in configuration order, src/flb_parser_decoder.c:593-776) handed to the device parser in the same order */
+#include <fluent-bit/flb_parser_decoder.h>
+static int add_decoders(flbgpu_parser *g, struct flb_parser *p)
+{
+    static const char *backends[] = { "json", "escaped", "escaped_utf8", "mysql_quoted" };
+    struct mk_list *head;
+    struct mk_list *r_head;
+    struct flb_parser_dec *dec;
+    struct flb_parser_dec_rule *rule;
+
+    if (!p->decoders) {
+        return 0;
+    }
+    mk_list_foreach(head, p->decoders) {
+        dec = mk_list_entry(head, struct flb_parser_dec, _head);
+        mk_list_foreach(r_head, &dec->rules) {
+            rule = mk_list_entry(r_head, struct flb_parser_dec_rule, _head);
+            if (rule->backend < 0 || rule->backend > 3) {
+                return -1;
+            }
+            if (flbgpu_parser_add_decoder(g, rule->type == FLB_PARSER_DEC_AS, backends[rule->backend], dec->key,
+                                          rule->action == FLB_PARSER_ACT_TRY_NEXT ? "try_next" :
+                                          rule->action == FLB_PARSER_ACT_DO_NEXT ? "do_next" : NULL) != 0) {
+                return -1;
+            }
+        }
+    }
+    return 0;
+}
+
 static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_config *config, void *data)
 {
     char *types;
@@ -263,9 +294,9 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             continue;
         }
         if ((p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON && p->type != FLB_PARSER_LOGFMT &&
-             p->type != FLB_PARSER_LTSV) || p->decoders != NULL ||
+             p->type != FLB_PARSER_LTSV) ||
             p->time_zone != NULL || p->time_system_timezone) {
-            flb_plg_error(f_ins, "parser '%s': only Format regex / json / logfmt / ltsv without decoders/time zones "
+            flb_plg_error(f_ins, "parser '%s': only Format regex / json / logfmt / ltsv without time zones "
                           "is on the GPU path", kv->val);
             goto error;
         }
@@ -294,6 +325,11 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
         flb_free(types);
         if (!ctx->parsers[ctx->n_parsers]) {
             flb_plg_error(f_ins, "%s", flbgpu_last_error());
+            goto error;
+        }
+        if (add_decoders(ctx->parsers[ctx->n_parsers], p) != 0) {
+            flb_plg_error(f_ins, "%s", flbgpu_last_error());
+            ctx->n_parsers++;
             goto error;
         }
         ctx->n_parsers++;
@@ -387,9 +423,23 @@ static char *twin_signature(struct flb_parser *parser, const char *types)
     size_t len;
     char *sig;
 
+    size_t at;
+    struct mk_list *head;
+    struct mk_list *r_head;
+    struct flb_parser_dec *dec;
+    struct flb_parser_dec_rule *rule;
+
     len = 96 + (parser->name ? strlen(parser->name) : 0) + (parser->p_regex ? strlen(parser->p_regex) : 0) +
           (parser->time_fmt_full ? strlen(parser->time_fmt_full) : 0) + (parser->time_key ? strlen(parser->time_key) : 0) +
           (types ? strlen(types) : 0);
+    if (parser->decoders) {
+        mk_list_foreach(head, parser->decoders) {
+            dec = mk_list_entry(head, struct flb_parser_dec, _head);
+            mk_list_foreach(r_head, &dec->rules) {
+                len += strlen(dec->key) + 16;
+            }
+        }
+    }
     sig = flb_malloc(len);
     if (!sig) {
         return NULL;
@@ -398,6 +448,16 @@ static char *twin_signature(struct flb_parser *parser, const char *types)
              parser->name ? parser->name : "", parser->p_regex ? parser->p_regex : "", parser->skip_empty,
              parser->time_fmt_full ? parser->time_fmt_full : "\x02", parser->time_key ? parser->time_key : "\x02",
              parser->time_offset, parser->time_keep, parser->time_strict, types ? types : "");
+    if (parser->decoders) {
+        mk_list_foreach(head, parser->decoders) {
+            dec = mk_list_entry(head, struct flb_parser_dec, _head);
+            mk_list_foreach(r_head, &dec->rules) {
+                rule = mk_list_entry(r_head, struct flb_parser_dec_rule, _head);
+                at = strlen(sig);
+                snprintf(sig + at, len - at, "\x01%s:%d%d%d", dec->key, rule->type, rule->backend, rule->action);
+            }
+        }
+    }
     return sig;
 }
 
@@ -414,8 +474,7 @@ int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
     char *sig;
     flbgpu_parser *g = NULL;
 
-    if (parser->type != FLB_PARSER_REGEX || parser->decoders != NULL || parser->time_zone != NULL ||
-        parser->time_system_timezone) {
+    if (parser->type != FLB_PARSER_REGEX || parser->time_zone != NULL || parser->time_system_timezone) {
         return -1;
     }
     types = types_to_str(parser);
@@ -441,6 +500,10 @@ int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
                                  parser->time_key, parser->time_offset ? off : NULL, parser->time_keep,
                                  parser->time_strict, types);
         if (!g) {
+            goto fail_locked;
+        }
+        if (add_decoders(g, parser) != 0) {
+            flbgpu_parser_destroy(g);
             goto fail_locked;
         }
         if (n_twins < MAX_TWINS) {

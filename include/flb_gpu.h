@@ -58,7 +58,7 @@ flbgpu_parser *flbgpu_parser_create(const char *name, const char *regex, int ski
                                     const char *time_fmt, const char *time_key, const char *time_offset,
                                     int time_keep, int time_strict, const char *types);
 /* Format json (src/flb_parser_json.c:28-247): the value is one JSON object; Time_Key (default "time") /
- * Time_Format / Time_Keep as in the parsers file.  Types and Decode_Field do not apply. */
+ * Time_Format / Time_Keep as in the parsers file.  Types do not apply; Decode_Field: flbgpu_parser_add_decoder. */
 flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt, const char *time_key,
                                          const char *time_offset, int time_keep, int time_strict);
 
@@ -68,10 +68,17 @@ flbgpu_parser *flbgpu_parser_create_json(const char *name, const char *time_fmt,
  * src/flb_unescape.c:186-277).  logfmt_no_bare_keys = the Logfmt_No_Bare_Keys property
  * (src/flb_parser.c:1319-1324).  `types` = "key:type ..." as for regex parsers: with Types every kept pair goes
  * through flb_parser_typecast on the raw value text (src/flb_parser_logfmt.c:176-182, src/flb_parser_ltsv.c:149-155).
- * Decoders have no place in this ABI. */
+ * Decode_Field: flbgpu_parser_add_decoder. */
 flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *format, const char *time_fmt, const char *time_key,
                                        const char *time_offset, int time_keep, int time_strict, int logfmt_no_bare_keys,
                                        const char *types);
+/* One Decode_Field / Decode_Field_As line of the parser's section -- `Decode_Field[_As] <backend> <key> [try_next | do_next]`
+ * (conf/parsers.conf:44-58; src/flb_parser_decoder.c:593-776 flb_parser_decoder_list_create builds struct flb_parser.decoders from
+ * them): as = 1 for Decode_Field_As, backend "json" | "escaped" | "escaped_utf8" | "mysql_quoted", action NULL / "" | "try_next" |
+ * "do_next".  Call in configuration order, before the parser is handed to flbgpu_filter_parser_create; the rules then run inside
+ * the filter exactly where flb_parser_decoder_do (:215-550) runs inside flb_parser_do (regex / logfmt / ltsv: on the packed
+ * map; Format json: before the time lookup).  0, or -1 with flbgpu_last_error(). */
+int flbgpu_parser_add_decoder(flbgpu_parser *p, int as, const char *backend, const char *key, const char *action);
 void flbgpu_parser_destroy(flbgpu_parser *p);
 /* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
  * consumed (>= 0: the end of the last named group that took part in the match, src/flb_regex.c:52-54)
