@@ -19,6 +19,11 @@
  *   kind 4 (in_tail's line packing): props = key, path_key, path, offset_key, stream_offset, skip_empty_lines, sec, nsec; data = text:
  *   the loop of process_content (plugins/in_tail/tail_file.c:783-786,840-1000, plain path) restated here, every line packed by the
  *   REAL encoder through flb_tail_file_pack_line's call sequence (:552-604); answer ret = lines, out = records, then u64 processed
+ *   kind 5 (multiline, src/multiline/*.c compiled in place): props = type regex|endswith|equal, match_string, negate, key_content, buffer_limit,
+ *   builtin (java|go|python|ruby: the built-in parser of that name instead of rules), rule (repeated: from_states \x1f regex \x1f to_state),
+ *   skip_empty_lines, final_flush; data = frames (u32 sec, u32 nsec, u32 len, text): every frame is what one read of in_tail appends to
+ *   the file's buffer -- the loop of process_content cuts it into lines (what follows the last newline waits for the next frame) and
+ *   hands each to the REAL flb_ml_append_text with the frame's time; answer ret = records flushed, out = what the flush callback received
  * answer: i32 ret (-100: cb_init failed), u64 out_len, out bytes; kind 3: f64 seconds, u64 records in, u64 records kept */
 #include <stdio.h>
 #include <stdlib.h>
@@ -43,6 +48,9 @@
 #include <fluent-bit/flb_time.h>
 #include <fluent-bit/flb_log_event_encoder.h>
 #include <fluent-bit/record_accessor/flb_ra_parser.h>
+#include <fluent-bit/multiline/flb_ml.h>
+#include <fluent-bit/multiline/flb_ml_parser.h>
+#include <fluent-bit/multiline/flb_ml_rule.h>
 
 extern struct flb_filter_plugin filter_grep_plugin;
 extern struct flb_filter_plugin filter_parser_plugin;
@@ -258,6 +266,101 @@ static struct mk_list *make_decoders(const char *spec)
     return list;
 }
 
+/* ---- kind 5: the multiline core behind in_tail's line loop */
+/* linked with --wrap=flb_time_get: a group flushed before any time was registered takes "now" (flb_ml.c:1619-1624); the case names it */
+int __real_flb_time_get(struct flb_time *tm);
+static int g_now_set; static struct flb_time g_now;
+int __wrap_flb_time_get(struct flb_time *tm) { if (g_now_set) { *tm = g_now; return 0; } return __real_flb_time_get(tm); }
+
+struct ml_out { char *buf; size_t len, cap; int records; };
+static int ml_flush_cb(struct flb_ml_parser *parser, struct flb_ml_stream *mst, void *data, char *buf_data, size_t buf_size)
+{
+    struct ml_out *o = data;
+    (void) parser; (void) mst;
+    if (o->len + buf_size > o->cap) { o->cap = (o->len + buf_size) * 2 + 4096; o->buf = realloc(o->buf, o->cap); }
+    memcpy(o->buf + o->len, buf_data, buf_size);
+    o->len += buf_size;
+    o->records++;
+    return 0;
+}
+
+static void run_multiline(struct flb_config *config, uint32_t nprops, char **keys, char **vals, char *data, uint64_t dlen)
+{
+    const char *type = "regex", *match_string = NULL, *key_content = NULL, *builtin = NULL;
+    int negate = 0, skip_empty = 0, final_flush = 0;
+    uint32_t i;
+    struct flb_ml *ml;
+    struct flb_ml_parser *mlp = NULL;
+    struct flb_ml_parser_ins *mlp_i;
+    struct ml_out out = {0};
+    uint64_t stream_id = 0, off = 0;
+    char *pend = NULL;
+    size_t pend_len = 0;
+    for (i = 0; i < nprops; i++) {
+        if (!strcmp(keys[i], "type")) type = vals[i];
+        else if (!strcmp(keys[i], "match_string")) match_string = vals[i];
+        else if (!strcmp(keys[i], "negate")) negate = atoi(vals[i]);
+        else if (!strcmp(keys[i], "key_content")) key_content = vals[i];
+        else if (!strcmp(keys[i], "builtin")) builtin = vals[i];
+        else if (!strcmp(keys[i], "skip_empty_lines")) skip_empty = atoi(vals[i]);
+        else if (!strcmp(keys[i], "final_flush")) final_flush = atoi(vals[i]);
+        else if (!strcmp(keys[i], "buffer_limit")) config->multiline_buffer_limit = vals[i];
+        else if (!strcmp(keys[i], "now_sec")) { g_now_set = 1; g_now.tm.tv_sec = (time_t) strtoull(vals[i], NULL, 10); }
+        else if (!strcmp(keys[i], "now_nsec")) { g_now_set = 1; g_now.tm.tv_nsec = (long) strtoull(vals[i], NULL, 10); }
+    }
+    if (builtin) {
+        if (flb_ml_parser_builtin_create(config) != 0) { wr_answer(-100, NULL, 0); return; }
+    }
+    else {
+        mlp = flb_ml_parser_create(config, "t", flb_ml_type_lookup((char *) type), (char *) match_string, negate, 0, (char *) key_content, NULL, NULL, NULL, NULL);
+        if (!mlp) { wr_answer(-100, NULL, 0); return; }
+        for (i = 0; i < nprops; i++) {
+            char *a, *b;
+            if (strcmp(keys[i], "rule")) continue;
+            a = strchr(vals[i], 0x1f);
+            b = a ? strchr(a + 1, 0x1f) : NULL;
+            if (!b) { wr_answer(-100, NULL, 0); return; }
+            *a = 0; *b = 0;
+            if (flb_ml_rule_create(mlp, vals[i], a + 1, b[1] ? b + 1 : NULL, NULL) != 0) { wr_answer(-100, NULL, 0); return; }
+        }
+        if (flb_ml_parser_init(mlp) != 0) { wr_answer(-100, NULL, 0); return; }
+    }
+    ml = flb_ml_create(config, "t");
+    mlp_i = ml ? flb_ml_parser_instance_create(ml, (char *) (builtin ? builtin : "t")) : NULL;
+    if (!mlp_i || flb_ml_stream_create(ml, "f", -1, ml_flush_cb, &out, &stream_id) != 0) { wr_answer(-100, NULL, 0); return; }
+    if (builtin && key_content) flb_ml_parser_instance_set(mlp_i, "key_content", (char *) key_content);
+    while (off + 12 <= dlen) {
+        uint32_t sec, nsec, len;
+        struct flb_time tm;
+        char *d, *end, *nl;
+        memcpy(&sec, data + off, 4); memcpy(&nsec, data + off + 4, 4); memcpy(&len, data + off + 8, 4);
+        off += 12;
+        pend = realloc(pend, pend_len + len + 1);
+        memcpy(pend + pend_len, data + off, len);
+        pend_len += len; off += len;
+        tm.tm.tv_sec = sec; tm.tm.tv_nsec = nsec;
+        d = pend; end = pend + pend_len;
+        while (d < end && *d == '\0') d++;                                       /* tail_file.c:783-786 */
+        while (d < end && (nl = memchr(d, '\n', end - d))) {                     /* :840 */
+            size_t ll = nl - d;
+            int crlf = 0;
+            if (skip_empty) {                                                    /* :863-874 */
+                if (ll == 0) { d++; continue; }
+                else if (ll == 1 && d[0] == '\r') { d += 2; continue; }
+            }
+            if (ll >= 2) crlf = (d[ll - 1] == '\r');                             /* :877-884 */
+            flb_ml_append_text(ml, stream_id, &tm, d, ll - crlf);                /* :893-898 */
+            d += ll + 1;
+        }
+        pend_len = end - d;
+        memmove(pend, d, pend_len);
+    }
+    if (final_flush) flb_ml_flush_pending_now(ml);
+    wr_answer(out.records, out.buf, out.len);
+    free(out.buf); free(pend);
+    g_now_set = 0;
+}
+
 int main(void)
 {
     signal(SIGSEGV, on_segv);
@@ -323,6 +426,7 @@ int main(void)
             ret = it.ins.p->cb_filter(data, dlen, "t", 1, &out, &out_size, &it.ins, NULL, it.ins.context, config);
             wr_answer(ret, out, ret == FLB_FILTER_MODIFIED ? out_size : 0);
         }
+        else if (kind == 5) run_multiline(config, nprops, keys, vals, data, dlen);
         else if (kind == 4) {
             const char *key = "log", *path_key = NULL, *path = "", *offset_key = NULL;
             uint64_t stream_offset = 0, processed = 0;

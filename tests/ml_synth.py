@@ -1,0 +1,100 @@
+"""Synthetic multiline cases: rule sets (state graphs over simple patterns) and text whose lines hit them, cut into the frames
+successive reads of in_tail would deliver.  Test infrastructure."""
+import random
+
+BUILTINS = ("java", "go", "python", "ruby")
+
+# lines that walk the built-in parsers' states (and near misses)
+SEED_LINES = {
+    "java": [b'Exception in thread "main" java.lang.IllegalStateException: ..null property', b"     at com.example.myproject.Author.getBookIds(xx.java:38)",
+             b"Caused by: java.lang.NullPointerException", b"     ... 1 more", b"single line", b"\tat a.b.C(D.java:1)", b"   nested exception is:  ",
+             b"javax.servlet.ServletException: Something bad happened", b"", b"\r", b"  --- End of inner exception stack trace ---",
+             b"--- End of stack trace from previous location where exception was thrown ---", b"Suppressed: x", b" ... 12 common frames omitted",
+             b"    eval at foo", b"xError:", b"Error: boom"],
+    "go": [b"panic: my panic", b"", b"goroutine 4 [running]:", b"panic(0x45cb40, 0x47ad70)", b"\t/usr/local/go/src/runtime/panic.go:542 +0x46c",
+           b"main.main.func1(0xc420024120)", b"created by main.main", b"\tfoo.go:5 +0x58", b"[signal SIGSEGV: segmentation violation]",
+           b"2021/01/01 http: panic serving 127.0.0.1", b"one more line, no multiline", b" x", b"goroutine 1 [chan receive]:", b"runtime.goexit()"],
+    "python": [b"Traceback (most recent call last):", b'  File "/base/data/home/runtimes/python27/webapp2.py", line 1535, in __call__',
+               b"    rv = self.handle_exception(request, response, e)", b"Exception: ('spam', 'eggs')", b"hello world, not multiline", b"", b"   ",
+               b"\tFile x", b"ValueError: bad", b"a.b.c: d"],
+    "ruby": [b"/app/config/routes.rb:6:in `/': divided by 0 (ZeroDivisionError)", b"\tfrom /app/config/routes.rb:6:in `block in <main>'",
+             b"  from /var/lib/gems/3.0.0/gems/x.rb:428:in `instance_exec'", b"hello world, not multiline", b"", b"x:1:in y", b" from a:2:in b"],
+}
+
+ATOMS = [(r"^\d+ ", b"12 "), (r"^\[", b"["), (r"^\s+", b"   "), (r"^\s+at ", b"  at "), (r"ERROR", b"ERROR"), (r"^$", b""), (r"end$", b"end"),
+         (r"^[A-Z][a-z]+:", b"Caused:"), (r"\bpanic: ", b"panic: "), (r"^--", b"--"), (r"[^\t ]", b"x"), (r"^\S", b"q"), (r"(?i)^warn", b"WaRn")]
+STATES = ["s1", "s2", "s3", "s4"]
+
+
+def random_rules(rng):
+    """a rule list the reference accepts: the first rule holds start_state, every to_state is some rule's from_state"""
+    n = rng.randrange(1, 7)
+    rules = []
+    for i in range(n):
+        froms = set()
+        if i == 0 or rng.random() < 0.25:
+            froms.add("start_state")
+        for _ in range(rng.randrange(0 if froms else 1, 3)):
+            froms.add(rng.choice(STATES))
+        rules.append([sorted(froms, key=lambda s: rng.random()), rng.choice(ATOMS)[0], None])
+    known = sorted({s for r in rules for s in r[0]})
+    for r in rules:
+        r[2] = rng.choice(known) if rng.random() < 0.9 else None
+    return [(", ".join(f) if rng.random() < 0.7 else ",".join(f), "/%s/" % rx, to) for f, rx, to in rules]
+
+
+def random_text(rng, nlines, seeds=None, crlf=0.05, empty=0.08, long_line=0.01, nul_lead=0.05):
+    words = [b"alpha", b"beta", b"  gamma", b"12 delta", b"[x]", b"ERROR", b"end", b"Caused: by", b"panic: now", b"--", b"\tTab", b"WARN", b"warn"]
+    out = bytearray()
+    if rng.random() < nul_lead:
+        out += b"\0" * rng.randrange(1, 5)
+    for _ in range(nlines):
+        r = rng.random()
+        if r < empty:
+            line = b""
+        elif seeds and r < 0.75:
+            line = rng.choice(seeds)
+        else:
+            k = rng.randrange(1, 4)
+            line = (rng.choice(ATOMS)[1] if rng.random() < 0.6 else b"") + b" ".join(rng.choice(words) for _ in range(k))
+            if rng.random() < 0.1:
+                line += rng.choice([b" end", b"\t", b" \xc3\xa9t\xc3\xa9", b"\xff"])
+        if rng.random() < long_line:
+            line = line + b" " + bytes(rng.choice(b"abcdefghij ") for _ in range(rng.randrange(300, 3000)))
+        out += line
+        out += b"\r\n" if rng.random() < crlf else b"\n"
+    return bytes(out)
+
+
+def frames_of(rng, text, max_frames=5, t0=1700000000):
+    """cuts anywhere (also inside a line, inside a CR LF); every frame carries its own time"""
+    k = rng.randrange(1, max_frames + 1)
+    cuts = sorted(rng.randrange(0, len(text) + 1) for _ in range(k - 1)) if text else []
+    parts, a = [], 0
+    for c in cuts + [len(text)]:
+        parts.append(text[a:c])
+        a = c
+    return [(t0 + 7 * i, (i * 1000003 + 5) % 1000000000, p) for i, p in enumerate(parts)]
+
+
+def random_case(rng, nlines=None):
+    """keyword arguments shared by ref_filters.ml_case / oracle_binding.Multiline / the product + frames"""
+    cfg = {}
+    seeds = None
+    r = rng.random()
+    if r < 0.35:
+        b = rng.choice(BUILTINS)
+        cfg["builtin"] = b
+        seeds = SEED_LINES[b]
+    elif r < 0.85:
+        cfg["rules"] = random_rules(rng)
+    elif r < 0.93:
+        cfg.update(type="endswith", match_string=rng.choice(["end", "\\", "d", ""]), negate=rng.random() < 0.3)
+    else:
+        cfg.update(type="equal", match_string=rng.choice(["", "--", "end"]), negate=rng.random() < 0.3)
+    if rng.random() < 0.4:
+        cfg["key_content"] = rng.choice(["log", "message", "k" * 40])
+    text = random_text(rng, nlines if nlines is not None else rng.randrange(0, 60), seeds)
+    if rng.random() < 0.2:
+        text = text[:-1] if text else text                    # the last line is not complete yet
+    return cfg, frames_of(rng, text), dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)

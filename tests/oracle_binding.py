@@ -197,3 +197,58 @@ def tail_process(text, key="log", path_key=None, path="", offset_key=None, strea
     n = L.oflb_tail_process(text, len(text), enc(key), enc(path_key), enc(path), enc(offset_key), stream_offset, 1 if skip_empty_lines else 0, sec, nsec,
                             byref(out), byref(sz), byref(proc))
     return n, _take(out, sz), int(proc.value)
+
+
+class Multiline:
+    """oracle/oml.c: the multiline core behind in_tail's line loop (one parser, text lines)"""
+    TYPES = {"regex": 0, "endswith": 1, "equal": 2, "eq": 2}
+
+    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1):
+        L = lib()
+        L.oml_create.restype = c_void_p
+        L.oml_create.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int64]
+        L.oml_destroy.argtypes = [c_void_p]
+        L.oml_add_rule.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p]
+        L.oml_init.argtypes = [c_void_p]
+        L.oml_builtin.argtypes = [c_void_p, c_char_p]
+        L.oml_tail_chunk.argtypes = [c_void_p, c_char_p, c_size_t, c_int, c_int64, c_int64]
+        L.oml_append_text.argtypes = [c_void_p, c_int64, c_int64, c_char_p, c_size_t]
+        L.oml_flush_pending.argtypes = [c_void_p]
+        L.oml_output.restype = c_size_t
+        L.oml_output.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int)]
+        L.oml_state.argtypes = [c_void_p, POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]
+        enc = lambda x: None if x is None else (x if isinstance(x, bytes) else x.encode())
+        self.h = L.oml_create(self.TYPES[type.lower()], enc(match_string), 1 if negate else 0, enc(key_content), buffer_limit)
+        if builtin:
+            if L.oml_builtin(self.h, enc(builtin)) != 0:
+                raise ValueError("multiline: built-in parser %r" % builtin)
+        else:
+            for fs, rx, to in (rules or []):
+                if L.oml_add_rule(self.h, enc(fs), enc(rx), enc(to)) != 0:
+                    raise ValueError("multiline: rule %r" % ((fs, rx, to),))
+            if L.oml_init(self.h) != 0:
+                raise ValueError("multiline: to_state not registered")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oml_destroy(self.h)
+            self.h = None
+
+    def append(self, text, sec, nsec, skip_empty_lines=False):
+        """one read of in_tail; returns (records bytes, record count, truncations)"""
+        lib().oml_tail_chunk(self.h, text, len(text), 1 if skip_empty_lines else 0, sec, nsec)
+        return self._out()
+
+    def flush(self):
+        lib().oml_flush_pending(self.h)
+        return self._out()
+
+    def _out(self):
+        p = c_void_p(); r = c_int(); t = c_int()
+        n = lib().oml_output(self.h, byref(p), byref(r), byref(t))
+        return (ctypes.string_at(p, n) if n else b""), r.value, t.value
+
+    def state(self):
+        a = c_int(); b = c_size_t(); c = c_size_t()
+        lib().oml_state(self.h, byref(a), byref(b), byref(c))
+        return a.value, b.value, c.value

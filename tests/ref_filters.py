@@ -94,3 +94,23 @@ def tail_result(res):
     lines, out = res
     (processed,) = struct.unpack("<Q", out[-8:])
     return lines, out[:-8], processed
+
+
+def ml_case(frames, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=None,
+            skip_empty_lines=False, final_flush=False, now=(1600000000, 77)):
+    """the multiline core (src/multiline/*.c) behind in_tail's line loop.  frames: [(sec, nsec, text)] -- what successive reads append to
+    the file's buffer; rules: [(from_states, regex, to_state)]"""
+    props = [("type", type), ("negate", 1 if negate else 0), ("skip_empty_lines", 1 if skip_empty_lines else 0), ("final_flush", 1 if final_flush else 0)]
+    props += [("now_sec", now[0]), ("now_nsec", now[1])]
+    if builtin:
+        props.append(("builtin", builtin))
+    if match_string is not None:
+        props.append(("match_string", match_string))
+    if key_content:
+        props.append(("key_content", key_content))
+    if buffer_limit is not None:
+        props.append(("buffer_limit", buffer_limit))
+    for fs, rx, to in (rules or []):
+        props.append(("rule", b"\x1f".join(x if isinstance(x, bytes) else x.encode() for x in (fs, rx, to or ""))))
+    data = b"".join(struct.pack("<III", s, ns, len(t)) + t for s, ns, t in frames)
+    return _case(5, props, [], data)
