@@ -329,6 +329,104 @@ class TailLines:
             self.h = None
 
 
+class MultilineParser:
+    """a multiline parser definition (src/multiline/flb_ml_parser.c flb_ml_parser_create + flb_ml_rule.c flb_ml_rule_create / _init) with the
+    instance's key_content and the context's buffer limit; rules: [(from_states, regex, to_state)] or builtin = java | go | python | ruby"""
+
+    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1):
+        L = lib()
+        L.flbgpu_ml_parser_create.restype = c_void_p
+        L.flbgpu_ml_parser_create.argtypes = [c_char_p, c_char_p, c_int, c_char_p, ctypes.c_int64]
+        L.flbgpu_ml_parser_add_rule.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p]
+        L.flbgpu_ml_parser_builtin.argtypes = [c_void_p, c_char_p]
+        L.flbgpu_ml_parser_init.argtypes = [c_void_p]
+        L.flbgpu_ml_parser_destroy.argtypes = [c_void_p]
+        e = lambda x: None if x is None else _b(x)
+        self.h = L.flbgpu_ml_parser_create(e(type), e(match_string), int(bool(negate)), e(key_content), int(buffer_limit))
+        if not self.h:
+            raise ValueError(last_error())
+        ok = True
+        if builtin:
+            ok = L.flbgpu_ml_parser_builtin(self.h, e(builtin)) == 0
+        else:
+            for fs, rx, to in (rules or []):
+                ok = ok and L.flbgpu_ml_parser_add_rule(self.h, e(fs), e(rx), e(to)) == 0
+            ok = ok and L.flbgpu_ml_parser_init(self.h) == 0
+        if not ok:
+            err = last_error()
+            self.close()
+            raise ValueError(err)
+
+    def stream(self):
+        return MultilineStream(self)
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_ml_parser_destroy(self.h)
+            self.h = None
+
+
+class MultilineStream:
+    """what one tailed file carries through a multiline parser (flb_ml_stream_create): in_tail's line loop + flb_ml_append_text per read"""
+
+    def __init__(self, parser):
+        L = lib()
+        L.flbgpu_ml_stream_create.restype = c_void_p
+        L.flbgpu_ml_stream_create.argtypes = [c_void_p]
+        L.flbgpu_ml_stream_destroy.argtypes = [c_void_p]
+        L.flbgpu_ml_stream_state.argtypes = [c_void_p, POINTER(c_int), POINTER(c_uint64)]
+        L.flbgpu_ml_append.argtypes = [c_void_p, c_void_p, c_size_t, ctypes.c_uint32, ctypes.c_uint32, c_int, c_int, POINTER(c_void_p), POINTER(c_size_t),
+                                       POINTER(c_uint64), POINTER(c_uint64)]
+        L.flbgpu_ml_append_dev.argtypes = [c_void_p, c_void_p, c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_int, c_int, POINTER(DevChunk), POINTER(c_uint64), POINTER(c_uint64)]
+        self.parser = parser
+        self.h = L.flbgpu_ml_stream_create(parser.h)
+        if not self.h:
+            raise ValueError(last_error())
+        self.pending = b""
+
+    def append(self, text, sec, nsec, skip_empty_lines=False, flush=False):
+        """one read of the file appended to its buffer (what follows the last newline waits, as in_tail keeps it) -> (records bytes, count)"""
+        buf = self.pending + text
+        out = c_void_p(); sz = c_size_t(); proc = c_uint64(); recs = c_uint64()
+        r = lib().flbgpu_ml_append(self.h, buf, len(buf), sec, nsec, int(bool(skip_empty_lines)), int(bool(flush)), byref(out), byref(sz), byref(proc), byref(recs))
+        if r != 0:
+            raise RuntimeError(last_error())
+        b = ctypes.string_at(out, sz.value) if out.value else b""
+        if out.value:
+            _libc.free(out)
+        self.pending = buf[proc.value:]
+        return b, int(recs.value)
+
+    def append_dev(self, d_text, nbytes, sec, nsec, skip_empty_lines=False, flush=False):
+        """text in HBM -> (DevChunk, records, processed bytes)"""
+        out = DevChunk(); proc = c_uint64(); recs = c_uint64()
+        r = lib().flbgpu_ml_append_dev(self.h, d_text, nbytes, sec, nsec, int(bool(skip_empty_lines)), int(bool(flush)), byref(out), byref(proc), byref(recs))
+        if r != 0:
+            raise RuntimeError(last_error())
+        return out, int(recs.value), int(proc.value)
+
+    def flush(self):
+        """the flush timer (flb_ml_flush_pending): the open group leaves"""
+        return self.append(b"", 0, 0, flush=True) if not self.pending else self._flush_keep()
+
+    def _flush_keep(self):
+        keep, self.pending = self.pending, b""
+        try:
+            return self.append(b"", 0, 0, flush=True)
+        finally:
+            self.pending = keep
+
+    def state(self):
+        a = c_int(); b = c_uint64()
+        lib().flbgpu_ml_stream_state(self.h, byref(a), byref(b))
+        return a.value, int(b.value)
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_ml_stream_destroy(self.h)
+            self.h = None
+
+
 class StreamTask:
     """one task of the stream processor (src/stream_processor/flb_sp.c: flb_sp_task_create :433, flb_sp_do :2007, the window
     timer of flb_sp_fd_event :2101) for aggregate queries: GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING."""

@@ -624,6 +624,67 @@ void launch_tl_fill(const uint64_t *masks, uint64_t bytes, const uint64_t *tile_
 void launch_tl_size(const TailArgs &a, hipStream_t st);
 void launch_tl_emit(const TailArgs &a, int cus, hipStream_t st);
 
+
+// ---- multiline in front of the path (ml_kernels.inc; src/multiline/flb_ml.c, flb_ml_rule.c, flb_ml_group.c): text lines of one stream,
+// ONE multiline parser.  Items: k = 0 is the buffer the stream carries from the previous call, k = 1.. the lines that reach
+// flb_ml_append_text (Skip_Empty_Lines applied).  rule_to_state: 0 none, r + 1 = rule r -- a line's transition is a function over
+// these <= 16 states, packed as 16 nibbles.
+constexpr int ML_MAX_RULES = 15;
+enum { ML_REGEX = 0, ML_ENDSWITH = 1, ML_EQ = 2 };                         // flb_ml.h FLB_ML_REGEX / ENDSWITH / EQ
+enum { MLK_CARRY = 0, MLK_CONT = 1, MLK_START = 2, MLK_ALONE = 3, MLK_APPEND = 4, MLK_DROPPED = 5, MLK_MASK = 7, MLK_BA = 8 };   // act[]: kind | flush after
+enum { MLT_EMPTY = 0, MLT_NL = 1, MLT_OTHER = 2 };                         // how the group buffer ends (act[] bits 4-5: after the item)
+enum { MLP_FIRST = 1, MLP_SEP = 2, MLP_TRAIL = 4, MLP_CARRY_TIME = 8, MLP_NLBODY = 16, MLP_OPEN = 32, MLP_TRUNC = 64 };   // pk[]
+struct MlParserDev {
+    int type, negate, nrules;
+    uint32_t start_mask;                 // rules with a start_state among their from_states
+    uint32_t cont_mask[16];              // by rule_to_state: the non-start rules its to_state leads to (rule order = to_state_map order)
+    uint32_t flush_after;                // rules whose to_state leads to a start rule (try_flushing_buffer)
+    uint32_t match_len;
+    uint8_t match_str[256];              // ENDSWITH / EQ
+    uint32_t has_key_content, key_len;
+    uint8_t key[264];                    // the packed msgpack string of key_content | "log"
+    uint64_t buffer_limit;               // 0: none
+};
+struct MlMisc {                          // device words of one call
+    unsigned long long lead, total, records, truncated;
+    unsigned int final_state, new_carry_len, new_tail, anyreg, refused, last_ba, has_open, open_first;
+};
+struct MlArgs {
+    MlParserDev p;
+    const GrepRule *rules;               // [nrules] match-only DFA + UTF-8 tables per rule (key unused)
+    const uint8_t *text; uint64_t bytes;
+    const uint64_t *nl_pos; uint64_t nl; // raw lines
+    int skip_empty_lines, flush_all;
+    uint64_t NB;                         // allocated items (nl + 1); the real count is koff[nl] + 1
+    uint32_t *keep; const uint64_t *koff;
+    uint64_t *ls; uint32_t *ll;          // [NB] line start / length (CR of a CR LF dropped)
+    uint32_t *info;                      // [NB] rule match bits | last byte << 16 | non-empty << 24
+    uint64_t *F;                         // [NB] transition functions
+    uint8_t *sin;                        // [NB] state entering the item
+    uint8_t *act;                        // [NB]
+    uint32_t *c; const uint64_t *coff;   // [NB] bytes the item adds to its group's buffer, their scan
+    uint32_t *head; const uint64_t *gidx;// [NB] first item of a group, scan = group index
+    uint64_t *ghead;                     // [groups + 1] first item of every group
+    uint32_t *plen; const uint64_t *po;  // [NB] bytes the item writes into the output, their scan
+    uint32_t *pk; uint32_t *gC;          // [NB] MLP_* / content length of the group (first items)
+    const uint8_t *carry; uint32_t carry_len, carry_tail, carry_state;
+    uint32_t carry_sec, carry_nsec, ts_sec, ts_nsec;
+    uint8_t *carry_out;
+    uint8_t *out;
+    MlMisc *misc;
+};
+void launch_ml_keep(const MlArgs &a, hipStream_t st);
+void launch_ml_compact(const MlArgs &a, hipStream_t st);
+void launch_ml_match(const MlArgs &a, int cus, hipStream_t st);
+size_t ml_fscan_tmp_bytes(uint64_t n);
+void launch_ml_fscan(const uint64_t *F, uint64_t n, uint32_t init, uint8_t *sin, void *tmp, unsigned int *final_state, hipStream_t st);
+void launch_ml_act(const MlArgs &a, hipStream_t st);
+void launch_ml_ghead(const MlArgs &a, hipStream_t st);
+void launch_ml_piece(const MlArgs &a, hipStream_t st);
+void launch_ml_rows(const MlArgs &a, uint64_t *row_off, hipStream_t st);
+void launch_ml_emit(const MlArgs &a, int cus, hipStream_t st);
+void launch_ml_carry(const MlArgs &a, hipStream_t st);
+
 struct GatherArgs {
     const uint8_t *data;
     const uint64_t *row_off;

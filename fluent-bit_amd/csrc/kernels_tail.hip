@@ -1,4 +1,4 @@
-// kernels_tail.hip -- in_tail's line packing (shares kdev.inc with the other kernel units)
+// kernels_tail.hip -- in_tail's line packing and the multiline core behind it (shares kdev.inc with the other kernel units)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -11,5 +11,6 @@ namespace flbgpu {
 #include "kdev.inc"
 
 #include "tail_kernels.inc"
+#include "ml_kernels.inc"
 
 }  // namespace flbgpu

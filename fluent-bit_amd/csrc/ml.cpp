@@ -1,0 +1,291 @@
+// ml.cpp -- the multiline core in front of the path, behind the C ABI (include/flb_gpu.h flbgpu_ml_*): what in_tail does with a
+// `multiline.parser` -- plugins/in_tail/tail_file.c:840-898 cuts the file buffer into lines and hands each to flb_ml_append_text
+// (src/multiline/flb_ml.c:685-762) -- for the text lines of one stream and ONE multiline parser of type regex (rules:
+// src/multiline/flb_ml_rule.c), endswith or equal, without a sub-parser.  Kernels: ml_kernels.inc.  Host side: the parser
+// definition (flb_ml_parser_create / flb_ml_rule_create / flb_ml_rule_init :279-299 restated as masks), the stream's carried
+// state (rule_to_state, the open group's bytes and time), buffers.  No CPU path: every line is matched and packed on the device.
+#include "host_int.hpp"
+
+using namespace flbgpu;
+
+struct MlRuleSrc { std::vector<std::string> from; std::string regex, to; bool start = false; };
+
+struct flbgpu_ml_parser {
+    MlParserDev dev;
+    std::vector<MlRuleSrc> src;
+    std::vector<GrepRule> rules;
+    std::vector<TableBlob *> blobs;
+    DevBuf d_rules;
+    bool inited = false;
+    flbgpu_ml_parser() { memset(&dev, 0, sizeof(dev)); }
+    ~flbgpu_ml_parser() {
+        for (TableBlob *b : blobs) delete b;
+        d_rules.release();
+    }
+};
+
+struct flbgpu_ml_stream {
+    flbgpu_ml_parser *p = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t state = 0;                       // rule_to_state: 0 none, r + 1
+    DevBuf carry[2];                          // the open group's bytes (flb_ml_stream_group.buf), double-buffered
+    int cur = 0;
+    uint32_t carry_len = 0, carry_tail = MLT_EMPTY, carry_sec = 0, carry_nsec = 0;       // mp_time of the group
+    DevBuf d_masks, d_tcnt, d_toff, d_scan_tmp, d_nl, d_keep, d_koff, d_ls, d_ll, d_info, d_F, d_sin, d_act, d_c, d_coff, d_head, d_gidx,
+           d_ghead, d_plen, d_po, d_pk, d_gC, d_fs_tmp, d_rows, d_out, d_misc, d_in;
+    ~flbgpu_ml_stream() {
+        DevBuf *all[] = {&carry[0], &carry[1], &d_masks, &d_tcnt, &d_toff, &d_scan_tmp, &d_nl, &d_keep, &d_koff, &d_ls, &d_ll, &d_info, &d_F, &d_sin,
+                         &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
+        for (DevBuf *b : all) b->release();
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+static int ml_type_lookup(const char *s) {        // flb_ml.c:84-100 flb_ml_type_lookup
+    if (!s || !strcasecmp(s, "regex")) return ML_REGEX;
+    if (!strcasecmp(s, "endswith")) return ML_ENDSWITH;
+    if (!strcasecmp(s, "equal") || !strcasecmp(s, "eq")) return ML_EQ;
+    return -1;
+}
+
+// flb_ml_parser_create (src/multiline/flb_ml_parser.c:46-140) + the instance's key_content (flb_ml_parser_instance_create / _set :281-352)
+// + the context's buffer limit (flb_ml_create :878-930; < 0: the default of 2 MB, 0: none)
+extern "C" flbgpu_ml_parser *flbgpu_ml_parser_create(const char *type, const char *match_string, int negate, const char *key_content, int64_t buffer_limit) {
+    if (flbgpu_device_cus() <= 0) { set_err("flbgpu_init has not run: libflbgpu has no CPU path"); return nullptr; }
+    const int ty = ml_type_lookup(type);
+    if (ty < 0) { set_err("multiline: unknown parser type '%s'", type); return nullptr; }
+    auto *p = new flbgpu_ml_parser();
+    p->dev.type = ty; p->dev.negate = negate ? 1 : 0;
+    if (match_string) {
+        const size_t n = strlen(match_string);
+        if (n > sizeof(p->dev.match_str)) { set_err("multiline: match_string too long for the GPU path"); delete p; return nullptr; }
+        memcpy(p->dev.match_str, match_string, n);
+        p->dev.match_len = (uint32_t) n;
+    }
+    const char *key = key_content && key_content[0] ? key_content : "log";
+    const size_t kn = strlen(key);
+    if (kn > 255) { set_err("multiline: key_content too long for the GPU path"); delete p; return nullptr; }
+    uint32_t o = 0;
+    if (kn < 32) p->dev.key[o++] = (uint8_t) (0xa0 | kn);
+    else { p->dev.key[o++] = 0xd9; p->dev.key[o++] = (uint8_t) kn; }
+    memcpy(p->dev.key + o, key, kn);
+    p->dev.key_len = o + (uint32_t) kn;
+    p->dev.has_key_content = key_content && key_content[0] ? 1 : 0;
+    p->dev.buffer_limit = buffer_limit < 0 ? 2ull * 1024 * 1024 : (uint64_t) buffer_limit;
+    return p;
+}
+
+extern "C" void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p) { delete p; }
+
+// flb_ml_rule_create (flb_ml_rule.c:48-118): from_states split at ',' with blanks trimmed (flb_slist_split_string), the first rule
+// must hold a start_state
+extern "C" int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_states, const char *regex, const char *to_state) {
+    if (!p || !from_states || !regex) { set_err("multiline rule: missing argument"); return -1; }
+    if (p->inited) { set_err("multiline rule: the parser is already initialised"); return -1; }
+    if (p->dev.type != ML_REGEX) { set_err("multiline rule: the parser is not of type regex"); return -1; }
+    if ((int) p->src.size() >= ML_MAX_RULES) { set_err("multiline: more than %d rules: not on the GPU path", ML_MAX_RULES); return -1; }
+    MlRuleSrc r;
+    const char *q = from_states;
+    while (*q) {
+        const char *e = strchr(q, ',');
+        if (!e) e = q + strlen(q);
+        const char *a = q, *b = e;
+        while (a < b && *a == ' ') a++;
+        while (b > a && b[-1] == ' ') b--;
+        if (b > a) { r.from.emplace_back(a, (size_t) (b - a)); if (r.from.back() == "start_state") r.start = true; }
+        q = *e ? e + 1 : e;
+    }
+    if (r.from.empty()) { set_err("[multiline] rule is empty or has invalid 'from_states' tokens"); return -1; }
+    if (!r.start && p->src.empty()) { set_err("[multiline] rule don't contain a 'start_state'"); return -1; }
+    r.regex = regex;
+    if (to_state && to_state[0]) r.to = to_state;
+    GrepRule gr;
+    memset(&gr, 0, sizeof(gr));
+    std::string why;
+    if (!compile_rule("$log", regex, gr, p->blobs, why)) { set_err("multiline: %s", why.c_str()); return -1; }
+    p->rules.push_back(gr);
+    p->src.push_back(r);
+    return 0;
+}
+
+// the built-in regex parsers: src/multiline/flb_ml_parser_java.c:59-128, _go.c:59-125, _python.c:60-83, _ruby.c:59-71
+extern "C" int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name) {
+    struct R { const char *from, *rx, *to; };
+    static const R java[] = {
+        {"start_state, java_start_exception", "/(.)(?:Exception|Error|Throwable|V8 errors stack trace)[:\\r\\n]/", "java_after_exception"},
+        {"java_after_exception", "/^[\\t ]*nested exception is:[\\t ]*/", "java_start_exception"},
+        {"java_after_exception", "/^[\\r\\n]*$/", "java_after_exception"},
+        {"java_after_exception, java", "/^[\\t ]+(?:eval )?at /", "java"},
+        {"java_after_exception, java", "/^[\\t ]+--- End of inner exception stack trace ---$/", "java"},
+        {"java_after_exception, java", "/^--- End of stack trace from previous (?x:)location where exception was thrown ---$/", "java"},
+        {"java_after_exception, java", "/^[\\t ]*(?:Caused by|Suppressed):/", "java_after_exception"},
+        {"java_after_exception, java", "/^[\\t ]*... \\d+ (?:more|common frames omitted)/", "java"}, {nullptr, nullptr, nullptr}};
+    static const R go[] = {
+        {"start_state", "/\\bpanic: /", "go_after_panic"},
+        {"start_state", "/http: panic serving/", "go_goroutine"},
+        {"go_after_panic", "/^$/", "go_goroutine"},
+        {"go_after_panic, go_after_signal, go_frame_1", "/^$/", "go_goroutine"},
+        {"go_after_panic", "/^\\[signal /", "go_after_signal"},
+        {"go_goroutine", "/^goroutine \\d+ \\[[^\\]]+\\]:$/", "go_frame_1"},
+        {"go_frame_1", "/^(?:[^\\s.:]+\\.)*[^\\s.():]+\\(|^created by /", "go_frame_2"},
+        {"go_frame_2", "/^\\s/", "go_frame_1"}, {nullptr, nullptr, nullptr}};
+    static const R python[] = {
+        {"start_state", "/^Traceback \\(most recent call last\\):$/", "python"},
+        {"python", "/^[\\t ]+File /", "python_code"},
+        {"python_code", "/[^\\t ]/", "python"},
+        {"python", "/^(?:[^\\s.():]+\\.)*[^\\s.():]+:/", "start_state"}, {nullptr, nullptr, nullptr}};
+    static const R ruby[] = {
+        {"start_state, ruby_start_exception", "/^.+:\\d+:in\\s+.*/", "ruby_after_exception"},
+        {"ruby_after_exception, ruby", "/^\\s+from\\s+.*:\\d+:in\\s+.*/", "ruby"}, {nullptr, nullptr, nullptr}};
+    if (!p || !name) { set_err("multiline: missing argument"); return -1; }
+    const R *t = !strcasecmp(name, "java") ? java : !strcasecmp(name, "go") ? go : !strcasecmp(name, "python") ? python : !strcasecmp(name, "ruby") ? ruby : nullptr;
+    if (!t) { set_err("multiline: built-in parser '%s' needs a sub-parser (docker, cri) or does not exist: not on the GPU path", name); return -1; }
+    for (int i = 0; t[i].from; i++) if (flbgpu_ml_parser_add_rule(p, t[i].from, t[i].rx, t[i].to) != 0) return -1;
+    return flbgpu_ml_parser_init(p);
+}
+
+// flb_ml_rule_init (flb_ml_rule.c:279-299): every rule's to_state_map, here as masks over the rules
+extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
+    if (!p) { set_err("multiline: no parser"); return -1; }
+    if (p->inited) return 0;
+    const int n = (int) p->src.size();
+    if (p->dev.type == ML_REGEX && n == 0) { set_err("multiline: a regex parser without rules"); return -1; }
+    p->dev.nrules = n;
+    for (int i = 0; i < n; i++) if (p->src[(size_t) i].start) p->dev.start_mask |= 1u << i;
+    for (int i = 0; i < n; i++) {
+        const MlRuleSrc &r = p->src[(size_t) i];
+        if (r.to.empty()) continue;
+        uint32_t map = 0;
+        for (int j = 0; j < n; j++)
+            for (const std::string &f : p->src[(size_t) j].from) if (f == r.to) { map |= 1u << j; break; }
+        if (!map) { set_err("[multiline parser] to_state='%s' is not registered", r.to.c_str()); return -1; }
+        p->dev.cont_mask[i + 1] = map & ~p->dev.start_mask;             // flb_ml_rule_process skips start rules among the continuations
+        if (map & p->dev.start_mask) p->dev.flush_after |= 1u << i;     // try_flushing_buffer: a start rule may follow
+    }
+    if (n) {
+        if (!p->d_rules.ensure((size_t) n * sizeof(GrepRule))) return -1;
+        if (hipMemcpy(p->d_rules.p, p->rules.data(), (size_t) n * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) { set_err("multiline: uploading the rules failed"); return -1; }
+    }
+    p->inited = true;
+    return 0;
+}
+
+extern "C" flbgpu_ml_stream *flbgpu_ml_stream_create(flbgpu_ml_parser *p) {
+    if (!p || !p->inited) { set_err("multiline: the parser is not initialised"); return nullptr; }
+    auto *s = new flbgpu_ml_stream();
+    s->p = p;
+    if (hipStreamCreate(&s->stream) != hipSuccess) { set_err("hipStreamCreate failed"); delete s; return nullptr; }
+    return s;
+}
+extern "C" void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s) { delete s; }
+
+// what the stream carries: rule_to_state (-1 none), bytes of the open group
+extern "C" void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_state, uint64_t *buffered) {
+    if (rule_to_state) *rule_to_state = s ? (int) s->state - 1 : -1;
+    if (buffered) *buffered = s ? s->carry_len : 0;
+}
+
+// one read of the file: text in HBM -> records in HBM.  flush != 0: the group still open afterwards leaves too (the flush timer,
+// flb_ml_flush_pending :123-139).  *processed: bytes consumed (the file's buffer keeps what follows the last newline).
+extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                                    flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records) {
+    auto fail = [](const char *w) -> int { set_err("multiline: %s", w); return -1; };
+    memset(out, 0, sizeof(*out));
+    *processed = 0; *records = 0;
+    if (!s) return fail("no stream");
+    if (bytes > 0xFFFF0000ull) return fail("more than 4 GB in one call");
+    hipStream_t st = s->stream;
+    const uint8_t *text = (const uint8_t *) d_text;
+    if (!s->d_misc.ensure(sizeof(MlMisc))) return -1;
+    MlMisc *dm = s->d_misc.as<MlMisc>();
+    if (hipMemsetAsync(dm, 0, sizeof(MlMisc), st) != hipSuccess) return fail("memset failed");
+    uint64_t nl = 0;
+    MlMisc hm;
+    memset(&hm, 0, sizeof(hm));
+    if (bytes) {
+        const size_t ntiles = tl_tiles(bytes);
+        if (!s->d_masks.ensure((bytes + 63) / 64 * sizeof(uint64_t)) || !s->d_tcnt.ensure(ntiles * sizeof(uint32_t)) ||
+            !s->d_toff.ensure((ntiles + 1) * sizeof(uint64_t)) || !s->d_scan_tmp.ensure(scan_tmp_elems(ntiles) * sizeof(uint64_t))) return -1;
+        launch_tl_lead(text, bytes, &dm->lead, st);
+        launch_tl_count(text, bytes, s->d_masks.as<uint64_t>(), s->d_tcnt.as<uint32_t>(), st);
+        launch_scan(s->d_tcnt.as<uint32_t>(), ntiles, s->d_scan_tmp.as<uint64_t>(), s->d_toff.as<uint64_t>(), st);
+        if (hipMemcpyAsync(&nl, s->d_toff.as<uint64_t>() + ntiles, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("mask pass failed");
+        if (nl == 0) *processed = hm.lead;                 // no complete line yet: only the leading NULs are consumed
+    }
+    if (nl == 0 && (!flush || s->carry_len == 0)) return 0;
+    const uint64_t NB = nl + 1;
+    if (!s->d_nl.ensure((nl + 1) * sizeof(uint64_t)) || !s->d_keep.ensure(NB * 4) || !s->d_koff.ensure((NB + 1) * 8) || !s->d_ls.ensure(NB * 8) || !s->d_ll.ensure(NB * 4) ||
+        !s->d_info.ensure(NB * 4) || !s->d_F.ensure(NB * 8) || !s->d_sin.ensure(NB) || !s->d_act.ensure(NB) || !s->d_c.ensure(NB * 4) || !s->d_coff.ensure((NB + 1) * 8) ||
+        !s->d_head.ensure(NB * 4) || !s->d_gidx.ensure((NB + 1) * 8) || !s->d_ghead.ensure((NB + 1) * 8) || !s->d_plen.ensure(NB * 4) || !s->d_po.ensure((NB + 1) * 8) ||
+        !s->d_pk.ensure(NB * 4) || !s->d_gC.ensure(NB * 4) || !s->d_rows.ensure((NB + 1) * 8) || !s->d_fs_tmp.ensure(ml_fscan_tmp_bytes(NB)) ||
+        !s->d_scan_tmp.ensure(scan_tmp_elems(NB) * sizeof(uint64_t)) || !s->carry[s->cur].ensure(64)) return -1;
+    if (nl) launch_tl_fill(s->d_masks.as<uint64_t>(), bytes, s->d_toff.as<uint64_t>(), s->d_nl.as<uint64_t>(), st);
+    MlArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = s->p->dev; a.rules = s->p->d_rules.as<GrepRule>();
+    a.text = text; a.bytes = bytes; a.nl_pos = s->d_nl.as<uint64_t>(); a.nl = nl;
+    a.skip_empty_lines = skip_empty_lines ? 1 : 0; a.flush_all = flush ? 1 : 0;
+    a.NB = NB; a.keep = s->d_keep.as<uint32_t>(); a.koff = s->d_koff.as<uint64_t>(); a.ls = s->d_ls.as<uint64_t>(); a.ll = s->d_ll.as<uint32_t>();
+    a.info = s->d_info.as<uint32_t>(); a.F = s->d_F.as<uint64_t>(); a.sin = s->d_sin.as<uint8_t>(); a.act = s->d_act.as<uint8_t>();
+    a.c = s->d_c.as<uint32_t>(); a.coff = s->d_coff.as<uint64_t>(); a.head = s->d_head.as<uint32_t>(); a.gidx = s->d_gidx.as<uint64_t>();
+    a.ghead = s->d_ghead.as<uint64_t>(); a.plen = s->d_plen.as<uint32_t>(); a.po = s->d_po.as<uint64_t>(); a.pk = s->d_pk.as<uint32_t>(); a.gC = s->d_gC.as<uint32_t>();
+    a.carry = s->carry[s->cur].as<uint8_t>(); a.carry_len = s->carry_len; a.carry_tail = s->carry_tail; a.carry_state = s->state;
+    a.carry_sec = s->carry_sec; a.carry_nsec = s->carry_nsec; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
+    a.misc = dm;
+    uint64_t *tmp = s->d_scan_tmp.as<uint64_t>();
+    launch_ml_keep(a, st);
+    launch_scan(a.keep, nl, tmp, s->d_koff.as<uint64_t>(), st);
+    launch_ml_compact(a, st);
+    launch_ml_match(a, flbgpu_device_cus(), st);
+    launch_ml_fscan(a.F, NB, a.p.type == ML_REGEX ? s->state : (uint32_t) MLT_EMPTY, a.sin, s->d_fs_tmp.p, &dm->final_state, st);
+    launch_ml_act(a, st);
+    launch_scan(a.c, NB, tmp, s->d_coff.as<uint64_t>(), st);
+    launch_scan(a.head, NB, tmp, s->d_gidx.as<uint64_t>(), st);
+    launch_ml_ghead(a, st);
+    launch_ml_piece(a, st);
+    launch_scan(a.plen, NB, tmp, s->d_po.as<uint64_t>(), st);
+    uint64_t total = 0, groups = 0, last_nl = 0;
+    if (hipMemcpyAsync(&total, s->d_po.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&groups, s->d_gidx.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (nl && hipMemcpyAsync(&last_nl, s->d_nl.as<uint64_t>() + (nl - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+        hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("size pass failed");
+    if (hm.refused) {
+        set_err("multiline: a group of this buffer exceeds the buffer limit (%llu bytes); truncated groups (flb_ml_group_cat) are not on the GPU path yet",
+                (unsigned long long) a.p.buffer_limit);
+        return -1;
+    }
+    const int nxt = s->cur ^ 1;
+    if (!s->d_out.ensure(total + 16) || !s->carry[nxt].ensure((size_t) hm.new_carry_len + 64)) return -1;
+    a.out = s->d_out.as<uint8_t>(); a.carry_out = s->carry[nxt].as<uint8_t>();
+    if (total > 0) launch_ml_emit(a, flbgpu_device_cus(), st);
+    launch_ml_rows(a, s->d_rows.as<uint64_t>(), st);
+    launch_ml_carry(a, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("emit pass failed");
+    // the stream's state after the call
+    if (a.p.type == ML_REGEX) s->state = hm.final_state;
+    s->cur = nxt;
+    s->carry_len = hm.has_open ? hm.new_carry_len : 0;
+    s->carry_tail = hm.has_open ? hm.new_tail : (uint32_t) MLT_EMPTY;
+    if (hm.anyreg) { s->carry_sec = ts_sec; s->carry_nsec = ts_nsec; }
+    if (nl) *processed = last_nl + 1;
+    *records = hm.records;
+    out->data = s->d_out.p; out->row_off = s->d_rows.as<uint64_t>(); out->n = groups; out->bytes = total;
+    return 0;
+}
+
+// the same on a host buffer; *out_buf is malloc()'d (nullptr when nothing was flushed)
+extern "C" int flbgpu_ml_append(flbgpu_ml_stream *s, const void *text, size_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                                void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *records) {
+    *out_buf = nullptr; *out_size = 0;
+    if (!s) { set_err("multiline: no stream"); return -1; }
+    if (bytes && (!s->d_in.ensure(bytes + 16) || hipMemcpyAsync(s->d_in.p, text, bytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)) { set_err("multiline: upload failed"); return -1; }
+    flbgpu_dev_chunk out;
+    if (flbgpu_ml_append_dev(s, s->d_in.p, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, &out, processed, records) != 0) return -1;
+    if (out.bytes == 0) return 0;
+    void *hb = malloc(out.bytes);
+    if (!hb) { set_err("out of memory"); return -1; }
+    if (hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(hb); set_err("multiline: download failed"); return -1; }
+    *out_buf = hb; *out_size = out.bytes;
+    return 0;
+}

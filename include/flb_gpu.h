@@ -255,6 +255,39 @@ int flbgpu_tail_run(flbgpu_tail *t, const void *text, size_t bytes, uint64_t str
 int flbgpu_tail_run_dev(flbgpu_tail *t, const void *d_text, uint64_t bytes, uint64_t stream_offset, uint32_t ts_sec, uint32_t ts_nsec,
                         flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *lines);
 
+/* ---- multiline in front of the path: in_tail with `multiline.parser` ----------------------------------------------------------
+ * plugins/in_tail/tail_file.c:840-898 (the line loop; every line goes to flb_ml_append_text instead of being packed) over
+ * src/multiline/flb_ml.c:685-762 (flb_ml_append_text), :197-364 (package_content), src/multiline/flb_ml_rule.c:245-436 (the regex
+ * rule state machine), flb_ml_group.c:87-122 (flb_ml_group_cat), flb_ml.c:1590-1790 (flb_ml_flush_stream_group: one record
+ * [[ts, {}], {key_content | "log": concatenated lines}] per group).  One multiline parser per context, types regex / endswith /
+ * equal, no sub-parser (the docker / cri built-ins need one: refused), no key_group / key_pattern (flb_ml_append_object's map path).
+ * A group that would exceed the buffer limit (truncation, flb_ml_group_cat) makes the call fail: not on the GPU path yet.
+ *
+ * flbgpu_ml_parser  = flb_ml_parser_create (src/multiline/flb_ml_parser.c:46-140) + the instance's key_content + flb_ml_create's
+ *                     buffer limit (< 0: the 2 MB default, 0: none); rules: flb_ml_rule_create (flb_ml_rule.c:48-118),
+ *                     flbgpu_ml_parser_init = flb_ml_parser_init / flb_ml_rule_init (:279-299);
+ *                     flbgpu_ml_parser_builtin: the rule tables of flb_ml_parser_java.c / _go.c / _python.c / _ruby.c (calls init)
+ * flbgpu_ml_stream  = flb_ml_stream_create: what one tailed file carries between reads (rule_to_state, the open group, its time)
+ * flbgpu_ml_append  = one read: the buffer is cut into lines (leading NULs, Skip_Empty_Lines, CR LF as in flbgpu_tail_run), every
+ *                     line runs through the parser; the reference stamps flb_time_get() per line, the caller passes the time of
+ *                     the call.  flush != 0: the group still open afterwards leaves too (the flush timer, flb_ml_flush_pending).
+ *                     *processed = bytes consumed (the caller keeps what follows the last newline), *records = records produced. */
+typedef struct flbgpu_ml_parser flbgpu_ml_parser;
+typedef struct flbgpu_ml_stream flbgpu_ml_stream;
+flbgpu_ml_parser *flbgpu_ml_parser_create(const char *type, const char *match_string, int negate, const char *key_content, int64_t buffer_limit);
+int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_states, const char *regex, const char *to_state);
+int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name);
+int flbgpu_ml_parser_init(flbgpu_ml_parser *p);
+void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p);
+flbgpu_ml_stream *flbgpu_ml_stream_create(flbgpu_ml_parser *p);
+void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s);
+void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_state, uint64_t *buffered);
+int flbgpu_ml_append(flbgpu_ml_stream *s, const void *text, size_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                     void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *records);
+/* text already in HBM -> a device chunk (one row per group, groups without content as empty rows) the filters take as it is */
+int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                         flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records);
+
 /* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
 int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);
 

@@ -1,0 +1,101 @@
+"""The multiline core on the device (csrc/ml.cpp, ml_kernels.inc) against the oracle (oracle/oml.c, pinned on the reference's own
+src/multiline/*.c by tests/test_multiline_oracle.py): the vectors of the reference's unit test, random parsers / texts / read
+boundaries, the state a stream carries from read to read, and a buffer of a few hundred thousand lines."""
+import json, os, random
+import pytest
+
+import flbamd_loader
+import ml_synth
+from test_multiline_oracle import VECTORS, ELASTIC_RULES, vector_text, contents, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+def device_run(g, cfg, frames, skip_empty_lines=False, final_flush=False):
+    p = g.MultilineParser(rules=cfg.get("rules"), builtin=cfg.get("builtin"), type=cfg.get("type", "regex"), match_string=cfg.get("match_string"),
+                          negate=cfg.get("negate", False), key_content=cfg.get("key_content"), buffer_limit=cfg.get("buffer_limit_bytes", -1))
+    s = p.stream()
+    out, n = b"", 0
+    try:
+        for sec, nsec, text in frames:
+            o, r = s.append(text, sec, nsec, skip_empty_lines)
+            out += o; n += r
+        if final_flush:
+            o, r = s.flush()
+            out += o; n += r
+        return out, n, s.state()
+    finally:
+        s.close(); p.close()
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    i = next((k for k in range(n) if a[k] != b[k]), n)
+    return i, len(a), len(b), a[max(0, i - 60):i + 40], b[max(0, i - 60):i + 40]
+
+
+@pytest.mark.parametrize("name", ["java", "ruby", "python", "go", "elastic"])
+def test_reference_vectors(g, name):
+    cfg = {"rules": ELASTIC_RULES} if name == "elastic" else {"builtin": name}
+    text = vector_text(name)
+    want = [o.encode("latin-1") for o in VECTORS[name]["output"]]
+    for frames in ([(1700000000, 1, text)], [(1700000000 + i, i, text[i:i + 97]) for i in range(0, len(text), 97)]):
+        out, n, _ = device_run(g, cfg, frames, final_flush=True)
+        assert contents(out) == want
+        assert n == len(want)
+        assert out == oracle_run(cfg, frames, final_flush=True)[0]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_cases(g, seed):
+    rng = random.Random(5200 + seed)
+    for _ in range(60):
+        cfg, frames, kw = ml_synth.random_case(rng)
+        want, n, _ = oracle_run(cfg, frames, **kw)
+        got, gn, _ = device_run(g, cfg, frames, **kw)
+        assert got == want, (cfg, frames, kw, first_diff(want, got))
+        assert gn == n
+
+
+def test_stream_state_is_carried(g):
+    rules = [("start_state", r"/^\d+ start/", "cont"), ("cont", r"/^\s+/", "cont")]
+    text = b"1 start\n  a\n\n  b\nnope\n  c\n2 start\n"
+    for cut in range(len(text) + 1):
+        frames = [(100, 5, text[:cut]), (200, 6, text[cut:])]
+        want, n, _ = oracle_run({"rules": rules}, frames)
+        got, gn, state = device_run(g, {"rules": rules}, frames)
+        assert got == want and gn == n, cut
+        assert state == (0, len(b"2 start"))                # rule 0 holds the stream; its start line waits in the buffer
+
+
+def test_a_large_buffer(g):
+    rng = random.Random(77)
+    text = ml_synth.random_text(rng, 300000, ml_synth.SEED_LINES["java"], long_line=0.0005)
+    cfg = {"builtin": "java"}
+    cuts = [0, len(text) // 3 + 11, 2 * len(text) // 3 + 5, len(text)]
+    frames = [(1700000000 + i, 9 * i, text[cuts[i]:cuts[i + 1]]) for i in range(3)]
+    want, n, _ = oracle_run(cfg, frames, final_flush=True)
+    got, gn, _ = device_run(g, cfg, frames, final_flush=True)
+    assert gn == n and n > 50000
+    assert got == want, first_diff(want, got)
+
+
+def test_refusals(g):
+    with pytest.raises(ValueError):
+        g.MultilineParser(builtin="cri")                     # needs the sub-parser
+    with pytest.raises(ValueError):
+        g.MultilineParser(rules=[("cont", r"/^\s/", "cont")])       # the first rule must hold a start_state
+    with pytest.raises(ValueError):
+        g.MultilineParser(rules=[("start_state", r"/^a/", "nowhere")])
+    p = g.MultilineParser(rules=[("start_state", r"/^a/", "c"), ("c", r"/^b/", "c")], buffer_limit=16)
+    s = p.stream()
+    with pytest.raises(RuntimeError):
+        s.append(b"a" * 40 + b"\n" + b"b" * 40 + b"\n", 1, 1)
+    s.close(); p.close()
