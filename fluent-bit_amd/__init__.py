@@ -405,14 +405,11 @@ class MultilineStream:
             raise RuntimeError(last_error())
         return out, int(recs.value), int(proc.value)
 
-    def flush(self):
-        """the flush timer (flb_ml_flush_pending): the open group leaves"""
-        return self.append(b"", 0, 0, flush=True) if not self.pending else self._flush_keep()
-
-    def _flush_keep(self):
+    def flush(self, sec=0, nsec=0):
+        """the flush timer (flb_ml_flush_pending): the open group leaves; (sec, nsec) = the clock, for a group that never saw a time"""
         keep, self.pending = self.pending, b""
         try:
-            return self.append(b"", 0, 0, flush=True)
+            return self.append(b"", sec, nsec, flush=True)
         finally:
             self.pending = keep
 
@@ -420,6 +417,11 @@ class MultilineStream:
         a = c_int(); b = c_uint64()
         lib().flbgpu_ml_stream_state(self.h, byref(a), byref(b))
         return a.value, int(b.value)
+
+    def truncations(self):
+        lib().flbgpu_ml_stream_truncations.restype = c_uint64
+        lib().flbgpu_ml_stream_truncations.argtypes = [c_void_p]
+        return int(lib().flbgpu_ml_stream_truncations(self.h))
 
     def close(self):
         if self.h:

@@ -631,7 +631,8 @@ void launch_tl_emit(const TailArgs &a, int cus, hipStream_t st);
 // these <= 16 states, packed as 16 nibbles.
 constexpr int ML_MAX_RULES = 15;
 enum { ML_REGEX = 0, ML_ENDSWITH = 1, ML_EQ = 2 };                         // flb_ml.h FLB_ML_REGEX / ENDSWITH / EQ
-enum { MLK_CARRY = 0, MLK_CONT = 1, MLK_START = 2, MLK_ALONE = 3, MLK_APPEND = 4, MLK_DROPPED = 5, MLK_MASK = 7, MLK_BA = 8 };   // act[]: kind | flush after
+enum { MLK_CARRY = 0, MLK_CONT = 1, MLK_START = 2, MLK_ALONE = 3, MLK_APPEND = 4, MLK_DROPPED = 5, MLK_MASK = 7, MLK_BA = 8,
+       MLK_SEP = 64, MLK_TRUNC = 128 };   // act[]: kind | flush after | bits 4-5 MLT_* | a '\n' goes in front | flb_ml_group_cat cut the item
 enum { MLT_EMPTY = 0, MLT_NL = 1, MLT_OTHER = 2 };                         // how the group buffer ends (act[] bits 4-5: after the item)
 enum { MLP_FIRST = 1, MLP_SEP = 2, MLP_TRAIL = 4, MLP_CARRY_TIME = 8, MLP_NLBODY = 16, MLP_OPEN = 32, MLP_TRUNC = 64 };   // pk[]
 struct MlParserDev {
@@ -646,8 +647,8 @@ struct MlParserDev {
     uint64_t buffer_limit;               // 0: none
 };
 struct MlMisc {                          // device words of one call
-    unsigned long long lead, total, records, truncated;
-    unsigned int final_state, new_carry_len, new_tail, anyreg, refused, last_ba, has_open, open_first;
+    unsigned long long lead, total, records, truncated, trunc_k;
+    unsigned int final_state, new_carry_len, new_tail, first_reg, refused, last_ba, has_open, open_first, new_carry_trunc, pad;
 };
 struct MlArgs {
     MlParserDev p;
@@ -667,7 +668,8 @@ struct MlArgs {
     uint64_t *ghead;                     // [groups + 1] first item of every group
     uint32_t *plen; const uint64_t *po;  // [NB] bytes the item writes into the output, their scan
     uint32_t *pk; uint32_t *gC;          // [NB] MLP_* / content length of the group (first items)
-    const uint8_t *carry; uint32_t carry_len, carry_tail, carry_state;
+    uint32_t *ovr;                       // [NB] continuations pinned as truncating: clipped bytes << 1 | separator (0xFFFFFFFF: not pinned)
+    const uint8_t *carry; uint32_t carry_len, carry_tail, carry_state, carry_trunc;
     uint32_t carry_sec, carry_nsec, ts_sec, ts_nsec;
     uint8_t *carry_out;
     uint8_t *out;
@@ -680,6 +682,9 @@ size_t ml_fscan_tmp_bytes(uint64_t n);
 void launch_ml_fscan(const uint64_t *F, uint64_t n, uint32_t init, uint8_t *sin, void *tmp, unsigned int *final_state, hipStream_t st);
 void launch_ml_act(const MlArgs &a, hipStream_t st);
 void launch_ml_ghead(const MlArgs &a, hipStream_t st);
+void launch_ml_reset(MlMisc *m, hipStream_t st);
+void launch_ml_trunc(const MlArgs &a, hipStream_t st);
+void launch_ml_override(const MlArgs &a, uint64_t k, hipStream_t st);
 void launch_ml_piece(const MlArgs &a, hipStream_t st);
 void launch_ml_rows(const MlArgs &a, uint64_t *row_off, hipStream_t st);
 void launch_ml_emit(const MlArgs &a, int cus, hipStream_t st);

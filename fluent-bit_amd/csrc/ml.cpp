@@ -31,11 +31,13 @@ struct flbgpu_ml_stream {
     DevBuf carry[2];                          // the open group's bytes (flb_ml_stream_group.buf), double-buffered
     int cur = 0;
     uint32_t carry_len = 0, carry_tail = MLT_EMPTY, carry_sec = 0, carry_nsec = 0;       // mp_time of the group
+    uint32_t carry_trunc = 0;                 // the open group was cut by the buffer limit (flb_ml_stream_group.truncated)
+    uint64_t truncations = 0;                 // lines that truncated a buffer (FLB_MULTILINE_TRUNCATED returns)
     DevBuf d_masks, d_tcnt, d_toff, d_scan_tmp, d_nl, d_keep, d_koff, d_ls, d_ll, d_info, d_F, d_sin, d_act, d_c, d_coff, d_head, d_gidx,
-           d_ghead, d_plen, d_po, d_pk, d_gC, d_fs_tmp, d_rows, d_out, d_misc, d_in;
+           d_ghead, d_plen, d_po, d_pk, d_gC, d_ovr, d_fs_tmp, d_rows, d_out, d_misc, d_in;
     ~flbgpu_ml_stream() {
         DevBuf *all[] = {&carry[0], &carry[1], &d_masks, &d_tcnt, &d_toff, &d_scan_tmp, &d_nl, &d_keep, &d_koff, &d_ls, &d_ll, &d_info, &d_F, &d_sin,
-                         &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
+                         &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_ovr, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
         for (DevBuf *b : all) b->release();
         if (stream) (void) hipStreamDestroy(stream);
     }
@@ -184,6 +186,8 @@ extern "C" void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_s
     if (rule_to_state) *rule_to_state = s ? (int) s->state - 1 : -1;
     if (buffered) *buffered = s ? s->carry_len : 0;
 }
+// lines that truncated a buffer so far (every one is a FLB_MULTILINE_TRUNCATED return of flb_ml_append_text: in_tail warns and counts them)
+extern "C" uint64_t flbgpu_ml_stream_truncations(const flbgpu_ml_stream *s) { return s ? s->truncations : 0; }
 
 // one read of the file: text in HBM -> records in HBM.  flush != 0: the group still open afterwards leaves too (the flush timer,
 // flb_ml_flush_pending :123-139).  *processed: bytes consumed (the file's buffer keeps what follows the last newline).
@@ -199,6 +203,7 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     if (!s->d_misc.ensure(sizeof(MlMisc))) return -1;
     MlMisc *dm = s->d_misc.as<MlMisc>();
     if (hipMemsetAsync(dm, 0, sizeof(MlMisc), st) != hipSuccess) return fail("memset failed");
+    launch_ml_reset(dm, st);
     uint64_t nl = 0;
     MlMisc hm;
     memset(&hm, 0, sizeof(hm));
@@ -218,7 +223,7 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     if (!s->d_nl.ensure((nl + 1) * sizeof(uint64_t)) || !s->d_keep.ensure(NB * 4) || !s->d_koff.ensure((NB + 1) * 8) || !s->d_ls.ensure(NB * 8) || !s->d_ll.ensure(NB * 4) ||
         !s->d_info.ensure(NB * 4) || !s->d_F.ensure(NB * 8) || !s->d_sin.ensure(NB) || !s->d_act.ensure(NB) || !s->d_c.ensure(NB * 4) || !s->d_coff.ensure((NB + 1) * 8) ||
         !s->d_head.ensure(NB * 4) || !s->d_gidx.ensure((NB + 1) * 8) || !s->d_ghead.ensure((NB + 1) * 8) || !s->d_plen.ensure(NB * 4) || !s->d_po.ensure((NB + 1) * 8) ||
-        !s->d_pk.ensure(NB * 4) || !s->d_gC.ensure(NB * 4) || !s->d_rows.ensure((NB + 1) * 8) || !s->d_fs_tmp.ensure(ml_fscan_tmp_bytes(NB)) ||
+        !s->d_pk.ensure(NB * 4) || !s->d_gC.ensure(NB * 4) || !s->d_ovr.ensure(NB * 4) || !s->d_rows.ensure((NB + 1) * 8) || !s->d_fs_tmp.ensure(ml_fscan_tmp_bytes(NB)) ||
         !s->d_scan_tmp.ensure(scan_tmp_elems(NB) * sizeof(uint64_t)) || !s->carry[s->cur].ensure(64)) return -1;
     if (nl) launch_tl_fill(s->d_masks.as<uint64_t>(), bytes, s->d_toff.as<uint64_t>(), s->d_nl.as<uint64_t>(), st);
     MlArgs a;
@@ -229,32 +234,41 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     a.NB = NB; a.keep = s->d_keep.as<uint32_t>(); a.koff = s->d_koff.as<uint64_t>(); a.ls = s->d_ls.as<uint64_t>(); a.ll = s->d_ll.as<uint32_t>();
     a.info = s->d_info.as<uint32_t>(); a.F = s->d_F.as<uint64_t>(); a.sin = s->d_sin.as<uint8_t>(); a.act = s->d_act.as<uint8_t>();
     a.c = s->d_c.as<uint32_t>(); a.coff = s->d_coff.as<uint64_t>(); a.head = s->d_head.as<uint32_t>(); a.gidx = s->d_gidx.as<uint64_t>();
-    a.ghead = s->d_ghead.as<uint64_t>(); a.plen = s->d_plen.as<uint32_t>(); a.po = s->d_po.as<uint64_t>(); a.pk = s->d_pk.as<uint32_t>(); a.gC = s->d_gC.as<uint32_t>();
-    a.carry = s->carry[s->cur].as<uint8_t>(); a.carry_len = s->carry_len; a.carry_tail = s->carry_tail; a.carry_state = s->state;
+    a.ghead = s->d_ghead.as<uint64_t>(); a.plen = s->d_plen.as<uint32_t>(); a.po = s->d_po.as<uint64_t>(); a.pk = s->d_pk.as<uint32_t>(); a.gC = s->d_gC.as<uint32_t>(); a.ovr = s->d_ovr.as<uint32_t>();
+    a.carry = s->carry[s->cur].as<uint8_t>(); a.carry_len = s->carry_len; a.carry_tail = s->carry_tail; a.carry_state = s->state; a.carry_trunc = s->carry_trunc;
     a.carry_sec = s->carry_sec; a.carry_nsec = s->carry_nsec; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
+    // a group that is flushed before any line registered a time takes flb_time_get() (flb_ml.c:1619-1624): the clock of this call
+    if (a.carry_sec == 0 && a.carry_nsec == 0) { a.carry_sec = ts_sec; a.carry_nsec = ts_nsec; }
     a.misc = dm;
     uint64_t *tmp = s->d_scan_tmp.as<uint64_t>();
     launch_ml_keep(a, st);
     launch_scan(a.keep, nl, tmp, s->d_koff.as<uint64_t>(), st);
     launch_ml_compact(a, st);
+    if (hipMemsetAsync(a.ovr, 0xFF, NB * 4, st) != hipSuccess) return fail("memset failed");
     launch_ml_match(a, flbgpu_device_cus(), st);
-    launch_ml_fscan(a.F, NB, a.p.type == ML_REGEX ? s->state : (uint32_t) MLT_EMPTY, a.sin, s->d_fs_tmp.p, &dm->final_state, st);
-    launch_ml_act(a, st);
-    launch_scan(a.c, NB, tmp, s->d_coff.as<uint64_t>(), st);
-    launch_scan(a.head, NB, tmp, s->d_gidx.as<uint64_t>(), st);
-    launch_ml_ghead(a, st);
-    launch_ml_piece(a, st);
-    launch_scan(a.plen, NB, tmp, s->d_po.as<uint64_t>(), st);
     uint64_t total = 0, groups = 0, last_nl = 0;
-    if (hipMemcpyAsync(&total, s->d_po.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&groups, s->d_gidx.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
-        (nl && hipMemcpyAsync(&last_nl, s->d_nl.as<uint64_t>() + (nl - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) ||
-        hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("size pass failed");
-    if (hm.refused) {
-        set_err("multiline: a group of this buffer exceeds the buffer limit (%llu bytes); truncated groups (flb_ml_group_cat) are not on the GPU path yet",
-                (unsigned long long) a.p.buffer_limit);
-        return -1;
+    const bool may_truncate = a.p.type == ML_REGEX && a.p.buffer_limit > 0;
+    for (uint64_t round = 0;; round++) {
+        // a continuation that does not fit its group's buffer resets rule_to_state: the lines behind it are met in another state.
+        // Such lines are pinned one at a time, the first first; a call without one (the rule) runs this body once
+        launch_ml_reset(dm, st);
+        launch_ml_fscan(a.F, NB, a.p.type == ML_REGEX ? s->state : (uint32_t) MLT_EMPTY, a.sin, s->d_fs_tmp.p, &dm->final_state, st);
+        launch_ml_act(a, st);
+        launch_scan(a.c, NB, tmp, s->d_coff.as<uint64_t>(), st);
+        launch_scan(a.head, NB, tmp, s->d_gidx.as<uint64_t>(), st);
+        launch_ml_ghead(a, st);
+        if (may_truncate) launch_ml_trunc(a, st);
+        launch_ml_piece(a, st);
+        launch_scan(a.plen, NB, tmp, s->d_po.as<uint64_t>(), st);
+        if (hipMemcpyAsync(&total, s->d_po.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&groups, s->d_gidx.as<uint64_t>() + NB, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            (nl && hipMemcpyAsync(&last_nl, s->d_nl.as<uint64_t>() + (nl - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("size pass failed");
+        if (hm.trunc_k == ~0ull) break;
+        if (round > nl) return fail("the truncation rounds do not settle");
+        launch_ml_override(a, hm.trunc_k, st);
     }
+    if (hm.refused) { set_err("multiline: a group of this buffer holds more than 4 GB"); return -1; }
     const int nxt = s->cur ^ 1;
     if (!s->d_out.ensure(total + 16) || !s->carry[nxt].ensure((size_t) hm.new_carry_len + 64)) return -1;
     a.out = s->d_out.as<uint8_t>(); a.carry_out = s->carry[nxt].as<uint8_t>();
@@ -267,7 +281,9 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     s->cur = nxt;
     s->carry_len = hm.has_open ? hm.new_carry_len : 0;
     s->carry_tail = hm.has_open ? hm.new_tail : (uint32_t) MLT_EMPTY;
-    if (hm.anyreg) { s->carry_sec = ts_sec; s->carry_nsec = ts_nsec; }
+    s->carry_trunc = hm.has_open ? hm.new_carry_trunc : 0;
+    s->truncations += hm.truncated;
+    if (hm.first_reg != 0xFFFFFFFFu) { s->carry_sec = ts_sec; s->carry_nsec = ts_nsec; }
     if (nl) *processed = last_nl + 1;
     *records = hm.records;
     out->data = s->d_out.p; out->row_off = s->d_rows.as<uint64_t>(); out->n = groups; out->bytes = total;

@@ -261,7 +261,7 @@ int flbgpu_tail_run_dev(flbgpu_tail *t, const void *d_text, uint64_t bytes, uint
  * rule state machine), flb_ml_group.c:87-122 (flb_ml_group_cat), flb_ml.c:1590-1790 (flb_ml_flush_stream_group: one record
  * [[ts, {}], {key_content | "log": concatenated lines}] per group).  One multiline parser per context, types regex / endswith /
  * equal, no sub-parser (the docker / cri built-ins need one: refused), no key_group / key_pattern (flb_ml_append_object's map path).
- * A group that would exceed the buffer limit (truncation, flb_ml_group_cat) makes the call fail: not on the GPU path yet.
+ * The buffer limit (flb_ml_group_cat's truncation, the "multiline_truncated" metadata of a cut group) is reproduced.
  *
  * flbgpu_ml_parser  = flb_ml_parser_create (src/multiline/flb_ml_parser.c:46-140) + the instance's key_content + flb_ml_create's
  *                     buffer limit (< 0: the 2 MB default, 0: none); rules: flb_ml_rule_create (flb_ml_rule.c:48-118),
@@ -282,6 +282,7 @@ void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p);
 flbgpu_ml_stream *flbgpu_ml_stream_create(flbgpu_ml_parser *p);
 void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s);
 void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_state, uint64_t *buffered);
+uint64_t flbgpu_ml_stream_truncations(const flbgpu_ml_stream *s);   /* lines that returned FLB_MULTILINE_TRUNCATED so far */
 int flbgpu_ml_append(flbgpu_ml_stream *s, const void *text, size_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
                      void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *records);
 /* text already in HBM -> a device chunk (one row per group, groups without content as empty rows) the filters take as it is */

@@ -28,9 +28,9 @@ def device_run(g, cfg, frames, skip_empty_lines=False, final_flush=False):
             o, r = s.append(text, sec, nsec, skip_empty_lines)
             out += o; n += r
         if final_flush:
-            o, r = s.flush()
+            o, r = s.flush(1900000000, 3)
             out += o; n += r
-        return out, n, s.state()
+        return out, n, s.state() + (s.truncations(),)
     finally:
         s.close(); p.close()
 
@@ -50,7 +50,7 @@ def test_reference_vectors(g, name):
         out, n, _ = device_run(g, cfg, frames, final_flush=True)
         assert contents(out) == want
         assert n == len(want)
-        assert out == oracle_run(cfg, frames, final_flush=True)[0]
+        assert out == oracle_run(cfg, frames, final_flush=True, clock_of_the_call=True)[0]
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -58,10 +58,13 @@ def test_random_cases(g, seed):
     rng = random.Random(5200 + seed)
     for _ in range(60):
         cfg, frames, kw = ml_synth.random_case(rng)
-        want, n, _ = oracle_run(cfg, frames, **kw)
-        got, gn, _ = device_run(g, cfg, frames, **kw)
+        if rng.random() < 0.3:
+            cfg["buffer_limit_bytes"] = rng.choice([0, 1, 8, 40, 200, 1000])
+        want, n, trunc = oracle_run(cfg, frames, clock_of_the_call=True, **kw)
+        got, gn, st = device_run(g, cfg, frames, **kw)
         assert got == want, (cfg, frames, kw, first_diff(want, got))
         assert gn == n
+        assert st[2] == trunc, (cfg, frames, kw)
 
 
 def test_stream_state_is_carried(g):
@@ -69,10 +72,10 @@ def test_stream_state_is_carried(g):
     text = b"1 start\n  a\n\n  b\nnope\n  c\n2 start\n"
     for cut in range(len(text) + 1):
         frames = [(100, 5, text[:cut]), (200, 6, text[cut:])]
-        want, n, _ = oracle_run({"rules": rules}, frames)
+        want, n, _ = oracle_run({"rules": rules}, frames, clock_of_the_call=True)
         got, gn, state = device_run(g, {"rules": rules}, frames)
         assert got == want and gn == n, cut
-        assert state == (0, len(b"2 start"))                # rule 0 holds the stream; its start line waits in the buffer
+        assert state[:2] == (0, len(b"2 start"))                # rule 0 holds the stream; its start line waits in the buffer
 
 
 def test_a_large_buffer(g):
@@ -81,7 +84,7 @@ def test_a_large_buffer(g):
     cfg = {"builtin": "java"}
     cuts = [0, len(text) // 3 + 11, 2 * len(text) // 3 + 5, len(text)]
     frames = [(1700000000 + i, 9 * i, text[cuts[i]:cuts[i + 1]]) for i in range(3)]
-    want, n, _ = oracle_run(cfg, frames, final_flush=True)
+    want, n, _ = oracle_run(cfg, frames, final_flush=True, clock_of_the_call=True)
     got, gn, _ = device_run(g, cfg, frames, final_flush=True)
     assert gn == n and n > 50000
     assert got == want, first_diff(want, got)
@@ -94,8 +97,23 @@ def test_refusals(g):
         g.MultilineParser(rules=[("cont", r"/^\s/", "cont")])       # the first rule must hold a start_state
     with pytest.raises(ValueError):
         g.MultilineParser(rules=[("start_state", r"/^a/", "nowhere")])
-    p = g.MultilineParser(rules=[("start_state", r"/^a/", "c"), ("c", r"/^b/", "c")], buffer_limit=16)
-    s = p.stream()
-    with pytest.raises(RuntimeError):
-        s.append(b"a" * 40 + b"\n" + b"b" * 40 + b"\n", 1, 1)
-    s.close(); p.close()
+
+
+def test_truncation_rounds(g):
+    """many groups over the limit in one buffer: every truncating continuation resets the state for what follows"""
+    rules = [("start_state", r"/^a/", "c"), ("c", r"/^b/", "c")]
+    rng = random.Random(3)
+    lines = []
+    for _ in range(400):
+        lines.append(b"a" * rng.randrange(1, 30))
+        for _ in range(rng.randrange(0, 12)):
+            lines.append(rng.choice([b"b" * rng.randrange(1, 25), b"", b"x", b"bb"]))
+    text = b"\n".join(lines) + b"\n"
+    for limit in (16, 33, 64):
+        cfg = {"rules": rules, "buffer_limit_bytes": limit}
+        frames = [(10, 1, text[:len(text) // 2]), (20, 2, text[len(text) // 2:])]
+        want, n, trunc = oracle_run(cfg, frames, final_flush=True, clock_of_the_call=True)
+        got, gn, st = device_run(g, cfg, frames, final_flush=True)
+        assert trunc > 5
+        assert got == want, first_diff(want, got)
+        assert gn == n and st[2] == trunc

@@ -24,16 +24,21 @@ def contents(records, key=b"log"):
     return [r[1][key] for r in u]
 
 
-def oracle_run(cfg, frames, skip_empty_lines=False, final_flush=False):
+def oracle_run(cfg, frames, skip_empty_lines=False, final_flush=False, clock_of_the_call=False, flush_time=(1900000000, 3)):
+    """clock_of_the_call: flb_time_get() (a group flushed before any time was registered) answers the time of the frame being appended"""
     m = ob.Multiline(rules=cfg.get("rules"), builtin=cfg.get("builtin"), type=cfg.get("type", "regex"), match_string=cfg.get("match_string"),
                      negate=cfg.get("negate", False), key_content=cfg.get("key_content"), buffer_limit=cfg.get("buffer_limit_bytes", -1))
     ob.lib().oml_set_now.argtypes = [ob.c_void_p, ob.c_int64, ob.c_int64]
     ob.lib().oml_set_now(m.h, 1600000000, 77)
     out, n, trunc = b"", 0, 0
     for sec, nsec, text in frames:
+        if clock_of_the_call:
+            ob.lib().oml_set_now(m.h, sec, nsec)
         o, r, t = m.append(text, sec, nsec, skip_empty_lines)
         out += o; n += r; trunc += t
     if final_flush:
+        if clock_of_the_call:
+            ob.lib().oml_set_now(m.h, *flush_time)
         o, r, t = m.flush()
         out += o; n += r
     return out, n, trunc
