@@ -360,6 +360,13 @@ class MultilineParser:
     def stream(self):
         return MultilineStream(self)
 
+    def product(self):
+        """(states, joint classes, non-absorbing states) of the product of the rules' match DFAs; states 0: rules walked one by one"""
+        a = ctypes.c_uint32(); b = ctypes.c_uint32(); c = ctypes.c_uint32()
+        lib().flbgpu_ml_parser_product.argtypes = [c_void_p, POINTER(ctypes.c_uint32), POINTER(ctypes.c_uint32), POINTER(ctypes.c_uint32)]
+        lib().flbgpu_ml_parser_product(self.h, byref(a), byref(b), byref(c))
+        return a.value, b.value, c.value
+
     def close(self):
         if self.h:
             lib().flbgpu_ml_parser_destroy(self.h)

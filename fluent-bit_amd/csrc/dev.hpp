@@ -648,11 +648,15 @@ struct MlParserDev {
 };
 struct MlMisc {                          // device words of one call
     unsigned long long lead, total, records, truncated, trunc_k;
-    unsigned int final_state, new_carry_len, new_tail, first_reg, refused, last_ba, has_open, open_first, new_carry_trunc, pad;
+    unsigned int final_state, new_carry_len, new_tail, first_reg, refused, last_ba, has_open, open_first, new_carry_trunc, nslow;
 };
 struct MlArgs {
     MlParserDev p;
     const GrepRule *rules;               // [nrules] match-only DFA + UTF-8 tables per rule (key unused)
+    // product of the rules' match-only DFAs (ml.cpp build_product): ONE table walk per line answers which rules match.
+    // blob = joint class of every byte [256] | rules matching if the line ended in the state, u16 [nS] | next state u16 [nS][nj]
+    // (0xFFFF: a byte >= 0x80 -- the per-rule UTF-8 tables decide); states >= prod_T are absorbing (every rule has matched or cannot any more)
+    const uint8_t *prod; uint32_t prod_bytes, prod_nj, prod_nS, prod_T, prod_init;
     const uint8_t *text; uint64_t bytes;
     const uint64_t *nl_pos; uint64_t nl; // raw lines
     int skip_empty_lines, flush_all;
@@ -668,6 +672,7 @@ struct MlArgs {
     uint64_t *ghead;                     // [groups + 1] first item of every group
     uint32_t *plen; const uint64_t *po;  // [NB] bytes the item writes into the output, their scan
     uint32_t *pk; uint32_t *gC;          // [NB] MLP_* / content length of the group (first items)
+    uint32_t *slow;                      // [NB] lines the product automaton left to the per-rule tables (a byte >= 0x80 before all rules were decided)
     uint32_t *ovr;                       // [NB] continuations pinned as truncating: clipped bytes << 1 | separator (0xFFFFFFFF: not pinned)
     const uint8_t *carry; uint32_t carry_len, carry_tail, carry_state, carry_trunc;
     uint32_t carry_sec, carry_nsec, ts_sec, ts_nsec;

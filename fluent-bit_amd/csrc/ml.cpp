@@ -4,6 +4,7 @@
 // src/multiline/flb_ml_rule.c), endswith or equal, without a sub-parser.  Kernels: ml_kernels.inc.  Host side: the parser
 // definition (flb_ml_parser_create / flb_ml_rule_create / flb_ml_rule_init :279-299 restated as masks), the stream's carried
 // state (rule_to_state, the open group's bytes and time), buffers.  No CPU path: every line is matched and packed on the device.
+#include <map>
 #include "host_int.hpp"
 
 using namespace flbgpu;
@@ -14,13 +15,15 @@ struct flbgpu_ml_parser {
     MlParserDev dev;
     std::vector<MlRuleSrc> src;
     std::vector<GrepRule> rules;
+    std::vector<rx::Program> progs;          // the rules' tables on the host: the product automaton is built from them
     std::vector<TableBlob *> blobs;
-    DevBuf d_rules;
+    DevBuf d_rules, d_prod;
+    uint32_t prod_bytes = 0, prod_nj = 0, prod_nS = 0, prod_T = 0, prod_init = 0;
     bool inited = false;
     flbgpu_ml_parser() { memset(&dev, 0, sizeof(dev)); }
     ~flbgpu_ml_parser() {
         for (TableBlob *b : blobs) delete b;
-        d_rules.release();
+        d_rules.release(); d_prod.release();
     }
 };
 
@@ -34,10 +37,10 @@ struct flbgpu_ml_stream {
     uint32_t carry_trunc = 0;                 // the open group was cut by the buffer limit (flb_ml_stream_group.truncated)
     uint64_t truncations = 0;                 // lines that truncated a buffer (FLB_MULTILINE_TRUNCATED returns)
     DevBuf d_masks, d_tcnt, d_toff, d_scan_tmp, d_nl, d_keep, d_koff, d_ls, d_ll, d_info, d_F, d_sin, d_act, d_c, d_coff, d_head, d_gidx,
-           d_ghead, d_plen, d_po, d_pk, d_gC, d_ovr, d_fs_tmp, d_rows, d_out, d_misc, d_in;
+           d_ghead, d_plen, d_po, d_pk, d_gC, d_ovr, d_slow, d_fs_tmp, d_rows, d_out, d_misc, d_in;
     ~flbgpu_ml_stream() {
         DevBuf *all[] = {&carry[0], &carry[1], &d_masks, &d_tcnt, &d_toff, &d_scan_tmp, &d_nl, &d_keep, &d_koff, &d_ls, &d_ll, &d_info, &d_F, &d_sin,
-                         &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_ovr, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
+                         &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_ovr, &d_slow, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
         for (DevBuf *b : all) b->release();
         if (stream) (void) hipStreamDestroy(stream);
     }
@@ -78,6 +81,12 @@ extern "C" flbgpu_ml_parser *flbgpu_ml_parser_create(const char *type, const cha
 }
 
 extern "C" void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p) { delete p; }
+// diagnostics: states / joint classes / non-absorbing states of the product automaton (0 states: the rules are walked one by one)
+extern "C" void flbgpu_ml_parser_product(const flbgpu_ml_parser *p, uint32_t *states, uint32_t *classes, uint32_t *live) {
+    if (states) *states = p && p->prod_bytes ? p->prod_nS : 0;
+    if (classes) *classes = p ? p->prod_nj : 0;
+    if (live) *live = p ? p->prod_T : 0;
+}
 
 // flb_ml_rule_create (flb_ml_rule.c:48-118): from_states split at ',' with blanks trimmed (flb_slist_split_string), the first rule
 // must hold a start_state
@@ -103,9 +112,17 @@ extern "C" int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_s
     if (to_state && to_state[0]) r.to = to_state;
     GrepRule gr;
     memset(&gr, 0, sizeof(gr));
-    std::string why;
-    if (!compile_rule("$log", regex, gr, p->blobs, why)) { set_err("multiline: %s", why.c_str()); return -1; }
+    const char *ps, *pe;
+    unsigned opts;
+    rx::split_flb_pattern(regex, &ps, &pe, &opts);
+    rx::Program prog;
+    std::string err;
+    if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) { set_err("multiline: could not compile regex pattern '%s' for the GPU path: %s", regex, err.c_str()); return -1; }
+    auto *b1 = new TableBlob(), *b2 = new TableBlob();
+    p->blobs.push_back(b1); p->blobs.push_back(b2);
+    if (!upload_dfa(prog.ascii, *b1, gr.dfa) || !upload_cap(prog.utf8, *b2, gr.utf8)) return -1;
     p->rules.push_back(gr);
+    p->progs.push_back(std::move(prog));
     p->src.push_back(r);
     return 0;
 }
@@ -146,6 +163,97 @@ extern "C" int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name) {
     return flbgpu_ml_parser_init(p);
 }
 
+// The product of the rules' match-only DFAs over the bytes a line can hold (no '\n': the line loop cuts there; a byte >= 0x80 leaves
+// the table -- the per-rule UTF-8 tables take the line).  A component is a state of its rule's DFA, ACC (the rule has matched: its
+// DFA said D_ACCEPT) or DEAD (no match can follow: nothing accepting is reachable).  States whose components are all ACC / DEAD are
+// absorbing and numbered last, so the walk leaves at `state >= T`.  False: too large for LDS -- the kernel then walks rule by rule.
+static bool build_product(flbgpu_ml_parser *p, std::vector<uint8_t> &blob) {
+    const int R = (int) p->progs.size();
+    constexpr uint16_t ACC = 0xFFFF, DEAD = 0xFFFE;
+    // joint classes of the bytes < 0x80 except '\n'; class nj - 1 = everything else
+    std::map<std::vector<int>, int> sig2cls;
+    std::vector<int> jcls(256, -1), rep;
+    for (int b = 0; b < 128; b++) {
+        if (b == '\n') continue;
+        std::vector<int> sig((size_t) R);
+        for (int r = 0; r < R; r++) sig[(size_t) r] = p->progs[(size_t) r].ascii.cls[b];
+        auto it = sig2cls.find(sig);
+        if (it == sig2cls.end()) { it = sig2cls.emplace(sig, (int) rep.size()).first; rep.push_back(b); }
+        jcls[(size_t) b] = it->second;
+    }
+    const int nj = (int) rep.size() + 1;
+    for (int b = 0; b < 256; b++) if (jcls[(size_t) b] < 0) jcls[(size_t) b] = nj - 1;
+    // per rule: the states from which a match is still possible over such bytes
+    std::vector<std::vector<uint8_t>> good((size_t) R);
+    for (int r = 0; r < R; r++) {
+        const rx::TableSet &t = p->progs[(size_t) r].ascii;
+        std::vector<uint8_t> &g = good[(size_t) r];
+        g.assign((size_t) t.nD, 0);
+        for (int s = 0; s < t.nD; s++) g[(size_t) s] = t.d_final[(size_t) s] ? 1 : 0;
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (int s = 0; s < t.nD; s++) {
+                if (g[(size_t) s]) continue;
+                for (int c = 0; c + 1 < nj && !g[(size_t) s]; c++) {
+                    const uint16_t n = t.ddelta[(size_t) s * t.ncls + t.cls[rep[(size_t) c]]];
+                    if (n == 0xFFFF || (n < 0xFFF0 && g[n])) { g[(size_t) s] = 1; changed = true; }
+                }
+            }
+        }
+    }
+    std::map<std::vector<uint16_t>, int> ids;
+    std::vector<std::vector<uint16_t>> states;
+    auto canon = [&](int r, uint16_t s) -> uint16_t { return (s == ACC || s == DEAD) ? s : good[(size_t) r][s] ? s : DEAD; };
+    std::vector<uint16_t> init((size_t) R);
+    for (int r = 0; r < R; r++) init[(size_t) r] = canon(r, (uint16_t) p->progs[(size_t) r].ascii.d_init);
+    ids.emplace(init, 0); states.push_back(init);
+    std::vector<uint32_t> delta;                  // [state][nj - 1]
+    for (size_t si = 0; si < states.size(); si++) {
+        if (states.size() > 4096 || states.size() * (size_t) nj * 2 > 60000) return false;
+        const std::vector<uint16_t> cur = states[si];
+        for (int c = 0; c + 1 < nj; c++) {
+            std::vector<uint16_t> nx((size_t) R);
+            for (int r = 0; r < R; r++) {
+                const rx::TableSet &t = p->progs[(size_t) r].ascii;
+                const uint16_t s = cur[(size_t) r];
+                if (s == ACC || s == DEAD) { nx[(size_t) r] = s; continue; }
+                const uint16_t n = t.ddelta[(size_t) s * t.ncls + t.cls[rep[(size_t) c]]];
+                if (n == 0xFFFE) return false;                       // a byte < 0x80 never poisons; be safe
+                nx[(size_t) r] = n == 0xFFFF ? ACC : canon(r, n);
+            }
+            auto it = ids.find(nx);
+            if (it == ids.end()) { it = ids.emplace(nx, (int) states.size()).first; states.push_back(nx); }
+            delta.push_back((uint32_t) it->second);
+        }
+    }
+    const int nS = (int) states.size();
+    if ((size_t) nS * (size_t) nj * 2 + 256 + (size_t) nS * 2 > 60000) return false;
+    // absorbing states last
+    std::vector<int> order((size_t) nS), newid((size_t) nS);
+    int T = 0;
+    auto absorbing = [&](int s) { for (uint16_t c : states[(size_t) s]) if (c != ACC && c != DEAD) return false; return true; };
+    for (int s = 0; s < nS; s++) if (!absorbing(s)) order[(size_t) T++] = s;
+    int q = T;
+    for (int s = 0; s < nS; s++) if (absorbing(s)) order[(size_t) q++] = s;
+    for (int i = 0; i < nS; i++) newid[(size_t) order[(size_t) i]] = i;
+    blob.assign(256 + (size_t) nS * 2 + (size_t) nS * (size_t) nj * 2, 0);
+    for (int b = 0; b < 256; b++) blob[(size_t) b] = (uint8_t) jcls[(size_t) b];
+    uint16_t *fm = (uint16_t *) (blob.data() + 256), *dl = fm + nS;
+    for (int i = 0; i < nS; i++) {
+        const int s = order[(size_t) i];
+        uint16_t m = 0;
+        for (int r = 0; r < R; r++) {
+            const uint16_t c = states[(size_t) s][(size_t) r];
+            if (c == ACC || (c != DEAD && p->progs[(size_t) r].ascii.d_final[c])) m |= (uint16_t) (1u << r);
+        }
+        fm[i] = m;
+        for (int c = 0; c + 1 < nj; c++) dl[(size_t) i * nj + c] = (uint16_t) newid[(size_t) delta[(size_t) s * (nj - 1) + c]];
+        dl[(size_t) i * nj + (nj - 1)] = 0xFFFF;
+    }
+    p->prod_nj = (uint32_t) nj; p->prod_nS = (uint32_t) nS; p->prod_T = (uint32_t) T; p->prod_init = (uint32_t) newid[0];
+    return true;
+}
+
 // flb_ml_rule_init (flb_ml_rule.c:279-299): every rule's to_state_map, here as masks over the rules
 extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
     if (!p) { set_err("multiline: no parser"); return -1; }
@@ -167,6 +275,14 @@ extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
     if (n) {
         if (!p->d_rules.ensure((size_t) n * sizeof(GrepRule))) return -1;
         if (hipMemcpy(p->d_rules.p, p->rules.data(), (size_t) n * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) { set_err("multiline: uploading the rules failed"); return -1; }
+        std::vector<uint8_t> blob;
+        const char *no = getenv("FLBGPU_ML_NO_PRODUCT");
+        if (!(no && no[0] == '1') && build_product(p, blob)) {
+            blob.resize((blob.size() + 15) & ~(size_t) 15);
+            if (!p->d_prod.ensure(blob.size())) return -1;
+            if (hipMemcpy(p->d_prod.p, blob.data(), blob.size(), hipMemcpyHostToDevice) != hipSuccess) { set_err("multiline: uploading the product table failed"); return -1; }
+            p->prod_bytes = (uint32_t) blob.size();
+        }
     }
     p->inited = true;
     return 0;
@@ -223,18 +339,19 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     if (!s->d_nl.ensure((nl + 1) * sizeof(uint64_t)) || !s->d_keep.ensure(NB * 4) || !s->d_koff.ensure((NB + 1) * 8) || !s->d_ls.ensure(NB * 8) || !s->d_ll.ensure(NB * 4) ||
         !s->d_info.ensure(NB * 4) || !s->d_F.ensure(NB * 8) || !s->d_sin.ensure(NB) || !s->d_act.ensure(NB) || !s->d_c.ensure(NB * 4) || !s->d_coff.ensure((NB + 1) * 8) ||
         !s->d_head.ensure(NB * 4) || !s->d_gidx.ensure((NB + 1) * 8) || !s->d_ghead.ensure((NB + 1) * 8) || !s->d_plen.ensure(NB * 4) || !s->d_po.ensure((NB + 1) * 8) ||
-        !s->d_pk.ensure(NB * 4) || !s->d_gC.ensure(NB * 4) || !s->d_ovr.ensure(NB * 4) || !s->d_rows.ensure((NB + 1) * 8) || !s->d_fs_tmp.ensure(ml_fscan_tmp_bytes(NB)) ||
+        !s->d_pk.ensure(NB * 4) || !s->d_gC.ensure(NB * 4) || !s->d_ovr.ensure(NB * 4) || !s->d_slow.ensure(NB * 4) || !s->d_rows.ensure((NB + 1) * 8) || !s->d_fs_tmp.ensure(ml_fscan_tmp_bytes(NB)) ||
         !s->d_scan_tmp.ensure(scan_tmp_elems(NB) * sizeof(uint64_t)) || !s->carry[s->cur].ensure(64)) return -1;
     if (nl) launch_tl_fill(s->d_masks.as<uint64_t>(), bytes, s->d_toff.as<uint64_t>(), s->d_nl.as<uint64_t>(), st);
     MlArgs a;
     memset(&a, 0, sizeof(a));
     a.p = s->p->dev; a.rules = s->p->d_rules.as<GrepRule>();
+    a.prod = s->p->d_prod.as<uint8_t>(); a.prod_bytes = s->p->prod_bytes; a.prod_nj = s->p->prod_nj; a.prod_nS = s->p->prod_nS; a.prod_T = s->p->prod_T; a.prod_init = s->p->prod_init;
     a.text = text; a.bytes = bytes; a.nl_pos = s->d_nl.as<uint64_t>(); a.nl = nl;
     a.skip_empty_lines = skip_empty_lines ? 1 : 0; a.flush_all = flush ? 1 : 0;
     a.NB = NB; a.keep = s->d_keep.as<uint32_t>(); a.koff = s->d_koff.as<uint64_t>(); a.ls = s->d_ls.as<uint64_t>(); a.ll = s->d_ll.as<uint32_t>();
     a.info = s->d_info.as<uint32_t>(); a.F = s->d_F.as<uint64_t>(); a.sin = s->d_sin.as<uint8_t>(); a.act = s->d_act.as<uint8_t>();
     a.c = s->d_c.as<uint32_t>(); a.coff = s->d_coff.as<uint64_t>(); a.head = s->d_head.as<uint32_t>(); a.gidx = s->d_gidx.as<uint64_t>();
-    a.ghead = s->d_ghead.as<uint64_t>(); a.plen = s->d_plen.as<uint32_t>(); a.po = s->d_po.as<uint64_t>(); a.pk = s->d_pk.as<uint32_t>(); a.gC = s->d_gC.as<uint32_t>(); a.ovr = s->d_ovr.as<uint32_t>();
+    a.ghead = s->d_ghead.as<uint64_t>(); a.plen = s->d_plen.as<uint32_t>(); a.po = s->d_po.as<uint64_t>(); a.pk = s->d_pk.as<uint32_t>(); a.gC = s->d_gC.as<uint32_t>(); a.ovr = s->d_ovr.as<uint32_t>(); a.slow = s->d_slow.as<uint32_t>();
     a.carry = s->carry[s->cur].as<uint8_t>(); a.carry_len = s->carry_len; a.carry_tail = s->carry_tail; a.carry_state = s->state; a.carry_trunc = s->carry_trunc;
     a.carry_sec = s->carry_sec; a.carry_nsec = s->carry_nsec; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
     // a group that is flushed before any line registered a time takes flb_time_get() (flb_ml.c:1619-1624): the clock of this call

@@ -279,6 +279,8 @@ int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_states, cons
 int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name);
 int flbgpu_ml_parser_init(flbgpu_ml_parser *p);
 void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p);
+/* diagnostics: size of the product of the rules' match-only DFAs (states 0: too large for LDS, the rules are walked one by one) */
+void flbgpu_ml_parser_product(const flbgpu_ml_parser *p, uint32_t *states, uint32_t *classes, uint32_t *live);
 flbgpu_ml_stream *flbgpu_ml_stream_create(flbgpu_ml_parser *p);
 void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s);
 void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_state, uint64_t *buffered);

@@ -67,6 +67,25 @@ def test_random_cases(g, seed):
         assert st[2] == trunc, (cfg, frames, kw)
 
 
+def test_rule_by_rule_walk(g, monkeypatch):
+    """the product automaton off (FLBGPU_ML_NO_PRODUCT=1, read when the parser is initialised): every rule's own DFA per line"""
+    monkeypatch.setenv("FLBGPU_ML_NO_PRODUCT", "1")
+    rng = random.Random(6100)
+    for _ in range(40):
+        cfg, frames, kw = ml_synth.random_case(rng)
+        want, n, _ = oracle_run(cfg, frames, clock_of_the_call=True, **kw)
+        got, gn, _ = device_run(g, cfg, frames, **kw)
+        assert got == want and gn == n, (cfg, frames, kw)
+
+
+def test_builtin_products(g):
+    for name in ml_synth.BUILTINS:
+        p = g.MultilineParser(builtin=name)
+        states, classes, live = p.product()
+        assert 0 < live <= states and classes > 1, (name, states, classes, live)
+        p.close()
+
+
 def test_stream_state_is_carried(g):
     rules = [("start_state", r"/^\d+ start/", "cont"), ("cont", r"/^\s+/", "cont")]
     text = b"1 start\n  a\n\n  b\nnope\n  c\n2 start\n"
