@@ -542,6 +542,44 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         f2.close(); g2.close(); tl.close(); L.flbgpu_dev_free(d_txt)
     except Exception as e:
         out["tail_lines"] = {"error": repr(e)[:300]}
+    # -- multiline in front of the path: a file buffer of Java stack traces (and plain lines) through the built-in `java` parser
+    #    (src/multiline/flb_ml_parser_java.c) on the device: rule matches, rule_to_state scan, concatenation into records
+    try:
+        import random as _rnd
+        import ml_synth, oracle_binding as _ob
+        rng_ = _rnd.Random(0x3a1)
+        block = ml_synth.random_text(rng_, 20000, ml_synth.SEED_LINES["java"], crlf=0.0, empty=0.02, long_line=0.0, nul_lead=0.0)
+        reps_ = max(1, min(n, 4_000_000) // 20000)
+        text_ = block * reps_
+        nlines = text_.count(b"\n")
+        d_ml = L.flbgpu_dev_alloc(len(text_)); L.flbgpu_memcpy_h2d(d_ml, text_, len(text_))
+        mp_ = g.MultilineParser(builtin="java")
+        ms_ = mp_.stream()
+        och, recs_, proc_ = ms_.append_dev(d_ml, len(text_), 1700000000, 5, flush=True)
+        # parity on what the oracle walks in about a second: the first blocks of the same text
+        k_ = min(reps_, 10)
+        om = _ob.Multiline(builtin="java")
+        want_ = om.append(block * k_, 1700000000, 5)[0]
+        got_ = ctypes.create_string_buffer(len(want_))
+        L.flbgpu_memcpy_d2h(got_, och.data, len(want_))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ms_.append_dev(d_ml, len(text_), 1700000000, 5, flush=True)
+        torch.cuda.synchronize()
+        dt_m = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        om2 = _ob.Multiline(builtin="java")
+        om2.append(block * k_, 1700000000, 5)
+        dt_o = time.perf_counter() - t0
+        out["multiline"] = {"parser": "java (built-in, 8 regex rules)", "lines_per_s_per_gpu": round(nlines / dt_m, 1), "ms_per_step": round(dt_m * 1e3, 3),
+                            "text_bytes": len(text_), "records": int(recs_), "record_bytes": int(och.bytes), "text_GBps": round(len(text_) / dt_m / 1e9, 1),
+                            "product_automaton": dict(zip(("states", "classes", "live"), mp_.product())),
+                            "prefix_matches_oracle": bool(got_.raw == want_), "prefix_lines": 20000 * k_,
+                            "cpu_oracle_lines_per_s_1core": round(20000 * k_ / dt_o, 1)}
+        ms_.close(); mp_.close(); L.flbgpu_dev_free(d_ml)
+    except Exception as e:
+        out["multiline"] = {"error": repr(e)[:300]}
     # -- flb_sp (BASELINE configs[4] shape): GROUP BY status, AVG(latency) over a tumbling window; the chunk is resident in HBM, the
     #    window's partial aggregates are exchanged over RCCL when N > 1 (one all-gather of KB-sized group states per timer)
     try:

@@ -73,6 +73,34 @@ int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end)
     return p->ngroups;
 }
 
+/* diagnostics of the compact tables: out[0] rows, [1] classes (+1: end of text), [2] look-ahead rows, [3] pair entries, [4] bytes;
+ * and over a text: [5] steps, [6] steps through a look-ahead cell, [7] steps through a pair cell */
+int flbgpu_rx_fx_profile(void *h, const char *s, int len, long *out)
+{
+    auto *p = (rx::Program *) h;
+    int ncap = 0;
+    for (uint8_t c : p->slot2cap) if (c != 0xFF) ncap++;
+    std::vector<uint8_t> b;
+    flbgpu::DevFx fx;
+    if (ncap == 0 || !flbgpu::build_fx(p->ascii, ncap, b, fx) || !fx.ok) return -4;
+    const rx::TableSet &t = p->ascii;
+    out[0] = (long) t.nX * t.NKp + 2; out[1] = t.ncls + 1; out[2] = (long) (t.ft2.size() >> t.fc_shift); out[3] = (long) ((b.size() - fx.off_p2) / 8); out[4] = (long) b.size();
+    auto u32at = [&](uint32_t at) -> uint32_t { uint32_t v; memcpy(&v, b.data() + at, 4); return v; };
+    auto cls_of = [&](int pos) -> uint32_t { return u32at(4 * (pos < len ? (uint8_t) s[pos] : 0xFFu)); };
+    uint32_t e = fx.start_off;
+    long steps = 0, look = 0, pair = 0;
+    for (int j = 0; j <= len; j++) {
+        e = u32at((e & flbgpu::FX_ROW_MASK) + cls_of(j));
+        steps++;
+        if (e & 0x80000000u) {
+            if (!(e & 0x40000000u)) { look++; e = u32at((e & flbgpu::FX_ROW_MASK) + cls_of(j + 1)); }
+            if (e & 0x80000000u) { pair++; e = u32at(fx.off_p2 + 8 * (e & 0x3FFFFFFFu)); }
+        }
+    }
+    out[5] += steps; out[6] += look; out[7] += pair;
+    return 0;
+}
+
 /* "name=group\n" lines in onig_foreach_name order */
 int flbgpu_rx_names(void *h, char *buf, int cap)
 {
