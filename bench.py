@@ -940,6 +940,20 @@ def main():
     # the parsed chunk itself, for the side measurements below (one unfused filter_parser run, untimed)
     r1, o1 = fparser.filter_dev(chunk)
     assert r1 == g.MODIFIED and int(o1.bytes) == parsed_bytes, (g.last_error(), int(o1.bytes), parsed_bytes)
+    # BASELINE configs[1] proper -- filter_parser ALONE (the headline adds configs[0]'s grep behind it): every record parsed and
+    # written back, SURVEY 8(d)'s 277 + 275 B/record
+    parser_only = None
+    if not args.no_secondary:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fparser.filter_dev(chunk)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / 3
+        parser_only = {"what": "filter_parser(apache2) alone, unfused kernels: k_parser_reg + scans + k_parser_emit", "records_per_s_per_gpu": round(n / dtp, 1),
+                       "ms_per_step": round(dtp * 1e3, 3), "algorithmic_bytes": int(in_bytes + parsed_bytes),
+                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round((in_bytes + parsed_bytes) / dtp / 1e9, 1),
+                                    "frac": round((in_bytes + parsed_bytes) / dtp / 8e12, 4)}}
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
@@ -961,6 +975,8 @@ def main():
     if not args.no_secondary:
         try:
             secondary = measure_secondary(g, torch, dist, rank, world, o1, n, args, raw_chunk=chunk, shared_gpu=shared_gpu)
+            if parser_only is not None:
+                secondary["parser_only"] = parser_only
             if rank == 0 and world == 1:
                 secondary["host_level"] = measure_host_level(g, data, off, n)
         except Exception as e:                      # the headline line must survive a failure here

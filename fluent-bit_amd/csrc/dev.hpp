@@ -640,6 +640,8 @@ struct MlParserDev {
     uint32_t start_mask;                 // rules with a start_state among their from_states
     uint32_t cont_mask[16];              // by rule_to_state: the non-start rules its to_state leads to (rule order = to_state_map order)
     uint32_t flush_after;                // rules whose to_state leads to a start rule (try_flushing_buffer)
+    int8_t look_idx[16];                 // rule "^(?!A)B" / "^(?=A)B": index of the automaton of ^(?:A) in rules[] (behind the nrules B parts), -1 none
+    uint32_t look_neg;                   // ... the look-ahead is negative
     uint32_t match_len;
     uint8_t match_str[256];              // ENDSWITH / EQ
     uint32_t has_key_content, key_len;

@@ -10,12 +10,19 @@
 using namespace flbgpu;
 
 struct MlRuleSrc { std::vector<std::string> from; std::string regex, to; bool start = false; };
+struct MlPending { int rule; std::string pat, shown; unsigned opts; bool neg; };
 
 struct flbgpu_ml_parser {
     MlParserDev dev;
     std::vector<MlRuleSrc> src;
     std::vector<GrepRule> rules;
     std::vector<rx::Program> progs;          // the rules' tables on the host: the product automaton is built from them
+    // a rule "^(?!A)B" / "^(?=A)B" (the documented idiom for "a line that does not start like a first line"): on a line -- no '\n' inside,
+    // so '^' is position 0 only -- it says [not] match(^(?:A)) and match(^B): two match-only automata, no look-around in the tables.
+    // rules / progs hold the B parts at [0, n) and the A parts behind them
+    std::vector<int> look_of;                // [rule] index of its A part in rules / progs, -1: none
+    std::vector<uint8_t> look_neg;
+    std::vector<MlPending> pending;           // A parts waiting for init
     std::vector<TableBlob *> blobs;
     DevBuf d_rules, d_prod;
     uint32_t prod_bytes = 0, prod_nj = 0, prod_nS = 0, prod_T = 0, prod_init = 0;
@@ -88,6 +95,50 @@ extern "C" void flbgpu_ml_parser_product(const flbgpu_ml_parser *p, uint32_t *st
     if (live) *live = p ? p->prod_T : 0;
 }
 
+// "^(?!A)B" / "^(?=A)B" -> A, B.  False: not of that form
+static bool split_leading_lookahead(const char *ps, const char *pe, std::string &A, std::string &B, bool &neg) {
+    if (pe - ps < 5 || ps[0] != '^' || ps[1] != '(' || ps[2] != '?' || (ps[3] != '!' && ps[3] != '=')) return false;
+    neg = ps[3] == '!';
+    int depth = 1;
+    bool cls = false;
+    const char *q = ps + 4;
+    for (; q < pe; q++) {
+        if (*q == '\\') { q++; continue; }
+        if (cls) { if (*q == ']') cls = false; continue; }
+        if (*q == '[') { cls = true; if (q + 1 < pe && q[1] == '^') q++; if (q + 1 < pe && q[1] == ']') q++; continue; }
+        if (*q == '(') depth++;
+        else if (*q == ')' && --depth == 0) break;
+    }
+    if (q >= pe) return false;
+    // an alternation at the top level ("^(?!A)B|C") scopes the look-ahead to its own branch: not this form
+    depth = 0; cls = false;
+    for (const char *t = q + 1; t < pe; t++) {
+        if (*t == '\\') { t++; continue; }
+        if (cls) { if (*t == ']') cls = false; continue; }
+        if (*t == '[') { cls = true; if (t + 1 < pe && t[1] == '^') t++; if (t + 1 < pe && t[1] == ']') t++; continue; }
+        if (*t == '(') depth++;
+        else if (*t == ')') depth--;
+        else if (*t == '|' && depth == 0) return false;
+    }
+    A.assign(ps + 4, (size_t) (q - (ps + 4)));
+    B.assign(q + 1, (size_t) (pe - (q + 1)));
+    return true;
+}
+
+static bool ml_compile(flbgpu_ml_parser *p, const std::string &pat, unsigned opts, const char *shown) {
+    GrepRule gr;
+    memset(&gr, 0, sizeof(gr));
+    rx::Program prog;
+    std::string err;
+    if (!rx::compile(pat.data(), pat.size(), opts, false, prog, err)) { set_err("multiline: could not compile regex pattern '%s' for the GPU path: %s", shown, err.c_str()); return false; }
+    auto *b1 = new TableBlob(), *b2 = new TableBlob();
+    p->blobs.push_back(b1); p->blobs.push_back(b2);
+    if (!upload_dfa(prog.ascii, *b1, gr.dfa) || !upload_cap(prog.utf8, *b2, gr.utf8)) return false;
+    p->rules.push_back(gr);
+    p->progs.push_back(std::move(prog));
+    return true;
+}
+
 // flb_ml_rule_create (flb_ml_rule.c:48-118): from_states split at ',' with blanks trimmed (flb_slist_split_string), the first rule
 // must hold a start_state
 extern "C" int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_states, const char *regex, const char *to_state) {
@@ -110,19 +161,19 @@ extern "C" int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_s
     if (!r.start && p->src.empty()) { set_err("[multiline] rule don't contain a 'start_state'"); return -1; }
     r.regex = regex;
     if (to_state && to_state[0]) r.to = to_state;
-    GrepRule gr;
-    memset(&gr, 0, sizeof(gr));
     const char *ps, *pe;
     unsigned opts;
     rx::split_flb_pattern(regex, &ps, &pe, &opts);
-    rx::Program prog;
-    std::string err;
-    if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) { set_err("multiline: could not compile regex pattern '%s' for the GPU path: %s", regex, err.c_str()); return -1; }
-    auto *b1 = new TableBlob(), *b2 = new TableBlob();
-    p->blobs.push_back(b1); p->blobs.push_back(b2);
-    if (!upload_dfa(prog.ascii, *b1, gr.dfa) || !upload_cap(prog.utf8, *b2, gr.utf8)) return -1;
-    p->rules.push_back(gr);
-    p->progs.push_back(std::move(prog));
+    std::string A, B;
+    bool neg = false;
+    if (split_leading_lookahead(ps, pe, A, B, neg)) {
+        // the B parts stay at the rules' own indexes: the A part is parked and appended behind all rules at init
+        if (!ml_compile(p, "^(?:" + B + ")", opts, regex)) return -1;
+        MlPending pd;
+        pd.rule = (int) p->src.size(); pd.pat = "^(?:" + A + ")"; pd.opts = opts; pd.neg = neg; pd.shown = regex;
+        p->pending.push_back(pd);
+    }
+    else if (!ml_compile(p, std::string(ps, (size_t) (pe - ps)), opts, regex)) return -1;
     p->src.push_back(r);
     return 0;
 }
@@ -242,9 +293,12 @@ static bool build_product(flbgpu_ml_parser *p, std::vector<uint8_t> &blob) {
     for (int i = 0; i < nS; i++) {
         const int s = order[(size_t) i];
         uint16_t m = 0;
-        for (int r = 0; r < R; r++) {
-            const uint16_t c = states[(size_t) s][(size_t) r];
-            if (c == ACC || (c != DEAD && p->progs[(size_t) r].ascii.d_final[c])) m |= (uint16_t) (1u << r);
+        auto acc = [&](int r) -> bool { const uint16_t c = states[(size_t) s][(size_t) r]; return c == ACC || (c != DEAD && p->progs[(size_t) r].ascii.d_final[c]); };
+        for (int r = 0; r < p->dev.nrules; r++) {
+            bool ok = acc(r);
+            const int la = p->dev.look_idx[r];
+            if (ok && la >= 0) ok = ((p->dev.look_neg >> r) & 1) ? !acc(la) : acc(la);
+            if (ok) m |= (uint16_t) (1u << r);
         }
         fm[i] = m;
         for (int c = 0; c + 1 < nj; c++) dl[(size_t) i * nj + c] = (uint16_t) newid[(size_t) delta[(size_t) s * (nj - 1) + c]];
@@ -261,6 +315,14 @@ extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
     const int n = (int) p->src.size();
     if (p->dev.type == ML_REGEX && n == 0) { set_err("multiline: a regex parser without rules"); return -1; }
     p->dev.nrules = n;
+    for (int i = 0; i < 16; i++) p->dev.look_idx[i] = -1;
+    for (const MlPending &pd : p->pending) {
+        if (p->rules.size() >= 32) { set_err("multiline: too many look-ahead rules for the GPU path"); return -1; }
+        p->dev.look_idx[pd.rule] = (int8_t) p->rules.size();
+        if (pd.neg) p->dev.look_neg |= 1u << pd.rule;
+        if (!ml_compile(p, pd.pat, pd.opts, pd.shown.c_str())) return -1;
+    }
+    p->pending.clear();
     for (int i = 0; i < n; i++) if (p->src[(size_t) i].start) p->dev.start_mask |= 1u << i;
     for (int i = 0; i < n; i++) {
         const MlRuleSrc &r = p->src[(size_t) i];
@@ -273,8 +335,8 @@ extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
         if (map & p->dev.start_mask) p->dev.flush_after |= 1u << i;     // try_flushing_buffer: a start rule may follow
     }
     if (n) {
-        if (!p->d_rules.ensure((size_t) n * sizeof(GrepRule))) return -1;
-        if (hipMemcpy(p->d_rules.p, p->rules.data(), (size_t) n * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) { set_err("multiline: uploading the rules failed"); return -1; }
+        if (!p->d_rules.ensure(p->rules.size() * sizeof(GrepRule))) return -1;
+        if (hipMemcpy(p->d_rules.p, p->rules.data(), p->rules.size() * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) { set_err("multiline: uploading the rules failed"); return -1; }
         std::vector<uint8_t> blob;
         const char *no = getenv("FLBGPU_ML_NO_PRODUCT");
         if (!(no && no[0] == '1') && build_product(p, blob)) {

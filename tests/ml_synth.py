@@ -22,7 +22,9 @@ SEED_LINES = {
 }
 
 ATOMS = [(r"^\d+ ", b"12 "), (r"^\[", b"["), (r"^\s+", b"   "), (r"^\s+at ", b"  at "), (r"ERROR", b"ERROR"), (r"^$", b""), (r"end$", b"end"),
-         (r"^[A-Z][a-z]+:", b"Caused:"), (r"\bpanic: ", b"panic: "), (r"^--", b"--"), (r"[^\t ]", b"x"), (r"^\S", b"q"), (r"(?i)^warn", b"WaRn")]
+         (r"^[A-Z][a-z]+:", b"Caused:"), (r"\bpanic: ", b"panic: "), (r"^--", b"--"), (r"[^\t ]", b"x"), (r"^\S", b"q"), (r"(?i)^warn", b"WaRn"),
+         # the documented "not a first line" idiom: a leading look-ahead behind the line anchor
+         (r"^(?!\d+ ).*", b"zz"), (r"^(?!\[|--)(?:\S+ e|x)", b"qq e"), (r"^(?=\s+at )\s+at [a-z]", b"  at b"), (r"^(?![A-Z][a-z]+:)", b"lower:")]
 STATES = ["s1", "s2", "s3", "s4"]
 
 

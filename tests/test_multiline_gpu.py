@@ -86,6 +86,28 @@ def test_builtin_products(g):
         p.close()
 
 
+def test_the_runtime_tests_parser_with_a_negative_lookahead(g):
+    """tests/runtime/data/tail/parsers_multiline.conf `multiline-regex`: the continuation rule is "a line that does not start like a
+    first line" -- ^(?!A).* -- which the tables answer with A's own automaton (ml.cpp split_leading_lookahead)"""
+    first = r"\[\d{4}-\d{2}-\d{2} \d{2}:\d{2}:\d{2},\d{3}\]"
+    rules = [("start_state", "/^%s/" % first, "cont"), ("cont", "/^(?!%s).*/" % first, "cont")]
+    rng = random.Random(11)
+    lines = []
+    for i in range(3000):
+        r = rng.random()
+        if r < 0.3:
+            lines.append(b"[2021-03-%02d 10:%02d:%02d,%03d] request %d" % (rng.randrange(1, 29), rng.randrange(60), rng.randrange(60), rng.randrange(1000), i))
+        elif r < 0.35:
+            lines.append(b"[2021-03-01 10:00:00.123] almost a first line")
+        else:
+            lines.append(rng.choice([b"  at x.y.Z(A.java:%d)" % i, b"Caused by: q", b"", b"[", b"\xc3\xa9t\xc3\xa9 [2021"]))
+    text = b"\n".join(lines) + b"\n"
+    frames = [(50, 1, text[:7777]), (60, 2, text[7777:])]
+    want, n, _ = oracle_run({"rules": rules}, frames, final_flush=True, clock_of_the_call=True)
+    got, gn, _ = device_run(g, {"rules": rules}, frames, final_flush=True)
+    assert got == want and gn == n and n > 500
+
+
 def test_stream_state_is_carried(g):
     rules = [("start_state", r"/^\d+ start/", "cont"), ("cont", r"/^\s+/", "cont")]
     text = b"1 start\n  a\n\n  b\nnope\n  c\n2 start\n"

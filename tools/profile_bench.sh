@@ -26,7 +26,10 @@ for d in ("pmc_fetch", "pmc_write"):
         for row in csv.DictReader(open(f)):
             res[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}
-json.dump({"command": "python bench.py --no-cpu --no-secondary --steps 5 --warmup 1", "unit": "KiB per launch (FETCH_SIZE / WRITE_SIZE), GRBM_GUI_ACTIVE cycles", "kernels": out},
+sys.path.insert(0, "/root/repo")
+import bench
+json.dump({"command": "python bench.py --no-cpu --no-secondary --steps 5 --warmup 1", "unit": "KiB per launch (FETCH_SIZE / WRITE_SIZE), GRBM_GUI_ACTIVE cycles",
+           "kernel_source_sha": bench.kernel_source_sha(), "kernels": out},
           open(os.path.join(O, "pmc_summary.json"), "w"), indent=1)
 for k, v in out.items():
     if "parser" in k or "grep" in k or "k_pg" in k: print(k, {c: round(x / 1e6, 3) for c, x in v.items()})
