@@ -542,6 +542,79 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         f2.close(); g2.close(); tl.close(); L.flbgpu_dev_free(d_txt)
     except Exception as e:
         out["tail_lines"] = {"error": repr(e)[:300]}
+    # -- the headline pair on MIXED shapes (the headline's chunk is one layout: 256-byte lines, one key): line lengths 80-600 B,
+    #    10 % multi-key bodies (the value is looked up among other keys), 1 % legacy [ts, map] events
+    try:
+        import random as _rnd
+        import numpy as np
+        import synth as _synth
+        import oracle_binding as _ob
+        rng_ = _rnd.Random(0x51ab)
+        lens_ = [80, 120, 160, 256, 400, 600]
+        import re as _re
+        cut_ = _re.compile(rb'^(\S+ - \S+ \[[^\]]+\] "\S+ /)(\S*)( HTTP/1.1" \d+ \d+)( ".*)$')
+        pools = []
+        for ll in lens_:
+            d_, o_, _e = _synth.apache_records(10000, line_len=max(ll, 256), seed=0xF1B17 + ll)
+            rec = int(o_[1] - o_[0])
+            arr = np.asarray(d_).reshape(10000, rec)
+            full = [bytes(arr[i, rec - max(ll, 256):]) for i in range(10000)]
+            if ll < 256:                   # shorter lines: the request path cut, no referer / agent (the pattern's optional tail)
+                short = []
+                for ln in full:
+                    m_ = cut_.match(ln)
+                    keep = max(0, ll - len(m_.group(1)) - len(m_.group(3)))
+                    short.append(m_.group(1) + m_.group(2)[:keep] + m_.group(3))
+                full = short
+            pools.append(full)
+        recs_ = []
+        for i in range(60000):
+            line = pools[rng_.randrange(len(lens_))][rng_.randrange(10000)]
+            r_ = rng_.random()
+            sec_ = 1700000000 + i
+            if r_ < 0.01:
+                recs_.append(_synth.legacy_record(_synth.ext_ts(sec_, 5), {"log": line}))
+            elif r_ < 0.11:
+                body = [("stream", "stdout"), ("log", line), ("pod", "api-%d" % rng_.randrange(100)), ("n", rng_.randrange(1000))]
+                rng_.shuffle(body)
+                recs_.append(_synth.v2_record(sec_, 7, dict(body)))
+            else:
+                recs_.append(_synth.v2_record(sec_, 7, {"log": line}))
+        pool_bytes = b"".join(recs_)
+        tiles_ = max(1, min(n, 3_000_000) // len(recs_))
+        mdata = pool_bytes * tiles_
+        sizes = np.array([len(x) for x in recs_], dtype=np.uint64)
+        moff = np.zeros(len(recs_) * tiles_ + 1, dtype=np.uint64)
+        np.cumsum(np.tile(sizes, tiles_), out=moff[1:])
+        mn = len(recs_) * tiles_
+        d_md = L.flbgpu_dev_alloc(len(mdata) + 16); d_mo = L.flbgpu_dev_alloc(moff.nbytes)
+        L.flbgpu_memcpy_h2d(d_md, mdata, len(mdata)); L.flbgpu_memcpy_h2d(d_mo, moff.ctypes.data, moff.nbytes)
+        mch = g.DevChunk(d_md, d_mo, mn, len(mdata))
+        p3 = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
+        f3 = g.FilterParser("log", [p3]); g3 = g.FilterGrep([GREP_RULE])
+        ch3 = g.FilterChain([f3, g3])
+        r3_, o3_ = ch3.filter_dev(mch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r3_, o3_ = ch3.filter_dev(mch)
+        torch.cuda.synchronize()
+        dt_x = (time.perf_counter() - t0) / steps
+        # the first 3 000 records through the oracle's two filters: what they keep is the head of the device's output
+        head_ = b"".join(recs_[:3000])
+        po_ = _ob.Parser(regex=APACHE2, time_fmt=TIME_FMT, time_key="time")
+        w1 = _ob.FilterParser("log", [po_]).filter(head_)
+        w2 = _ob.Grep([GREP_RULE]).filter(w1[1] if w1[0] == 1 else head_)
+        want_ = w2[1] if w2[0] == 1 else (w1[1] if w1[0] == 1 else head_)
+        got_ = ctypes.create_string_buffer(max(1, len(want_)))
+        if len(want_):
+            L.flbgpu_memcpy_d2h(got_, o3_.data, len(want_))
+        out["mixed_shapes"] = {"records": mn, "chunk_bytes": len(mdata), "line_lengths": lens_, "multi_key_bodies": 0.10, "legacy_events": 0.01,
+                               "records_per_s_per_gpu": round(mn / dt_x, 1), "ms_per_step": round(dt_x * 1e3, 3), "chunk_GBps": round(len(mdata) / dt_x / 1e9, 1),
+                               "kept": int(ch3.last_stats()[1]["out_records"]), "head_matches_oracle": bool(got_.raw[:len(want_)] == want_), "head_records": 3000}
+        f3.close(); g3.close(); p3.close(); L.flbgpu_dev_free(d_md); L.flbgpu_dev_free(d_mo)
+    except Exception as e:
+        out["mixed_shapes"] = {"error": repr(e)[:300]}
     # -- multiline in front of the path: a file buffer of Java stack traces (and plain lines) through the built-in `java` parser
     #    (src/multiline/flb_ml_parser_java.c) on the device: rule matches, rule_to_state scan, concatenation into records
     try:
