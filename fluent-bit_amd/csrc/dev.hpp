@@ -51,8 +51,11 @@ struct DevFx {
     uint32_t start_off, absorb_off, poison_off;   // row addresses
     uint32_t nslots;               // capture columns per lane: dummy + 2 * fields + 4
     int ok;                        // 0: the pattern has no compact tables (classic kernels only)
+    uint32_t pair_bias, ncls1;     // pair tables (fx.cpp build_fx pair = true): an entry names a row by the address of its pair section, the
+                                   // single-step cells sit pair_bias = ncls1 * 4 bytes in front of it; 0: single-step rows only
 };
 constexpr uint32_t FX_SLOT_SHIFT = 16, FX_ROW_MASK = 0xFFFFu, FX_LOOK = 0x80000000u, FX_PAIR = 0xC0000000u;
+constexpr uint32_t FX2_LOOK3 = 0x80000000u, FX2_SPECIAL = 0xC0000000u;      // kinds of a pair cell (bit 31 clear: next row | slot 1 << 16 | slot 2 << 24)
 enum { FXS_END_EOT = 1, FXS_END_MID = 2, FXS_DEAD_EOT = 3, FXS_FAIL = 4 };   // + ncap
 
 // ---- match-only DFA
@@ -145,7 +148,8 @@ struct DevParser {
     // flb_parser_typecast, src/flb_parser.c:2067-2164); names live in names[]
     int nkvtypes;
     int kvtype_off[MAX_NAMES], kvtype_len[MAX_NAMES], kvtype_kind[MAX_NAMES];
-    DevFx fx;                            // compact forward tables of the tile kernel (ok == 0: none)
+    DevFx fx;
+    DevFx fx2;                     // the same tables with a pair section per row (two steps per read); ok = 0: does not fit                            // compact forward tables of the tile kernel (ok == 0: none)
     const DevDecoders *decs;             // Decode_Field / Decode_Field_As rules (device memory; nullptr: none) -- dec_dev.inc
 };
 
@@ -279,6 +283,7 @@ struct ParserMatchArgs {
     uint32_t *pg_keep_len;           // [n] written by k_parser_finish: out_len when kept, 0, or PG_UNDECIDED
     // k_parser_tile: dynamic LDS layout = fx tables | rule DFAs (pg_lds_off) | per wave: record tile + capture columns
     uint32_t tile_lds_off;           // first wave's area
+    uint32_t use_fx2;                // parsers[0].fx2 (pair cells) instead of .fx: k_parser_reg<.., PAIR2>
     uint32_t tile_wave_bytes;        // bytes per wave (tile + capture columns)
     // pair mode: one descriptor of dstride dwords per ROW, written for the rows the single pass keeps -- ONE aligned store
     // of whole 64-byte sectors instead of 34 column stores of 4 bytes (each of which costs a sector write):

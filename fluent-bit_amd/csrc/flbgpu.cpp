@@ -107,9 +107,9 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     return true;
 }
 
-bool flbgpu::upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out) {
+bool flbgpu::upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out, bool pair) {
     std::vector<uint8_t> b;
-    if (!build_fx(t, ncap, b, out) || !out.ok) { out.ok = 0; return true; }
+    if (!build_fx(t, ncap, b, out, pair) || !out.ok) { out.ok = 0; return true; }
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     out.base = (const uint8_t *) blob.dev;
@@ -133,7 +133,7 @@ bool flbgpu::upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
 struct flbgpu_parser {
     std::string name;
     rx::Program prog;
-    TableBlob blob_ascii, blob_utf8, blob_fx;
+    TableBlob blob_ascii, blob_utf8, blob_fx, blob_fx2;
     DevParser dev;                 // host copy (device pointers inside)
     flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
     DevDecoders decs;              // Decode_Field / Decode_Field_As (flbgpu_parser_add_decoder), uploaded when a filter takes the parser
@@ -406,6 +406,8 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
     // compact forward tables of the single-pass tile kernel (start-anchored patterns: the forward walk needs no reverse pass)
     if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE")) {
         if (!upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx, d.fx)) { delete p; return nullptr; }
+        // the same with a cell per pair of byte classes (two steps per table read) when that fits the LDS too
+        if (d.fx.ok && !upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx2, d.fx2, true)) { delete p; return nullptr; }
     }
     return p;
 }
@@ -766,7 +768,11 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     uint32_t lds_bytes = tab_bytes;                          // staged table bytes (0: tables stay in global memory)
     // single-pass tile kernel (tile_kernels.inc) instead of locate / rx / finish: parser 0 start-anchored with compact
     // tables; a workgroup's waves share one copy of the tables, every wave owns a record tile + its capture columns
-    const DevFx &fx = f->parsers[0]->dev.fx;
+    const char *tmode0 = getenv("FLBGPU_TILE_MODE");
+    // (pair cells -- two positions per table read -- are built and tested but measured SLOWER, DESIGN 4.0: off unless FLBGPU_PAIR2=1)
+    const char *pair2 = getenv("FLBGPU_PAIR2");
+    const bool use_fx2 = f->parsers[0]->dev.fx2.ok && !(tmode0 && !strcmp(tmode0, "tile")) && pair2 && pair2[0] == '1';
+    const DevFx &fx = use_fx2 ? f->parsers[0]->dev.fx2 : f->parsers[0]->dev.fx;
     bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
     for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
     uint32_t tile_wave_bytes = 0, tile_pg_room = 0;
@@ -821,7 +827,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
-    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes;
+    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? 1 : 0;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit

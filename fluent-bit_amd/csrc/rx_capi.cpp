@@ -50,7 +50,11 @@ void flbgpu_rx_debug_stats(long *out3) { rx::debug_stats(out3); }
  * >= 0: groups, beg/end of the NAMED groups filled (-1 elsewhere), beg[0] = 0, end[0] = end of the match;
  * -1: the forward walk from boundary 0 does not settle this text (the kernel falls back to the classic walk);
  * -2: a byte >= 0x80 (UTF-8 tables); -4: the pattern has no compact tables. */
-int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end)
+static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair);
+int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, false); }
+/* the same over the tables with a cell per pair of byte classes (k_parser_reg<PAIR2>: two positions per table read); -4 also when they do not fit */
+int flbgpu_rx_simulate_fx2(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, true); }
+static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair)
 {
     auto *p = (rx::Program *) h;
     int ncap = 0;
@@ -58,7 +62,7 @@ int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end)
     if (ncap == 0) return -4;
     std::vector<uint8_t> blob;
     flbgpu::DevFx fx;
-    if (!flbgpu::build_fx(p->ascii, ncap, blob, fx) || !fx.ok) return -4;
+    if (!flbgpu::build_fx(p->ascii, ncap, blob, fx, pair) || !fx.ok) return -4;
     std::vector<uint16_t> caps(fx.nslots);
     const int r = flbgpu::simulate_fx(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
     if (r < 0) return r;

@@ -216,3 +216,81 @@ def test_fx_tables_on_random_patterns():
                 settled += 1
         L.flbgpu_rx_free(h)
     assert patterns > 200 and settled > 300, (patterns, settled)
+
+
+def test_pair_cells_give_the_single_steps_answers():
+    """fx.cpp build_fx(pair = true) -- a cell per (row, class of byte j, class of byte j + 1), what k_parser_reg<PAIR2> walks two
+    positions at a time -- must answer like the single-step tables: same return, same spans, on the golden corpus, on apache lines
+    with every kind of damage, and on random texts over the patterns' own alphabets"""
+    import random
+    L = _lib()
+    L.flbgpu_rx_simulate_fx2.argtypes = L.flbgpu_rx_simulate_fx.argtypes
+    kat = json.load(open(os.path.join(HERE, "golden", "regex_kat.json")))
+    rng = random.Random(5)
+    compared = with_pairs = 0
+
+    def both(h, s):
+        nonlocal compared
+        b1 = (ctypes.c_int * 40)(); e1 = (ctypes.c_int * 40)(); b2 = (ctypes.c_int * 40)(); e2 = (ctypes.c_int * 40)()
+        n1 = L.flbgpu_rx_simulate_fx(h, s, len(s), b1, e1)
+        n2 = L.flbgpu_rx_simulate_fx2(h, s, len(s), b2, e2)
+        if n2 == -4:
+            return False                                  # the pair tables do not fit: the kernel keeps the single steps
+        assert n1 == n2, (s, n1, n2)
+        if n1 >= 0:
+            assert list(b1[:n1 + 1]) == list(b2[:n1 + 1]) and list(e1[:n1 + 1]) == list(e2[:n1 + 1]), (s, list(b1[:n1 + 1]), list(b2[:n1 + 1]))
+        compared += 1
+        return True
+
+    for ent in kat:
+        pat = base64.b64decode(ent["pattern"])
+        if not ent["compiles"] or not ent["names"] or not (pat.startswith(b"^") or pat.startswith(b"\\A")):
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        if not h:
+            continue
+        ok = True
+        texts = [base64.b64decode(s64) for s64, _ in ent["cases"]]
+        alphabet = sorted(set(b"".join(texts) + pat)) or [97]
+        for s in texts:
+            ok = ok and both(h, s)
+            if not ok:
+                break
+        for _ in range(200 if ok else 0):
+            base = bytearray(rng.choice(texts)) if texts and rng.random() < 0.7 else bytearray()
+            for _ in range(rng.randrange(0, 6)):
+                if base and rng.random() < 0.5:
+                    base[rng.randrange(len(base))] = rng.choice(alphabet)
+                else:
+                    base.insert(rng.randrange(len(base) + 1), rng.choice(alphabet))
+            both(h, bytes(base))
+        with_pairs += 1 if ok else 0
+        L.flbgpu_rx_free(h)
+    assert with_pairs >= 10 and compared > 2500, (with_pairs, compared)
+
+    from bench import APACHE2
+    import synth
+    import numpy as np
+    err = ctypes.create_string_buffer(256)
+    h = L.flbgpu_rx_compile(APACHE2.encode(), len(APACHE2), 0, 1, err, 256)
+    data, off, _ = synth.apache_records(600)
+    ev = np.asarray(data).reshape(600, 277)
+    n0 = compared
+    for i in range(600):
+        line = bytes(ev[i, 21:])
+        assert both(h, line)
+        for _ in range(6):
+            b = bytearray(line)
+            k = rng.randrange(4)
+            if k == 0:
+                b = b[:rng.randrange(len(b) + 1)]
+            elif k == 1:
+                b[rng.randrange(len(b))] = rng.choice(b' "[]\\x-\xc3\xff\n')
+            elif k == 2:
+                del b[rng.randrange(len(b))]
+            else:
+                b.insert(rng.randrange(len(b)), rng.choice(b' "[]'))
+            both(h, bytes(b))
+    L.flbgpu_rx_free(h)
+    assert compared - n0 > 4000
