@@ -100,3 +100,35 @@ def random_case(rng, nlines=None):
     if rng.random() < 0.2:
         text = text[:-1] if text else text                    # the last line is not complete yet
     return cfg, frames_of(rng, text), dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)
+
+
+def java_service_log(rng, nlines):
+    """what a JVM service writes: timestamped log lines of 80-160 bytes, now and then an exception with its stack trace (frames of
+    60-110 bytes, Caused by sections, "... n more"); the shape the built-in `java` parser exists for"""
+    pk = ["com.example.orders", "org.springframework.web.servlet", "io.netty.channel", "java.util.concurrent", "com.fasterxml.jackson.databind", "org.hibernate.engine.jdbc"]
+    cl = ["OrderService", "DispatcherServlet", "AbstractChannelHandlerContext", "ThreadPoolExecutor$Worker", "ObjectMapper", "SqlExceptionHelper", "HttpRequestHandlerAdapter"]
+    ex = ["java.lang.IllegalStateException", "java.lang.NullPointerException", "java.sql.SQLTransientConnectionException", "javax.servlet.ServletException", "java.util.concurrent.TimeoutException"]
+    out = []
+    n = 0
+    while n < nlines:
+        if rng.random() < 0.06:
+            out.append(("2024-03-10 10:%02d:%02d,%03d ERROR [http-nio-8080-exec-%d] %s.%s - request failed" % (rng.randrange(60), rng.randrange(60), rng.randrange(1000), rng.randrange(40), rng.choice(pk), rng.choice(cl))).encode())
+            out.append(("%s: %s while handling order %d for customer %d" % (rng.choice(ex), rng.choice(["timeout", "connection is not available", "..null property", "unexpected state"]), rng.randrange(10 ** 7), rng.randrange(10 ** 5))).encode())
+            n += 2
+            for sect in range(rng.randrange(1, 4)):
+                if sect:
+                    out.append(("Caused by: %s: %s" % (rng.choice(ex), rng.choice(["upstream closed the stream", "pool exhausted after 30000ms", "value was null"]))).encode())
+                    n += 1
+                for _ in range(rng.randrange(4, 28)):
+                    out.append(("\tat %s.%s.%s(%s.java:%d)" % (rng.choice(pk), rng.choice(cl), rng.choice(["invoke", "doDispatch", "run", "fireChannelRead", "handle", "lambda$process$3", "readValue"]), rng.choice(cl).split("$")[0], rng.randrange(20, 2000))).encode())
+                    n += 1
+                if rng.random() < 0.7:
+                    out.append(("\t... %d more" % rng.randrange(3, 60)).encode())
+                    n += 1
+        else:
+            out.append(("2024-03-10 10:%02d:%02d,%03d %s [http-nio-8080-exec-%d] %s.%s - %s order=%d customer=%d items=%d total=%d.%02d took %d ms" % (
+                rng.randrange(60), rng.randrange(60), rng.randrange(1000), rng.choice(["INFO", "INFO", "INFO", "DEBUG", "WARN"]), rng.randrange(40), rng.choice(pk), rng.choice(cl),
+                rng.choice(["accepted", "validated", "persisted", "shipped", "rejected"]), rng.randrange(10 ** 7), rng.randrange(10 ** 5), rng.randrange(1, 30), rng.randrange(10 ** 4), rng.randrange(100),
+                rng.randrange(1, 900))).encode())
+            n += 1
+    return b"\n".join(out[:nlines]) + b"\n"
