@@ -158,3 +158,45 @@ def test_truncation_rounds(g):
         assert trunc > 5
         assert got == want, first_diff(want, got)
         assert gn == n and st[2] == trunc
+
+
+def test_long_lines_long_groups_and_two_streams(g):
+    """lines and carried buffers larger than the emit pass' staging area (copied by the whole wave), groups that stay open across
+    reads, and two streams of one parser fed alternately (each carries its own state)"""
+    rules = [("start_state", r"/^START/", "c"), ("c", r"/^\s/", "c")]
+    rng = random.Random(21)
+
+    def text_of(seed):
+        r = random.Random(seed)
+        lines = []
+        for i in range(300):
+            k = r.random()
+            if k < 0.2:
+                lines.append(b"START %d " % i + bytes(r.choice(b"abcdefg ") for _ in range(r.choice([5, 40, 30000, 120000]))))
+            elif k < 0.9:
+                lines.append(b"  cont " + bytes(r.choice(b"xyz \t") for _ in range(r.choice([0, 3, 70, 25000]))))
+            else:
+                lines.append(b"other " + b"q" * r.choice([1, 20000]))
+        return b"\n".join(lines) + b"\n"
+
+    cfg = {"rules": rules, "buffer_limit_bytes": 0}          # no limit: groups of megabytes stay whole
+    ta, tb = text_of(1), text_of(2)
+    cuts_a = sorted(rng.randrange(len(ta)) for _ in range(6))
+    cuts_b = sorted(rng.randrange(len(tb)) for _ in range(6))
+    fa = [(100 + i, i, ta[a:b]) for i, (a, b) in enumerate(zip([0] + cuts_a, cuts_a + [len(ta)]))]
+    fb = [(500 + i, i, tb[a:b]) for i, (a, b) in enumerate(zip([0] + cuts_b, cuts_b + [len(tb)]))]
+    want_a = oracle_run(cfg, fa, final_flush=True, clock_of_the_call=True)
+    want_b = oracle_run(cfg, fb, final_flush=True, clock_of_the_call=True)
+    p = g.MultilineParser(rules=rules, buffer_limit=0)
+    sa, sb = p.stream(), p.stream()
+    got_a = got_b = b""
+    na = nb = 0
+    for (x, y) in zip(fa, fb):
+        o, r = sa.append(x[2], x[0], x[1]); got_a += o; na += r
+        o, r = sb.append(y[2], y[0], y[1]); got_b += o; nb += r
+    o, r = sa.flush(1900000000, 3); got_a += o; na += r
+    o, r = sb.flush(1900000000, 3); got_b += o; nb += r
+    sa.close(); sb.close(); p.close()
+    assert (got_a, na) == want_a[:2], first_diff(want_a[0], got_a)
+    assert (got_b, nb) == want_b[:2], first_diff(want_b[0], got_b)
+    assert max(len(x) for x in contents(got_a)) > 100000
