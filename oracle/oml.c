@@ -18,15 +18,25 @@
  * Pinned on the reference itself: tests/test_multiline_oracle.py runs the same frames through oracle/_ref/ref_filters kind 5 (the
  * reference's own src/multiline/*.c compiled in place) and wants identical bytes, and checks the vectors of tests/internal/multiline.c.
  *
- * Not restated (the product refuses the same configurations): a sub-parser (docker / cri built-ins, `parser` of a [MULTILINE_PARSER]),
- * key_group / key_pattern, several parsers in one context (flb_ml_append_text's LRU), flb_ml_append_object.
+ *   src/multiline/flb_ml.c:505-532 ml_append_try_parser_type_text, :403-503 process_append (TYPE_MAP), :366-401 get_key_id,
+ *   src/multiline/flb_ml_stream.c:91-133 flb_ml_stream_group_get, flb_ml_parser_cri.c / _docker.c   a sub-parser in front of an endswith /
+ *                                    equal parser: the line is parsed first, key_content / key_pattern / key_group come from its map, one
+ *                                    buffer per key_group value, the first line's map re-packed with the concatenation at the flush
+ * Not restated (the product refuses the same configurations): a sub-parser in front of a REGEX parser, several parsers in one context
+ * (flb_ml_append_text's LRU), flb_ml_append_object.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include "omp.h"
 
 typedef struct oflb_regex oflb_regex;
+typedef struct oflb_parser oflb_parser;
+oflb_parser *oflb_parser_create(const char *regex, int skip_empty, const char *time_fmt, const char *time_key, const char *time_offset, int time_keep,
+                                int time_strict, const char *types_str);
+void oflb_parser_destroy(oflb_parser *p);
+int oflb_parser_do(oflb_parser *parser, const char *buf, size_t length, char **out, size_t *out_size, int64_t *out_sec, int64_t *out_nsec);
 oflb_regex *oflb_regex_create(const char *pattern);
 void oflb_regex_destroy(oflb_regex *r);
 int oflb_regex_match(oflb_regex *r, const char *s, size_t len);
@@ -34,6 +44,7 @@ int oflb_regex_match(oflb_regex *r, const char *s, size_t len);
 enum { OML_REGEX = 0, OML_ENDSWITH = 1, OML_EQ = 2 };      /* flb_ml.h FLB_ML_REGEX / ENDSWITH / EQ */
 #define OML_MAX_RULES 64
 #define OML_MAX_STATES 16
+#define OML_MAX_GROUPS 6                   /* FLB_ML_MAX_GROUPS */
 
 struct oml_rule {
     char *from[OML_MAX_STATES];
@@ -49,11 +60,19 @@ typedef struct oml {
     size_t buffer_limit;
     struct oml_rule rules[OML_MAX_RULES];
     int nrules;
-    /* the stream group */
-    char *buf; size_t len, cap;
-    int rule_to_state;                                       /* -1: none */
-    int64_t t_sec, t_nsec, now_sec, now_nsec;                /* mp_time; "now" for a group that never saw a time */
-    int truncated;
+    /* the stream groups: [0] "_default", then one per key_group value in order of appearance (flb_ml_stream.c:91-133, at most 6) */
+    struct oml_group {
+        char *name; size_t name_len;
+        char *buf; size_t len, cap;                          /* flb_ml_stream_group.buf */
+        char *map; size_t map_len;                           /* mp_sbuf: the first line's map (sub-parser path) */
+        int64_t t_sec, t_nsec;                               /* mp_time */
+        int truncated;
+    } groups[OML_MAX_GROUPS], *g;                            /* g: the group at work */
+    int ngroups;
+    int rule_to_state;                                       /* -1: none (regex parsers use the default group only) */
+    int64_t now_sec, now_nsec;                               /* "now" for a group that never saw a time */
+    oflb_parser *sub;                                        /* the parser in front (cri: regex, docker: json) */
+    char *key_group, *key_pattern;
     /* in_tail's file buffer */
     char *pend; size_t pend_len;
     /* flushed records */
@@ -62,9 +81,9 @@ typedef struct oml {
 
 static void cat_raw(oml *m, const char *d, size_t n)        /* flb_sds_cat_safe */
 {
-    if (m->len + n + 1 > m->cap) { m->cap = (m->len + n + 1) * 2 + 64; m->buf = realloc(m->buf, m->cap); }
-    memcpy(m->buf + m->len, d, n);
-    m->len += n;
+    if (m->g->len + n + 1 > m->g->cap) { m->g->cap = (m->g->len + n + 1) * 2 + 64; m->g->buf = realloc(m->g->buf, m->g->cap); }
+    memcpy(m->g->buf + m->g->len, d, n);
+    m->g->len += n;
 }
 
 static void out_put(oml *m, const void *d, size_t n)
@@ -91,6 +110,8 @@ oml *oml_create(int type, const char *match_str, int negate, const char *key_con
     m->key_content = key_content && key_content[0] ? strdup(key_content) : NULL;
     m->buffer_limit = buffer_limit >= 0 ? (size_t) buffer_limit : 2 * 1024 * 1024;   /* flb_ml.c:896-902, FLB_ML_BUFFER_LIMIT_DEFAULT */
     m->rule_to_state = -1;
+    m->ngroups = 1; m->groups[0].name = strdup("_default"); m->groups[0].name_len = 8;
+    m->g = &m->groups[0];
     return m;
 }
 
@@ -103,7 +124,9 @@ void oml_destroy(oml *m)
         free(m->rules[i].to_state);
         oflb_regex_destroy(m->rules[i].rx);
     }
-    free(m->match_str); free(m->key_content); free(m->buf); free(m->pend); free(m->out); free(m);
+    for (i = 0; i < m->ngroups; i++) { free(m->groups[i].name); free(m->groups[i].buf); free(m->groups[i].map); }
+    if (m->sub) oflb_parser_destroy(m->sub);
+    free(m->match_str); free(m->key_content); free(m->key_group); free(m->key_pattern); free(m->pend); free(m->out); free(m);
 }
 
 void oml_set_now(oml *m, int64_t sec, int64_t nsec) { m->now_sec = sec; m->now_nsec = nsec; }
@@ -200,35 +223,89 @@ static int group_cat(oml *m, const char *d, size_t n)
     int status = 0;
     if (m->buffer_limit > 0) {
         size_t avail;
-        if (m->len >= m->buffer_limit) { m->truncated = 1; return 1; }
-        avail = m->buffer_limit - m->len;
-        if (n > avail) { n = avail; m->truncated = 1; status = 1; }
+        if (m->g->len >= m->buffer_limit) { m->g->truncated = 1; return 1; }
+        avail = m->buffer_limit - m->g->len;
+        if (n > avail) { n = avail; m->g->truncated = 1; status = 1; }
     }
     if (n) cat_raw(m, d, n);
     return status;
 }
 
 /* flb_ml.c:1590-1790, text mode (the group holds no first-line map) */
-static void flush_group(oml *m)
+/* the time a flush stamps (:1619-1624) and whether the encoder takes it (flb_log_event_encoder_set_timestamp:
+ * src/flb_log_event_encoder.c:345-363 -- a parsed time that is no time, e.g. tm2time of an all-zero struct tm, is refused) */
+static int flush_time_ok(const oml *m)
 {
-    if (!m->key_content && m->len > 0 && m->buf[m->len - 1] != '\n') cat_raw(m, "\n", 1);      /* breakline_prepare :179-195 */
-    if (m->len > 0) {
-        const char *key = m->key_content ? m->key_content : "log";
-        int64_t sec = m->t_sec, nsec = m->t_nsec;
-        if (sec == 0 && nsec == 0) { sec = m->now_sec; nsec = m->now_nsec; }                       /* :1619-1624 */
-        out_u8(m, 0x92); out_u8(m, 0x92); out_u8(m, 0xd7); out_u8(m, 0x00);                         /* [[ext 0 (sec, nsec), metadata], body] */
-        out_be(m, (uint64_t) sec, 4); out_be(m, (uint64_t) nsec, 4);
-        out_u8(m, 0xdf); out_be(m, m->truncated ? 1 : 0, 4);                                        /* the encoder's map32 */
-        if (m->truncated) { out_str_hdr(m, 19); out_put(m, "multiline_truncated", 19); out_u8(m, 0xc3); }   /* :1733-1738 */
-        out_u8(m, 0x81); out_str_hdr(m, strlen(key)); out_put(m, key, strlen(key));
-        out_str_hdr(m, m->len); out_put(m, m->buf, m->len);
-        m->records++;
-    }
-    m->len = 0;
-    m->truncated = 0;
+    int64_t sec = m->g->t_sec, nsec = m->g->t_nsec;
+    if (sec == 0 && nsec == 0) { sec = m->now_sec; nsec = m->now_nsec; }
+    return sec >= 0 && sec <= 0xFFFFFFFFll && nsec >= 0 && nsec < 1000000000ll;
 }
 
-static void register_time(oml *m, int64_t sec, int64_t nsec) { m->t_sec = sec; m->t_nsec = nsec; }     /* flb_ml_register_context, no map */
+static void out_record_head(oml *m)
+{
+    int64_t sec = m->g->t_sec, nsec = m->g->t_nsec;
+    if (sec == 0 && nsec == 0) { sec = m->now_sec; nsec = m->now_nsec; }                           /* :1619-1624 */
+    out_u8(m, 0x92); out_u8(m, 0x92); out_u8(m, 0xd7); out_u8(m, 0x00);                             /* [[ext 0 (sec, nsec), metadata], body] */
+    out_be(m, (uint64_t) sec, 4); out_be(m, (uint64_t) nsec, 4);
+    out_u8(m, 0xdf); out_be(m, m->g->truncated ? 1 : 0, 4);                                        /* the encoder's map32 */
+    if (m->g->truncated) { out_str_hdr(m, 19); out_put(m, "multiline_truncated", 19); out_u8(m, 0xc3); }   /* :1733-1738 */
+}
+
+/* flb_ml.c:1590-1790 on the group at work */
+static void flush_group(oml *m)
+{
+    if (!m->key_content && m->g->len > 0 && m->g->buf[m->g->len - 1] != '\n') cat_raw(m, "\n", 1);      /* breakline_prepare :179-195 */
+    if (m->g->map_len > 0) {
+        /* :1626-1690 the first line's map, the value of key_content replaced by the buffer (an empty buffer: the map as it is) */
+        omp_arena ar;
+        omp_obj map;
+        size_t off = 0;
+        omp_buf body;
+        omp_arena_init(&ar);
+        omp_buf_init(&body);
+        if (omp_unpack_next(&ar, &map, m->g->map, m->g->map_len, &off) == OMP_UNPACK_SUCCESS && map.type == OMP_MAP) {
+            if (m->g->len > 0) {
+                const size_t klen = m->key_content ? strlen(m->key_content) : 0;
+                uint32_t i;
+                omp_pack_map(&body, map.via.map.size);
+                for (i = 0; i < map.via.map.size; i++) {
+                    const omp_obj *k = &map.via.map.ptr[i].key, *v = &map.via.map.ptr[i].val;
+                    omp_pack_object(&body, k);
+                    if (k->type == OMP_STR && m->key_content && k->via.str.size == klen && !strncmp(k->via.str.ptr, m->key_content, klen))
+                        omp_pack_str_with_body(&body, m->g->buf, m->g->len);
+                    else omp_pack_object(&body, v);
+                }
+            }
+            else omp_pack_object(&body, &map);
+            if (!flush_time_ok(m)) {
+                /* "[multiline] error packing event": the function returns before it empties the buffer (:1744-1752) -- the first-line
+                 * map is gone (:1687), the bytes stay and the next line of the group becomes its first line */
+                omp_buf_free(&body);
+                omp_arena_free(&ar);
+                m->g->map_len = 0;
+                return;
+            }
+            out_record_head(m);
+            out_put(m, body.data, body.size);
+            m->records++;
+        }
+        omp_buf_free(&body);
+        omp_arena_free(&ar);
+        m->g->map_len = 0;
+    }
+    else if (m->g->len > 0) {
+        const char *key = m->key_content ? m->key_content : "log";
+        if (!flush_time_ok(m)) return;
+        out_record_head(m);
+        out_u8(m, 0x81); out_str_hdr(m, strlen(key)); out_put(m, key, strlen(key));
+        out_str_hdr(m, m->g->len); out_put(m, m->g->buf, m->g->len);
+        m->records++;
+    }
+    m->g->len = 0;
+    m->g->truncated = 0;
+}
+
+static void register_time(oml *m, int64_t sec, int64_t nsec) { m->g->t_sec = sec; m->g->t_nsec = nsec; }     /* flb_ml_register_context, no map */
 
 /* flb_ml_rule.c:329-436: 0 processed, 1 truncated, -1 no rule takes the line */
 static int rule_process(oml *m, const char *d, size_t n, int64_t sec, int64_t nsec)
@@ -240,7 +317,7 @@ static int rule_process(oml *m, const char *d, size_t n, int64_t sec, int64_t ns
             const struct oml_rule *c = &m->rules[cur->map[i]];
             if (c->start_state) continue;
             if (oflb_regex_match(c->rx, d, n)) {
-                if (m->len >= 1 && m->buf[m->len - 1] != '\n') cat_raw(m, "\n", 1);
+                if (m->g->len >= 1 && m->g->buf[m->g->len - 1] != '\n') cat_raw(m, "\n", 1);
                 if (n == 0) cat_raw(m, "\n", 1);
                 else if (group_cat(m, d, n) == 1) {
                     flush_group(m);                          /* "Buffer is full. Flush immediately to send the truncated record." */
@@ -256,7 +333,7 @@ static int rule_process(oml *m, const char *d, size_t n, int64_t sec, int64_t ns
         for (i = 0; i < m->nrules; i++)                       /* try_start_state */
             if (m->rules[i].start_state && oflb_regex_match(m->rules[i].rx, d, n)) { rule = i; break; }
         if (rule >= 0) {
-            if (m->len > 0) flush_group(m);
+            if (m->g->len > 0) flush_group(m);
             m->rule_to_state = rule;
             if (group_cat(m, d, n) == 1) return 1;
             register_time(m, sec, nsec);
@@ -267,7 +344,7 @@ static int rule_process(oml *m, const char *d, size_t n, int64_t sec, int64_t ns
         int next_start = 0;
         m->rule_to_state = rule;
         for (i = 0; i < r->nmap; i++) if (m->rules[r->map[i]].start_state) { next_start = 1; break; }      /* try_flushing_buffer */
-        if (next_start && m->len > 0) flush_group(m);
+        if (next_start && m->g->len > 0) flush_group(m);
         return 0;
     }
     return -1;
@@ -275,11 +352,100 @@ static int rule_process(oml *m, const char *d, size_t n, int64_t sec, int64_t ns
 
 static int match_negate(const oml *m, int matched) { return m->negate ? !matched : matched; }
 
+/* flb_ml.c:366-401 get_key_id: the first entry whose key is the string `name` and whose value is a string */
+static const omp_obj *map_str_value(const omp_obj *map, const char *name)
+{
+    uint32_t i;
+    const size_t len = name ? strlen(name) : 0;
+    if (!name) return NULL;
+    for (i = 0; i < map->via.map.size; i++) {
+        const omp_obj *k = &map->via.map.ptr[i].key, *v = &map->via.map.ptr[i].val;
+        if (k->type != OMP_STR || v->type != OMP_STR) continue;
+        if (k->via.str.size != len) continue;
+        if (!strncmp(k->via.str.ptr, name, len)) return v;
+    }
+    return NULL;
+}
+
+/* the parser in front of an ENDSWITH / EQ parser: the cri regex, docker's json (flb_ml_parser_cri.c, _docker.c: time_keep on) */
+int oml_set_subparser(oml *m, const char *regex, const char *time_fmt, const char *time_key, int skip_empty, const char *key_group, const char *key_pattern)
+{
+    if (m->type == OML_REGEX) return -1;
+    m->sub = oflb_parser_create(regex && regex[0] ? regex : NULL, skip_empty, time_fmt, time_key, NULL, 1, 0, NULL);
+    if (!m->sub) return -1;
+    m->key_group = key_group && key_group[0] ? strdup(key_group) : NULL;
+    m->key_pattern = key_pattern && key_pattern[0] ? strdup(key_pattern) : NULL;
+    return 0;
+}
+
+/* ml_append_try_parser_type_text + process_append (TYPE_MAP) + package_content for ENDSWITH / EQ: 0 processed, -1 nobody takes the line */
+static int process_with_subparser(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
+{
+    char *pm = NULL;
+    size_t pn = 0, off = 0;
+    int64_t psec = 0, pnsec = 0;
+    omp_arena ar;
+    omp_obj map;
+    const omp_obj *vc, *vp, *vg, *val;
+    int ret = -1, rule_match, i;
+    if (oflb_parser_do(m->sub, d, n, &pm, &pn, &psec, &pnsec) < 0) return -1;                    /* :518-531 */
+    if (psec == 0 && pnsec == 0) { psec = sec; pnsec = nsec; }                                      /* :521-523, :642-649 */
+    omp_arena_init(&ar);
+    if (omp_unpack_next(&ar, &map, pm, pn, &off) != OMP_UNPACK_SUCCESS || map.type != OMP_MAP) goto done;
+    vc = map_str_value(&map, m->key_content);                                                      /* :455-466 */
+    if (!vc) goto done;
+    vp = map_str_value(&map, m->key_pattern);
+    vg = map_str_value(&map, m->key_group);
+    /* flb_ml_stream_group_get (flb_ml_stream.c:91-133) */
+    m->g = &m->groups[0];
+    if (m->key_group && vg) {
+        for (i = 0; i < m->ngroups; i++)
+            if (m->groups[i].name_len == vg->via.str.size && !memcmp(m->groups[i].name, vg->via.str.ptr, vg->via.str.size)) break;
+        if (i == m->ngroups) {
+            if (m->ngroups >= OML_MAX_GROUPS) { m->g = &m->groups[0]; goto done; }                   /* (the reference walks into a NULL group here) */
+            m->groups[i].name = malloc(vg->via.str.size + 1);
+            memcpy(m->groups[i].name, vg->via.str.ptr, vg->via.str.size);
+            m->groups[i].name_len = vg->via.str.size;
+            m->ngroups++;
+        }
+        m->g = &m->groups[i];
+    }
+    val = vp ? vp : vc;
+    if (m->type == OML_ENDSWITH) {
+        const size_t len = m->match_str ? strlen(m->match_str) : 0;
+        if (len > val->via.str.size) goto done;                                                    /* processed stays FLB_FALSE: -1 on this path (:498-500) */
+        rule_match = match_negate(m, memcmp(val->via.str.ptr + (val->via.str.size - len), m->match_str, len) == 0);
+    }
+    else {
+        const size_t len = m->match_str ? strlen(m->match_str) : 0;
+        rule_match = match_negate(m, val->via.str.size == len && memcmp(val->via.str.ptr, m->match_str, len) == 0);
+    }
+    if (m->g->map_len == 0) {                                                                      /* flb_ml_register_context: the time and the map of the first line */
+        omp_buf fb;
+        omp_buf_init(&fb);
+        omp_pack_object(&fb, &map);
+        free(m->g->map);
+        m->g->map = fb.data; m->g->map_len = fb.size;
+        m->g->t_sec = psec; m->g->t_nsec = pnsec;
+    }
+    if (!m->key_content && m->g->len > 0 && m->g->buf[m->g->len - 1] != '\n') cat_raw(m, "\n", 1);      /* breakline_prepare */
+    cat_raw(m, vc->via.str.ptr, vc->via.str.size);
+    if (rule_match) flush_group(m);
+    ret = 0;
+done:
+    omp_arena_free(&ar);
+    free(pm);
+    m->g = &m->groups[0];
+    return ret;
+}
+
 /* flb_ml_append_text with one parser instance; returns 1 when the line truncated a buffer */
 int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
 {
-    int ret = -1, truncated = 0;
-    if (m->type == OML_REGEX) {
+    int ret = -1, truncated = 0, i;
+    m->g = &m->groups[0];
+    if (m->sub) ret = process_with_subparser(m, sec, nsec, d, n);
+    else if (m->type == OML_REGEX) {
         ret = rule_process(m, d, n, sec, nsec);
         if (ret == 1) truncated = 1;
         if (ret == 0) register_time(m, sec, nsec);           /* package_content :263-265 (the text path's first-line map is always empty) */
@@ -290,7 +456,7 @@ int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
         if (len <= n) {
             const int rule_match = match_negate(m, memcmp(d + (n - len), m->match_str, len) == 0);
             register_time(m, sec, nsec);
-            if (!m->key_content && m->len > 0 && m->buf[m->len - 1] != '\n') cat_raw(m, "\n", 1);
+            if (!m->key_content && m->g->len > 0 && m->g->buf[m->g->len - 1] != '\n') cat_raw(m, "\n", 1);
             cat_raw(m, d, n);
             if (rule_match) flush_group(m);
         }
@@ -300,13 +466,15 @@ int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
         const int rule_match = match_negate(m, n == len && memcmp(d, m->match_str, n) == 0);
         ret = 0;
         register_time(m, sec, nsec);
-        if (!m->key_content && m->len > 0 && m->buf[m->len - 1] != '\n') cat_raw(m, "\n", 1);
+        if (!m->key_content && m->g->len > 0 && m->g->buf[m->g->len - 1] != '\n') cat_raw(m, "\n", 1);
         cat_raw(m, d, n);
         if (rule_match) flush_group(m);
     }
     if (ret < 0) {
-        /* flb_ml.c:729-757: "A non-matching line breaks any multiline sequence", then the line alone */
-        flush_group(m);
+        /* flb_ml.c:729-757: "A non-matching line breaks any multiline sequence" (every group of the stream, in the order they were
+         * created), then the line alone through the default group */
+        for (i = 0; i < m->ngroups; i++) { m->g = &m->groups[i]; flush_group(m); }
+        m->g = &m->groups[0];
         register_time(m, sec, nsec);
         if (group_cat(m, d, n) == 1) truncated = 1;
         flush_group(m);
@@ -315,7 +483,12 @@ int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
     return truncated;
 }
 
-void oml_flush_pending(oml *m) { flush_group(m); }           /* flb_ml_flush_pending(_now): the timer's forced flush */
+void oml_flush_pending(oml *m)                               /* flb_ml_flush_pending(_now): the timer's forced flush, every group */
+{
+    int i;
+    for (i = 0; i < m->ngroups; i++) { m->g = &m->groups[i]; flush_group(m); }
+    m->g = &m->groups[0];
+}
 
 /* plugins/in_tail/tail_file.c process_content: what one read appends to the file's buffer */
 void oml_tail_chunk(oml *m, const char *text, size_t bytes, int skip_empty, int64_t sec, int64_t nsec)
@@ -351,4 +524,9 @@ size_t oml_output(oml *m, const char **out, int *records, int *truncations)
 }
 
 /* what the stream carries between calls: rule_to_state (-1 none), buffered bytes, unconsumed tail of the file buffer */
-void oml_state(const oml *m, int *rule_to_state, size_t *buffered, size_t *pending) { *rule_to_state = m->rule_to_state; *buffered = m->len; *pending = m->pend_len; }
+void oml_state(const oml *m, int *rule_to_state, size_t *buffered, size_t *pending)
+{
+    int i;
+    *rule_to_state = m->rule_to_state; *buffered = 0; *pending = m->pend_len;
+    for (i = 0; i < m->ngroups; i++) *buffered += m->groups[i].len;
+}

@@ -132,3 +132,52 @@ def java_service_log(rng, nlines):
                 rng.randrange(1, 900))).encode())
             n += 1
     return b"\n".join(out[:nlines]) + b"\n"
+
+
+def cri_text(rng, nlines, damage=0.08):
+    """containerd's log format (time stream P|F log) with partial lines on two streams interleaved, and lines the cri parser refuses"""
+    out = []
+    for i in range(nlines):
+        r = rng.random()
+        if r < damage:
+            out.append(rng.choice([b"not a cri line", b"", b"2021-05-17T17:35:01Z stdout X bad flag", b"2021-05-17T17:35:01Z stdin F other stream",
+                                   b"2021-05-17T17:35:01.1Z stdout F", b" stdout F leading blank", b"\xff\xfe stdout F x"]))
+            continue
+        t = "2021-05-17T17:%02d:%02d.%09dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(10 ** 9)) if rng.random() < 0.9 else rng.choice(["garbage-time", "2021-05-17T17:35:01+02:00", "1"])
+        stream = rng.choice(["stdout", "stdout", "stderr"])
+        flag = "F" if rng.random() < 0.6 else "P"
+        log = rng.choice([b"", b"x", b"[DEBUG] start multiline - ", b"part of a long line that was split by the runtime at 16 KB ", b'{"json":"inside"}', b"caf\xc3\xa9 \t tab", b"ends with space "])
+        if rng.random() < 0.02:
+            log = bytes(rng.choice(b"abc ") for _ in range(rng.randrange(1000, 20000)))
+        out.append(("%s %s %s " % (t, stream, flag)).encode() + log)
+    return b"".join(l + (b"\r\n" if rng.random() < 0.03 else b"\n") for l in out)
+
+
+def docker_text(rng, nlines, damage=0.08):
+    """docker's json-file lines ({"log": "...", "stream": "...", "time": "..."}; a message is complete when log ends with a newline)"""
+    import json
+    out = []
+    for i in range(nlines):
+        r = rng.random()
+        if r < damage:
+            out.append(rng.choice([b"plain text", b"", b'{"log": 5, "stream": "stdout"}', b'{"stream":"stdout","time":"2021-02-01T01:40:03.5Z"}', b'["log","x"]', b'{"log":"unterminated',
+                                   b'{"log":"a\\n","stream":7,"time":"2021-02-01T01:40:03.5Z"}', b'{"log":"a\\n","extra":{"k":[1,2.5,null]},"stream":"stdout"}']))
+            continue
+        log = rng.choice(["one, ", "two, ", "three\n", "\n", "", "caf\u00e9\n", "tab\there\n", "x" * rng.randrange(1, 300) + ("\n" if rng.random() < 0.5 else "")])
+        d = {"log": log, "stream": rng.choice(["stdout", "stdout", "stderr"]), "time": "2021-02-01T01:%02d:%02d.%06dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(10 ** 6))}
+        if rng.random() < 0.1:
+            d = dict(reversed(list(d.items())))
+        if rng.random() < 0.05:
+            d["attrs"] = {"tag": "t%d" % i}
+        out.append(json.dumps(d).encode())
+    return b"\n".join(out) + b"\n"
+
+
+def random_sub_case(rng, nlines=None):
+    """the built-in parsers with a parser in front: (cfg, frames, kwargs) like random_case"""
+    b = rng.choice(["cri", "docker"])
+    n = nlines if nlines is not None else rng.randrange(0, 80)
+    text = cri_text(rng, n) if b == "cri" else docker_text(rng, n)
+    if rng.random() < 0.2 and text:
+        text = text[:-1]
+    return {"builtin": b}, frames_of(rng, text), dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)

@@ -203,8 +203,23 @@ class Multiline:
     """oracle/oml.c: the multiline core behind in_tail's line loop (one parser, text lines)"""
     TYPES = {"regex": 0, "endswith": 1, "equal": 2, "eq": 2}
 
-    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1):
+    # the built-in parsers with a parser in front (src/multiline/flb_ml_parser_cri.c:24-75, flb_ml_parser_docker.c:25-105)
+    SUB_BUILTINS = {
+        "cri": dict(type="equal", match_string="F", key_content="log", key_group="stream", key_pattern="_p",
+                    subparser=dict(regex=r"^(?<time>.+?) (?<stream>stdout|stderr) (?<_p>F|P) (?<log>.*)$", time_fmt="%Y-%m-%dT%H:%M:%S.%L%z", time_key="time", skip_empty=False)),
+        "docker": dict(type="endswith", match_string="\n", key_content="log", key_group="stream", key_pattern=None,
+                       subparser=dict(regex=None, time_fmt="%Y-%m-%dT%H:%M:%S.%L", time_key="time", skip_empty=True)),
+    }
+
+    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1,
+                 subparser=None, key_group=None, key_pattern=None):
+        if builtin in self.SUB_BUILTINS:
+            b = self.SUB_BUILTINS[builtin]
+            type, match_string, subparser, key_group, key_pattern = b["type"], b["match_string"], b["subparser"], b["key_group"], b["key_pattern"]
+            key_content = key_content or b["key_content"]
+            builtin = None
         L = lib()
+        L.oml_set_subparser.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p, c_int, c_char_p, c_char_p]
         L.oml_create.restype = c_void_p
         L.oml_create.argtypes = [c_int, c_char_p, c_int, c_char_p, c_int64]
         L.oml_destroy.argtypes = [c_void_p]
@@ -228,6 +243,10 @@ class Multiline:
                     raise ValueError("multiline: rule %r" % ((fs, rx, to),))
             if L.oml_init(self.h) != 0:
                 raise ValueError("multiline: to_state not registered")
+        if subparser is not None:
+            if L.oml_set_subparser(self.h, enc(subparser.get("regex")), enc(subparser.get("time_fmt")), enc(subparser.get("time_key")),
+                                   1 if subparser.get("skip_empty") else 0, enc(key_group), enc(key_pattern)) != 0:
+                raise ValueError("multiline: sub-parser")
 
     def __del__(self):
         if getattr(self, "h", None):

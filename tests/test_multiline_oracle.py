@@ -101,3 +101,20 @@ def test_random_cases_against_the_reference(seed):
     for (ret, out), (want, n, _), d in zip(rf.run(cases), wants, descr):
         assert out == want, d
         assert ret == n, d
+
+
+@pytest.mark.skipif(not rf.available(), reason="oracle/_ref/ref_filters not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(4))
+def test_cri_and_docker_against_the_reference(seed):
+    """the built-in parsers with a parser in front (cri: regex, docker: json): key_content / key_pattern / key_group from the parsed
+    map, one buffer per stream, the first line's map re-packed at the flush, refused lines flushing every group"""
+    rng = random.Random(8800 + seed)
+    cases, wants, descr = [], [], []
+    for _ in range(100):
+        cfg, frames, kw = ml_synth.random_sub_case(rng)
+        cases.append(ref_case(cfg, frames, **kw))
+        wants.append(oracle_run(cfg, frames, **kw))
+        descr.append((cfg, frames, kw))
+    for (ret, out), (want, n, _), d in zip(rf.run(cases), wants, descr):
+        assert out == want, d
+        assert ret == n, d
