@@ -333,8 +333,11 @@ class MultilineParser:
     """a multiline parser definition (src/multiline/flb_ml_parser.c flb_ml_parser_create + flb_ml_rule.c flb_ml_rule_create / _init) with the
     instance's key_content and the context's buffer limit; rules: [(from_states, regex, to_state)] or builtin = java | go | python | ruby"""
 
-    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1):
+    def __init__(self, rules=None, builtin=None, type="regex", match_string=None, negate=False, key_content=None, buffer_limit=-1,
+                 subparser=None, key_group=None, key_pattern=None):
         L = lib()
+        L.flbgpu_ml_parser_set_subparser.argtypes = [c_void_p, c_void_p, c_char_p, c_char_p]
+        self.subparser = subparser                              # (kept alive: the library borrows it)
         L.flbgpu_ml_parser_create.restype = c_void_p
         L.flbgpu_ml_parser_create.argtypes = [c_char_p, c_char_p, c_int, c_char_p, ctypes.c_int64]
         L.flbgpu_ml_parser_add_rule.argtypes = [c_void_p, c_char_p, c_char_p, c_char_p]
@@ -351,6 +354,8 @@ class MultilineParser:
         else:
             for fs, rx, to in (rules or []):
                 ok = ok and L.flbgpu_ml_parser_add_rule(self.h, e(fs), e(rx), e(to)) == 0
+            if subparser is not None:
+                ok = ok and L.flbgpu_ml_parser_set_subparser(self.h, subparser.h, e(key_group), e(key_pattern)) == 0
             ok = ok and L.flbgpu_ml_parser_init(self.h) == 0
         if not ok:
             err = last_error()

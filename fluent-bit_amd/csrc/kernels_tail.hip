@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
+#include "mlo.hpp"
 
 namespace flbgpu {
 
@@ -12,5 +13,6 @@ namespace flbgpu {
 
 #include "tail_kernels.inc"
 #include "ml_kernels.inc"
+#include "mlo_kernels.inc"
 
 }  // namespace flbgpu

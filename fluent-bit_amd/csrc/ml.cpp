@@ -6,6 +6,7 @@
 // state (rule_to_state, the open group's bytes and time), buffers.  No CPU path: every line is matched and packed on the device.
 #include <map>
 #include "host_int.hpp"
+#include "mlo.hpp"
 
 using namespace flbgpu;
 
@@ -23,6 +24,10 @@ struct flbgpu_ml_parser {
     std::vector<int> look_of;                // [rule] index of its A part in rules / progs, -1: none
     std::vector<uint8_t> look_neg;
     std::vector<MlPending> pending;           // A parts waiting for init
+    // a parser in front (cri, docker, flbgpu_ml_parser_set_subparser): lines are parsed first, the groups live per key_group value
+    flbgpu_parser *sub = nullptr;
+    bool sub_owned = false;
+    std::string key_content, key_group, key_pattern;
     std::vector<TableBlob *> blobs;
     DevBuf d_rules, d_prod;
     uint32_t prod_bytes = 0, prod_nj = 0, prod_nS = 0, prod_T = 0, prod_init = 0;
@@ -31,6 +36,7 @@ struct flbgpu_ml_parser {
     ~flbgpu_ml_parser() {
         for (TableBlob *b : blobs) delete b;
         d_rules.release(); d_prod.release();
+        if (sub && sub_owned) flbgpu_parser_destroy(sub);
     }
 };
 
@@ -43,12 +49,26 @@ struct flbgpu_ml_stream {
     uint32_t carry_len = 0, carry_tail = MLT_EMPTY, carry_sec = 0, carry_nsec = 0;       // mp_time of the group
     uint32_t carry_trunc = 0;                 // the open group was cut by the buffer limit (flb_ml_stream_group.truncated)
     uint64_t truncations = 0;                 // lines that truncated a buffer (FLB_MULTILINE_TRUNCATED returns)
+    // a parser in front: in_tail's packing + filter_parser(sub) give the rows; one carried buffer + first-line map per group
+    flbgpu_tail *tail[2] = {nullptr, nullptr};             // [skip_empty_lines]
+    flbgpu_filter *subf = nullptr;
+    std::vector<std::string> gnames;          // [0] the default group
+    DevBuf gc_content[MLO_G][2], gc_map[MLO_G][2];
+    int gc_cur[MLO_G] = {0, 0, 0, 0};
+    uint32_t gc_content_len[MLO_G] = {0, 0, 0, 0}, gc_map_len[MLO_G] = {0, 0, 0, 0}, gc_sec[MLO_G] = {0, 0, 0, 0}, gc_nsec[MLO_G] = {0, 0, 0, 0};
+    DevBuf o_rows, o_st, o_nrec, o_base, o_recs, o_size, o_off, o_idx, o_tmp, o_misc;
     DevBuf d_masks, d_tcnt, d_toff, d_scan_tmp, d_nl, d_keep, d_koff, d_ls, d_ll, d_info, d_F, d_sin, d_act, d_c, d_coff, d_head, d_gidx,
            d_ghead, d_plen, d_po, d_pk, d_gC, d_ovr, d_slow, d_fs_tmp, d_rows, d_out, d_misc, d_in;
     ~flbgpu_ml_stream() {
         DevBuf *all[] = {&carry[0], &carry[1], &d_masks, &d_tcnt, &d_toff, &d_scan_tmp, &d_nl, &d_keep, &d_koff, &d_ls, &d_ll, &d_info, &d_F, &d_sin,
                          &d_act, &d_c, &d_coff, &d_head, &d_gidx, &d_ghead, &d_plen, &d_po, &d_pk, &d_gC, &d_ovr, &d_slow, &d_fs_tmp, &d_rows, &d_out, &d_misc, &d_in};
         for (DevBuf *b : all) b->release();
+        for (int g = 0; g < MLO_G; g++) for (int k = 0; k < 2; k++) { gc_content[g][k].release(); gc_map[g][k].release(); }
+        DevBuf *oall[] = {&o_rows, &o_st, &o_nrec, &o_base, &o_recs, &o_size, &o_off, &o_idx, &o_tmp, &o_misc};
+        for (DevBuf *b : oall) b->release();
+        if (tail[0]) flbgpu_tail_destroy(tail[0]);
+        if (tail[1]) flbgpu_tail_destroy(tail[1]);
+        if (subf) flbgpu_filter_destroy(subf);
         if (stream) (void) hipStreamDestroy(stream);
     }
 };
@@ -83,6 +103,7 @@ extern "C" flbgpu_ml_parser *flbgpu_ml_parser_create(const char *type, const cha
     memcpy(p->dev.key + o, key, kn);
     p->dev.key_len = o + (uint32_t) kn;
     p->dev.has_key_content = key_content && key_content[0] ? 1 : 0;
+    p->key_content = key_content && key_content[0] ? key_content : "";
     p->dev.buffer_limit = buffer_limit < 0 ? 2ull * 1024 * 1024 : (uint64_t) buffer_limit;
     return p;
 }
@@ -208,6 +229,23 @@ extern "C" int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name) {
         {"start_state, ruby_start_exception", "/^.+:\\d+:in\\s+.*/", "ruby_after_exception"},
         {"ruby_after_exception, ruby", "/^\\s+from\\s+.*:\\d+:in\\s+.*/", "ruby"}, {nullptr, nullptr, nullptr}};
     if (!p || !name) { set_err("multiline: missing argument"); return -1; }
+    if (!strcasecmp(name, "cri") || !strcasecmp(name, "docker")) {
+        // src/multiline/flb_ml_parser_cri.c:24-75: EQ "F" on _p, content log, groups by stream, the regex parser in front;
+        // flb_ml_parser_docker.c:25-105: ENDSWITH "\n" on log, groups by stream, docker's json parser in front (both: Time_Keep on)
+        const bool cri = !strcasecmp(name, "cri");
+        flbgpu_parser *sub = cri ? flbgpu_parser_create("_ml_cri", "^(?<time>.+?) (?<stream>stdout|stderr) (?<_p>F|P) (?<log>.*)$", 0, "%Y-%m-%dT%H:%M:%S.%L%z", "time", nullptr, 1, 0, nullptr)
+                                 : flbgpu_parser_create_json("_ml_json_docker", "%Y-%m-%dT%H:%M:%S.%L", "time", nullptr, 1, 0);
+        if (!sub) return -1;
+        p->dev.type = cri ? ML_EQ : ML_ENDSWITH; p->dev.negate = 0;
+        p->dev.match_len = 1; p->dev.match_str[0] = cri ? 'F' : '\n';
+        if (p->key_content.empty()) {
+            p->key_content = "log";
+            p->dev.key[0] = 0xa3; memcpy(p->dev.key + 1, "log", 3); p->dev.key_len = 4; p->dev.has_key_content = 1;
+        }
+        p->sub = sub; p->sub_owned = true;
+        p->key_group = "stream"; p->key_pattern = cri ? "_p" : "";
+        return flbgpu_ml_parser_init(p);
+    }
     const R *t = !strcasecmp(name, "java") ? java : !strcasecmp(name, "go") ? go : !strcasecmp(name, "python") ? python : !strcasecmp(name, "ruby") ? ruby : nullptr;
     if (!t) { set_err("multiline: built-in parser '%s' needs a sub-parser (docker, cri) or does not exist: not on the GPU path", name); return -1; }
     for (int i = 0; t[i].from; i++) if (flbgpu_ml_parser_add_rule(p, t[i].from, t[i].rx, t[i].to) != 0) return -1;
@@ -308,6 +346,18 @@ static bool build_product(flbgpu_ml_parser *p, std::vector<uint8_t> &blob) {
     return true;
 }
 
+// a [MULTILINE_PARSER] with `parser`, key_group, key_pattern (src/multiline/flb_ml_parser.c:46-140; flb_ml_parsers_init resolves the name):
+// ENDSWITH / EQ types only -- a parser in front of a regex state machine is not on the GPU path.  `sub` stays the caller's.
+extern "C" int flbgpu_ml_parser_set_subparser(flbgpu_ml_parser *p, flbgpu_parser *sub, const char *key_group, const char *key_pattern) {
+    if (!p || !sub) { set_err("multiline: missing argument"); return -1; }
+    if (p->inited) { set_err("multiline: the parser is already initialised"); return -1; }
+    if (p->dev.type == ML_REGEX) { set_err("multiline: a parser in front of a regex parser is not on the GPU path"); return -1; }
+    if (p->key_content.empty()) { set_err("multiline: a parser in front needs key_content"); return -1; }
+    p->sub = sub; p->sub_owned = false;
+    p->key_group = key_group ? key_group : ""; p->key_pattern = key_pattern ? key_pattern : "";
+    return 0;
+}
+
 // flb_ml_rule_init (flb_ml_rule.c:279-299): every rule's to_state_map, here as masks over the rules
 extern "C" int flbgpu_ml_parser_init(flbgpu_ml_parser *p) {
     if (!p) { set_err("multiline: no parser"); return -1; }
@@ -355,14 +405,138 @@ extern "C" flbgpu_ml_stream *flbgpu_ml_stream_create(flbgpu_ml_parser *p) {
     auto *s = new flbgpu_ml_stream();
     s->p = p;
     if (hipStreamCreate(&s->stream) != hipSuccess) { set_err("hipStreamCreate failed"); delete s; return nullptr; }
+    if (p->sub) {
+        // the rows: in_tail's packing of the lines (key "log"), then filter_parser(Key_Name log, the parser in front) on them
+        flbgpu_parser *arr[1] = {p->sub};
+        s->tail[0] = flbgpu_tail_create("log", nullptr, nullptr, nullptr, 0);
+        s->tail[1] = flbgpu_tail_create("log", nullptr, nullptr, nullptr, 1);
+        s->subf = flbgpu_filter_parser_create("log", 0, 0, 1, arr);
+        if (!s->tail[0] || !s->tail[1] || !s->subf) { delete s; return nullptr; }
+        s->gnames.push_back("_default");
+    }
     return s;
 }
 extern "C" void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s) { delete s; }
 
+// ---- a parser in front (mlo_kernels.inc)
+static void put_name(uint8_t *dst, uint32_t *len, const std::string &v, size_t cap) { *len = (uint32_t) (v.size() < cap ? v.size() : cap); memcpy(dst, v.data(), *len); }
+
+static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                          flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records) {
+    auto fail = [](const char *w) -> int { set_err("multiline: %s", w); return -1; };
+    flbgpu_ml_parser *p = s->p;
+    hipStream_t st = s->stream;
+    if (p->key_content.size() > 63 || p->key_group.size() > 63 || p->key_pattern.size() > 63 || p->dev.match_len > 64) return fail("key names / match string too long for the GPU path");
+    flbgpu_dev_chunk T, P;
+    memset(&T, 0, sizeof(T)); memset(&P, 0, sizeof(P));
+    uint64_t lines = 0;
+    // (the line packing and the parser in front run on their own streams: what this stream still copies into d_text must have landed)
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("upload failed");
+    if (bytes && flbgpu_tail_run_dev(s->tail[skip_empty_lines ? 1 : 0], d_text, bytes, 0, ts_sec, ts_nsec, &T, processed, &lines) != 0) return -1;
+    const uint64_t n = T.n;
+    bool pending = false;
+    for (int g = 0; g < MLO_G; g++) pending = pending || s->gc_map_len[g] > 0;
+    if (n == 0 && !(flush && pending)) return 0;
+    const uint32_t *pinfo = nullptr;
+    if (n) {
+        const int r = flbgpu_filter_run_dev(s->subf, &T, &P, nullptr);
+        pinfo = s->subf->d_info.as<uint32_t>();
+        if (r != FLBGPU_FILTER_MODIFIED) { P = T; pinfo = nullptr; }     // nothing was emitted: every row is a skipped line -- or a dropped record (refused)
+        if (P.n != n) return fail("the parser in front changed the number of rows");
+    }
+    const uint64_t N1 = n + 1;
+    static const uint64_t zero_row[2] = {0, 0};
+    (void) zero_row;
+    if (!s->o_rows.ensure(N1 * sizeof(MloRow)) || !s->o_st.ensure(N1 * sizeof(MloState)) || !s->o_nrec.ensure(N1 * 4) || !s->o_base.ensure((N1 + 1) * 8) ||
+        !s->o_idx.ensure((size_t) MLO_G * (n ? n : 1) * 4) || !s->o_tmp.ensure(mlo_vscan_tmp_bytes(N1)) || !s->o_misc.ensure(32 * 4) ||
+        !s->d_scan_tmp.ensure(scan_tmp_elems(N1 * (MLO_G + 1)) * sizeof(uint64_t))) return -1;
+    unsigned int hmisc[32];
+    memset(hmisc, 0, sizeof(hmisc));
+    hmisc[0] = 0xFFFFFFFFu;
+    if (hipMemcpyAsync(s->o_misc.p, hmisc, sizeof(hmisc), hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload failed");
+    MloArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tdata = (const uint8_t *) T.data; a.trow = T.row_off; a.pdata = (const uint8_t *) P.data; a.prow = P.row_off; a.pinfo = pinfo;
+    a.n = n; a.flush_all = flush ? 1 : 0;
+    a.type = p->dev.type; a.negate = p->dev.negate; a.match_len = p->dev.match_len; memcpy(a.match_str, p->dev.match_str, a.match_len);
+    put_name(a.kc, &a.kc_len, p->key_content, 64); put_name(a.kp, &a.kp_len, p->key_pattern, 64); put_name(a.kg, &a.kg_len, p->key_group, 64);
+    a.key_len = p->dev.key_len; memcpy(a.key, p->dev.key, a.key_len <= sizeof(a.key) ? a.key_len : sizeof(a.key));
+    a.buffer_limit = p->dev.buffer_limit; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
+    a.rows = s->o_rows.as<MloRow>(); a.st = s->o_st.as<MloState>(); a.nrec = s->o_nrec.as<uint32_t>(); a.rec_base = s->o_base.as<uint64_t>();
+    a.idx = s->o_idx.as<uint32_t>(); a.misc = s->o_misc.as<unsigned int>();
+    auto fill_groups = [&]() {
+        a.ngroups = (uint32_t) s->gnames.size();
+        for (uint32_t g = 0; g < a.ngroups; g++) put_name(a.names[g], &a.name_len[g], s->gnames[g], 32);
+        for (int g = 0; g < MLO_G; g++) {
+            a.carry[g].content = s->gc_content[g][s->gc_cur[g]].as<uint8_t>(); a.carry[g].map = s->gc_map[g][s->gc_cur[g]].as<uint8_t>();
+            a.carry[g].content_len = s->gc_content_len[g]; a.carry[g].map_len = s->gc_map_len[g]; a.carry[g].sec = s->gc_sec[g]; a.carry[g].nsec = s->gc_nsec[g];
+        }
+    };
+    fill_groups();
+    launch_mlo_extract(a, st);
+    // group names the stream has not seen yet join its dictionary in the order they appear (flb_ml_stream_group_get creates them so)
+    for (int round = 0;; round++) {
+        launch_mlo_gid(a, st);
+        if (hipMemcpyAsync(hmisc, s->o_misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("group pass failed");
+        if (hmisc[0] == 0xFFFFFFFFu) break;
+        if (round > MLO_G || s->gnames.size() >= (size_t) MLO_G) {
+            set_err("multiline: more than %d key_group values in one stream: not on the GPU path", MLO_G - 1);
+            return -1;
+        }
+        MloRow hr;
+        if (hipMemcpy(&hr, a.rows + hmisc[0], sizeof(hr), hipMemcpyDeviceToHost) != hipSuccess) return fail("group pass failed");
+        if (hr.g_len > 31) return fail("a key_group value longer than 31 bytes: not on the GPU path");
+        std::string nm(hr.g_len, '\0');
+        if (hr.g_len && hipMemcpy(&nm[0], a.pdata + hr.g_off, hr.g_len, hipMemcpyDeviceToHost) != hipSuccess) return fail("group pass failed");
+        s->gnames.push_back(nm);
+        fill_groups();
+        hmisc[0] = 0xFFFFFFFFu;
+        if (hipMemcpyAsync(s->o_misc.p, hmisc, 4, hipMemcpyHostToDevice, st) != hipSuccess) return fail("upload failed");
+    }
+    launch_mlo_vscan(a, s->o_tmp.p, st);
+    launch_mlo_count(a, st);
+    launch_scan(a.nrec, N1, s->d_scan_tmp.as<uint64_t>(), s->o_base.as<uint64_t>(), st);
+    uint64_t R = 0;
+    if (hipMemcpyAsync(&R, s->o_base.as<uint64_t>() + N1, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hmisc, s->o_misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("count pass failed");
+    if (hmisc[1] == 1) return fail("a line parsed with a time the event encoder refuses (the reference drops the group's record and keeps its bytes): not on the GPU path");
+    if (!s->o_recs.ensure((R ? R : 1) * sizeof(MloRec)) || !s->o_size.ensure((R ? R : 1) * 4) || !s->o_off.ensure((R + 1) * 8) ||
+        !s->d_scan_tmp.ensure(scan_tmp_elems(R ? R : 1) * sizeof(uint64_t))) return -1;
+    a.recs = s->o_recs.as<MloRec>(); a.rec_size = s->o_size.as<uint32_t>(); a.rec_off = s->o_off.as<uint64_t>();
+    if (n) launch_mlo_idx(a, st);
+    launch_mlo_recs(a, st);
+    launch_mlo_size(a, R, st);
+    launch_scan(a.rec_size, R, s->d_scan_tmp.as<uint64_t>(), s->o_off.as<uint64_t>(), st);
+    launch_mlo_carry(a, 0, st);
+    uint64_t total = 0;
+    if (hipMemcpyAsync(&total, s->o_off.as<uint64_t>() + R, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hmisc, s->o_misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("size pass failed");
+    if (hmisc[1] == 2) return fail("the first line of a group holds key_content twice: not on the GPU path");
+    if (!s->d_out.ensure(total + 16)) return -1;
+    a.out = s->d_out.as<uint8_t>();
+    int nxt[MLO_G];
+    for (int g = 0; g < MLO_G; g++) {
+        nxt[g] = s->gc_cur[g] ^ 1;
+        if (!s->gc_content[g][nxt[g]].ensure((size_t) hmisc[2 + g] + 64) || !s->gc_map[g][nxt[g]].ensure((size_t) hmisc[6 + g] + 64)) return -1;
+        a.carry_out_content[g] = s->gc_content[g][nxt[g]].as<uint8_t>(); a.carry_out_map[g] = s->gc_map[g][nxt[g]].as<uint8_t>();
+    }
+    launch_mlo_emit(a, R, st);
+    launch_mlo_carry(a, 1, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("emit pass failed");
+    for (int g = 0; g < MLO_G; g++) {
+        s->gc_cur[g] = nxt[g];
+        s->gc_content_len[g] = hmisc[2 + g]; s->gc_map_len[g] = hmisc[6 + g]; s->gc_sec[g] = hmisc[10 + g]; s->gc_nsec[g] = hmisc[14 + g];
+    }
+    s->truncations += hmisc[18];
+    *records = R;
+    out->data = s->d_out.p; out->row_off = s->o_off.as<uint64_t>(); out->n = R; out->bytes = total;
+    return 0;
+}
+
 // what the stream carries: rule_to_state (-1 none), bytes of the open group
 extern "C" void flbgpu_ml_stream_state(const flbgpu_ml_stream *s, int *rule_to_state, uint64_t *buffered) {
     if (rule_to_state) *rule_to_state = s ? (int) s->state - 1 : -1;
-    if (buffered) *buffered = s ? s->carry_len : 0;
+    if (buffered) { *buffered = s ? s->carry_len : 0; if (s && s->p->sub) for (int g = 0; g < MLO_G; g++) *buffered += s->gc_content_len[g]; }
 }
 // lines that truncated a buffer so far (every one is a FLB_MULTILINE_TRUNCATED return of flb_ml_append_text: in_tail warns and counts them)
 extern "C" uint64_t flbgpu_ml_stream_truncations(const flbgpu_ml_stream *s) { return s ? s->truncations : 0; }
@@ -376,6 +550,7 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
     *processed = 0; *records = 0;
     if (!s) return fail("no stream");
     if (bytes > 0xFFFF0000ull) return fail("more than 4 GB in one call");
+    if (s->p->sub) return mlo_append_dev(s, d_text, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, out, processed, records);
     hipStream_t st = s->stream;
     const uint8_t *text = (const uint8_t *) d_text;
     if (!s->d_misc.ensure(sizeof(MlMisc))) return -1;

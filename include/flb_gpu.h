@@ -260,13 +260,14 @@ int flbgpu_tail_run_dev(flbgpu_tail *t, const void *d_text, uint64_t bytes, uint
  * src/multiline/flb_ml.c:685-762 (flb_ml_append_text), :197-364 (package_content), src/multiline/flb_ml_rule.c:245-436 (the regex
  * rule state machine), flb_ml_group.c:87-122 (flb_ml_group_cat), flb_ml.c:1590-1790 (flb_ml_flush_stream_group: one record
  * [[ts, {}], {key_content | "log": concatenated lines}] per group).  One multiline parser per context, types regex / endswith /
- * equal, no sub-parser (the docker / cri built-ins need one: refused), no key_group / key_pattern (flb_ml_append_object's map path).
+ * equal; a parser in front (the built-in docker / cri parsers, flbgpu_ml_parser_set_subparser) for endswith / equal types.
  * The buffer limit (flb_ml_group_cat's truncation, the "multiline_truncated" metadata of a cut group) is reproduced.
  *
  * flbgpu_ml_parser  = flb_ml_parser_create (src/multiline/flb_ml_parser.c:46-140) + the instance's key_content + flb_ml_create's
  *                     buffer limit (< 0: the 2 MB default, 0: none); rules: flb_ml_rule_create (flb_ml_rule.c:48-118),
  *                     flbgpu_ml_parser_init = flb_ml_parser_init / flb_ml_rule_init (:279-299);
- *                     flbgpu_ml_parser_builtin: the rule tables of flb_ml_parser_java.c / _go.c / _python.c / _ruby.c (calls init)
+ *                     flbgpu_ml_parser_builtin: the rule tables of flb_ml_parser_java.c / _go.c / _python.c / _ruby.c, and cri / docker
+ *                     (flb_ml_parser_cri.c, flb_ml_parser_docker.c: the parser in front is created with them) (calls init)
  * flbgpu_ml_stream  = flb_ml_stream_create: what one tailed file carries between reads (rule_to_state, the open group, its time)
  * flbgpu_ml_append  = one read: the buffer is cut into lines (leading NULs, Skip_Empty_Lines, CR LF as in flbgpu_tail_run), every
  *                     line runs through the parser; the reference stamps flb_time_get() per line, the caller passes the time of
@@ -277,6 +278,10 @@ typedef struct flbgpu_ml_stream flbgpu_ml_stream;
 flbgpu_ml_parser *flbgpu_ml_parser_create(const char *type, const char *match_string, int negate, const char *key_content, int64_t buffer_limit);
 int flbgpu_ml_parser_add_rule(flbgpu_ml_parser *p, const char *from_states, const char *regex, const char *to_state);
 int flbgpu_ml_parser_builtin(flbgpu_ml_parser *p, const char *name);
+/* `parser` + key_group + key_pattern of a [MULTILINE_PARSER] of type endswith / equal (the shape of the built-in cri / docker parsers):
+ * every line is parsed first (ml_append_try_parser_type_text, flb_ml.c:505-532), the buffers live per key_group value, a flush re-packs the
+ * first line's map with the concatenation under key_content.  `sub` stays the caller's. */
+int flbgpu_ml_parser_set_subparser(flbgpu_ml_parser *p, flbgpu_parser *sub, const char *key_group, const char *key_pattern);
 int flbgpu_ml_parser_init(flbgpu_ml_parser *p);
 void flbgpu_ml_parser_destroy(flbgpu_ml_parser *p);
 /* diagnostics: size of the product of the rules' match-only DFAs (states 0: too large for LDS, the rules are walked one by one) */

@@ -134,16 +134,16 @@ def java_service_log(rng, nlines):
     return b"\n".join(out[:nlines]) + b"\n"
 
 
-def cri_text(rng, nlines, damage=0.08):
+def cri_text(rng, nlines, damage=0.08, bad_times=True):
     """containerd's log format (time stream P|F log) with partial lines on two streams interleaved, and lines the cri parser refuses"""
     out = []
     for i in range(nlines):
         r = rng.random()
         if r < damage:
             out.append(rng.choice([b"not a cri line", b"", b"2021-05-17T17:35:01Z stdout X bad flag", b"2021-05-17T17:35:01Z stdin F other stream",
-                                   b"2021-05-17T17:35:01.1Z stdout F", b" stdout F leading blank", b"\xff\xfe stdout F x"]))
+                                   b"2021-05-17T17:35:01.1Z stdout F", b" stdout F leading blank"] + ([b"\xff\xfe stdout F x"] if bad_times else [])))
             continue
-        t = "2021-05-17T17:%02d:%02d.%09dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(10 ** 9)) if rng.random() < 0.9 else rng.choice(["garbage-time", "2021-05-17T17:35:01+02:00", "1"])
+        t = "2021-05-17T17:%02d:%02d.%09dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(10 ** 9)) if rng.random() < 0.9 or not bad_times else rng.choice(["garbage-time", "2021-05-17T17:35:01+02:00", "1"])
         stream = rng.choice(["stdout", "stdout", "stderr"])
         flag = "F" if rng.random() < 0.6 else "P"
         log = rng.choice([b"", b"x", b"[DEBUG] start multiline - ", b"part of a long line that was split by the runtime at 16 KB ", b'{"json":"inside"}', b"caf\xc3\xa9 \t tab", b"ends with space "])
@@ -173,11 +173,11 @@ def docker_text(rng, nlines, damage=0.08):
     return b"\n".join(out) + b"\n"
 
 
-def random_sub_case(rng, nlines=None):
+def random_sub_case(rng, nlines=None, bad_times=True):
     """the built-in parsers with a parser in front: (cfg, frames, kwargs) like random_case"""
     b = rng.choice(["cri", "docker"])
     n = nlines if nlines is not None else rng.randrange(0, 80)
-    text = cri_text(rng, n) if b == "cri" else docker_text(rng, n)
+    text = cri_text(rng, n, bad_times=bad_times) if b == "cri" else docker_text(rng, n)
     if rng.random() < 0.2 and text:
         text = text[:-1]
     return {"builtin": b}, frames_of(rng, text), dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)

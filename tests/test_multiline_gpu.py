@@ -133,8 +133,6 @@ def test_a_large_buffer(g):
 
 def test_refusals(g):
     with pytest.raises(ValueError):
-        g.MultilineParser(builtin="cri")                     # needs the sub-parser
-    with pytest.raises(ValueError):
         g.MultilineParser(rules=[("cont", r"/^\s/", "cont")])       # the first rule must hold a start_state
     with pytest.raises(ValueError):
         g.MultilineParser(rules=[("start_state", r"/^a/", "nowhere")])
@@ -200,3 +198,41 @@ def test_long_lines_long_groups_and_two_streams(g):
     assert (got_a, na) == want_a[:2], first_diff(want_a[0], got_a)
     assert (got_b, nb) == want_b[:2], first_diff(want_b[0], got_b)
     assert max(len(x) for x in contents(got_a)) > 100000
+
+
+CRI_SAMPLE = (b"2021-05-17T17:35:01.184675702Z stdout F [DEBUG] 1 start multiline - \n"
+              b"2021-05-17T17:35:01.184747208Z stdout P partial one \n2021-05-17T17:35:01.184747209Z stderr P err part \n"
+              b"2021-05-17T17:35:01.184747210Z stdout F and the end\nnot a cri line\n2021-05-17T17:35:02.1Z stderr F err end\n"
+              b"2021-05-17T17:35:03.1Z stdout P dangling\n")
+DOCKER_SAMPLE = (b'{"log":"one, ","stream":"stdout","time":"2021-02-01T01:40:03.53413Z"}\n{"log":"two\\n","stream":"stdout","time":"2021-02-01T01:40:03.53414Z"}\n'
+                 b'plain\n{"log":"x","stream":"stderr","time":"2021-02-01T01:40:03.5Z"}\n')
+
+
+@pytest.mark.parametrize("name,text", [("cri", CRI_SAMPLE), ("docker", DOCKER_SAMPLE)])
+def test_cri_and_docker_samples(g, name, text):
+    """the built-in parsers with a parser in front: lines parsed on the device, one buffer per stream, the first line's map re-packed"""
+    for cut in range(0, len(text) + 1, 7):
+        frames = [(100, 5, text[:cut]), (200, 6, text[cut:])]
+        want, n, _ = oracle_run({"builtin": name}, frames, final_flush=True, clock_of_the_call=True)
+        got, gn, _ = device_run(g, {"builtin": name}, frames, final_flush=True)
+        assert got == want, (cut, first_diff(want, got))
+        assert gn == n
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_cri_and_docker_random(g, seed):
+    rng = random.Random(9100 + seed)
+    for _ in range(50):
+        cfg, frames, kw = ml_synth.random_sub_case(rng, bad_times=False)
+        want, n, _ = oracle_run(cfg, frames, clock_of_the_call=True, **kw)
+        got, gn, _ = device_run(g, cfg, frames, **kw)
+        assert got == want, (cfg, frames, kw, first_diff(want, got))
+        assert gn == n
+
+
+def test_cri_refuses_what_it_cannot_reproduce(g):
+    p = g.MultilineParser(builtin="cri")
+    s = p.stream()
+    with pytest.raises(RuntimeError):            # the parser takes the line, its time is no time: the reference drops the record and keeps the bytes
+        s.append(b"garbage-time stdout F x\n", 100, 5)
+    s.close(); p.close()

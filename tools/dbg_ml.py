@@ -9,11 +9,15 @@ from test_multiline_oracle import oracle_run
 from test_multiline_gpu import device_run
 g = flbamd_loader.load(); g.init(0)
 seed = int(sys.argv[1])
+sub = len(sys.argv) > 2 and sys.argv[2] == "sub"
 rng = random.Random(seed)
 for it in range(60):
-    cfg, frames, kw = ml_synth.random_case(rng)
-    if rng.random() < 0.3:
-        cfg["buffer_limit_bytes"] = rng.choice([0, 1, 8, 40, 200, 1000])
+    if sub:
+        cfg, frames, kw = ml_synth.random_sub_case(rng, bad_times=False)
+    else:
+        cfg, frames, kw = ml_synth.random_case(rng)
+        if rng.random() < 0.3:
+            cfg["buffer_limit_bytes"] = rng.choice([0, 1, 8, 40, 200, 1000])
     want, n, trunc = oracle_run(cfg, frames, clock_of_the_call=True, **kw)
     got, gn, st = device_run(g, cfg, frames, **kw)
     if got != want:
