@@ -1,7 +1,7 @@
 // ml.cpp -- the multiline core in front of the path, behind the C ABI (include/flb_gpu.h flbgpu_ml_*): what in_tail does with a
 // `multiline.parser` -- plugins/in_tail/tail_file.c:840-898 cuts the file buffer into lines and hands each to flb_ml_append_text
 // (src/multiline/flb_ml.c:685-762) -- for the text lines of one stream and ONE multiline parser of type regex (rules:
-// src/multiline/flb_ml_rule.c), endswith or equal, without a sub-parser.  Kernels: ml_kernels.inc.  Host side: the parser
+// src/multiline/flb_ml_rule.c), endswith or equal; for the latter two also with a parser in front (cri, docker).  Kernels: ml_kernels.inc, mlo_kernels.inc.  Host side: the parser
 // definition (flb_ml_parser_create / flb_ml_rule_create / flb_ml_rule_init :279-299 restated as masks), the stream's carried
 // state (rule_to_state, the open group's bytes and time), buffers.  No CPU path: every line is matched and packed on the device.
 #include <map>

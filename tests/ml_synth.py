@@ -134,7 +134,7 @@ def java_service_log(rng, nlines):
     return b"\n".join(out[:nlines]) + b"\n"
 
 
-def cri_text(rng, nlines, damage=0.08, bad_times=True):
+def cri_text(rng, nlines, damage=0.08, bad_times=True, ascii_only=False, long_lines=0.02):
     """containerd's log format (time stream P|F log) with partial lines on two streams interleaved, and lines the cri parser refuses"""
     out = []
     for i in range(nlines):
@@ -146,8 +146,9 @@ def cri_text(rng, nlines, damage=0.08, bad_times=True):
         t = "2021-05-17T17:%02d:%02d.%09dZ" % (rng.randrange(60), rng.randrange(60), rng.randrange(10 ** 9)) if rng.random() < 0.9 or not bad_times else rng.choice(["garbage-time", "2021-05-17T17:35:01+02:00", "1"])
         stream = rng.choice(["stdout", "stdout", "stderr"])
         flag = "F" if rng.random() < 0.6 else "P"
-        log = rng.choice([b"", b"x", b"[DEBUG] start multiline - ", b"part of a long line that was split by the runtime at 16 KB ", b'{"json":"inside"}', b"caf\xc3\xa9 \t tab", b"ends with space "])
-        if rng.random() < 0.02:
+        log = rng.choice([b"", b"x", b"[DEBUG] start multiline - ", b"part of a long line that was split by the runtime at 16 KB ", b'{"json":"inside"}',
+                          b"cafe \t tab" if ascii_only else b"caf\xc3\xa9 \t tab", b"ends with space "])
+        if rng.random() < long_lines:
             log = bytes(rng.choice(b"abc ") for _ in range(rng.randrange(1000, 20000)))
         out.append(("%s %s %s " % (t, stream, flag)).encode() + log)
     return b"".join(l + (b"\r\n" if rng.random() < 0.03 else b"\n") for l in out)

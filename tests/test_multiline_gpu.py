@@ -236,3 +236,54 @@ def test_cri_refuses_what_it_cannot_reproduce(g):
     with pytest.raises(RuntimeError):            # the parser takes the line, its time is no time: the reference drops the record and keeps the bytes
         s.append(b"garbage-time stdout F x\n", 100, 5)
     s.close(); p.close()
+
+
+def test_cri_large_and_custom_parser_in_front(g):
+    """200 k containerd lines in three reads; and a [MULTILINE_PARSER] of type endswith with its own `parser` (Format json), key_content
+    message, key_group svc: flbgpu_ml_parser_set_subparser"""
+    rng = random.Random(31)
+    text = ml_synth.cri_text(rng, 200000, damage=0.01, bad_times=False)
+    cuts = [0, len(text) // 3 + 5, 2 * len(text) // 3 + 17, len(text)]
+    frames = [(1700000000 + i, 7 * i, text[cuts[i]:cuts[i + 1]]) for i in range(3)]
+    want, n, _ = oracle_run({"builtin": "cri"}, frames, final_flush=True, clock_of_the_call=True)
+    got, gn, _ = device_run(g, {"builtin": "cri"}, frames, final_flush=True)
+    assert gn == n and n > 50000
+    assert got == want, first_diff(want, got)
+
+    import json
+    lines = []
+    for i in range(3000):
+        d = {"svc": rng.choice(["a", "b"]), "message": rng.choice(["part ", "more ", "done;", ";", ""]), "n": i}
+        if rng.random() < 0.1:
+            d.pop("svc")
+        lines.append(json.dumps(d).encode() if rng.random() < 0.95 else b"not json")
+    text = b"\n".join(lines) + b"\n"
+    frames = [(50, 1, text[:len(text) // 2]), (60, 2, text[len(text) // 2:])]
+    sub_o = dict(regex=None, time_fmt=None, time_key=None, skip_empty=True)
+    mo = ob_multiline(type="endswith", match_string=";", key_content="message", subparser=sub_o, key_group="svc")
+    want = b""; n = 0
+    for sec, nsec, t in frames:
+        mo_set_now(mo, sec, nsec)
+        o, r, _ = mo.append(t, sec, nsec); want += o; n += r
+    mo_set_now(mo, 1900000000, 3)
+    o, r, _ = mo.flush(); want += o; n += r
+    pj = g.Parser(format="json")
+    p = g.MultilineParser(type="endswith", match_string=";", key_content="message", subparser=pj, key_group="svc")
+    s = p.stream()
+    got = b""; gn = 0
+    for sec, nsec, t in frames:
+        o, r = s.append(t, sec, nsec); got += o; gn += r
+    o, r = s.flush(1900000000, 3); got += o; gn += r
+    s.close(); p.close(); pj.close()
+    assert (got, gn) == (want, n), first_diff(want, got)
+
+
+def ob_multiline(**kw):
+    import oracle_binding as ob
+    return ob.Multiline(**kw)
+
+
+def mo_set_now(m, sec, nsec):
+    import oracle_binding as ob
+    ob.lib().oml_set_now.argtypes = [ob.c_void_p, ob.c_int64, ob.c_int64]
+    ob.lib().oml_set_now(m.h, sec, nsec)
