@@ -443,7 +443,8 @@ class MultilineStream:
 
 class StreamTask:
     """one task of the stream processor (src/stream_processor/flb_sp.c: flb_sp_task_create :433, flb_sp_do :2007, the window
-    timer of flb_sp_fd_event :2101) for aggregate queries: GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING."""
+    timer of flb_sp_fd_event :2101): aggregate queries (GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING | HOPPING) and
+    SELECTs without aggregation functions (keys, aliases, `*`, WHERE: sp_process_data :1607)."""
 
     def __init__(self, sql, str_conv=True):
         L = lib()
@@ -477,6 +478,8 @@ class StreamTask:
         self.source = src.value.decode()
         self.stream_name = name.value.decode() if name.value else None
         self.key_names = [L.flbgpu_sp_key_name(self.h, i).decode() for i in range(L.flbgpu_sp_key_count(self.h))]
+        L.flbgpu_sp_select_only.argtypes = [c_void_p]
+        self.select_only = bool(L.flbgpu_sp_select_only(self.h))     # sp_process_data: do() answers (records that passed WHERE, projected records)
 
     def stream_prop(self, key):
         v = lib().flbgpu_sp_stream_prop(self.h, _b(key))

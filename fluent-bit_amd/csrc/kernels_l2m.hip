@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
+#include "spsel.hpp"
 
 namespace flbgpu {
 
@@ -13,5 +14,7 @@ namespace flbgpu {
 #include "l2m_kernels.inc"
 
 #include "sp_kernels.inc"
+
+#include "sp_select.inc"
 
 }  // namespace flbgpu

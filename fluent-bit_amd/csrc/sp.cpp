@@ -8,7 +8,9 @@
 // Host side: the SQL front end (the token rules of parser/sql.l and the grammar of parser/sql.y, restated -- flex / bison
 // resolve the precedence-less AND / OR / NOT rules by shifting: right-associative, NOT takes everything after it), the plan
 // the kernels interpret, and package_results over the order-independent group rows the kernels maintain (dev.hpp, SpArgs).
-// Queries outside that set (TIMESERIES_FORECAST, snapshots, plain SELECTs) are refused at create time; inputs on
+// A SELECT without aggregation functions (keys, aliases, `*`) is flb_sp_do's other branch, sp_process_data (:1607-1850): records in,
+// projected records out per appended chunk (sp_select.inc); WINDOW / GROUP BY are then never looked at, as in the reference.
+// Queries outside that set (TIMESERIES_FORECAST, snapshots, time / record functions as select keys) are refused at create time; inputs on
 // which the reference's own result depends on the rb-tree's shape (a GROUP BY column mixing numbers and strings, NaN keys)
 // make the call fail instead of answering something else.
 #include <hip/hip_runtime.h>
@@ -24,6 +26,7 @@
 #include "../../include/flb_gpu.h"
 #include "dev.hpp"
 #include "host_int.hpp"
+#include "spsel.hpp"
 #include "numconv.hpp"
 
 using namespace flbgpu;
@@ -123,6 +126,8 @@ struct SelKey {
     bool star = false;
     KeyName k;
     std::string out_name;
+    bool has_alias = false;
+    std::string alias;
     int gb = -1;
 };
 struct Node {                   // condition tree
@@ -143,6 +148,7 @@ struct Query {
     int source_type = 0;        // 0 stream, 1 tag
     std::string source, stream_name;
     std::vector<std::pair<std::string, std::string>> props;
+    bool select_only = false;   // no aggregation function, no GROUP BY: sp_process_data (flb_sp.c:1607-1850), records out per appended chunk
 };
 
 struct Parser {
@@ -184,7 +190,11 @@ struct Parser {
         SelKey k;
         std::string al;
         bool has = false;
-        if (eat(TK_CH, "*")) return fail("SELECT * is not an aggregate query");
+        if (eat(TK_CH, "*")) {
+            // flb_sp_key_create (flb_sp_parser.c:172-184): the wildcard only as the first select key
+            if (!q.keys.empty()) return fail("wildcard after other select keys");
+            k.star = true; k.out_name = "*"; q.keys.push_back(k); return true;
+        }
         if (is(TK_IDENT)) {
             k.k.name = cur().s; i++;
             if (!subkeys(k.k.sub) || !alias(al, has)) return false;
@@ -205,6 +215,8 @@ struct Parser {
         }
         else return fail("select key expected");
         k.out_name = out_name(k, has, al);
+        // flb_sp_key_create :206-222: a key with sub-keys and no alias gets "k['a']['b']" as its alias -- that is what sp_process_data packs
+        k.has_alias = has || !k.k.sub.empty(); k.alias = has ? al : k.out_name;
         q.keys.push_back(k);
         return true;
     }
@@ -370,6 +382,14 @@ struct Parser {
         if (!is(TK_EOF)) return fail("trailing input");
         // sp_cmd_aggregated_keys (flb_sp.c:201-262)
         int aggr = 0;
+        for (auto &k : q.keys) if (k.func) aggr++;
+        if (!aggr) {
+            // sp_cmd_aggregated_keys returns 0: flb_sp_task_create leaves aggregate_keys off and never looks at WINDOW / GROUP BY again
+            q.select_only = true; q.window = 0; q.gb.clear();
+            return true;
+        }
+        for (auto &k : q.keys) if (!k.func && k.star) return fail("SELECT * next to aggregation functions");
+        aggr = 0;
         for (auto &k : q.keys) {
             if (k.func) { aggr++; continue; }
             for (size_t g = 0; g < q.gb.size(); g++) {
@@ -391,6 +411,9 @@ struct flbgpu_sp {
     SpPlan plan;
     int str_conv = 1;
     std::vector<int> key_src;           // select key -> aggregated source index (-1: none)
+    std::vector<SpSelKey> sel;          // a plain SELECT: its keys in order (sp_select.inc)
+    DevBuf d_slen, d_soff, d_sout;
+    std::string sel_out;                // what the last appended chunk left (finish_do hands it over)
     hipStream_t stream = nullptr;
     L2mState tab;                       // group dictionary + rows (the table part of the log_to_metrics state)
     DevBuf d_plan, d_gid, d_val, d_vt, d_misc, d_in, d_off;
@@ -499,6 +522,22 @@ bool compile(flbgpu_sp *t, std::string &why) {
         pl.gb_key[pl.ngb++] = (uint8_t) k;
     }
     t->key_src.assign(t->q.keys.size(), -1);
+    t->sel.clear();
+    if (t->q.select_only) {
+        for (const SelKey &k : t->q.keys) {
+            SpSelKey sk;
+            memset(&sk, 0, sizeof(sk));
+            if (k.star) sk.star = 1;
+            else {
+                const int kr = key_ref(t, b, k.k, why);
+                if (kr < 0) return false;
+                sk.key = (uint8_t) kr;
+                if (k.has_alias) { sk.has_alias = 1; if (!b.put(k.alias, sk.alias_off, sk.alias_len)) { why = "query text too long"; return false; } }
+            }
+            if (t->sel.size() >= (size_t) SP_MAX_KEYS) { why = "too many select keys"; return false; }
+            t->sel.push_back(sk);
+        }
+    }
     for (size_t i = 0; i < t->q.keys.size(); i++) {
         const SelKey &k = t->q.keys[i];
         if (!k.func || k.star) continue;
@@ -769,7 +808,52 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
     return true;
 }
 
+// a plain SELECT over one chunk: size pass, scan, emit; what leaves is kept in t->sel_out for finish_do
+bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
+    uint64_t n = in->n;
+    t->sel_out.clear();
+    t->records = 0;
+    if (n == 0) return true;
+    if (!t->d_slen.ensure(n * 4) || !t->d_soff.ensure((n + 1) * 8) || !t->d_misc.ensure(sizeof(SpMisc)) || !t->d_gid.ensure(scan_tmp_elems(n) * 8)) return false;
+    SpMisc *dm = t->d_misc.as<SpMisc>();
+    SpSelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.data = (const uint8_t *) in->data; a.row_off = in->row_off; a.bytes = in->bytes; a.plan = t->d_plan.as<SpPlan>();
+    a.nsel = (int) t->sel.size();
+    for (int i = 0; i < a.nsel; i++) a.sel[i] = t->sel[(size_t) i];
+    a.out_len = t->d_slen.as<uint32_t>(); a.out_off = t->d_soff.as<uint64_t>();
+    a.first_bad = &dm->first_bad; a.records = &dm->counts[0]; a.flags = &dm->flags;
+    SpMisc hm;
+    uint64_t total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        // (a chunk with an object that does not decode: msgpack_unpack_next stops there -- the rows before it, once more)
+        memset(&hm, 0, sizeof(hm));
+        hm.first_bad = ~0ull;
+        HIPOK(hipMemcpyAsync(t->d_misc.p, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+        a.n = n;
+        launch_sp_select(a, false, st);
+        launch_scan(a.out_len, n, t->d_gid.as<uint64_t>(), t->d_soff.as<uint64_t>(), st);
+        HIPOK(hipMemcpyAsync(&hm, t->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&total, t->d_soff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        if (hm.first_bad >= n) break;
+        n = hm.first_bad;
+        if (n == 0) { total = 0; hm.counts[0] = 0; break; }
+    }
+    if (hm.flags & SPF_BAD_RECORD) { set_err("stream processor: a record is not [time, map] / [[time, metadata], map]"); return false; }
+    t->records = hm.counts[0];
+    if (total == 0) return true;
+    if (!t->d_sout.ensure(total + 16)) return false;
+    a.out = t->d_sout.as<uint8_t>();
+    launch_sp_select(a, true, st);
+    t->sel_out.resize(total);
+    HIPOK(hipMemcpyAsync(&t->sel_out[0], a.out, total, hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    return true;
+}
+
 bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
+    if (t->q.select_only) return run_select(t, in, st);
     L2mState &s = t->tab;
     const SpPlan &pl = t->plan;
     const uint64_t n = in->n;
@@ -939,6 +1023,18 @@ int finish_do(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
     if (records) *records = (int64_t) t->records;
     if (out_buf) *out_buf = nullptr;
     if (out_size) *out_size = 0;
+    if (t->q.select_only) {
+        // sp_process_data: "records == 0 -> return 0" (nothing handed on); otherwise the buffer, which may be empty
+        if (out_buf && out_size && t->records > 0 && !t->sel_out.empty()) {
+            *out_buf = malloc(t->sel_out.size());
+            if (!*out_buf) { set_err("out of memory"); return -1; }
+            memcpy(*out_buf, t->sel_out.data(), t->sel_out.size());
+            *out_size = t->sel_out.size();
+        }
+        t->sel_out.clear();
+        t->records = 0;
+        return 0;
+    }
     if (t->q.window == 0) {
         // no WINDOW: packaged per appended chunk (flb_sp.c:2051-2054), then pruned (only a window that saw records is)
         std::string out;
@@ -1039,7 +1135,7 @@ extern "C" void flbgpu_sp_destroy(flbgpu_sp *t) {
     if (!t) return;
     L2mState &s = t->tab;
     DevBuf *all[] = {&s.d_slot_hash, &s.d_slot_sid, &s.d_arena, &s.d_key_off, &s.d_key_len, &s.d_series_hash, &s.d_rows, &s.d_ctr,
-                     &t->d_plan, &t->d_gid, &t->d_val, &t->d_vt, &t->d_misc, &t->d_in, &t->d_off};
+                     &t->d_plan, &t->d_gid, &t->d_val, &t->d_vt, &t->d_misc, &t->d_in, &t->d_off, &t->d_slen, &t->d_soff, &t->d_sout};
     for (auto *b : all) b->release();
     for (auto &e : t->ev) if (e) (void) hipEventDestroy(e);
     if (t->stream) (void) hipStreamDestroy(t->stream);
@@ -1065,6 +1161,7 @@ extern "C" int flbgpu_sp_key_count(const flbgpu_sp *t) { return t ? (int) t->q.k
 extern "C" const char *flbgpu_sp_key_name(const flbgpu_sp *t, int i) {
     return (t && i >= 0 && (size_t) i < t->q.keys.size()) ? t->q.keys[i].out_name.c_str() : nullptr;
 }
+extern "C" int flbgpu_sp_select_only(const flbgpu_sp *t) { return t && t->q.select_only ? 1 : 0; }
 extern "C" void flbgpu_sp_set_index_base(flbgpu_sp *t, uint64_t base) { if (t) t->idx_base = base; }
 
 extern "C" int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
@@ -1147,6 +1244,7 @@ extern "C" int64_t flbgpu_sp_window_advance(const flbgpu_sp *t) { return t ? t->
 extern "C" int64_t flbgpu_sp_export(flbgpu_sp *t, void *buf, size_t cap) {
     if (!t) { set_err("stream processor: null argument"); return -1; }
     if (t->q.window == 2) { set_err("stream processor: HOPPING windows are not sharded (their slots live on the host of one task)"); return -1; }
+    if (t->q.select_only) { set_err("stream processor: a SELECT without aggregation functions keeps no window state"); return -1; }
     Snapshot sn;
     if (!snapshot(t, sn)) return -1;
     const std::string o = serialize(sn, t->tab.W);

@@ -299,7 +299,7 @@ int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes
 /* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
 int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);
 
-/* ---- stream processor, aggregate queries: replaces flb_sp_task_create / flb_sp_do / the window timer of flb_sp_fd_event -------
+/* ---- stream processor: replaces flb_sp_task_create / flb_sp_do / the window timer of flb_sp_fd_event -------------------------
  * src/stream_processor/flb_sp.c:433-560 (task), :2007-2097 -> sp_process_data_aggr :1435-1601 (one appended chunk),
  * :2101-2160 -> package_results :1161-1278 + flb_sp_window_prune (timer).  `sql` is the task's Exec string, parsed with the
  * token rules of parser/sql.l and the grammar of parser/sql.y:
@@ -309,8 +309,12 @@ int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_of
  * key IS [NOT] NULL, NOT / AND / OR / parentheses with the reference's (precedence-less, right-associative) binding.
  * str_conv = the engine's stream_processor_str_conv (src/flb_config.c:482, default on): numeric strings count as numbers.
  * NULL (flbgpu_last_error says why) for what flb_sp_task_create rejects and for what this path does not take:
- * TIMESERIES_FORECAST, time / record functions as select keys, snapshots, SELECTs without an aggregate, a HOPPING window that
- * advances by its size or more.
+ * TIMESERIES_FORECAST, time / record functions as select keys, snapshots, a HOPPING window that advances by its size or more.
+ * A SELECT without aggregation functions -- SELECT key [AS alias] | key['sub'] | *, ... [WHERE condition] -- is flb_sp_do's other
+ * branch, sp_process_data (flb_sp.c:1607-1850): every appended chunk answers with the projected records, [record's own time
+ * element, {selected pairs}], in *out_buf, *records = the records that passed WHERE; WINDOW / GROUP BY are ignored there as in
+ * the reference (flb_sp_info reports window_type 0), and the map-header quirk of :1801-1815 (a fixmap header patched with more
+ * than 15 entries) is kept byte for byte.
  * State lives in HBM as order-independent integer words per group (counts, wrapping int64 sums, exact fixed-point sums,
  * min / max): chunks and GPUs can be visited in any order; float SUM / AVG are the exact sum rounded once where the
  * reference adds sequentially (both leave as float32: msgpack_pack_float). */
@@ -321,6 +325,7 @@ void flbgpu_sp_destroy(flbgpu_sp *t);
  * window_sec seconds) / 2 hopping (see flbgpu_sp_hop); source_type 0 STREAM: / 1 TAG:; stream_name NULL unless CREATE STREAM */
 int flbgpu_sp_info(const flbgpu_sp *t, int *window_type, int64_t *window_sec, int *source_type, const char **source, const char **stream_name);
 const char *flbgpu_sp_stream_prop(const flbgpu_sp *t, const char *key);        /* WITH (tag='...') */
+int flbgpu_sp_select_only(const flbgpu_sp *t);      /* 1: no aggregation function (task->aggregate_keys off, flb_sp.c:491): flbgpu_sp_do hands back records */
 int flbgpu_sp_key_count(const flbgpu_sp *t);
 const char *flbgpu_sp_key_name(const flbgpu_sp *t, int i);                     /* output name: alias, "AVG(k)", "k['a']" */
 /* flb_sp_do for one chunk (host memory / device resident).  *records = task->window.records after the chunk.  Without a

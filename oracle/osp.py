@@ -1,5 +1,6 @@
 """osp.py -- TEST INFRASTRUCTURE: a CPU restatement of the reference's stream processor for aggregate queries
-(SELECT ... COUNT/SUM/AVG/MIN/MAX ... FROM ... [WINDOW TUMBLING (n SECOND)] [WHERE ...] [GROUP BY ...];).
+(SELECT ... COUNT/SUM/AVG/MIN/MAX ... FROM ... [WINDOW TUMBLING (n SECOND)] [WHERE ...] [GROUP BY ...];) and for SELECTs
+without aggregation functions (flb_sp.c:1607-1850 sp_process_data -> Task._do_select: keys, aliases, `*`).
 
 Follows, record by record and in arrival order (so also the order-dependent parts: float sums, first-seen group order,
 the I64 -> F64 switch of a sum at the first non-zero float):
@@ -17,7 +18,7 @@ Pinned on the reference itself: tests/test_sp_oracle.py runs the same queries ov
 oracle/_ref/ref_sp (the reference's own sources compiled in place) and wants identical bytes.
 
 Not restated (Unsupported is raised, the product refuses the same queries): TIMESERIES_FORECAST, snapshots,
-non-aggregate SELECTs; a GROUP BY column whose values mix number / string classes in one window (the reference's rb-tree
+time / record functions as select keys; a GROUP BY column whose values mix number / string classes in one window (the reference's rb-tree
 comparator is not an order there: flb_sp_groupby.c:77 "Sides have different types -> -1", and it rewrites nodes in place :37-44).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file."""
@@ -97,6 +98,7 @@ def tokenize(sql):
 class Key:
     def __init__(self, func, name, subkeys, alias):
         self.func, self.name, self.subkeys = func, name, subkeys       # func 0 = plain key; name None = '*'
+        self.alias = alias
         self.gb = None
         if alias is not None:
             self.out_name = alias
@@ -121,6 +123,7 @@ class Query:
         self.keys, self.gb_keys, self.cond = [], [], None
         self.window, self.window_size, self.advance_by = "default", 0, 0
         self.source_type, self.source, self.stream_name, self.props, self.limit = None, None, None, [], 0
+        self.select_only = False
 
     def finish(self):
         aggr = not_aggr = 0
@@ -140,7 +143,13 @@ class Query:
             if not mapped:
                 not_aggr += 1
         if aggr == 0:
-            raise Unsupported("not an aggregate query")
+            # sp_cmd_aggregated_keys returns 0: flb_sp_task_create (flb_sp.c:491-508) leaves aggregate_keys off, the task's window type
+            # stays DEFAULT and flb_sp_do takes the sp_process_data branch; GROUP BY is never looked at
+            self.select_only = True
+            self.window, self.gb_keys = "default", []
+            for k in self.keys:
+                k.gb = None
+            return
         if not_aggr > 0:
             raise ParseError("aggregated query cannot include the aggregated keys")
 
@@ -188,7 +197,7 @@ class _P:
     def record_key(self, q):
         if self.eat("ch", "*"):
             if q.keys:
-                raise ParseError("wildcard after keys")
+                raise ParseError("wildcard after keys")                 # flb_sp_key_create, flb_sp_parser.c:172-184
             q.keys.append(Key(0, None, None, None))
             return
         if self.is_("ident"):
@@ -476,7 +485,9 @@ def _sp_value(o):
 def key_to_value(name, m, subkeys):
     nb = name.encode()
     for k, v in m.pairs:
-        if not isinstance(k, str) or _b(k) != nb:
+        # (flb_sp_key_to_value compares key.via.str without looking at key.type -- :189 -- and a bin key shares that layout: the
+        # first entry called `name` wins, string or binary; the sub-key levels do check the type, :104)
+        if not isinstance(k, (str, bytes)) or _b(k) != nb:
             continue
         if isinstance(v, Map) and subkeys is not None:
             cur, matched, found = v, 0, False
@@ -496,6 +507,147 @@ def key_to_value(name, m, subkeys):
             return _sp_value(cur)
         return _sp_value(v)
     return NOVALUE
+
+
+# ------------------------------------------------------------------------------------------ raw objects (sp_process_data re-packs them)
+def _raw_tok(b, o):
+    """one msgpack head at b[o] -> (kind, value, next): scalars carry their value and `next` is their end; str / bin / ext carry
+    (body offset, length[, type]) and `next` is their end; array / map carry the count and `next` is the first child"""
+    c = b[o]
+    if c <= 0x7f:
+        return "uint", c, o + 1
+    if c >= 0xe0:
+        return "int", c - 256, o + 1
+    if 0x80 <= c <= 0x8f:
+        return "map", c & 15, o + 1
+    if 0x90 <= c <= 0x9f:
+        return "array", c & 15, o + 1
+    if 0xa0 <= c <= 0xbf:
+        n = c & 31
+        if o + 1 + n > len(b):
+            raise IndexError
+        return "str", (o + 1, n), o + 1 + n
+    if c == 0xc0:
+        return "nil", None, o + 1
+    if c == 0xc1:
+        raise ValueError("0xc1")
+    if c in (0xc2, 0xc3):
+        return "bool", c == 0xc3, o + 1
+    def be(n, at=o + 1):
+        if at + n > len(b):
+            raise IndexError
+        return int.from_bytes(b[at:at + n], "big")
+    if c in (0xc4, 0xc5, 0xc6, 0xd9, 0xda, 0xdb):
+        w = {0xc4: 1, 0xc5: 2, 0xc6: 4, 0xd9: 1, 0xda: 2, 0xdb: 4}[c]
+        n = be(w)
+        if o + 1 + w + n > len(b):
+            raise IndexError
+        return ("bin" if c <= 0xc6 else "str"), (o + 1 + w, n), o + 1 + w + n
+    if c in (0xc7, 0xc8, 0xc9):
+        w = {0xc7: 1, 0xc8: 2, 0xc9: 4}[c]
+        n = be(w)
+        t = be(1, o + 1 + w)
+        if o + 2 + w + n > len(b):
+            raise IndexError
+        return "ext", (o + 2 + w, n, t - 256 if t > 127 else t), o + 2 + w + n
+    if c == 0xca:
+        be(4)
+        return "f32", struct.unpack(">f", b[o + 1:o + 5])[0], o + 5
+    if c == 0xcb:
+        be(8)
+        return "f64", struct.unpack(">d", b[o + 1:o + 9])[0], o + 9
+    if 0xcc <= c <= 0xcf:
+        w = 1 << (c - 0xcc)
+        return "uint", be(w), o + 1 + w
+    if 0xd0 <= c <= 0xd3:
+        w = 1 << (c - 0xd0)
+        v = be(w)
+        if v >= 1 << (8 * w - 1):
+            v -= 1 << (8 * w)
+        return ("uint" if v >= 0 else "int"), v, o + 1 + w
+    if 0xd4 <= c <= 0xd8:
+        n = 1 << (c - 0xd4)
+        t = be(1)
+        if o + 2 + n > len(b):
+            raise IndexError
+        return "ext", (o + 2, n, t - 256 if t > 127 else t), o + 2 + n
+    w = 2 if c in (0xdc, 0xde) else 4
+    return ("array" if c <= 0xdd else "map"), be(w), o + 1 + w
+
+
+def _raw_skip(b, o):
+    kind, v, nxt = _raw_tok(b, o)
+    if kind in ("array", "map"):
+        for _ in range(v * (2 if kind == "map" else 1)):
+            nxt = _raw_skip(b, nxt)
+    return nxt
+
+
+def _raw_repack(b, o):
+    """msgpack_pack_object (lib/msgpack-c/src/objectc.c:39-126) of the object at b[o] -> (bytes, end): every head in its shortest
+    form, non-negative integers in the unsigned family, float32 stays float32"""
+    kind, v, nxt = _raw_tok(b, o)
+    if kind in ("uint", "int"):
+        return _pack_int(v), nxt
+    if kind == "str":
+        return _pack_str(b[v[0]:v[0] + v[1]]), nxt
+    if kind == "bin":
+        n = v[1]
+        h = b"\xc4" + bytes([n]) if n < 256 else b"\xc5" + struct.pack(">H", n) if n < 65536 else b"\xc6" + struct.pack(">I", n)
+        return h + b[v[0]:v[0] + n], nxt
+    if kind == "ext":
+        n, t = v[1], v[2] & 0xFF
+        if n in (1, 2, 4, 8, 16):
+            h = bytes([0xd4 + (1, 2, 4, 8, 16).index(n), t])
+        elif n < 256:
+            h = b"\xc7" + bytes([n, t])
+        elif n < 65536:
+            h = b"\xc8" + struct.pack(">H", n) + bytes([t])
+        else:
+            h = b"\xc9" + struct.pack(">I", n) + bytes([t])
+        return h + b[v[0]:v[0] + n], nxt
+    if kind in ("array", "map"):
+        fix, w16, w32 = (0x90, 0xdc, 0xdd) if kind == "array" else (0x80, 0xde, 0xdf)
+        out = bytearray(bytes([fix | v]) if v < 16 else bytes([w16]) + struct.pack(">H", v) if v < 65536 else bytes([w32]) + struct.pack(">I", v))
+        for _ in range(v * (2 if kind == "map" else 1)):
+            piece, nxt = _raw_repack(b, nxt)
+            out += piece
+        return bytes(out), nxt
+    return b[o:nxt], nxt                                               # nil, bool, f32, f64: as they came
+
+
+def _raw_key_to_value(rec, pairs, name, subkeys):
+    """flb_sp_key_to_value (flb_sp_key.c:54-231) on the raw record: the offset of the value object of the FIRST entry called
+    `name` (sub-keys walked through nested maps, all of them or nothing), None where the reference answers NULL -- no such
+    key, or a value the stream processor has no class for (array, bin, ext)"""
+    for ks, vs, _ve in pairs:
+        kk, kv, _n = _raw_tok(rec, ks)
+        if kk not in ("str", "bin") or rec[kv[0]:kv[0] + kv[1]] != name:      # (no type check up here: flb_sp_key.c:189)
+            continue
+        cur = vs
+        kind, cnt, nxt = _raw_tok(rec, cur)
+        if kind == "map" and subkeys is not None:
+            matched, found = 0, False
+            for want in subkeys:
+                kind, cnt, nxt = _raw_tok(rec, cur)
+                if kind != "map":
+                    break
+                found = False
+                for _ in range(cnt):
+                    k2, v2, _e = _raw_tok(rec, nxt)
+                    val = _raw_skip(rec, nxt)
+                    if k2 == "str" and rec[v2[0]:v2[0] + v2[1]] == want.encode():
+                        found, cur = True, val
+                        matched += 1
+                        break
+                    nxt = _raw_skip(rec, val)
+                if matched == len(subkeys):
+                    break
+            if not found or (matched > 0 and matched != len(subkeys)):
+                return None
+        kind = _raw_tok(rec, cur)[0]
+        return None if kind in ("array", "bin", "ext") else cur
+    return None
 
 
 # ------------------------------------------------------------------------------------------ WHERE
@@ -630,7 +782,7 @@ class Task:
         found = 0
         for k, _v in m.pairs:
             for gi, (gname, gsub) in enumerate(q.gb_keys):
-                if not isinstance(k, str) or _b(k) != gname.encode():
+                if not isinstance(k, (str, bytes)) or _b(k) != gname.encode():      # (no type check in this loop: flb_sp.c:1317-1326)
                     continue
                 v = key_to_value(gname, m, gsub)
                 if v is NOVALUE:
@@ -675,8 +827,79 @@ class Task:
             node["records"] += 1
         return node
 
+    def _do_select(self, chunk):
+        """sp_process_data (flb_sp.c:1607-1850): per record WHERE, then [the record's first element re-packed, a map of the
+        selected pairs]; the map header keeps the width msgpack_pack_map chose for the INCOMING size, the count of what was
+        written is patched in afterwards (:1801-1815 -- a fixmap byte takes more than 15 as it comes); a record none of
+        whose keys exist leaves nothing (:1796-1799).  Returns (records that passed WHERE, bytes) -- (0, b"") when none did."""
+        q = self.q
+        b = bytes(chunk)
+        out = bytearray()
+        records = 0
+        off = 0
+        while off < len(b):
+            try:
+                end = _raw_skip(b, off)
+            except (IndexError, struct.error, ValueError):
+                break                                                    # msgpack_unpack_next stops at what does not decode
+            rec = b[off:end]
+            off = end
+            kind, cnt, p = _raw_tok(rec, 0)
+            if kind != "array" or cnt != 2:
+                raise Unsupported("record is not [time, map]")
+            e0_end = _raw_skip(rec, p)
+            mkind, map_size, mp = _raw_tok(rec, e0_end)
+            if mkind != "map":
+                raise Unsupported("record body is not a map")
+            (ts, m), = decode_chunk(rec)
+            if q.cond is not None:
+                r = _reduce(q.cond, ts, m)
+                if r is None or not r[1]:
+                    continue
+            records += 1
+            pairs = []
+            for _ in range(map_size):
+                ks = mp
+                vs = _raw_skip(rec, ks)
+                mp = _raw_skip(rec, vs)
+                pairs.append((ks, vs, mp))
+            body = bytearray()
+            entries = 0
+            for ck in q.keys:
+                for ks, vs, ve in pairs:
+                    kk, kv, _n = _raw_tok(rec, ks)
+                    if kk != "str":
+                        continue
+                    if ck.name is None:
+                        body += _raw_repack(rec, ks)[0] + _raw_repack(rec, vs)[0]
+                        entries += 1
+                        continue
+                    if rec[kv[0]:kv[0] + kv[1]] != ck.name.encode():
+                        continue
+                    # flb_sp_key_create gives a key with sub-keys and no alias the alias "k['a']['b']" (flb_sp_parser.c:206-222)
+                    body += _pack_str(ck.out_name.encode()) if (ck.alias is not None or ck.subkeys) else _raw_repack(rec, ks)[0]
+                    v = _raw_key_to_value(rec, pairs, ck.name.encode(), ck.subkeys)
+                    if v is not None:
+                        body += _raw_repack(rec, v)[0]                   # (a NULL value: the key stays alone in the map)
+                    entries += 1
+            if entries == 0:
+                continue
+            out += b"\x92" + _raw_repack(rec, p)[0]
+            if map_size < 16:
+                out += bytes([0x80 | (entries & 0xFF)])
+            elif map_size < 65536:
+                out += b"\xde" + struct.pack(">H", entries & 0xFFFF)
+            else:
+                out += b"\xdf" + struct.pack(">I", entries & 0xFFFFFFFF)
+            out += body
+        if records == 0:
+            return 0, b""
+        return records, bytes(out)
+
     def do(self, chunk):
         q = self.q
+        if q.select_only:
+            return self._do_select(chunk)
         for ts, m in decode_chunk(chunk):
             if not isinstance(m, Map):
                 raise Unsupported("record body is not a map")

@@ -477,6 +477,8 @@ int sp_process_data_aggr(const char *buf_data, size_t buf_size, const char *tag,
                          int convert_str_to_num);
 void package_results(const char *tag, int tag_len, char **out_buf, size_t *out_size, struct flb_sp_task *task);
 int sp_process_hopping_slot(const char *tag, int tag_len, struct flb_sp_task *task);
+int sp_process_data(const char *tag, int tag_len, const char *buf_data, size_t buf_size, char **out_buf, size_t *out_size, struct flb_sp_task *task,
+                    struct flb_sp *sp);
 
 int main(void)
 {
@@ -502,7 +504,8 @@ int main(void)
             if (task) { flb_sp_task_destroy(task); task = NULL; }
             task = flb_sp_task_create(sp, "t", sql);
             if (task && task->stream) task->stream = NULL;
-            wr_answer(task && task->aggregate_keys == FLB_TRUE ? 0 : -1, NULL, 0);
+            /* 0: an aggregate task, 1: a task of flb_sp_do's other branch (sp_process_data), -1: refused */
+            wr_answer(!task ? -1 : task->aggregate_keys == FLB_TRUE ? 0 : 1, NULL, 0);
             free(sql);
         }
         else if (op == 2) {
@@ -514,6 +517,14 @@ int main(void)
             data = malloc(n + 1);
             if (n && !rd(data, n)) break;
             if (!task) { wr_answer(-1, NULL, 0); free(data); continue; }
+            if (task->aggregate_keys != FLB_TRUE) {
+                /* flb_sp.c:2059-2069, the other branch of flb_sp_do: the answer is sp_process_data's return value and buffer */
+                ret = sp_process_data("t", 1, data, n, &out, &out_size, task, sp);
+                wr_answer(ret, ret > 0 ? out : NULL, ret > 0 ? out_size : 0);
+                if (ret > 0 && out) flb_free(out);
+                free(data);
+                continue;
+            }
             /* tests/internal/stream_processor.c:92-150 (flb_sp_do_test), the aggregate branch */
             ret = sp_process_data_aggr(data, n, "t", 1, task, sp, (int) str_conv);
             if (ret != -1 && flb_sp_window_populate(task, data, n) != -1 && task->window.type == FLB_SP_WINDOW_DEFAULT) {

@@ -21,7 +21,8 @@ class RefSp:
         self.p.stdin.write(struct.pack("<IIII", 1, 1 if str_conv else 0, now[0], now[1]) + struct.pack("<I", len(q)) + q)
         self.p.stdin.flush()
         ret, _ = self._answer()
-        self.ok = ret == 0
+        self.ok = ret >= 0
+        self.select_only = ret == 1          # no aggregation function: do() answers with sp_process_data's records
 
     def _answer(self):
         h = self.p.stdout.read(12)

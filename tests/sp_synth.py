@@ -64,6 +64,8 @@ def chunk(rng, n, clean=False):
             d["code"] = rng.choice([200, 404, 503]) if clean else rng.choice([200, 404, 503, "200", "503", 0, -1])
         if not clean and rng.random() < 0.05:
             d[5] = 1
+        if not clean and rng.random() < 0.05:
+            d[rng.choice([b"host", b"bytes", b"latency", b"svc"])] = rng.choice([3, "bin key", {"name": "x", "n": 9}])   # a bin key: flb_sp_key.c:189
         items = list(d.items())
         rng.shuffle(items)
         body = msgpack.packb(dict(items), use_bin_type=True)
@@ -105,3 +107,79 @@ def config4_chunk(n, seed=0x5ca1e, base_sec=1700000000):
 
 
 CONFIG4_SQL = "SELECT status, COUNT(*), AVG(latency) FROM STREAM:x WINDOW TUMBLING (60 SECOND) GROUP BY status;"
+
+
+# SELECTs without aggregation functions: flb_sp_do's other branch, sp_process_data (flb_sp.c:1607-1850)
+SELECT_QUERIES = [
+    "SELECT * FROM STREAM:x;",
+    "SELECT host, status FROM STREAM:x;",
+    "SELECT host AS h, svc['name'], svc['n'] AS n, svc FROM TAG:'app.*' WHERE status >= 200;",
+    "SELECT *, host, bytes AS b FROM STREAM:x WHERE @record.contains(host) AND NOT (latency < 50 OR flag);",
+    "SELECT latency, blob, tags, big, nope FROM STREAM:x WHERE latency IS NOT NULL;",
+    "SELECT svc['name']['deep'], svc['missing'], host['x'] FROM STREAM:x;",
+    "CREATE STREAM sel WITH (tag='sel.out') AS SELECT code, host FROM STREAM:x WHERE @record.time() > 1700000005.5 OR host = 'cc';",
+    "SELECT status, host FROM STREAM:x WINDOW TUMBLING (5 SECOND) WHERE code < 500.5 AND code GROUP BY status;",
+    "SELECT *, k00, k01, k02 FROM STREAM:x;",
+]
+
+
+def select_chunk(rng, n, legacy=False):
+    """n records for the projections: every value class msgpack_pack_object re-packs (ints in every width -- also wider than
+    needed --, float32 / float64, str8 of a short string, bin, ext, arrays, nested maps), duplicate keys, maps of more than 15
+    entries (a map16 header to patch; a fixmap of 14 that `*` plus named keys push past 15), non-string keys"""
+    out = bytearray()
+    for i in range(n):
+        pairs = []
+        def add(k, v):
+            pairs.append(msgpack.packb(k, use_bin_type=True) + v)
+        P = lambda v: msgpack.packb(v, use_bin_type=True)
+        if rng.random() < 0.9:
+            v = rng.choice([200, 404, 500, 301, "200", True])
+            add("status", rng.choice([P(v), b"\xcd" + struct.pack(">H", v) if isinstance(v, int) and not isinstance(v, bool) else P(v)]))
+        if rng.random() < 0.85:
+            v = rng.choice([rng.random() * 100, rng.randrange(100), -3, None, "12", 2 ** 63 + 5, -2 ** 63])
+            add("latency", rng.choice([P(v), b"\xca" + struct.pack(">f", 1.5), b"\xd3" + struct.pack(">q", -7), b"\xcf" + struct.pack(">Q", 9)]))
+        if rng.random() < 0.9:
+            add("bytes", P(rng.choice([rng.randrange(10 ** 6), 7, 70000, 2 ** 33])))
+        if rng.random() < 0.8:
+            add("svc", P(rng.choice([{"name": rng.choice(["api", "db"]), "n": rng.randrange(3)}, {"name": {"deep": rng.choice([1, "x", [2]])}}, {}, "flat", {"n": None}])))
+        if rng.random() < 0.7:
+            h = rng.choice(["a", "b", "cc", "", "h" * 40])
+            add("host", rng.choice([P(h), b"\xd9" + bytes([len(h)]) + h.encode(), b"\xda" + struct.pack(">H", len(h)) + h.encode()]))
+        if rng.random() < 0.15:
+            add("flag", P(rng.choice([True, False, None])))
+        if rng.random() < 0.8:
+            add("code", P(rng.choice([200, 404, 503, "200", 0, -1])))
+        if rng.random() < 0.3:
+            add("blob", P(rng.choice([b"\x00\x01\x02", b"", b"x" * 300])))
+        if rng.random() < 0.3:
+            add("tags", P(rng.choice([[1, "a", [2.5]], [], [{"k": 1}]])))
+        if rng.random() < 0.2:
+            add("big", rng.choice([P(msgpack.ExtType(5, b"12345678")), b"\xc7\x03\x7d123", b"\xc7\x04\x07abcd", P(msgpack.ExtType(1, b"z" * 20))]))
+        if rng.random() < 0.06:
+            add(99, P(1))
+        if rng.random() < 0.06:
+            add(b"host", P("a bin key"))
+        if rng.random() < 0.1 and pairs:
+            pairs.append(rng.choice(pairs))                             # a duplicate key
+        r = rng.random()
+        if r < 0.12:
+            for j in range(rng.choice([14, 16, 20]) - len(pairs)):
+                add("k%02d" % j, P(j))
+        rng.shuffle(pairs)
+        cnt = len(pairs)
+        body = b"".join(pairs)
+        if cnt < 16 and rng.random() < 0.9:
+            hdr = bytes([0x80 | cnt])
+        elif cnt < 65536 and rng.random() < 0.9:
+            hdr = b"\xde" + struct.pack(">H", cnt)
+        else:
+            hdr = b"\xdf" + struct.pack(">I", cnt)
+        if legacy:
+            t = rng.choice([b"\xd7\x00" + struct.pack(">II", 1700000000 + i, 5), P(1700000000 + i), b"\xcb" + struct.pack(">d", 1700000000.25 + i)])
+            out += b"\x92" + t + hdr + body
+        else:
+            ts = b"\xd7\x00" + struct.pack(">II", 1700000000 + i, rng.randrange(10 ** 9))
+            meta = rng.choice([b"\x80", b"\x81\xa1m\x01", b"\xde\x00\x00"])
+            out += b"\x92\x92" + ts + meta + hdr + body
+    return bytes(out)

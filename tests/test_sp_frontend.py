@@ -80,7 +80,7 @@ def oracle_describe(sql):
         keys, gb, win, 1 if q.source_type == "tag" else 0, q.source, q.stream_name or "", " ".join(ops))
 
 
-QUERIES = sp_synth.QUERIES + sp_synth.HOPPING_QUERIES + [
+QUERIES = sp_synth.QUERIES + sp_synth.HOPPING_QUERIES + sp_synth.SELECT_QUERIES + [
     "select a.b['x']['y'] as k, count(*) , Avg(v) from tag:'t.*' window tumbling (2 minute) where not a = 1 and b <> 'it''s' or c group by a.b['x']['y'];",
     "SELECT COUNT(*) FROM STREAM:s WHERE (a > 1.5 OR NOT (b IS NOT NULL)) AND 'x' OR true AND -3 AND @record.time() >= 10;",
     "SELECT SUM(x['a']), MIN(x['a']), MAX(y) AS top FROM STREAM:s WHERE @record.contains(x['a']) != false GROUP BY z;".replace("GROUP BY z", ""),
@@ -100,7 +100,7 @@ def test_front_end_refuses_what_the_reference_refuses(L):
            "SELECT COUNT(*) FROM STREAM:FLB", "SELECT COUNT() FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WHERE time > 3;",
            "SELECT COUNT(*) FROM STREAM:s WHERE a = 99999999999;", "SELECT COUNT(*) FROM s;", "SELECT COUNT(*) FROM STREAM:s WHERE a == 1;",
            # outside this path (refused loudly rather than answered differently)
-           "SELECT * FROM STREAM:s;", "SELECT a FROM STREAM:s;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND);",
+           "SELECT a, * FROM STREAM:s;", "SELECT *, * FROM STREAM:s;", "SELECT RECORD_TAG(), a FROM STREAM:s;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND);",
            "SELECT TIMESERIES_FORECAST(a, 10) FROM STREAM:s;", "SELECT NOW(), COUNT(*) FROM STREAM:s;",
            "CREATE SNAPSHOT s AS SELECT * FROM STREAM:x LIMIT 5;"]
     for q in bad:

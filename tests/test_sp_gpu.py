@@ -5,6 +5,7 @@ hostile chunks, and -- at the bench size -- the reference binary itself (oracle/
 Bar: byte-identical records (group order, key names, value types, integers) -- except float32 fields fed by float SUM / AVG,
 where the reference adds in arrival order and the device rounds the exact sum once: those may differ by one float32 ULP
 (the tolerance north_star states for the sums)."""
+import ctypes
 import json
 import os
 import random
@@ -153,7 +154,7 @@ def test_window_life_cycle(g):
 
 
 def test_refusals(g):
-    for bad in ["SELECT id, MIN(id) FROM STREAM:FLB;", "SELECT * FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);"]:
+    for bad in ["SELECT id, MIN(id) FROM STREAM:FLB;", "SELECT id, * FROM STREAM:FLB;", "SELECT NOW() FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);"]:
         with pytest.raises(ValueError):
             g.StreamTask(bad)
     # a GROUP BY column that mixes strings and numbers inside one window: the reference's tree comparator is not an order
@@ -307,4 +308,93 @@ def test_hopping_windows(g):
     t = g.StreamTask(sp_synth.HOPPING_QUERIES[0])
     with pytest.raises(RuntimeError):
         t.export()
+    t.close()
+
+
+# ---- SELECTs without aggregation functions: flb_sp_do's other branch, sp_process_data (flb_sp.c:1607-1850).  Bit-exact.
+def test_select_reference_answers(g):
+    with open(os.path.join(HERE, "golden", "sp_select_cases.json")) as f:
+        cases = json.load(f)
+    n = 0
+    for c in cases:
+        t = g.StreamTask(c["sql"])
+        assert t.select_only and t.window == "default"
+        try:
+            for ch, (ret, out) in zip(c["chunks"], c["do"]):
+                assert t.do(bytes.fromhex(ch)) == (ret, bytes.fromhex(out)), c["sql"]
+                n += 1
+            assert t.timer() == b""
+        finally:
+            t.close()
+    assert n >= 40
+
+
+def test_select_hostile_chunks_against_the_oracle(g):
+    rng = random.Random(0x5E1)
+    compared = out_bytes = 0
+    for q in sp_synth.SELECT_QUERIES:
+        t = g.StreamTask(q)
+        o = osp.Task(q)
+        try:
+            for rep in range(6):
+                c = sp_synth.select_chunk(rng, rng.choice([1, 65, 3000]), legacy=rep == 4)
+                if rep == 5:
+                    c = c[:len(c) - rng.randrange(1, 30)]             # msgpack_unpack_next stops inside the last record
+                want = o.do(c)
+                assert t.do(c) == want, q
+                compared += 1
+                out_bytes += len(want[1])
+            assert t.do(b"") == (0, b"")
+        finally:
+            t.close()
+    assert compared >= 50 and out_bytes > 1_000_000
+
+
+def test_select_quirks(g):
+    body = {"k%02d" % i: i for i in range(14)}
+    rec = b"\x92\x92\xd7\x00" + struct.pack(">II", 7, 0) + b"\x80" + msgpack.packb(body)
+    for q in ["SELECT *, k00, k01 FROM STREAM:s;", "SELECT nope FROM STREAM:s;", "SELECT * FROM STREAM:s WHERE k00 = 5;",
+              "SELECT k03 AS x, k04, nope FROM STREAM:s WINDOW TUMBLING (5 SECOND) GROUP BY k03;"]:
+        t = g.StreamTask(q)
+        assert t.do(rec * 3) == osp.Task(q).do(rec * 3), q
+        t.close()
+    t = g.StreamTask("SELECT *, k00, k01 FROM STREAM:s;")
+    assert t.do(rec)[1][13] == 0x90                                   # 0x80 | 16 entries: the reference's fixmap patch, kept
+    # a record that is not [time, map]: the reference reads ptr[1] as a map whatever it is -- refused loudly here
+    with pytest.raises(RuntimeError):
+        t.do(b"\x92\x01\x02")
+    t.close()
+
+
+def test_select_at_size_device_resident(g):
+    """BASELINE configs[4]'s record shape, 1 M records resident in HBM: SELECT with WHERE.  The head of the output against the oracle,
+    the whole of it through properties (every record of the same length here: count and size follow from the statuses)"""
+    import numpy as np
+    data, off = sp_synth.config4_chunk(1_000_000)
+    q = "SELECT status, host AS h, latency FROM STREAM:x WHERE status >= 400;"
+    t = g.StreamTask(q)
+    L = g.lib()
+    L.flbgpu_dev_alloc.restype = ctypes.c_void_p
+    L.flbgpu_dev_alloc.argtypes = [ctypes.c_size_t]
+    L.flbgpu_dev_free.argtypes = [ctypes.c_void_p]
+    L.flbgpu_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    d_d = L.flbgpu_dev_alloc(data.nbytes + 16)
+    d_o = L.flbgpu_dev_alloc(off.nbytes)
+    L.flbgpu_memcpy_h2d(d_d, data.ctypes.data, data.nbytes)
+    L.flbgpu_memcpy_h2d(d_o, off.ctypes.data, off.nbytes)
+    ret, out = t.do_dev(g.DevChunk(d_d, d_o, 1_000_000, data.nbytes))
+    assert t.do(data.tobytes()) == (ret, out)                         # the host entry point indexes the chunk itself: same answer
+    L.flbgpu_dev_free(d_d); L.flbgpu_dev_free(d_o)
+    raw = data.reshape(1_000_000, -1)
+    RL = raw.shape[1]
+    st = raw[:, 22].astype(np.uint32) * 256 + raw[:, 23]
+    assert ret == int((st >= 400).sum())
+    one = len(osp.Task(q).do(data[:RL * 64].tobytes())[1]) // int((st[:64] >= 400).sum())
+    assert len(out) == ret * one
+    head = 20_000
+    want = osp.Task(q).do(data[:RL * head].tobytes())
+    assert out[:len(want[1])] == want[1] and want[0] == int((st[:head] >= 400).sum())
+    # the last record that leaves is the last record that passes
+    last = int(np.nonzero(st >= 400)[0][-1])
+    assert out[-one:] == osp.Task(q).do(raw[last].tobytes())[1]
     t.close()
