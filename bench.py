@@ -715,7 +715,41 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
                 e["cpu_baseline"] = {"value": round(k_ / dt_r, 1), "unit": "records/s", "cores": 1, "kind": "reference",
                                      "sample": "%d records through the reference's own flb_sp (oracle/_ref/ref_sp)" % k_, "identical_output": got_ == want_}
         out["flb_sp_group_by"] = e
-        st_.close(); L.flbgpu_dev_free(d_sd); L.flbgpu_dev_free(d_so)
+        st_.close()
+        # -- flb_sp's other branch (sp_process_data): a SELECT without aggregation functions over the same resident chunk -- WHERE + projection,
+        #    the projected records come back to the host (that copy is inside the time: it is what the call returns)
+        try:
+            SEL_SQL = "SELECT status, host AS h, latency FROM STREAM:x WHERE status >= 400;"
+            ss_ = g.StreamTask(SEL_SQL)
+            ret_s, out_s = ss_.do_dev(sch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ss_.do_dev(sch)
+            torch.cuda.synchronize()
+            dt_q = (time.perf_counter() - t0) / steps
+            es = {"records_per_s_per_gpu": round(m / dt_q, 1), "ms_per_step": round(dt_q * 1e3, 3), "query": SEL_SQL, "records_out": int(ret_s),
+                  "bytes_out": len(out_s), "note": "size pass + scan + emit pass + the D2H copy of the projected records"}
+            if rank == 0:
+                import ref_sp
+                k_ = min(m, 200_000)
+                sample = sdata[: int(soff[k_])].tobytes()
+                got_ = ss_.do(sample)
+                if ref_sp.available():
+                    rr = ref_sp.RefSp(SEL_SQL)
+                    t0 = time.perf_counter()
+                    want_ = rr.do(sample)
+                    dt_r = time.perf_counter() - t0
+                    rr.close()
+                    es["cpu_baseline"] = {"value": round(k_ / dt_r, 1), "unit": "records/s", "cores": 1, "kind": "reference",
+                                          "sample": "%d records through the reference's own sp_process_data (oracle/_ref/ref_sp)" % k_,
+                                          "identical_output": got_ == want_}
+                es["head_is_prefix_of_full_output"] = out_s[:len(got_[1])] == got_[1]
+            ss_.close()
+            out["flb_sp_select"] = es
+        except Exception as e:
+            out["flb_sp_select"] = {"error": repr(e)[:300]}
+        L.flbgpu_dev_free(d_sd); L.flbgpu_dev_free(d_so)
     except Exception as e:
         out["flb_sp_group_by"] = {"error": repr(e)[:300]}
     if "rccl" in out:

@@ -446,7 +446,7 @@ class StreamTask:
     timer of flb_sp_fd_event :2101): aggregate queries (GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING | HOPPING) and
     SELECTs without aggregation functions (keys, aliases, `*`, WHERE: sp_process_data :1607)."""
 
-    def __init__(self, sql, str_conv=True):
+    def __init__(self, sql, str_conv=True, tag=b""):
         L = lib()
         L.flbgpu_sp_create.restype = c_void_p
         L.flbgpu_sp_create.argtypes = [c_char_p, c_int]
@@ -479,7 +479,15 @@ class StreamTask:
         self.stream_name = name.value.decode() if name.value else None
         self.key_names = [L.flbgpu_sp_key_name(self.h, i).decode() for i in range(L.flbgpu_sp_key_count(self.h))]
         L.flbgpu_sp_select_only.argtypes = [c_void_p]
+        L.flbgpu_sp_set_tag.argtypes = [c_void_p, c_char_p, c_size_t]
+        L.flbgpu_sp_set_tag.restype = None
+        self.set_tag(tag)
         self.select_only = bool(L.flbgpu_sp_select_only(self.h))     # sp_process_data: do() answers (records that passed WHERE, projected records)
+
+    def set_tag(self, tag):
+        """the tag of the chunks this task is fed: what RECORD_TAG() packs"""
+        tag = _b(tag)
+        lib().flbgpu_sp_set_tag(self.h, tag, len(tag))
 
     def stream_prop(self, key):
         v = lib().flbgpu_sp_stream_prop(self.h, _b(key))

@@ -10,7 +10,8 @@
 // the kernels interpret, and package_results over the order-independent group rows the kernels maintain (dev.hpp, SpArgs).
 // A SELECT without aggregation functions (keys, aliases, `*`) is flb_sp_do's other branch, sp_process_data (:1607-1850): records in,
 // projected records out per appended chunk (sp_select.inc); WINDOW / GROUP BY are then never looked at, as in the reference.
-// Queries outside that set (TIMESERIES_FORECAST, snapshots, time / record functions as select keys) are refused at create time; inputs on
+// NOW() / UNIX_TIMESTAMP() / RECORD_TAG() / RECORD_TIME() are select keys of both branches (the caller's `now` stands for time(NULL)).
+// Queries outside that set (TIMESERIES_FORECAST, snapshots) are refused at create time; inputs on
 // which the reference's own result depends on the rb-tree's shape (a GROUP BY column mixing numbers and strings, NaN keys)
 // make the call fail instead of answering something else.
 #include <hip/hip_runtime.h>
@@ -18,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <deque>
 #include <map>
@@ -35,6 +37,8 @@ namespace {
 
 enum { F_NOP = 0, F_AVG = 1, F_SUM = 2, F_COUNT = 3, F_MIN = 4, F_MAX = 5 };
 const char *FUNC_NAME[] = {"", "AVG", "SUM", "COUNT", "MIN", "MAX"};
+enum { TF_NONE = 0, TF_NOW = 1, TF_UNIX = 2, TF_TAG = 3, TF_TIME = 4 };
+const char *TFUNC_NAME[] = {"", "NOW()", "UNIX_TIMESTAMP()", "RECORD_TAG()", "RECORD_TIME()"};
 
 // ------------------------------------------------------------------------------------------ sql.l
 enum { TK_EOF, TK_IDENT, TK_INT, TK_FLOAT, TK_STR, TK_BOOL, TK_KW, TK_CH, TK_OP, TK_BAD };
@@ -128,6 +132,7 @@ struct SelKey {
     std::string out_name;
     bool has_alias = false;
     std::string alias;
+    int tfunc = 0;              // TF_*: NOW() / UNIX_TIMESTAMP() / RECORD_TAG() / RECORD_TIME() (flb_sp_func_time.c, flb_sp_func_record.c)
     int gb = -1;
 };
 struct Node {                   // condition tree
@@ -201,6 +206,16 @@ struct Parser {
         }
         else if (is(TK_KW)) {
             const std::string f = cur().s;
+            k.tfunc = f == "NOW" ? TF_NOW : f == "UNIX_TIMESTAMP" ? TF_UNIX : f == "RECORD_TAG" ? TF_TAG : f == "RECORD_TIME" ? TF_TIME : 0;
+            if (k.tfunc) {
+                // sql.y: time_record_func '(' ')' key_alias
+                i++;
+                if (!need(TK_CH, "(") || !need(TK_CH, ")") || !alias(al, has)) return false;
+                k.out_name = has ? al : TFUNC_NAME[k.tfunc];
+                k.has_alias = has; k.alias = al;
+                q.keys.push_back(k);
+                return true;
+            }
             k.func = f == "AVG" ? F_AVG : f == "SUM" ? F_SUM : f == "COUNT" ? F_COUNT : f == "MIN" ? F_MIN : f == "MAX" ? F_MAX : 0;
             if (!k.func) return fail(f + ": not supported in a select key here");
             i++;
@@ -391,6 +406,7 @@ struct Parser {
         for (auto &k : q.keys) if (!k.func && k.star) return fail("SELECT * next to aggregation functions");
         aggr = 0;
         for (auto &k : q.keys) {
+            if (k.tfunc) continue;                  // neither kind (flb_sp.c:243-245)
             if (k.func) { aggr++; continue; }
             for (size_t g = 0; g < q.gb.size(); g++) {
                 if (k.k.name == q.gb[g].name && k.k.sub == q.gb[g].sub) { k.gb = (int) g; break; }
@@ -414,6 +430,9 @@ struct flbgpu_sp {
     std::vector<SpSelKey> sel;          // a plain SELECT: its keys in order (sp_select.inc)
     DevBuf d_slen, d_soff, d_sout;
     std::string sel_out;                // what the last appended chunk left (finish_do hands it over)
+    std::string tag;                    // RECORD_TAG(): the tag of the chunks this task sees (flbgpu_sp_set_tag)
+    std::string sel_const;              // the packed constant pairs of the current call (time / record functions)
+    DevBuf d_sconst;
     hipStream_t stream = nullptr;
     L2mState tab;                       // group dictionary + rows (the table part of the log_to_metrics state)
     DevBuf d_plan, d_gid, d_val, d_vt, d_misc, d_in, d_off;
@@ -528,6 +547,7 @@ bool compile(flbgpu_sp *t, std::string &why) {
             SpSelKey sk;
             memset(&sk, 0, sizeof(sk));
             if (k.star) sk.star = 1;
+            else if (k.tfunc) sk.star = k.tfunc == TF_TIME ? 3 : 2;      // constant bytes per call (run_select fills alias_off / alias_len)
             else {
                 const int kr = key_ref(t, b, k.k, why);
                 if (kr < 0) return false;
@@ -540,7 +560,7 @@ bool compile(flbgpu_sp *t, std::string &why) {
     }
     for (size_t i = 0; i < t->q.keys.size(); i++) {
         const SelKey &k = t->q.keys[i];
-        if (!k.func || k.star) continue;
+        if (!k.func || k.star || k.tfunc) continue;
         int kr = key_ref(t, b, k.k, why);
         if (kr < 0) return false;
         int src = -1;
@@ -615,6 +635,33 @@ void pk_int64(std::string &o, int64_t v) {
     else if (v >= -32768) { o.push_back((char) 0xd1); pk_be(o, (uint64_t) v, 2); }
     else if (v >= -(1ll << 31)) { o.push_back((char) 0xd2); pk_be(o, (uint64_t) v, 4); }
     else { o.push_back((char) 0xd3); pk_be(o, (uint64_t) v, 8); }
+}
+void pk_uint64(std::string &o, uint64_t v) {
+    if (v < 128) o.push_back((char) v);
+    else if (v < 256) { o.push_back((char) 0xcc); pk_be(o, v, 1); }
+    else if (v < 65536) { o.push_back((char) 0xcd); pk_be(o, v, 2); }
+    else if (v < (1ull << 32)) { o.push_back((char) 0xce); pk_be(o, v, 4); }
+    else { o.push_back((char) 0xcf); pk_be(o, v, 8); }
+}
+// the value half of flb_sp_func_time / flb_sp_func_record (flb_sp_func_time.c:39-83, flb_sp_func_record.c:39-63); `now` stands for
+// time(NULL) (NOW, UNIX_TIMESTAMP) and, where the reference hands over the package time, for that (RECORD_TIME of an aggregate)
+void pk_tfunc_value(std::string &o, int tfunc, const std::string &tag, uint32_t now_sec, uint32_t now_nsec) {
+    if (tfunc == TF_NOW) {
+        time_t now = (time_t) now_sec;
+        struct tm local;
+        char buf[32];
+        localtime_r(&now, &local);
+        const size_t len = strftime(buf, sizeof(buf) - 1, "%Y-%m-%d %H:%M:%S", &local);
+        pk_str(o, buf, len);
+    }
+    else if (tfunc == TF_UNIX) pk_uint64(o, now_sec);
+    else if (tfunc == TF_TAG) pk_str(o, tag.data(), tag.size());
+    else {
+        const double d = (double) now_sec + (double) now_nsec / 1000000000.0;      // flb_time_to_double
+        uint64_t b;
+        memcpy(&b, &d, 8);
+        o.push_back((char) 0xcb); pk_be(o, b, 8);
+    }
 }
 void pk_float(std::string &o, double d) {              // msgpack_pack_float: the value leaves as binary32
     float f = (float) d;
@@ -764,6 +811,7 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
         for (size_t ki = 0; ki < nk; ki++) {
             const SelKey &k = t->q.keys[ki];
             pk_str(out, k.out_name.data(), k.out_name.size());
+            if (k.tfunc) { pk_tfunc_value(out, k.tfunc, t->tag, now_sec, now_nsec); continue; }   // flb_sp.c:1199-1206 (RECORD_TIME: the package time)
             if (k.func == F_NOP) {
                 const int gi = k.gb;
                 if (gcls[gi] == 'i') pk_int64(out, (int64_t) gu[gi]);
@@ -809,18 +857,35 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
 }
 
 // a plain SELECT over one chunk: size pass, scan, emit; what leaves is kept in t->sel_out for finish_do
-bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
+bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32_t now_sec, uint32_t now_nsec) {
     uint64_t n = in->n;
     t->sel_out.clear();
     t->records = 0;
     if (n == 0) return true;
+    // time / record functions: the pair (RECORD_TIME: its key) packed once per call
+    t->sel_const.clear();
+    std::vector<SpSelKey> sel = t->sel;
+    for (size_t i = 0; i < sel.size(); i++) {
+        if (sel[i].star < 2) continue;
+        const SelKey &k = t->q.keys[i];
+        const size_t at = t->sel_const.size();
+        pk_str(t->sel_const, k.out_name.data(), k.out_name.size());
+        if (sel[i].star == 2) pk_tfunc_value(t->sel_const, k.tfunc, t->tag, now_sec, now_nsec);
+        if (t->sel_const.size() > 60000) { set_err("stream processor: time / record function pairs too long"); return false; }
+        sel[i].alias_off = (uint16_t) at; sel[i].alias_len = (uint16_t) (t->sel_const.size() - at);
+    }
+    if (!t->sel_const.empty()) {
+        if (!t->d_sconst.ensure(t->sel_const.size() + 16)) return false;
+        HIPOK(hipMemcpyAsync(t->d_sconst.p, t->sel_const.data(), t->sel_const.size(), hipMemcpyHostToDevice, st));
+    }
     if (!t->d_slen.ensure(n * 4) || !t->d_soff.ensure((n + 1) * 8) || !t->d_misc.ensure(sizeof(SpMisc)) || !t->d_gid.ensure(scan_tmp_elems(n) * 8)) return false;
     SpMisc *dm = t->d_misc.as<SpMisc>();
     SpSelArgs a;
     memset(&a, 0, sizeof(a));
     a.data = (const uint8_t *) in->data; a.row_off = in->row_off; a.bytes = in->bytes; a.plan = t->d_plan.as<SpPlan>();
-    a.nsel = (int) t->sel.size();
-    for (int i = 0; i < a.nsel; i++) a.sel[i] = t->sel[(size_t) i];
+    a.nsel = (int) sel.size();
+    for (int i = 0; i < a.nsel; i++) a.sel[i] = sel[(size_t) i];
+    a.consts = t->d_sconst.as<uint8_t>();
     a.out_len = t->d_slen.as<uint32_t>(); a.out_off = t->d_soff.as<uint64_t>();
     a.first_bad = &dm->first_bad; a.records = &dm->counts[0]; a.flags = &dm->flags;
     SpMisc hm;
@@ -852,8 +917,8 @@ bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
     return true;
 }
 
-bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st) {
-    if (t->q.select_only) return run_select(t, in, st);
+bool run_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32_t now_sec, uint32_t now_nsec) {
+    if (t->q.select_only) return run_select(t, in, st, now_sec, now_nsec);
     L2mState &s = t->tab;
     const SpPlan &pl = t->plan;
     const uint64_t n = in->n;
@@ -1135,7 +1200,7 @@ extern "C" void flbgpu_sp_destroy(flbgpu_sp *t) {
     if (!t) return;
     L2mState &s = t->tab;
     DevBuf *all[] = {&s.d_slot_hash, &s.d_slot_sid, &s.d_arena, &s.d_key_off, &s.d_key_len, &s.d_series_hash, &s.d_rows, &s.d_ctr,
-                     &t->d_plan, &t->d_gid, &t->d_val, &t->d_vt, &t->d_misc, &t->d_in, &t->d_off, &t->d_slen, &t->d_soff, &t->d_sout};
+                     &t->d_plan, &t->d_gid, &t->d_val, &t->d_vt, &t->d_misc, &t->d_in, &t->d_off, &t->d_slen, &t->d_soff, &t->d_sout, &t->d_sconst};
     for (auto *b : all) b->release();
     for (auto &e : t->ev) if (e) (void) hipEventDestroy(e);
     if (t->stream) (void) hipStreamDestroy(t->stream);
@@ -1161,6 +1226,7 @@ extern "C" int flbgpu_sp_key_count(const flbgpu_sp *t) { return t ? (int) t->q.k
 extern "C" const char *flbgpu_sp_key_name(const flbgpu_sp *t, int i) {
     return (t && i >= 0 && (size_t) i < t->q.keys.size()) ? t->q.keys[i].out_name.c_str() : nullptr;
 }
+extern "C" void flbgpu_sp_set_tag(flbgpu_sp *t, const char *tag, size_t len) { if (t) t->tag.assign(tag ? tag : "", tag ? len : 0); }
 extern "C" int flbgpu_sp_select_only(const flbgpu_sp *t) { return t && t->q.select_only ? 1 : 0; }
 extern "C" void flbgpu_sp_set_index_base(flbgpu_sp *t, uint64_t base) { if (t) t->idx_base = base; }
 
@@ -1168,7 +1234,7 @@ extern "C" int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *
                                 size_t *out_size, int64_t *records) {
     if (!t || !in) { set_err("stream processor: null argument"); return -1; }
     hipStream_t st = stream ? (hipStream_t) stream : t->stream;
-    if (!run_dev(t, in, st)) return -1;
+    if (!run_dev(t, in, st, now_sec, now_nsec)) return -1;
     return finish_do(t, now_sec, now_nsec, out_buf, out_size, records);
 }
 
@@ -1191,7 +1257,7 @@ extern "C" int flbgpu_sp_do(flbgpu_sp *t, const void *data, size_t bytes, uint32
         HIPOK(hipMemcpyAsync(t->d_off.p, off.data(), ((size_t) n + 1) * 8, hipMemcpyHostToDevice, t->stream));
         flbgpu_dev_chunk ch;
         ch.data = t->d_in.p; ch.row_off = t->d_off.as<uint64_t>(); ch.n = (uint64_t) n; ch.bytes = consumed;
-        if (!run_dev(t, &ch, t->stream)) return -1;
+        if (!run_dev(t, &ch, t->stream, now_sec, now_nsec)) return -1;
     }
     return finish_do(t, now_sec, now_nsec, out_buf, out_size, records);
 }

@@ -7,12 +7,16 @@
 
 namespace flbgpu {
 
-struct SpSelKey { uint8_t star, key, has_alias, pad; uint16_t alias_off, alias_len; };     // key: index into SpPlan::keys; alias: in SpPlan::blob
+// star 0: a named key (key: index into SpPlan::keys; alias: in SpPlan::blob) / 1: `*` / 2: a pair that is constant for the call (NOW(),
+// UNIX_TIMESTAMP(), RECORD_TAG(): packed key + value at consts[alias_off..]) / 3: RECORD_TIME() (packed key at consts[alias_off..], then
+// the record's own time as a float64)
+struct SpSelKey { uint8_t star, key, has_alias, pad; uint16_t alias_off, alias_len; };
 struct SpSelArgs {
     const uint8_t *data; const uint64_t *row_off; uint64_t n, bytes;
     const SpPlan *plan;                 // keys + the WHERE program (device memory)
     int nsel;
     SpSelKey sel[SP_MAX_KEYS];
+    const uint8_t *consts;
     uint32_t *out_len;                  // [n] bytes the record leaves (0: filtered out, or no selected key found in it)
     const uint64_t *out_off;
     uint8_t *out;

@@ -309,7 +309,8 @@ int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_of
  * key IS [NOT] NULL, NOT / AND / OR / parentheses with the reference's (precedence-less, right-associative) binding.
  * str_conv = the engine's stream_processor_str_conv (src/flb_config.c:482, default on): numeric strings count as numbers.
  * NULL (flbgpu_last_error says why) for what flb_sp_task_create rejects and for what this path does not take:
- * TIMESERIES_FORECAST, time / record functions as select keys, snapshots, a HOPPING window that advances by its size or more.
+ * TIMESERIES_FORECAST, snapshots, a HOPPING window that advances by its size or more.  NOW() / UNIX_TIMESTAMP() / RECORD_TAG() /
+ * RECORD_TIME() are select keys of both kinds of task; the `now` of the calls below stands for the reference's time(NULL).
  * A SELECT without aggregation functions -- SELECT key [AS alias] | key['sub'] | *, ... [WHERE condition] -- is flb_sp_do's other
  * branch, sp_process_data (flb_sp.c:1607-1850): every appended chunk answers with the projected records, [record's own time
  * element, {selected pairs}], in *out_buf, *records = the records that passed WHERE; WINDOW / GROUP BY are ignored there as in
@@ -325,6 +326,7 @@ void flbgpu_sp_destroy(flbgpu_sp *t);
  * window_sec seconds) / 2 hopping (see flbgpu_sp_hop); source_type 0 STREAM: / 1 TAG:; stream_name NULL unless CREATE STREAM */
 int flbgpu_sp_info(const flbgpu_sp *t, int *window_type, int64_t *window_sec, int *source_type, const char **source, const char **stream_name);
 const char *flbgpu_sp_stream_prop(const flbgpu_sp *t, const char *key);        /* WITH (tag='...') */
+void flbgpu_sp_set_tag(flbgpu_sp *t, const char *tag, size_t len);   /* what RECORD_TAG() packs: the tag flb_sp_do is called with (default "") */
 int flbgpu_sp_select_only(const flbgpu_sp *t);      /* 1: no aggregation function (task->aggregate_keys off, flb_sp.c:491): flbgpu_sp_do hands back records */
 int flbgpu_sp_key_count(const flbgpu_sp *t);
 const char *flbgpu_sp_key_name(const flbgpu_sp *t, int i);                     /* output name: alias, "AVG(k)", "k['a']" */

@@ -17,8 +17,7 @@ the I64 -> F64 switch of a sum at the first non-zero float):
 Pinned on the reference itself: tests/test_sp_oracle.py runs the same queries over the same chunks through
 oracle/_ref/ref_sp (the reference's own sources compiled in place) and wants identical bytes.
 
-Not restated (Unsupported is raised, the product refuses the same queries): TIMESERIES_FORECAST, snapshots,
-time / record functions as select keys; a GROUP BY column whose values mix number / string classes in one window (the reference's rb-tree
+Not restated (Unsupported is raised, the product refuses the same queries): TIMESERIES_FORECAST, snapshots; a GROUP BY column whose values mix number / string classes in one window (the reference's rb-tree
 comparator is not an order there: flb_sp_groupby.c:77 "Sides have different types -> -1", and it rewrites nodes in place :37-44).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file."""
@@ -95,12 +94,18 @@ def tokenize(sql):
     return out
 
 
+TFUNC_NAMES = {"NOW": "NOW()", "UNIX_TIMESTAMP": "UNIX_TIMESTAMP()", "RECORD_TAG": "RECORD_TAG()", "RECORD_TIME": "RECORD_TIME()"}
+
+
 class Key:
-    def __init__(self, func, name, subkeys, alias):
+    def __init__(self, func, name, subkeys, alias, tfunc=None):
         self.func, self.name, self.subkeys = func, name, subkeys       # func 0 = plain key; name None = '*'
         self.alias = alias
+        self.tfunc = tfunc                                             # NOW / UNIX_TIMESTAMP / RECORD_TAG / RECORD_TIME
         self.gb = None
-        if alias is not None:
+        if tfunc is not None:
+            self.out_name = alias if alias is not None else TFUNC_NAMES[tfunc]
+        elif alias is not None:
             self.out_name = alias
         elif subkeys:
             base = name + "".join("['%s']" % s for s in subkeys)
@@ -128,6 +133,8 @@ class Query:
     def finish(self):
         aggr = not_aggr = 0
         for k in self.keys:
+            if k.tfunc is not None:
+                continue                                                # neither kind (flb_sp.c:243-245)
             if k.func:
                 aggr += 1
                 continue
@@ -209,7 +216,14 @@ class _P:
             f = self.cur()[1]
             code = {"AVG": 1, "SUM": 2, "COUNT": 3, "MIN": 4, "MAX": 5}.get(f)
             if code is None:
-                if f in ("TIMESERIES_FORECAST", "NOW", "UNIX_TIMESTAMP", "RECORD_TAG", "RECORD_TIME"):
+                if f in TFUNC_NAMES:
+                    # sql.y: time_record_func '(' ')' key_alias
+                    self.adv()
+                    self.need("ch", "(")
+                    self.need("ch", ")")
+                    q.keys.append(Key(0, None, None, self.alias(), tfunc=f))
+                    return
+                if f == "TIMESERIES_FORECAST":
                     raise Unsupported(f)
                 raise ParseError("unexpected " + f)
             self.adv()
@@ -755,10 +769,24 @@ def _wrap(i):
     return (i + 2 ** 63) % 2 ** 64 - 2 ** 63
 
 
+def _tfunc_value(tfunc, tag, now):
+    """the value half of flb_sp_func_time.c:39-83 / flb_sp_func_record.c:39-63; `now` stands for time(NULL) and, for RECORD_TIME
+    of a packaged aggregate, for the package time"""
+    import time as _time
+    if tfunc == "NOW":
+        return _pack_str(_time.strftime("%Y-%m-%d %H:%M:%S", _time.localtime(now[0])).encode())
+    if tfunc == "UNIX_TIMESTAMP":
+        return _pack_int(now[0])
+    if tfunc == "RECORD_TAG":
+        return _pack_str(tag)
+    return b"\xcb" + struct.pack(">d", float(now[0]) + float(now[1]) / 1000000000.0)
+
+
 class Task:
-    def __init__(self, sql, str_conv=True):
+    def __init__(self, sql, str_conv=True, now=(1, 0), tag=b"t"):
         self.q = parse(sql) if isinstance(sql, str) else sql
         self.conv = str_conv
+        self.now, self.tag = now, tag                                  # time(NULL) and the tag of the chunks (time / record functions)
         self._reset()
 
     def _reset(self):
@@ -866,6 +894,15 @@ class Task:
             body = bytearray()
             entries = 0
             for ck in q.keys:
+                if ck.tfunc is not None:
+                    # flb_sp_func_time / flb_sp_func_record (:1732-1746): one entry whatever the record holds
+                    body += _pack_str(ck.out_name.encode())
+                    if ck.tfunc == "RECORD_TIME":
+                        body += b"\xcb" + struct.pack(">d", time_to_double(ts))
+                    else:
+                        body += _tfunc_value(ck.tfunc, self.tag, self.now)
+                    entries += 1
+                    continue
                 for ks, vs, ve in pairs:
                     kk, kv, _n = _raw_tok(rec, ks)
                     if kk != "str":
@@ -981,6 +1018,9 @@ class Task:
             rec += p.pack_map_header(n)
             for ki, ck in enumerate(self.q.keys):
                 rec += _pack_str(ck.out_name.encode())
+                if ck.tfunc is not None:
+                    rec += _tfunc_value(ck.tfunc, self.tag, now)           # flb_sp.c:1199-1206 (time(NULL) == the package time here)
+                    continue
                 num = node["nums"][ki]
                 if ck.gb is not None and node["gb"] is not None:
                     num = node["gb"][ck.gb]

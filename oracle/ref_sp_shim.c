@@ -62,6 +62,8 @@ void flb_sp_stream_destroy(struct flb_sp_stream *stream, struct flb_sp *sp) { (v
 /* ---- the clock of package_results */
 static struct flb_time g_now;
 int __wrap_flb_time_get(struct flb_time *tm) { *tm = g_now; return 0; }
+/* NOW() / UNIX_TIMESTAMP() read time(NULL) (flb_sp_func_time.c:54,75): the same given time */
+time_t __wrap_time(time_t *t) { if (t) *t = g_now.tm.tv_sec; return g_now.tm.tv_sec; }
 
 /* ---- parser/sql.l + sql.y by hand (see the header of this file) */
 typedef void *yyscan_t;

@@ -14,6 +14,8 @@ QUERIES = [
     "SELECT MIN(bytes), MAX(bytes), SUM(bytes), AVG(bytes) FROM STREAM:x WHERE host = 'cc' OR host <= 'a' OR bytes <> 7;",
     "CREATE STREAM agg WITH (tag='agg.out') AS SELECT host, COUNT(*) FROM STREAM:x WHERE flag IS NULL AND host != '' GROUP BY host;",
     "SELECT code, COUNT(*), SUM(code) FROM STREAM:x WINDOW TUMBLING (2 HOUR) WHERE code < 500.5 AND code GROUP BY code;",
+    # time / record functions next to aggregates (package_results, flb_sp.c:1199-1206)
+    "SELECT host, NOW() AS n, COUNT(*), RECORD_TAG(), UNIX_TIMESTAMP(), RECORD_TIME() AS rt FROM STREAM:x WINDOW TUMBLING (5 SECOND) GROUP BY host;",
 ]
 
 
@@ -120,6 +122,8 @@ SELECT_QUERIES = [
     "CREATE STREAM sel WITH (tag='sel.out') AS SELECT code, host FROM STREAM:x WHERE @record.time() > 1700000005.5 OR host = 'cc';",
     "SELECT status, host FROM STREAM:x WINDOW TUMBLING (5 SECOND) WHERE code < 500.5 AND code GROUP BY status;",
     "SELECT *, k00, k01, k02 FROM STREAM:x;",
+    "SELECT NOW(), UNIX_TIMESTAMP() AS u, RECORD_TAG(), RECORD_TIME() AS rt, host FROM STREAM:x WHERE status >= 200;",
+    "SELECT RECORD_TIME() FROM STREAM:x;",
 ]
 
 

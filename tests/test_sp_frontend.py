@@ -100,8 +100,8 @@ def test_front_end_refuses_what_the_reference_refuses(L):
            "SELECT COUNT(*) FROM STREAM:FLB", "SELECT COUNT() FROM STREAM:FLB;", "SELECT COUNT(*) FROM STREAM:s WHERE time > 3;",
            "SELECT COUNT(*) FROM STREAM:s WHERE a = 99999999999;", "SELECT COUNT(*) FROM s;", "SELECT COUNT(*) FROM STREAM:s WHERE a == 1;",
            # outside this path (refused loudly rather than answered differently)
-           "SELECT a, * FROM STREAM:s;", "SELECT *, * FROM STREAM:s;", "SELECT RECORD_TAG(), a FROM STREAM:s;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND);",
-           "SELECT TIMESERIES_FORECAST(a, 10) FROM STREAM:s;", "SELECT NOW(), COUNT(*) FROM STREAM:s;",
+           "SELECT a, * FROM STREAM:s;", "SELECT *, * FROM STREAM:s;", "SELECT NOW(), * FROM STREAM:s;", "SELECT NOW FROM STREAM:s;", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND, ADVANCE BY 5 SECOND);", "SELECT COUNT(*) FROM STREAM:s WINDOW HOPPING (5 SECOND);",
+           "SELECT TIMESERIES_FORECAST(a, 10) FROM STREAM:s;", "SELECT NOW(), a, COUNT(*) FROM STREAM:s;",
            "CREATE SNAPSHOT s AS SELECT * FROM STREAM:x LIMIT 5;"]
     for q in bad:
         assert describe(L, q) is None, q

@@ -10,6 +10,10 @@ import sys
 import msgpack
 import pytest
 
+os.environ["TZ"] = "UTC"          # NOW() formats localtime: the committed answers were written under UTC
+import time as _time
+_time.tzset()
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
