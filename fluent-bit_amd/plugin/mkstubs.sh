@@ -21,5 +21,5 @@ printf '#ifndef CIO_INFO_H\n#define CIO_INFO_H\n#define CIO_HAVE_BACKEND_FILESYS
 for lib in cfl:CFL:cfl cmetrics:CMT:cmt ctraces:CTR:ctr cprofiles:CPROF:cprof; do
   IFS=: read d P p <<< "$lib"
   printf "#ifndef ${P}_VERSION_H\n#define ${P}_VERSION_H\n#define ${P}_VERSION_MAJOR 0\n#define ${P}_VERSION_MINOR 0\n#define ${P}_VERSION_PATCH 0\n#define ${P}_VERSION_STR \"0\"\n#endif\n" > $T/$d/${p}_version.h
-  printf "#ifndef ${P}_INFO_H\n#define ${P}_INFO_H\n#define CFL_HAVE_TIMESPEC_GET 1\n#define CFL_HAVE_GMTIME_R 1\n#define CFL_HAVE_CLOCK_GET_TIME 1\n#endif\n" > $T/$d/${p}_info.h
+  printf "#ifndef ${P}_INFO_H\n#define ${P}_INFO_H\n#define CFL_HAVE_TIMESPEC_GET 1\n#define CFL_HAVE_GMTIME_R 1\n#define CMT_HAVE_TIMESPEC_GET 1\n#define CMT_HAVE_GMTIME_R 1\n#endif\n" > $T/$d/${p}_info.h
 done

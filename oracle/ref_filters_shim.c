@@ -19,6 +19,9 @@
  *   kind 4 (in_tail's line packing): props = key, path_key, path, offset_key, stream_offset, skip_empty_lines, sec, nsec; data = text:
  *   the loop of process_content (plugins/in_tail/tail_file.c:783-786,840-1000, plain path) restated here, every line packed by the
  *   REAL encoder through flb_tail_file_pack_line's call sequence (:552-604); answer ret = lines, out = records, then u64 processed
+ *   kind 6 (filter_log_to_metrics, plugins/filter_log_to_metrics/log_to_metrics.c + lib/cmetrics + lib/cfl compiled in place): props = the
+ *   plugin's own properties; data = chunks, each behind a u64 length; the answer is described at run_log_to_metrics.  The emitter input
+ *   and the flush timer cb_init asks the engine for are stubs (see below): records in, cmetrics state out is what is pinned.
  *   kind 5 (multiline, src/multiline/*.c compiled in place): props = type regex|endswith|equal, match_string, negate, key_content, buffer_limit,
  *   builtin (java|go|python|ruby: the built-in parser of that name instead of rules), rule (repeated: from_states \x1f regex \x1f to_state),
  *   skip_empty_lines, final_flush; data = frames (u32 sec, u32 nsec, u32 len, text): every frame is what one read of in_tail appends to
@@ -52,8 +55,37 @@
 #include <fluent-bit/multiline/flb_ml_parser.h>
 #include <fluent-bit/multiline/flb_ml_rule.h>
 
+#include <fluent-bit/flb_input.h>
+#include <fluent-bit/flb_scheduler.h>
+#include <cmetrics/cmetrics.h>
+#include <cmetrics/cmt_counter.h>
+#include <cmetrics/cmt_gauge.h>
+#include <cmetrics/cmt_histogram.h>
+#include <cmetrics/cmt_map.h>
+#include <cmetrics/cmt_metric.h>
+#include "log_to_metrics.h"
+
 extern struct flb_filter_plugin filter_grep_plugin;
 extern struct flb_filter_plugin filter_parser_plugin;
+extern struct flb_filter_plugin filter_log_to_metrics_plugin;
+
+/* ---- what cb_log_to_metrics_init asks of the engine (plugins/filter_log_to_metrics/log_to_metrics.c:873-968): an emitter input and a
+ * timer.  Neither is on the path that is pinned here -- records in, cmetrics state out --: the input is a zeroed instance nobody runs,
+ * the timer is never armed, appended metric contexts are counted. */
+static int g_metrics_appended;
+int flb_input_name_exists(const char *name, struct flb_config *config) { (void) name; (void) config; return FLB_FALSE; }
+struct flb_input_instance *flb_input_new(struct flb_config *config, const char *input, void *data, int public_only)
+{ (void) config; (void) input; (void) data; (void) public_only; return flb_calloc(1, sizeof(struct flb_input_instance)); }
+int flb_input_set_property(struct flb_input_instance *ins, const char *k, const char *v) { (void) ins; (void) k; (void) v; return 0; }
+int flb_input_instance_init(struct flb_input_instance *ins, struct flb_config *config) { (void) ins; (void) config; return 0; }
+int flb_storage_input_create(struct cio_ctx *cio, struct flb_input_instance *in) { (void) cio; (void) in; return 0; }
+struct flb_sched *flb_sched_ctx_get(void) { static long fake; return (struct flb_sched *) &fake; }
+int flb_sched_timer_cb_create(struct flb_sched *sched, int type, int ms, void (*cb)(struct flb_config *, void *), void *data, struct flb_sched_timer **out_timer)
+{ (void) sched; (void) type; (void) ms; (void) cb; (void) data; if (out_timer) *out_timer = NULL; return 0; }
+int flb_sched_timer_cb_disable(struct flb_sched_timer *timer) { (void) timer; return 0; }
+int flb_sched_timer_destroy(struct flb_sched_timer *timer) { (void) timer; return 0; }
+int flb_input_metrics_append(struct flb_input_instance *ins, const char *tag, size_t tag_len, struct cmt *cmt)
+{ (void) ins; (void) tag; (void) tag_len; (void) cmt; g_metrics_appended++; return 0; }
 
 /* ---- the logger: the worker context stays NULL and the print hooks do nothing */
 FLB_TLS_DEFINE(struct flb_worker, flb_worker_ctx);
@@ -266,6 +298,82 @@ static struct mk_list *make_decoders(const char *spec)
     return list;
 }
 
+/* ---- kind 6: filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c compiled in place, the real cmetrics under it).
+ * data = chunks, each behind a u64 length: cb_filter runs once per chunk on the same instance.  Answer: i32 ret of the LAST call (-100:
+ * cb_init failed), then  u32 nchunks, per chunk i32 ret + u64 out_size;  u32 mode, u32 timer_mode, u32 metrics appended, u32 label keys +
+ * strings, u32 buckets + f64 bounds, u32 series, per series: the label strings, f64 value | u64 buckets[nb + 1], u64 count, f64 sum --
+ * the metric's map in list order (a map without label keys: its one static metric once it is set). */
+static void wb(char **b, size_t *n, size_t *cap, const void *p, size_t len)
+{
+    if (*n + len > *cap) { *cap = (*n + len) * 2 + 256; *b = realloc(*b, *cap); }
+    memcpy(*b + *n, p, len); *n += len;
+}
+static void wb_u32(char **b, size_t *n, size_t *cap, uint32_t v) { wb(b, n, cap, &v, 4); }
+static void wb_str(char **b, size_t *n, size_t *cap, const char *s) { uint32_t l = s ? (uint32_t) strlen(s) : 0; wb_u32(b, n, cap, l); if (l) wb(b, n, cap, s, l); }
+
+static void run_log_to_metrics(struct flb_config *config, uint32_t nprops, char **keys, char **vals, const char *data, uint64_t dlen)
+{
+    struct inst it;
+    struct log_to_metrics_ctx *ctx;
+    struct cmt_map *map;
+    struct cfl_list *head, *lh;
+    char *b = NULL;
+    size_t n = 0, cap = 0, at = 0, cnt_at;
+    uint32_t nchunks = 0, nb = 0, ns = 0, i;
+    int32_t last = 0;
+    g_metrics_appended = 0;
+    inst_open(&it, config, &filter_log_to_metrics_plugin, nprops, keys, vals);
+    if (!it.ok) { wr_answer(-100, NULL, 0); return; }
+    ctx = it.ins.context;
+    cnt_at = n; wb_u32(&b, &n, &cap, 0);
+    while (at + 8 <= dlen) {
+        uint64_t len;
+        void *out = NULL;
+        size_t out_size = 0;
+        uint64_t o64;
+        memcpy(&len, data + at, 8); at += 8;
+        if (at + len > dlen) break;
+        last = it.ins.p->cb_filter(data + at, len, "t", 1, &out, &out_size, &it.ins, NULL, it.ins.context, config);
+        at += len;
+        o64 = out_size;
+        wb(&b, &n, &cap, &last, 4); wb(&b, &n, &cap, &o64, 8);
+        nchunks++;
+    }
+    memcpy(b + cnt_at, &nchunks, 4);
+    wb_u32(&b, &n, &cap, (uint32_t) ctx->mode); wb_u32(&b, &n, &cap, (uint32_t) ctx->timer_mode); wb_u32(&b, &n, &cap, (uint32_t) g_metrics_appended);
+    map = ctx->mode == FLB_LOG_TO_METRICS_COUNTER ? ctx->c->map : ctx->mode == FLB_LOG_TO_METRICS_GAUGE ? ctx->g->map : ctx->h->map;
+    wb_u32(&b, &n, &cap, (uint32_t) map->label_count);
+    cfl_list_foreach(head, &map->label_keys) wb_str(&b, &n, &cap, cfl_list_entry(head, struct cmt_map_label, _head)->name);
+    if (ctx->mode == FLB_LOG_TO_METRICS_HISTOGRAM) {
+        nb = (uint32_t) ctx->histogram_buckets->count;
+        wb_u32(&b, &n, &cap, nb);
+        wb(&b, &n, &cap, ctx->histogram_buckets->upper_bounds, 8 * (size_t) nb);
+    }
+    else wb_u32(&b, &n, &cap, 0);
+    if (map->label_count == 0) ns = map->metric_static_set ? 1 : 0;
+    else ns = (uint32_t) cfl_list_size(&map->metrics);
+    wb_u32(&b, &n, &cap, ns);
+    for (i = 0; i < ns; i++) {
+        struct cmt_metric *mt = NULL;
+        uint32_t k = 0;
+        if (map->label_count == 0) mt = &map->metric;
+        else cfl_list_foreach(head, &map->metrics) { if (k++ == i) { mt = cfl_list_entry(head, struct cmt_metric, _head); break; } }
+        if (map->label_count) cfl_list_foreach(lh, &mt->labels) wb_str(&b, &n, &cap, cfl_list_entry(lh, struct cmt_map_label, _head)->name);
+        if (ctx->mode != FLB_LOG_TO_METRICS_HISTOGRAM) { double v = cmt_metric_get_value(mt); wb(&b, &n, &cap, &v, 8); }
+        else {
+            uint32_t q;
+            uint64_t c;
+            double sm;
+            for (q = 0; q <= nb; q++) { uint64_t bv = cmt_metric_hist_get_value(mt, (int) q); wb(&b, &n, &cap, &bv, 8); }
+            c = cmt_metric_hist_get_count_value(mt); wb(&b, &n, &cap, &c, 8);
+            sm = cmt_metric_hist_get_sum_value(mt); wb(&b, &n, &cap, &sm, 8);
+        }
+    }
+    wr_answer(last, b, n);
+    free(b);
+    if (it.ins.p->cb_exit) it.ins.p->cb_exit(it.ins.context, config);
+}
+
 /* ---- kind 5: the multiline core behind in_tail's line loop */
 /* linked with --wrap=flb_time_get: a group flushed before any time was registered takes "now" (flb_ml.c:1619-1624); the case names it */
 int __real_flb_time_get(struct flb_time *tm);
@@ -427,6 +535,7 @@ int main(void)
             wr_answer(ret, out, ret == FLB_FILTER_MODIFIED ? out_size : 0);
         }
         else if (kind == 5) run_multiline(config, nprops, keys, vals, data, dlen);
+        else if (kind == 6) run_log_to_metrics(config, nprops, keys, vals, data, dlen);
         else if (kind == 4) {
             const char *key = "log", *path_key = NULL, *path = "", *offset_key = NULL;
             uint64_t stream_offset = 0, processed = 0;

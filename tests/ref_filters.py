@@ -114,3 +114,58 @@ def ml_case(frames, rules=None, builtin=None, type="regex", match_string=None, n
         props.append(("rule", b"\x1f".join(x if isinstance(x, bytes) else x.encode() for x in (fs, rx, to or ""))))
     data = b"".join(struct.pack("<III", s, ns, len(t)) + t for s, ns, t in frames)
     return _case(5, props, [], data)
+
+
+def l2m_case(mode, props, chunks, kubernetes_mode=False, value_field=None, discard_logs=False, extra=()):
+    """filter_log_to_metrics: the reference's own plugin (plugins/filter_log_to_metrics/log_to_metrics.c over the real cmetrics).
+    `props` as oracle_binding.L2M takes them (regex / exclude / label_field / add_label / bucket in configuration order); one
+    cb_filter call per chunk on one instance"""
+    p = [("metric_mode", mode), ("metric_name", "m"), ("metric_description", "d"), ("tag", "metrics")] + [(k, v) for k, v in props]
+    if kubernetes_mode:
+        p.append(("kubernetes_mode", "true"))
+    if value_field is not None:
+        p.append(("value_field", value_field))
+    if discard_logs:
+        p.append(("discard_logs", "true"))
+    p += list(extra)
+    data = b"".join(struct.pack("<Q", len(c)) + bytes(c) for c in chunks)
+    return _case(6, p, [], data)
+
+
+def l2m_result(res):
+    """-> None when cb_init refused, else dict(rets=[(ret, out_size)], mode, timer_mode, appended, keys, bounds, series) with series as
+    oracle_binding.L2M.snapshot() lists them"""
+    ret, b = res
+    if ret == -100:
+        return None
+    o = 0
+    def u32():
+        nonlocal o
+        v = struct.unpack_from("<I", b, o)[0]; o += 4
+        return v
+    def s():
+        nonlocal o
+        n = u32()
+        v = b[o:o + n]; o += n
+        return v
+    nch = u32()
+    rets = []
+    for _ in range(nch):
+        r, sz = struct.unpack_from("<iQ", b, o); o += 12
+        rets.append((r, sz))
+    mode, timer_mode, appended = u32(), u32(), u32()
+    keys = [s().decode("latin1") for _ in range(u32())]
+    nb = u32()
+    bounds = list(struct.unpack_from("<%dd" % nb, b, o)); o += 8 * nb
+    series = []
+    for _ in range(u32()):
+        labels = tuple(s() for _ in keys)
+        if mode != 2:
+            v = struct.unpack_from("<d", b, o)[0]; o += 8
+            series.append(dict(labels=labels, value=v, buckets=[0], count=0, sum=0.0))
+        else:
+            bk = list(struct.unpack_from("<%dQ" % (nb + 1), b, o)); o += 8 * (nb + 1)
+            cnt, sm = struct.unpack_from("<Qd", b, o); o += 16
+            series.append(dict(labels=labels, value=0.0, buckets=bk, count=cnt, sum=sm))
+    assert o == len(b), (o, len(b))
+    return dict(rets=rets, mode=mode, timer_mode=timer_mode, appended=appended, keys=keys, bounds=bounds, series=series)
