@@ -53,6 +53,13 @@ struct DevFx {
     int ok;                        // 0: the pattern has no compact tables (classic kernels only)
     uint32_t pair_bias, ncls1;     // pair tables (fx.cpp build_fx pair = true): an entry names a row by the address of its pair section, the
                                    // single-step cells sit pair_bias = ncls1 * 4 bytes in front of it; 0: single-step rows only
+    // The tail of the pattern (fx.cpp find_tail): rows at addresses >= tail_min (they sit last, in front of the two absorbing rows) form a
+    // set the walk cannot leave except through a "kill" byte (>= 0x80, or one of kill[0 .. nkill-1]) and in which the row after a byte
+    // depends on that byte alone -- `(?<message>.*)$`, `"(?<agent>.*)")?$`.  Once every lane of a wave stands there (or in an absorbing
+    // row) the rest of the text needs no steps: no kill byte in it, then the last byte and the end-of-text column decide.
+    // tail_min == absorb_off: no such set (the walk still ends early when every lane is absorbed).
+    uint32_t tail_min, nkill;
+    uint8_t kill[4];
 };
 constexpr uint32_t FX_SLOT_SHIFT = 16, FX_ROW_MASK = 0xFFFFu, FX_LOOK = 0x80000000u, FX_PAIR = 0xC0000000u;
 constexpr uint32_t FX2_LOOK3 = 0x80000000u, FX2_SPECIAL = 0xC0000000u;      // kinds of a pair cell (bit 31 clear: next row | slot 1 << 16 | slot 2 << 24)

@@ -1,6 +1,8 @@
 // fx.cpp -- compact forward tables of the single-pass tile kernel (dev.hpp DevFx): builder + a host execution of the
 // SAME tables with the kernel's rules (sentinel byte, result slots), so that the CPU-only tests can check the table
 // transformation against the golden vectors of the real engine.  Host only; the filters never call the simulation.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,6 +87,127 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
             ft2[m * r2stride + c] = v;
         }
     if (!fits) return true;
+    // ---- the tail (DevFx::tail_min): a set Q of rows, closed under every byte class outside a small kill set K, in which all rows hold
+    // the SAME plain entry per class (the row after a byte depends on the byte alone), with a class whose end-of-text step reports a
+    // match (a tail, not a field in the middle), and whose capture writes do not outlive the last byte: every class behind which the text
+    // may end in a match writes the one slot the set writes at all.  Chosen: fewest kill bytes, then the larger set.  The rows of Q move
+    // to the end of the table so that "row address >= tail_min" is the test.
+    std::vector<uint32_t> tail_rows;
+    std::vector<uint8_t> tail_kill;
+    if (!pair) {
+        auto row_of = [&](uint32_t at) -> uint32_t { return (at - ft_at) / rowb; };
+        // slots an entry writes (a pair entry: two); `end` = it reports a match
+        auto slots_of = [&](uint32_t v, uint32_t *sl) -> int {
+            if (!(v & 0x80000000u)) { sl[0] = (v >> FX_SLOT_SHIFT) / 128u; return 1; }
+            const uint32_t k = v & 0x3FFFFFFFu;
+            sl[0] = (p2[2 * k] >> FX_SLOT_SHIFT) / 128u; sl[1] = p2[2 * k + 1] / 128u;
+            return 2;
+        };
+        auto next_of = [&](uint32_t v) -> uint32_t { return row_of(((v & 0x80000000u) ? p2[2 * (v & 0x3FFFFFFFu)] : v) & FX_ROW_MASK); };
+        auto is_look = [&](uint32_t v) -> bool { return (v & FX_PAIR) == FX_LOOK; };
+        size_t best_kill = 99;
+        for (uint32_t r0 = 0; r0 < nrows; r0++) {
+            std::vector<uint32_t> Q{r0};
+            std::vector<char> K((size_t) t.ncls, 0);
+            if (t.high_cls >= 0) K[(size_t) t.high_cls] = 1;
+            auto in_q = [&](uint32_t r) -> bool { for (uint32_t q : Q) if (q == r) return true; return false; };
+            // a target row: false = the class that led to it becomes a kill class
+            auto take = [&](uint32_t tr, bool &changed) -> bool {
+                if (tr >= nrows) return false;                                         // an absorbing row: the walk leaves the set
+                if (in_q(tr)) return true;
+                if (Q.size() >= 8) return false;
+                Q.push_back(tr); changed = true;
+                return true;
+            };
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                for (uint32_t c = 0; c < (uint32_t) t.ncls && !changed; c++) {
+                    if (K[c]) continue;
+                    const uint32_t v0 = ft[(size_t) Q[0] * rstride + c];
+                    bool uni = (v0 & FX_PAIR) != FX_PAIR;                              // plain or look-ahead; a double write is not taken
+                    for (uint32_t q : Q) if (ft[(size_t) q * rstride + c] != v0) uni = false;
+                    if (!uni) { K[c] = 1; changed = true; break; }
+                    if (!is_look(v0)) { if (!take(row_of(v0 & FX_ROW_MASK), changed)) { K[c] = 1; changed = true; } continue; }
+                    // a look-ahead cell: what the class of the NEXT byte selects must be a plain step inside the set too
+                    const size_t m = ((v0 & FX_ROW_MASK) - ft2_at) / row2b;
+                    for (uint32_t c2 = 0; c2 < (uint32_t) t.ncls && !changed; c2++) {
+                        if (K[c2]) continue;
+                        const uint32_t w = ft2[m * r2stride + c2];
+                        if ((w & 0x80000000u) || !take(row_of(w & FX_ROW_MASK), changed)) { K[c] = 1; changed = true; }
+                    }
+                }
+            }
+            std::vector<uint8_t> kb;
+            for (int b8 = 0; b8 < 128; b8++) if (K[(size_t) t.cls[b8]]) kb.push_back((uint8_t) b8);
+            if (getenv("FLBGPU_FX_DEBUG") && kb.size() <= 6) {
+                fprintf(stderr, "seed %u Q=%zu kill bytes:", r0, Q.size());
+                for (uint8_t x : kb) fprintf(stderr, " %u", x);
+                fprintf(stderr, "\n");
+            }
+            if (kb.size() > 3) continue;
+            // the one slot written inside the set (steps that are not the last one)
+            uint32_t wslot = 0;
+            bool ok = true, accepting = false;
+            auto inner = [&](uint32_t v) { const uint32_t sl = (v >> FX_SLOT_SHIFT) / 128u; if (sl) { if (wslot && wslot != sl) ok = false; wslot = sl; } };
+            for (uint32_t c = 0; c < (uint32_t) t.ncls; c++) {
+                if (K[c]) continue;
+                const uint32_t v = ft[(size_t) Q[0] * rstride + c];
+                if (!is_look(v)) { inner(v); continue; }
+                const size_t m = ((v & FX_ROW_MASK) - ft2_at) / row2b;
+                for (uint32_t c2 = 0; c2 < (uint32_t) t.ncls; c2++) if (!K[c2]) inner(ft2[m * r2stride + c2]);
+            }
+            // the last byte: its entry (a look-ahead cell sees the end of the text), then the end-of-text step
+            for (uint32_t c = 0; c < (uint32_t) t.ncls && ok; c++) {
+                if (K[c]) continue;
+                uint32_t v = ft[(size_t) Q[0] * rstride + c];
+                if (is_look(v)) v = ft2[((v & FX_ROW_MASK) - ft2_at) / row2b * r2stride + (uint32_t) t.ncls];
+                if (is_look(v)) { ok = false; break; }
+                uint32_t sl[4] = {0, 0, 0, 0};
+                int ns = slots_of(v, sl);
+                const uint32_t g = next_of(v);
+                bool acc = false;
+                for (int k = 0; k < ns; k++) acc |= sl[k] == S_END_EOT || sl[k] == S_END_MID;
+                if (g < nrows) {
+                    const uint32_t ve = ft[(size_t) g * rstride + (uint32_t) t.ncls];
+                    if (is_look(ve)) { ok = false; break; }
+                    uint32_t se[2] = {0, 0};
+                    const int ne = slots_of(ve, se);
+                    for (int k = 0; k < ne; k++) { acc |= se[k] == S_END_EOT || se[k] == S_END_MID; sl[ns + k] = se[k]; }
+                    ns += ne;
+                }
+                if (!acc) continue;
+                accepting = true;
+                if (wslot) { bool has = false; for (int k = 0; k < ns; k++) has |= sl[k] == wslot; if (!has) ok = false; }
+            }
+            if (getenv("FLBGPU_FX_DEBUG")) fprintf(stderr, "  seed %u ok %d accepting %d wslot %u\n", r0, (int) ok, (int) accepting, wslot);
+            if (!ok || !accepting) continue;
+            if (kb.size() < best_kill || (kb.size() == best_kill && Q.size() > tail_rows.size())) { best_kill = kb.size(); tail_rows = Q; tail_kill = kb; }
+        }
+    }
+    uint32_t tail_min = absorb;
+    if (!tail_rows.empty()) {
+        std::vector<uint32_t> perm(nrows + 2);
+        std::vector<char> inq(nrows, 0);
+        for (uint32_t q : tail_rows) inq[q] = 1;
+        uint32_t at = 0;
+        for (uint32_t r = 0; r < nrows; r++) if (!inq[r]) perm[r] = at++;
+        tail_min = rowaddr(at);
+        for (uint32_t r = 0; r < nrows; r++) if (inq[r]) perm[r] = at++;
+        perm[nrows] = nrows; perm[nrows + 1] = nrows + 1;
+        auto remap = [&](uint32_t v) -> uint32_t {
+            if (v & 0x80000000u) return v;
+            return (v & ~FX_ROW_MASK) | rowaddr(perm[(v & FX_ROW_MASK) >= ft_at ? ((v & FX_ROW_MASK) - ft_at) / rowb : 0]);
+        };
+        std::vector<uint32_t> nft(ft.size());
+        for (uint32_t r = 0; r < nrows + 2; r++)
+            for (uint32_t c = 0; c < rstride; c++) nft[(size_t) perm[r] * rstride + c] = c < stride ? remap(ft[(size_t) r * rstride + c]) : 0u;
+        ft.swap(nft);
+        for (auto &v : ft2) v = remap(v);
+        for (size_t k = 0; k + 1 < p2.size(); k += 2) p2[k] = remap(p2[k]);
+        out.start_off = 0;      // (set below, through perm)
+        tail_rows.assign(perm.begin(), perm.end());          // now: logical -> physical
+    }
     if (pair) {
         // cell (row, c1, c2) = the two single steps folded: next row | slot of the first step << 16 | slot of the second << 24;
         // FX2_LOOK3 | slot1 << 16 | look-ahead row: the SECOND step's cell waits for the byte behind the pair;
@@ -117,7 +240,12 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
     if (total > 60000) return true;                                             // addresses are 16 bits; the record tiles need the rest of the LDS
     out.base = nullptr; out.bytes = (uint32_t) total;
     out.off_p2 = (uint32_t) p2_at64;
-    out.start_off = rowaddr(((uint32_t) t.nX - 1) * (uint32_t) t.NKp + (uint32_t) t.kind_edge);
+    {
+        const uint32_t start_row = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + (uint32_t) t.kind_edge;
+        out.start_off = rowaddr(tail_min != absorb ? tail_rows[start_row] : start_row);
+    }
+    out.tail_min = tail_min; out.nkill = (uint32_t) tail_kill.size();
+    for (size_t k = 0; k < tail_kill.size() && k < 4; k++) out.kill[k] = tail_kill[k];
     out.absorb_off = absorb; out.poison_off = poison; out.nslots = nslots;
     out.pair_bias = bias; out.ncls1 = stride;
     out.ok = 1;
@@ -128,7 +256,7 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
 // The walk of k_parser_tile (tile_kernels.inc fx_walk + the result rules that follow it) on the host.
 // caps: nslots u16 columns (0xFFFF = unset).  Returns >= 0 end of the match, -1 the forward walk from boundary 0 does
 // not settle the value (the kernel then runs the reverse pass + classic walk), -2 a byte >= 0x80 / a real 0xFF.
-int flbgpu::simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps) {
+int flbgpu::simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps, bool use_tail) {
     auto u32at = [&](uint32_t at) -> uint32_t { uint32_t v; memcpy(&v, b.data() + at, 4); return v; };
     for (uint32_t i = 0; i < fx.nslots; i++) caps[i] = 0xFFFF;
     uint32_t e = fx.start_off;
@@ -146,7 +274,28 @@ int flbgpu::simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap
         }
         caps[(e >> FX_SLOT_SHIFT) / 128] = (uint16_t) j;
     };
-    if (!bias) for (uint32_t j = 0; j <= len; j++) step1(j);
+    if (!bias) {
+        // k_parser_reg: every 16 positions the wave looks whether all its lanes stand in the pattern's tail (or are absorbed); here the
+        // one lane leaves at the FIRST such boundary -- the most the tail logic is ever asked to do
+        const bool allow = use_tail && len < 272;            // (the kernel scans the value's registers for kill bytes)
+        for (uint32_t i = 0; i < fx.nslots; i++) caps[i] = 0xFFFF;
+        e = fx.start_off;
+        for (uint32_t j = 0; j <= len; j++) {
+            if (allow && j > 0 && (j & 15) == 0 && (e & FX_ROW_MASK) >= fx.tail_min) {
+                if ((e & FX_ROW_MASK) >= fx.absorb_off) break;                            // absorbed: nothing changes any more
+                bool kill = false;
+                for (uint32_t q = j; q < len; q++) {
+                    kill |= s[q] >= 0x80;
+                    for (uint32_t k = 0; k < fx.nkill; k++) kill |= s[q] == fx.kill[k];
+                }
+                if (kill) return -2;                                                      // the way of the poisoned records: the complete algorithm decides
+                if (len > j) step1(len - 1);              // the row it stands in is as good as the one it would have reached: the last byte decides
+                step1(len);
+                break;
+            }
+            step1(j);
+        }
+    }
     else {
         // k_parser_reg<PAIR2>: two positions per table read; like the kernel it walks whole pairs (positions behind the end of the
         // text meet the sentinel's column in an absorbing row)

@@ -80,7 +80,7 @@ bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out);
 bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out);
 bool upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out, bool pair = false);
 bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pair = false);
-int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
+int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps, bool use_tail = true);
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool parse_ra(const char *pat, DevKey &k, std::string &why);
 // "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)

@@ -50,11 +50,13 @@ void flbgpu_rx_debug_stats(long *out3) { rx::debug_stats(out3); }
  * >= 0: groups, beg/end of the NAMED groups filled (-1 elsewhere), beg[0] = 0, end[0] = end of the match;
  * -1: the forward walk from boundary 0 does not settle this text (the kernel falls back to the classic walk);
  * -2: a byte >= 0x80 (UTF-8 tables); -4: the pattern has no compact tables. */
-static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair);
+static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair, bool use_tail = true);
 int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, false); }
+/* the same with every position walked (the pattern's tail, DevFx::tail_min, not used): what the skipping walk must equal */
+int flbgpu_rx_simulate_fx_walk_all(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, false, false); }
 /* the same over the tables with a cell per pair of byte classes (k_parser_reg<PAIR2>: two positions per table read); -4 also when they do not fit */
 int flbgpu_rx_simulate_fx2(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, true); }
-static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair)
+static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair, bool use_tail)
 {
     auto *p = (rx::Program *) h;
     int ncap = 0;
@@ -64,7 +66,7 @@ static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *en
     flbgpu::DevFx fx;
     if (!flbgpu::build_fx(p->ascii, ncap, blob, fx, pair) || !fx.ok) return -4;
     std::vector<uint16_t> caps(fx.nslots);
-    const int r = flbgpu::simulate_fx(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
+    const int r = flbgpu::simulate_fx(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data(), use_tail);
     if (r < 0) return r;
     for (int g = 0; g <= p->ngroups; g++) { beg[g] = -1; end[g] = -1; }
     beg[0] = 0; end[0] = r;
@@ -103,6 +105,37 @@ int flbgpu_rx_fx_profile(void *h, const char *s, int len, long *out)
     }
     out[5] += steps; out[6] += look; out[7] += pair;
     return 0;
+}
+
+/* the tail of the compact tables (dev.hpp DevFx::tail_min): rows in it (0: none), its kill bytes; and over a text: *first = the first
+ * position (a multiple of 16) from which a lane alone in its wave would skip to the end (-1: it never stands in the tail at a boundary) */
+int flbgpu_rx_fx_tail(void *h, const char *s, int len, int *nkill, unsigned char *kill4, int *first)
+{
+    auto *p = (rx::Program *) h;
+    int ncap = 0;
+    for (uint8_t c : p->slot2cap) if (c != 0xFF) ncap++;
+    std::vector<uint8_t> b;
+    flbgpu::DevFx fx;
+    if (ncap == 0 || !flbgpu::build_fx(p->ascii, ncap, b, fx) || !fx.ok) return -4;
+    *nkill = (int) fx.nkill;
+    for (uint32_t k = 0; k < fx.nkill && k < 4; k++) kill4[k] = fx.kill[k];
+    *first = -1;
+    const uint32_t stride = (((uint32_t) p->ascii.ncls + 1) | 1u) * 4;
+    if (s && fx.tail_min < fx.absorb_off) {
+        auto u32at = [&](uint32_t at) -> uint32_t { uint32_t v; memcpy(&v, b.data() + at, 4); return v; };
+        auto cls_of = [&](int pos) -> uint32_t { return u32at(4 * (pos < len ? (uint8_t) s[pos] : 0xFFu)); };
+        uint32_t e = fx.start_off;
+        for (int j = 0; j <= len; j++) {
+            const uint32_t row = e & flbgpu::FX_ROW_MASK;
+            if (j > 0 && (j & 15) == 0 && row >= fx.tail_min && row < fx.absorb_off) { *first = j; break; }
+            e = u32at(row + cls_of(j));
+            if (e & 0x80000000u) {
+                if (!(e & 0x40000000u)) e = u32at((e & flbgpu::FX_ROW_MASK) + cls_of(j + 1));
+                if (e & 0x80000000u) e = u32at(fx.off_p2 + 8 * (e & 0x3FFFFFFFu));
+            }
+        }
+    }
+    return (int) ((fx.absorb_off - fx.tail_min) / stride);
 }
 
 /* "name=group\n" lines in onig_foreach_name order */

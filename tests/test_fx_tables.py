@@ -225,6 +225,7 @@ def test_pair_cells_give_the_single_steps_answers():
     import random
     L = _lib()
     L.flbgpu_rx_simulate_fx2.argtypes = L.flbgpu_rx_simulate_fx.argtypes
+    L.flbgpu_rx_simulate_fx_walk_all.argtypes = L.flbgpu_rx_simulate_fx.argtypes
     kat = json.load(open(os.path.join(HERE, "golden", "regex_kat.json")))
     rng = random.Random(5)
     compared = with_pairs = 0
@@ -232,7 +233,7 @@ def test_pair_cells_give_the_single_steps_answers():
     def both(h, s):
         nonlocal compared
         b1 = (ctypes.c_int * 40)(); e1 = (ctypes.c_int * 40)(); b2 = (ctypes.c_int * 40)(); e2 = (ctypes.c_int * 40)()
-        n1 = L.flbgpu_rx_simulate_fx(h, s, len(s), b1, e1)
+        n1 = L.flbgpu_rx_simulate_fx_walk_all(h, s, len(s), b1, e1)      # (every position walked: the pair tables carry no tail)
         n2 = L.flbgpu_rx_simulate_fx2(h, s, len(s), b2, e2)
         if n2 == -4:
             return False                                  # the pair tables do not fit: the kernel keeps the single steps
@@ -294,3 +295,73 @@ def test_pair_cells_give_the_single_steps_answers():
             both(h, bytes(b))
     L.flbgpu_rx_free(h)
     assert compared - n0 > 4000
+
+
+def test_tail_skip_equals_the_full_walk():
+    """dev.hpp DevFx::tail_min -- the rows of `(?<message>.*)$` and the like sit last in the table; a lane standing there at a multiple
+    of 16 skips to the end of its text: no kill byte in what it skips, then the last byte and the end-of-text column decide.  The
+    host execution of the skipping walk (the earliest exit a lane can take) against the walk over every position: same return and
+    spans, or -2 (the complete algorithm decides, as for a byte >= 0x80) when a kill byte sits in the skipped part -- on the stock
+    parsers that have a tail, with their sample lines cut, stretched, damaged and with kill bytes thrown in."""
+    import random
+    import re
+    L = _lib()
+    L.flbgpu_rx_simulate_fx_walk_all.argtypes = L.flbgpu_rx_simulate_fx.argtypes
+    L.flbgpu_rx_fx_tail.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    PATS = {
+        "apache2": (rb'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$',
+                    [b'192.168.2.20 - - [29/Jul/2015:10:27:10 -0300] "GET /cgi-bin/try/ HTTP/1.0" 200 3395 "http://example.com/a" "Mozilla/5.0 (X11; Linux x86_64) AppleWebKit/537.36 (KHTML, like Gecko) Chrome/44.0"',
+                     b'127.0.0.1 - frank [10/Oct/2000:13:55:36 -0700] "GET /apache_pb.gif HTTP/1.0" 200 2326']),
+        "apache_error": (rb'^\[[^ ]* (?<time>[^\]]*)\] \[(?<level>[^\]]*)\](?: \[pid (?<pid>[^\]]*)\])?( \[client (?<client>[^\]]*)\])? (?<message>.*)$',
+                         [b'[Wed Oct 11 14:32:52 2000] [error] [pid 1234] [client 127.0.0.1] client denied by server configuration: /export/home/live/ap/htdocs/test and more text to make it long']),
+        "syslog-rfc3164-local": (rb'^\<(?<pri>[0-9]+)\>(?<time>[^ ]* {1,2}[^ ]* [^ ]*) (?<ident>[a-zA-Z0-9_\/\.\-]*)(?:\[(?<pid>[0-9]+)\])?(?:[^\:]*\:)? *(?<message>.*)$',
+                                 [b'<34>Oct 11 22:14:15 su[123]: pam_unix(su:session): session opened for user root by (uid=0) and it goes on and on for a while']),
+        "cri": (rb'^(?<time>[^ ]+) (?<stream>stdout|stderr) (?<logtag>[^ ]*) (?<message>.*)$',
+                [b'2020-10-10T00:10:00.333333333Z stdout F Hello Fluent Bit, this is a fairly long container log line that keeps going']),
+        "message_only": (rb'^(?<level>[A-Z]+) (?<message>.*)$', [b'INFO ' + b'x' * 200, b'WARN short']),
+    }
+    rng = random.Random(0x7A11)
+    compared = skipped = declined = 0
+    for name, (pat, samples) in PATS.items():
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        assert h, (name, err.value)
+        nk = ctypes.c_int(); kill = ctypes.create_string_buffer(4); first = ctypes.c_int()
+        rows = L.flbgpu_rx_fx_tail(h, None, 0, ctypes.byref(nk), kill, ctypes.byref(first))
+        assert rows >= 1 and list(kill.raw[:nk.value]) == [10], (name, rows, list(kill.raw[:nk.value]))
+        texts = []
+        for smp in samples:
+            texts.append(smp)
+            for _ in range(400):
+                t = bytearray(smp)
+                r = rng.random()
+                if r < 0.25:
+                    t = t[:rng.randrange(len(t) + 1)]
+                elif r < 0.5:
+                    t += bytes(rng.choice(b'abc "\\]x') for _ in range(rng.randrange(120)))
+                elif r < 0.7:
+                    for _ in range(rng.randrange(1, 4)):
+                        t[rng.randrange(len(t))] = rng.choice(b'\n"\xe9 ]:\t\x00')
+                elif r < 0.8:
+                    t += rng.choice([b'"', b'\n', b'"\n', b'\n\n', b' ', b'\r\n'])
+                else:
+                    k = rng.randrange(len(t))
+                    t = t[:k] + bytes(rng.choice(b'ab "') for _ in range(rng.randrange(40))) + t[k:]
+                texts.append(bytes(t[:271]))
+        for s in texts:
+            b1 = (ctypes.c_int * 40)(); e1 = (ctypes.c_int * 40)(); b2 = (ctypes.c_int * 40)(); e2 = (ctypes.c_int * 40)()
+            n1 = L.flbgpu_rx_simulate_fx(h, s, len(s), b1, e1)
+            n2 = L.flbgpu_rx_simulate_fx_walk_all(h, s, len(s), b2, e2)
+            L.flbgpu_rx_fx_tail(h, s, len(s), ctypes.byref(nk), kill, ctypes.byref(first))
+            compared += 1
+            if first.value >= 0:
+                skipped += 1
+            if n1 != n2:
+                # only ever the decline, and only with a kill byte behind the point the lane left the walk at
+                assert n1 == -2 and first.value >= 0 and any(c == 10 or c >= 0x80 for c in s[first.value:]), (name, s, n1, n2, first.value)
+                declined += 1
+                continue
+            if n1 >= 0:
+                assert list(b1[:n1 + 1]) == list(b2[:n1 + 1]) and list(e1[:n1 + 1]) == list(e2[:n1 + 1]), (name, s)
+        L.flbgpu_rx_free(h)
+    assert compared > 2500 and skipped > 700 and declined > 20, (compared, skipped, declined)
