@@ -728,8 +728,19 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
                 ss_.do_dev(sch)
             torch.cuda.synchronize()
             dt_q = (time.perf_counter() - t0) / steps
+            ss_.profile(True)
+            for _ in range(steps):
+                ss_.do_dev(sch)
+            prof_q = ss_.profile(False)
             es = {"records_per_s_per_gpu": round(m / dt_q, 1), "ms_per_step": round(dt_q * 1e3, 3), "query": SEL_SQL, "records_out": int(ret_s),
-                  "bytes_out": len(out_s), "note": "size pass + scan + emit pass + the D2H copy of the projected records"}
+                  "bytes_out": len(out_s), "kernel_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in prof_q.items()},
+                  "note": "size pass + scan + emit pass + the D2H copy of the projected records into the caller's buffer (the call returns host memory; "
+                          "the Python binding's own copy of it is in the time too)"}
+            ke_q = sum(v[0] / max(v[1], 1) for v in prof_q.values())
+            if ke_q:
+                ab_q = sdata.nbytes * 2 + 2 * len(out_s)         # both passes read the chunk; the emit pass writes the records, the copy reads them
+                es["roofline"] = {"kernel": "k_sp_select (both passes)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(ab_q / (ke_q / 1e3) / 1e9, 1),
+                                  "frac": round(ab_q / (ke_q / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
             if rank == 0:
                 import ref_sp
                 k_ = min(m, 200_000)

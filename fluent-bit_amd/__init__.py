@@ -573,6 +573,8 @@ class StreamTask:
     def profile(self, enable=True):
         ms = (c_double * 2)(); n = (c_uint64 * 2)()
         lib().flbgpu_sp_profile(self.h, int(bool(enable)), ms, n)
+        if self.select_only:
+            return {"k_sp_select<size>": (ms[0], int(n[0])), "k_sp_select<emit>": (ms[1], int(n[1]))}
         return {"k_sp_extract": (ms[0], int(n[0])), "k_sp_aggregate": (ms[1], int(n[1]))}
 
     def close(self):

@@ -429,7 +429,8 @@ struct flbgpu_sp {
     std::vector<int> key_src;           // select key -> aggregated source index (-1: none)
     std::vector<SpSelKey> sel;          // a plain SELECT: its keys in order (sp_select.inc)
     DevBuf d_slen, d_soff, d_sout;
-    std::string sel_out;                // what the last appended chunk left (finish_do hands it over)
+    void *sel_out = nullptr;            // what the last appended chunk left: a malloc()'d buffer the D2H copy filled (finish_do hands it over)
+    size_t sel_bytes = 0;
     std::string tag;                    // RECORD_TAG(): the tag of the chunks this task sees (flbgpu_sp_set_tag)
     std::string sel_const;              // the packed constant pairs of the current call (time / record functions)
     DevBuf d_sconst;
@@ -856,10 +857,10 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
     return true;
 }
 
-// a plain SELECT over one chunk: size pass, scan, emit; what leaves is kept in t->sel_out for finish_do
+// a plain SELECT over one chunk: size pass, scan, emit; what leaves is copied straight into the buffer finish_do hands over
 bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32_t now_sec, uint32_t now_nsec) {
     uint64_t n = in->n;
-    t->sel_out.clear();
+    free(t->sel_out); t->sel_out = nullptr; t->sel_bytes = 0;
     t->records = 0;
     if (n == 0) return true;
     // time / record functions: the pair (RECORD_TIME: its key) packed once per call
@@ -896,7 +897,7 @@ bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32
         hm.first_bad = ~0ull;
         HIPOK(hipMemcpyAsync(t->d_misc.p, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
         a.n = n;
-        launch_sp_select(a, false, st);
+        { Profile pr(t, 0, st); launch_sp_select(a, false, st); }       // (flbgpu_sp_profile: [0] the size pass, [1] the emit pass)
         launch_scan(a.out_len, n, t->d_gid.as<uint64_t>(), t->d_soff.as<uint64_t>(), st);
         HIPOK(hipMemcpyAsync(&hm, t->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipMemcpyAsync(&total, t->d_soff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
@@ -910,9 +911,11 @@ bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32
     if (total == 0) return true;
     if (!t->d_sout.ensure(total + 16)) return false;
     a.out = t->d_sout.as<uint8_t>();
-    launch_sp_select(a, true, st);
-    t->sel_out.resize(total);
-    HIPOK(hipMemcpyAsync(&t->sel_out[0], a.out, total, hipMemcpyDeviceToHost, st));
+    { Profile pr(t, 1, st); launch_sp_select(a, true, st); }
+    t->sel_out = malloc(total);
+    if (!t->sel_out) { set_err("out of memory"); return false; }
+    t->sel_bytes = total;
+    HIPOK(hipMemcpyAsync(t->sel_out, a.out, total, hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
     return true;
 }
@@ -1090,13 +1093,8 @@ int finish_do(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
     if (out_size) *out_size = 0;
     if (t->q.select_only) {
         // sp_process_data: "records == 0 -> return 0" (nothing handed on); otherwise the buffer, which may be empty
-        if (out_buf && out_size && t->records > 0 && !t->sel_out.empty()) {
-            *out_buf = malloc(t->sel_out.size());
-            if (!*out_buf) { set_err("out of memory"); return -1; }
-            memcpy(*out_buf, t->sel_out.data(), t->sel_out.size());
-            *out_size = t->sel_out.size();
-        }
-        t->sel_out.clear();
+        if (out_buf && out_size && t->records > 0 && t->sel_out) { *out_buf = t->sel_out; *out_size = t->sel_bytes; t->sel_out = nullptr; }
+        free(t->sel_out); t->sel_out = nullptr; t->sel_bytes = 0;
         t->records = 0;
         return 0;
     }
@@ -1202,6 +1200,7 @@ extern "C" void flbgpu_sp_destroy(flbgpu_sp *t) {
     DevBuf *all[] = {&s.d_slot_hash, &s.d_slot_sid, &s.d_arena, &s.d_key_off, &s.d_key_len, &s.d_series_hash, &s.d_rows, &s.d_ctr,
                      &t->d_plan, &t->d_gid, &t->d_val, &t->d_vt, &t->d_misc, &t->d_in, &t->d_off, &t->d_slen, &t->d_soff, &t->d_sout, &t->d_sconst};
     for (auto *b : all) b->release();
+    free(t->sel_out);
     for (auto &e : t->ev) if (e) (void) hipEventDestroy(e);
     if (t->stream) (void) hipStreamDestroy(t->stream);
     delete t;
