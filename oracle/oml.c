@@ -77,6 +77,10 @@ typedef struct oml {
     char *pend; size_t pend_len;
     /* flushed records */
     char *out; size_t out_len, out_cap; int records, truncations;
+    /* a list of parsers on one stream (flb_ml.c:671-760, in_tail's `multiline.parser a, b`): the head holds the others in order; what
+     * any of them flushes lands in the head's output */
+    struct oml *chain[7]; int nchain; int lru;               /* lru: index into {head, chain...}, -1 none (flb_ml_group.lru_parser) */
+    struct oml *sink;
 } oml;
 
 static void cat_raw(oml *m, const char *d, size_t n)        /* flb_sds_cat_safe */
@@ -88,6 +92,7 @@ static void cat_raw(oml *m, const char *d, size_t n)        /* flb_sds_cat_safe 
 
 static void out_put(oml *m, const void *d, size_t n)
 {
+    if (m->sink) m = m->sink;
     if (m->out_len + n > m->out_cap) { m->out_cap = (m->out_len + n) * 2 + 4096; m->out = realloc(m->out, m->out_cap); }
     memcpy(m->out + m->out_len, d, n);
     m->out_len += n;
@@ -110,6 +115,7 @@ oml *oml_create(int type, const char *match_str, int negate, const char *key_con
     m->key_content = key_content && key_content[0] ? strdup(key_content) : NULL;
     m->buffer_limit = buffer_limit >= 0 ? (size_t) buffer_limit : 2 * 1024 * 1024;   /* flb_ml.c:896-902, FLB_ML_BUFFER_LIMIT_DEFAULT */
     m->rule_to_state = -1;
+    m->lru = -1;
     m->ngroups = 1; m->groups[0].name = strdup("_default"); m->groups[0].name_len = 8;
     m->g = &m->groups[0];
     return m;
@@ -287,7 +293,7 @@ static void flush_group(oml *m)
             }
             out_record_head(m);
             out_put(m, body.data, body.size);
-            m->records++;
+            (m->sink ? m->sink : m)->records++;
         }
         omp_buf_free(&body);
         omp_arena_free(&ar);
@@ -299,7 +305,7 @@ static void flush_group(oml *m)
         out_record_head(m);
         out_u8(m, 0x81); out_str_hdr(m, strlen(key)); out_put(m, key, strlen(key));
         out_str_hdr(m, m->g->len); out_put(m, m->g->buf, m->g->len);
-        m->records++;
+        (m->sink ? m->sink : m)->records++;
     }
     m->g->len = 0;
     m->g->truncated = 0;
@@ -440,14 +446,14 @@ done:
 }
 
 /* flb_ml_append_text with one parser instance; returns 1 when the line truncated a buffer */
-int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
+/* ml_append_try_parser (flb_ml.c:591-669): >= 0 the parser took the line (1: truncated), -1 it did not */
+static int try_parser(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
 {
-    int ret = -1, truncated = 0, i;
+    int ret = -1;
     m->g = &m->groups[0];
     if (m->sub) ret = process_with_subparser(m, sec, nsec, d, n);
     else if (m->type == OML_REGEX) {
         ret = rule_process(m, d, n, sec, nsec);
-        if (ret == 1) truncated = 1;
         if (ret == 0) register_time(m, sec, nsec);           /* package_content :263-265 (the text path's first-line map is always empty) */
     }
     else if (m->type == OML_ENDSWITH) {
@@ -470,10 +476,45 @@ int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
         cat_raw(m, d, n);
         if (rule_match) flush_group(m);
     }
+    return ret;
+}
+
+static void flush_all_groups(oml *m)
+{
+    int i;
+    for (i = 0; i < m->ngroups; i++) { m->g = &m->groups[i]; flush_group(m); }
+    m->g = &m->groups[0];
+}
+
+/* another parser behind the head's (in_tail: one flb_ml_parser_instance_create per name of `multiline.parser`) */
+int oml_chain_add(oml *head, oml *next)
+{
+    if (head->nchain >= 7 || next->sink || next->nchain) return -1;
+    head->chain[head->nchain++] = next;
+    next->sink = head;
+    return 0;
+}
+
+int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
+{
+    int ret = -1, truncated = 0, i;
+    const int np = 1 + m->nchain;
+    /* flb_ml_append_text :686-728: the parser that took the stream's last line first, then the others in order */
+    if (m->lru >= 0) {
+        oml *p = m->lru == 0 ? m : m->chain[m->lru - 1];
+        ret = try_parser(p, sec, nsec, d, n);
+    }
+    for (i = 0; ret < 0 && i < np; i++) {
+        oml *p = i == 0 ? m : m->chain[i - 1];
+        if (i == m->lru) continue;
+        ret = try_parser(p, sec, nsec, d, n);
+        if (ret >= 0) m->lru = i;
+    }
+    if (ret == 1) truncated = 1;
     if (ret < 0) {
-        /* flb_ml.c:729-757: "A non-matching line breaks any multiline sequence" (every group of the stream, in the order they were
-         * created), then the line alone through the default group */
-        for (i = 0; i < m->ngroups; i++) { m->g = &m->groups[i]; flush_group(m); }
+        /* :729-757: "A non-matching line breaks any multiline sequence" (every parser's groups of the stream, in the order they were
+         * created), then the line alone through the FIRST parser's default group */
+        for (i = 0; i < np; i++) flush_all_groups(i == 0 ? m : m->chain[i - 1]);
         m->g = &m->groups[0];
         register_time(m, sec, nsec);
         if (group_cat(m, d, n) == 1) truncated = 1;
@@ -483,11 +524,11 @@ int oml_append_text(oml *m, int64_t sec, int64_t nsec, const char *d, size_t n)
     return truncated;
 }
 
-void oml_flush_pending(oml *m)                               /* flb_ml_flush_pending(_now): the timer's forced flush, every group */
+void oml_flush_pending(oml *m)                               /* flb_ml_flush_pending(_now): the timer's forced flush, every parser's every group */
 {
     int i;
-    for (i = 0; i < m->ngroups; i++) { m->g = &m->groups[i]; flush_group(m); }
-    m->g = &m->groups[0];
+    flush_all_groups(m);
+    for (i = 0; i < m->nchain; i++) flush_all_groups(m->chain[i]);
 }
 
 /* plugins/in_tail/tail_file.c process_content: what one read appends to the file's buffer */
@@ -527,6 +568,8 @@ size_t oml_output(oml *m, const char **out, int *records, int *truncations)
 void oml_state(const oml *m, int *rule_to_state, size_t *buffered, size_t *pending)
 {
     int i;
+    int k;
     *rule_to_state = m->rule_to_state; *buffered = 0; *pending = m->pend_len;
     for (i = 0; i < m->ngroups; i++) *buffered += m->groups[i].len;
+    for (k = 0; k < m->nchain; k++) for (i = 0; i < m->chain[k]->ngroups; i++) *buffered += m->chain[k]->groups[i].len;
 }

@@ -434,9 +434,23 @@ static void run_multiline(struct flb_config *config, uint32_t nprops, char **key
         if (flb_ml_parser_init(mlp) != 0) { wr_answer(-100, NULL, 0); return; }
     }
     ml = flb_ml_create(config, "t");
-    mlp_i = ml ? flb_ml_parser_instance_create(ml, (char *) (builtin ? builtin : "t")) : NULL;
+    if (builtin && strchr(builtin, ',')) {
+        /* a list, as in_tail's `multiline.parser docker, cri` builds it (plugins/in_tail/tail_config.c: one instance per name, in order) */
+        char *names = flb_strdup(builtin), *nm = names;
+        while (ml && nm) {
+            char *c = strchr(nm, ',');
+            if (c) *c = 0;
+            while (*nm == ' ') nm++;
+            mlp_i = flb_ml_parser_instance_create(ml, nm);
+            if (!mlp_i) break;
+            if (key_content) flb_ml_parser_instance_set(mlp_i, "key_content", (char *) key_content);
+            nm = c ? c + 1 : NULL;
+        }
+        flb_free(names);
+    }
+    else mlp_i = ml ? flb_ml_parser_instance_create(ml, (char *) (builtin ? builtin : "t")) : NULL;
     if (!mlp_i || flb_ml_stream_create(ml, "f", -1, ml_flush_cb, &out, &stream_id) != 0) { wr_answer(-100, NULL, 0); return; }
-    if (builtin && key_content) flb_ml_parser_instance_set(mlp_i, "key_content", (char *) key_content);
+    if (builtin && key_content && !strchr(builtin, ',')) flb_ml_parser_instance_set(mlp_i, "key_content", (char *) key_content);
     while (off + 12 <= dlen) {
         uint32_t sec, nsec, len;
         struct flb_time tm;

@@ -253,6 +253,15 @@ class Multiline:
             lib().oml_destroy(self.h)
             self.h = None
 
+    def chain(self, other):
+        """`other` becomes the next parser of this one's list (in_tail: `multiline.parser a, b`); self stays the handle of the stream"""
+        L = lib()
+        L.oml_chain_add.argtypes = [c_void_p, c_void_p]
+        if L.oml_chain_add(self.h, other.h) != 0:
+            raise ValueError("multiline: chain")
+        self._chain = getattr(self, "_chain", []) + [other]             # (keeps them alive)
+        return self
+
     def append(self, text, sec, nsec, skip_empty_lines=False):
         """one read of in_tail; returns (records bytes, record count, truncations)"""
         lib().oml_tail_chunk(self.h, text, len(text), 1 if skip_empty_lines else 0, sec, nsec)

@@ -26,8 +26,15 @@ def contents(records, key=b"log"):
 
 def oracle_run(cfg, frames, skip_empty_lines=False, final_flush=False, clock_of_the_call=False, flush_time=(1900000000, 3)):
     """clock_of_the_call: flb_time_get() (a group flushed before any time was registered) answers the time of the frame being appended"""
-    m = ob.Multiline(rules=cfg.get("rules"), builtin=cfg.get("builtin"), type=cfg.get("type", "regex"), match_string=cfg.get("match_string"),
-                     negate=cfg.get("negate", False), key_content=cfg.get("key_content"), buffer_limit=cfg.get("buffer_limit_bytes", -1))
+    names = [x.strip() for x in cfg["builtin"].split(",")] if cfg.get("builtin") and "," in cfg["builtin"] else None
+    if names:
+        # in_tail's `multiline.parser a, b`: one instance per name on the same stream (flb_ml.c:671-760)
+        m = ob.Multiline(builtin=names[0], key_content=cfg.get("key_content"))
+        for nm in names[1:]:
+            m.chain(ob.Multiline(builtin=nm, key_content=cfg.get("key_content")))
+    else:
+        m = ob.Multiline(rules=cfg.get("rules"), builtin=cfg.get("builtin"), type=cfg.get("type", "regex"), match_string=cfg.get("match_string"),
+                         negate=cfg.get("negate", False), key_content=cfg.get("key_content"), buffer_limit=cfg.get("buffer_limit_bytes", -1))
     ob.lib().oml_set_now.argtypes = [ob.c_void_p, ob.c_int64, ob.c_int64]
     ob.lib().oml_set_now(m.h, 1600000000, 77)
     out, n, trunc = b"", 0, 0
@@ -118,3 +125,40 @@ def test_cri_and_docker_against_the_reference(seed):
     for (ret, out), (want, n, _), d in zip(rf.run(cases), wants, descr):
         assert out == want, d
         assert ret == n, d
+
+
+@pytest.mark.skipif(not rf.available(), reason="oracle/_ref/ref_filters not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", range(3))
+def test_parser_lists_against_the_reference(seed):
+    """in_tail's `multiline.parser docker, cri` (and the other order, and java behind them): flb_ml_append_text tries the parser that took
+    the stream's last line first, then the others in order; a line nobody takes flushes every parser's groups and leaves alone through the
+    FIRST parser's default group (flb_ml.c:671-760).  Homogeneous files, and files that switch format half way or line by line."""
+    rng = random.Random(9900 + seed)
+    cases, wants, descr = [], [], []
+    for _ in range(80):
+        lst = rng.choice(["docker, cri", "cri, docker", "docker,cri", "cri, docker, java", "java, cri"])
+        n = rng.randrange(0, 60)
+        kind = rng.random()
+        if kind < 0.35:
+            text = ml_synth.cri_text(rng, n, bad_times=False)
+        elif kind < 0.7:
+            text = ml_synth.docker_text(rng, n)
+        elif kind < 0.85:
+            text = ml_synth.cri_text(rng, n // 2, bad_times=False) + ml_synth.docker_text(rng, n - n // 2)
+        else:
+            a = ml_synth.cri_text(rng, n, bad_times=False).split(b"\n")
+            b = ml_synth.docker_text(rng, n).split(b"\n")
+            mix = [rng.choice([x, y]) for x, y in zip(a, b)]
+            text = b"\n".join(mix) + b"\n"
+        cfg = {"builtin": lst}
+        frames = ml_synth.frames_of(rng, text)
+        kw = dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)
+        cases.append(ref_case(cfg, frames, **kw))
+        wants.append(oracle_run(cfg, frames, **kw))
+        descr.append((cfg, frames, kw))
+    produced = 0
+    for (ret, out), (want, n, _), d in zip(rf.run(cases), wants, descr):
+        assert out == want, d
+        assert ret == n, d
+        produced += n
+    assert produced > 300
