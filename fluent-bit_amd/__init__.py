@@ -441,6 +441,59 @@ class MultilineStream:
             self.h = None
 
 
+class MultilineList:
+    """several multiline parsers on one tailed file -- in_tail's `multiline.parser docker, cri` (flb_ml_append_text's loop over the parser
+    instances, src/multiline/flb_ml.c:671-760).  `parsers`: MultilineParser objects in configuration order, each with a parser in front.
+    A read whose lines split between parsers raises RuntimeError (the caller keeps it on the CPU)."""
+
+    def __init__(self, parsers):
+        L = lib()
+        L.flbgpu_ml_list_create.restype = c_void_p
+        L.flbgpu_ml_list_create.argtypes = [POINTER(c_void_p), c_int]
+        L.flbgpu_ml_list_destroy.argtypes = [c_void_p]
+        L.flbgpu_ml_list_lru.argtypes = [c_void_p]
+        L.flbgpu_ml_list_append.argtypes = [c_void_p, c_void_p, c_size_t, ctypes.c_uint32, ctypes.c_uint32, c_int, c_int, POINTER(c_void_p), POINTER(c_size_t),
+                                            POINTER(c_uint64), POINTER(c_uint64)]
+        self.streams = [p.stream() for p in parsers]
+        arr = (c_void_p * len(self.streams))(*[s.h for s in self.streams])
+        self.h = L.flbgpu_ml_list_create(arr, len(self.streams))
+        if not self.h:
+            raise ValueError(last_error())
+        self.pending = b""
+
+    def append(self, text, sec, nsec, skip_empty_lines=False, flush=False):
+        buf = self.pending + text
+        out = c_void_p(); sz = c_size_t(); proc = c_uint64(); recs = c_uint64()
+        r = lib().flbgpu_ml_list_append(self.h, buf, len(buf), sec, nsec, int(bool(skip_empty_lines)), int(bool(flush)), byref(out), byref(sz), byref(proc), byref(recs))
+        if r != 0:
+            raise RuntimeError(last_error())
+        b = ctypes.string_at(out, sz.value) if out.value else b""
+        if out.value:
+            _libc.free(out)
+        self.pending = buf[proc.value:]
+        return b, int(recs.value)
+
+    def flush(self, sec=0, nsec=0):
+        keep, self.pending = self.pending, b""
+        try:
+            return self.append(b"", sec, nsec, flush=True)
+        finally:
+            self.pending = keep
+
+    @property
+    def lru(self):
+        """index of the parser that took the last line (-1: none yet)"""
+        return int(lib().flbgpu_ml_list_lru(self.h))
+
+    def close(self):
+        if self.h:
+            lib().flbgpu_ml_list_destroy(self.h)
+            self.h = None
+        for s in self.streams:
+            s.close()
+        self.streams = []
+
+
 class StreamTask:
     """one task of the stream processor (src/stream_processor/flb_sp.c: flb_sp_task_create :433, flb_sp_do :2007, the window
     timer of flb_sp_fd_event :2101): aggregate queries (GROUP BY / COUNT SUM AVG MIN MAX / WHERE / WINDOW TUMBLING | HOPPING) and

@@ -52,6 +52,10 @@ struct flbgpu_ml_stream {
     // a parser in front: in_tail's packing + filter_parser(sub) give the rows; one carried buffer + first-line map per group
     flbgpu_tail *tail[2] = {nullptr, nullptr};             // [skip_empty_lines]
     flbgpu_filter *subf = nullptr;
+    // between the two halves of a read (mlo_phase1 / mlo_phase2; a list of parsers looks at what every parser's first half says)
+    MloArgs ph_a;
+    uint64_t ph_n = 0, ph_lines = 0, ph_taken = 0;
+    bool ph_empty = true;
     std::vector<std::string> gnames;          // [0] the default group
     DevBuf gc_content[MLO_G][2], gc_map[MLO_G][2];
     int gc_cur[MLO_G] = {0, 0, 0, 0};
@@ -421,11 +425,23 @@ extern "C" void flbgpu_ml_stream_destroy(flbgpu_ml_stream *s) { delete s; }
 // ---- a parser in front (mlo_kernels.inc)
 static void put_name(uint8_t *dst, uint32_t *len, const std::string &v, size_t cap) { *len = (uint32_t) (v.size() < cap ? v.size() : cap); memcpy(dst, v.data(), *len); }
 
-static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
-                          flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records) {
+static void mlo_fill_groups(flbgpu_ml_stream *s, MloArgs &a) {
+    a.ngroups = (uint32_t) s->gnames.size();
+    for (uint32_t g = 0; g < a.ngroups; g++) put_name(a.names[g], &a.name_len[g], s->gnames[g], 32);
+    for (int g = 0; g < MLO_G; g++) {
+        a.carry[g].content = s->gc_content[g][s->gc_cur[g]].as<uint8_t>(); a.carry[g].map = s->gc_map[g][s->gc_cur[g]].as<uint8_t>();
+        a.carry[g].content_len = s->gc_content_len[g]; a.carry[g].map_len = s->gc_map_len[g]; a.carry[g].sec = s->gc_sec[g]; a.carry[g].nsec = s->gc_nsec[g];
+    }
+}
+
+// The first half of a read: the lines through in_tail's packing and the parser in front, every line classified (k_mlo_extract).  Nothing
+// of the stream's state changes; ph_lines / ph_taken say how many lines there are and how many this parser takes (count: only then).
+static int mlo_phase1(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                      uint64_t *processed, bool count) {
     auto fail = [](const char *w) -> int { set_err("multiline: %s", w); return -1; };
     flbgpu_ml_parser *p = s->p;
     hipStream_t st = s->stream;
+    s->ph_empty = true; s->ph_n = 0; s->ph_lines = 0; s->ph_taken = 0;
     if (p->key_content.size() > 63 || p->key_group.size() > 63 || p->key_pattern.size() > 63 || p->dev.match_len > 64) return fail("key names / match string too long for the GPU path");
     flbgpu_dev_chunk T, P;
     memset(&T, 0, sizeof(T)); memset(&P, 0, sizeof(P));
@@ -437,6 +453,7 @@ static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t byte
     bool pending = false;
     for (int g = 0; g < MLO_G; g++) pending = pending || s->gc_map_len[g] > 0;
     if (n == 0 && !(flush && pending)) return 0;
+    s->ph_empty = false; s->ph_n = n;
     const uint32_t *pinfo = nullptr;
     if (n) {
         const int r = flbgpu_filter_run_dev(s->subf, &T, &P, nullptr);
@@ -464,16 +481,29 @@ static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t byte
     a.buffer_limit = p->dev.buffer_limit; a.ts_sec = ts_sec; a.ts_nsec = ts_nsec;
     a.rows = s->o_rows.as<MloRow>(); a.st = s->o_st.as<MloState>(); a.nrec = s->o_nrec.as<uint32_t>(); a.rec_base = s->o_base.as<uint64_t>();
     a.idx = s->o_idx.as<uint32_t>(); a.misc = s->o_misc.as<unsigned int>();
-    auto fill_groups = [&]() {
-        a.ngroups = (uint32_t) s->gnames.size();
-        for (uint32_t g = 0; g < a.ngroups; g++) put_name(a.names[g], &a.name_len[g], s->gnames[g], 32);
-        for (int g = 0; g < MLO_G; g++) {
-            a.carry[g].content = s->gc_content[g][s->gc_cur[g]].as<uint8_t>(); a.carry[g].map = s->gc_map[g][s->gc_cur[g]].as<uint8_t>();
-            a.carry[g].content_len = s->gc_content_len[g]; a.carry[g].map_len = s->gc_map_len[g]; a.carry[g].sec = s->gc_sec[g]; a.carry[g].nsec = s->gc_nsec[g];
-        }
-    };
-    fill_groups();
+    mlo_fill_groups(s, a);
     launch_mlo_extract(a, st);
+    s->ph_a = a;
+    if (count && n) {
+        launch_mlo_kinds(a, st);
+        if (hipMemcpyAsync(hmisc, s->o_misc.p, sizeof(hmisc), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("count pass failed");
+        s->ph_lines = hmisc[19]; s->ph_taken = hmisc[20];
+    }
+    return 0;
+}
+
+// The second half: groups, scans, records, the carried buffers -- the stream moves on.
+static int mlo_phase2(flbgpu_ml_stream *s, flbgpu_dev_chunk *out, uint64_t *records) {
+    auto fail = [](const char *w) -> int { set_err("multiline: %s", w); return -1; };
+    hipStream_t st = s->stream;
+    if (s->ph_empty) return 0;
+    s->ph_empty = true;
+    MloArgs a = s->ph_a;
+    const uint64_t n = s->ph_n, N1 = n + 1;
+    unsigned int hmisc[32];
+    memset(hmisc, 0, sizeof(hmisc));
+    hmisc[0] = 0xFFFFFFFFu;
+    auto fill_groups = [&]() { mlo_fill_groups(s, a); };
     // group names the stream has not seen yet join its dictionary in the order they appear (flb_ml_stream_group_get creates them so)
     for (int round = 0;; round++) {
         launch_mlo_gid(a, st);
@@ -531,6 +561,12 @@ static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t byte
     *records = R;
     out->data = s->d_out.p; out->row_off = s->o_off.as<uint64_t>(); out->n = R; out->bytes = total;
     return 0;
+}
+
+static int mlo_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                          flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records) {
+    if (mlo_phase1(s, d_text, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, processed, false) != 0) return -1;
+    return mlo_phase2(s, out, records);
 }
 
 // what the stream carries: rule_to_state (-1 none), bytes of the open group
@@ -652,6 +688,92 @@ extern "C" int flbgpu_ml_append(flbgpu_ml_stream *s, const void *text, size_t by
     if (bytes && (!s->d_in.ensure(bytes + 16) || hipMemcpyAsync(s->d_in.p, text, bytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)) { set_err("multiline: upload failed"); return -1; }
     flbgpu_dev_chunk out;
     if (flbgpu_ml_append_dev(s, s->d_in.p, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, &out, processed, records) != 0) return -1;
+    if (out.bytes == 0) return 0;
+    void *hb = malloc(out.bytes);
+    if (!hb) { set_err("out of memory"); return -1; }
+    if (hipMemcpy(hb, out.data, out.bytes, hipMemcpyDeviceToHost) != hipSuccess) { free(hb); set_err("multiline: download failed"); return -1; }
+    *out_buf = hb; *out_size = out.bytes;
+    return 0;
+}
+
+// ---- a list of parsers on one stream: in_tail's `multiline.parser docker, cri` (plugins/in_tail/tail_config.c builds one instance per name).
+// flb_ml_append_text (src/multiline/flb_ml.c:671-760) offers every line to the parser that took the stream's last line, then to the others
+// in order; a line nobody takes flushes every parser's groups and leaves alone through the FIRST parser's default group.  Taking a line is
+// stateless for parsers with a parser in front (the parse succeeds, the content key is there): the first half of a read says per parser
+// how many lines it takes.  What runs here is the case files are made of -- ONE parser takes every line that is taken at all in a read
+// (then the list behaves exactly like that parser alone: the others only ever see lines they turn down, and the lone lines leave with the
+// same key) -- and the call FAILS for a read whose lines split between parsers, or that changes parsers while a group is open: the caller
+// keeps those on the CPU.
+struct flbgpu_ml_list {
+    std::vector<flbgpu_ml_stream *> s;
+    int lru = -1;
+    DevBuf d_in;
+};
+
+extern "C" flbgpu_ml_list *flbgpu_ml_list_create(flbgpu_ml_stream **streams, int n) {
+    if (!streams || n < 1 || n > 8) { set_err("multiline list: 1 to 8 streams"); return nullptr; }
+    for (int i = 0; i < n; i++) {
+        if (!streams[i] || !streams[i]->p->sub) { set_err("multiline list: every parser of a list needs a parser in front (docker, cri, or flbgpu_ml_parser_set_subparser)"); return nullptr; }
+        if (streams[i]->p->key_content != streams[0]->p->key_content) { set_err("multiline list: the parsers of a list must share key_content"); return nullptr; }
+    }
+    auto *l = new flbgpu_ml_list();
+    l->s.assign(streams, streams + n);
+    return l;
+}
+extern "C" void flbgpu_ml_list_destroy(flbgpu_ml_list *l) { if (l) { l->d_in.release(); delete l; } }
+extern "C" int flbgpu_ml_list_lru(const flbgpu_ml_list *l) { return l ? l->lru : -1; }
+
+extern "C" int flbgpu_ml_list_append_dev(flbgpu_ml_list *l, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                                         flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records) {
+    memset(out, 0, sizeof(*out));
+    *processed = 0; *records = 0;
+    if (!l) { set_err("multiline list: no list"); return -1; }
+    if (bytes > 0xFFFF0000ull) { set_err("multiline: more than 4 GB in one call"); return -1; }
+    const int n = (int) l->s.size();
+    auto pending = [](const flbgpu_ml_stream *s) { for (int g = 0; g < MLO_G; g++) if (s->gc_map_len[g] > 0 || s->gc_content_len[g] > 0) return true; return false; };
+    auto drop_phases = [&]() { for (auto *s : l->s) s->ph_empty = true; };
+    const int A = l->lru >= 0 ? l->lru : 0;
+    if (mlo_phase1(l->s[(size_t) A], d_text, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, processed, true) != 0) { drop_phases(); return -1; }
+    int chosen = A;
+    const uint64_t lines = l->s[(size_t) A]->ph_lines, taken_a = l->s[(size_t) A]->ph_taken;
+    if (taken_a < lines) {
+        // lines the first parser in turn leaves to the others: does anybody take one?
+        int first_other = -1, others = 0;
+        for (int j = 0; j < n; j++) {
+            if (j == A) continue;
+            uint64_t pr = 0;
+            if (mlo_phase1(l->s[(size_t) j], d_text, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, &pr, true) != 0) { drop_phases(); return -1; }
+            if (l->s[(size_t) j]->ph_taken > 0) { others++; if (first_other < 0) first_other = j; }
+        }
+        if (first_other >= 0) {
+            const uint64_t taken_b = l->s[(size_t) first_other]->ph_taken;
+            if (taken_a > 0 || (others > 1 && taken_b < lines)) {
+                drop_phases();
+                set_err("multiline list: the lines of one read split between parsers (%llu of %llu for parser %d, parser %d takes others): not on the GPU path",
+                        (unsigned long long) taken_a, (unsigned long long) lines, A, first_other);
+                return -1;
+            }
+            for (int j = 0; j < n; j++)
+                if (j != first_other && pending(l->s[(size_t) j])) { drop_phases(); set_err("multiline list: the stream changes parsers while a group of parser %d is open: not on the GPU path", j); return -1; }
+            chosen = first_other;
+        }
+    }
+    flbgpu_ml_stream *sc = l->s[(size_t) chosen];
+    const uint64_t taken_c = sc->ph_taken;
+    for (int j = 0; j < n; j++) if (j != chosen) l->s[(size_t) j]->ph_empty = true;
+    if (mlo_phase2(sc, out, records) != 0) { drop_phases(); return -1; }
+    if (taken_c > 0) l->lru = chosen;
+    return 0;
+}
+
+extern "C" int flbgpu_ml_list_append(flbgpu_ml_list *l, const void *text, size_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                                     void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *records) {
+    *out_buf = nullptr; *out_size = 0;
+    if (!l) { set_err("multiline list: no list"); return -1; }
+    // (uploaded with a blocking copy: every parser's stream reads it)
+    if (bytes && (!l->d_in.ensure(bytes + 16) || hipMemcpy(l->d_in.p, text, bytes, hipMemcpyHostToDevice) != hipSuccess)) { set_err("multiline: upload failed"); return -1; }
+    flbgpu_dev_chunk out;
+    if (flbgpu_ml_list_append_dev(l, l->d_in.p, bytes, ts_sec, ts_nsec, skip_empty_lines, flush, &out, processed, records) != 0) return -1;
     if (out.bytes == 0) return 0;
     void *hb = malloc(out.bytes);
     if (!hb) { set_err("out of memory"); return -1; }

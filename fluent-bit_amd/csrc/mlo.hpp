@@ -55,6 +55,7 @@ struct MloArgs {
 
 
 void launch_mlo_extract(const MloArgs &a, hipStream_t st);
+void launch_mlo_kinds(const MloArgs &a, hipStream_t st);
 void launch_mlo_gid(const MloArgs &a, hipStream_t st);
 size_t mlo_vscan_tmp_bytes(uint64_t n);
 void launch_mlo_vscan(const MloArgs &a, void *tmp, hipStream_t st);

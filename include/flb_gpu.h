@@ -295,6 +295,20 @@ int flbgpu_ml_append(flbgpu_ml_stream *s, const void *text, size_t bytes, uint32
 /* text already in HBM -> a device chunk (one row per group, groups without content as empty rows) the filters take as it is */
 int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
                          flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records);
+/* A list of parsers on one stream -- in_tail's `multiline.parser docker, cri` (flb_ml_append_text's loop over the instances, src/multiline/
+ * flb_ml.c:671-760: the parser that took the stream's last line first, then the others in order; a line nobody takes flushes every parser's
+ * groups and leaves alone).  Every parser of the list needs a parser in front (taking a line is then stateless) and the same key_content.
+ * A read in which ONE parser takes every line that is taken at all behaves exactly like that parser alone and runs here; a read whose lines
+ * split between parsers, or a change of parsers while a group is open, makes the call fail (-1, flbgpu_last_error): the caller keeps it on
+ * the CPU.  The streams stay the caller's (one per parser, created from it, used by this list only). */
+typedef struct flbgpu_ml_list flbgpu_ml_list;
+flbgpu_ml_list *flbgpu_ml_list_create(flbgpu_ml_stream **streams, int n);
+void flbgpu_ml_list_destroy(flbgpu_ml_list *l);
+int flbgpu_ml_list_lru(const flbgpu_ml_list *l);     /* which parser took the last line (-1: none yet): flb_ml_group.lru_parser */
+int flbgpu_ml_list_append(flbgpu_ml_list *l, const void *text, size_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                          void **out_buf, size_t *out_size, uint64_t *processed, uint64_t *records);
+int flbgpu_ml_list_append_dev(flbgpu_ml_list *l, const void *d_text, uint64_t bytes, uint32_t ts_sec, uint32_t ts_nsec, int skip_empty_lines, int flush,
+                              flbgpu_dev_chunk *out, uint64_t *processed, uint64_t *records);
 
 /* row offsets of an NDJSON buffer (each line with its '\n'); returns the row count or -1 if cap is short */
 int64_t flbgpu_split_lines_host(const void *data, size_t bytes, uint64_t *row_off, size_t cap);

@@ -287,3 +287,66 @@ def mo_set_now(m, sec, nsec):
     import oracle_binding as ob
     ob.lib().oml_set_now.argtypes = [ob.c_void_p, ob.c_int64, ob.c_int64]
     ob.lib().oml_set_now(m.h, sec, nsec)
+
+
+def list_run(g, names, frames, skip_empty_lines=False, final_flush=False):
+    ps = [g.MultilineParser(builtin=nm) for nm in names]
+    ml = g.MultilineList(ps)
+    out, n = b"", 0
+    try:
+        for sec, nsec, text in frames:
+            o, r = ml.append(text, sec, nsec, skip_empty_lines)
+            out += o; n += r
+        if final_flush:
+            o, r = ml.flush(1900000000, 3)
+            out += o; n += r
+        return out, n, ml.lru
+    finally:
+        ml.close()
+        for p in ps:
+            p.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_parser_lists(g, seed):
+    """in_tail's `multiline.parser docker, cri` (both orders): flb_ml_append_text's loop over the parser instances.  Files of one
+    runtime -- every line that is taken at all is taken by one parser, damaged lines leave alone -- equal the oracle's list (which
+    equals the reference's, test_multiline_oracle.py::test_parser_lists_against_the_reference) at every read boundary"""
+    rng = random.Random(9300 + seed)
+    ran = 0
+    for _ in range(40):
+        names = rng.choice([["docker", "cri"], ["cri", "docker"]])
+        n = rng.randrange(0, 70)
+        text = ml_synth.cri_text(rng, n, bad_times=False) if rng.random() < 0.5 else ml_synth.docker_text(rng, n)
+        if rng.random() < 0.2 and text:
+            text = text[:-1]
+        frames = ml_synth.frames_of(rng, text)
+        kw = dict(skip_empty_lines=rng.random() < 0.4, final_flush=rng.random() < 0.7)
+        cfg = {"builtin": ", ".join(names)}
+        want, wn, _ = oracle_run(cfg, frames, clock_of_the_call=True, **kw)
+        got, gn, lru = list_run(g, names, frames, **kw)
+        assert got == want, (names, frames, kw, first_diff(want, got))
+        assert gn == wn
+        ran += 1
+    assert ran == 40
+
+
+def test_parser_list_refuses_a_split_read(g):
+    """lines of both runtimes in one read: the reference hands them to different parsers line by line -- the device path says no"""
+    rng = random.Random(5)
+    a = ml_synth.cri_text(rng, 20, bad_times=False, damage=0.0)
+    b = ml_synth.docker_text(rng, 20)
+    ps = [g.MultilineParser(builtin="docker"), g.MultilineParser(builtin="cri")]
+    ml = g.MultilineList(ps)
+    with pytest.raises(RuntimeError):
+        ml.append(a + b, 100, 5)
+    # nothing moved: the same list still takes a clean file, and remembers who took it
+    out, n = ml.append(a, 100, 5)
+    assert ml.lru == 1 and n > 0
+    want, wn, _ = oracle_run({"builtin": "docker, cri"}, [(100, 5, a)], clock_of_the_call=True)
+    assert out == want and n == wn
+    ml.close()
+    for p in ps:
+        p.close()
+    with pytest.raises(ValueError):
+        g.MultilineList([g.MultilineParser(builtin="java")])          # no parser in front: taking a line depends on the parser's state
