@@ -1,4 +1,6 @@
-cd /root/repo
-mkdir -p gpurun_out/r3h
-echo "--- tile"; python tools/perf_json.py 4000000 2>&1 | head -3
-echo "--- direct"; FLBGPU_JSON_DIRECT=1 python tools/perf_json.py 4000000 2>&1 | head -3
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r3k
+timeout 1200 python -m pytest tests/test_json_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+python tools/perf_json.py 4000000 2>&1 | tail -2 | tee gpurun_out/r3k/perf_json.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
