@@ -382,7 +382,14 @@ struct GrepArgs {
     // table reads per byte of a tested value, ~100 cycles from LDS against ~400 through L2
     uint32_t rule_lds_off[MAX_RULES], rule_lds_bytes[MAX_RULES];   // offset 0xFFFFFFFF: not staged
     uint32_t rules_lds_total;
+    // the rules' top-level keys, each once: ONE walk over the body map finds the value of every key (the last entry of that name, as
+    // flb_ra_key.c's backward lookup does) instead of one walk per rule.  nslots == 0: more than GREP_SLOTS distinct keys -- every rule
+    // looks its key up itself
+    int nslots;
+    uint8_t slot_rule[8];       // a rule that carries the slot's key
+    uint8_t rule_slot[MAX_RULES];
 };
+constexpr int GREP_SLOTS = 8;
 
 
 // ---- msgpack -> JSON output formatter (fmt_dev.inc / kernels_fmt.hip): flb_pack_msgpack_to_json_format

@@ -1110,6 +1110,27 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
         }
         ga.rules_lds_total = used;
     }
+    {
+        // the rules' distinct top-level keys: one map walk per record finds them all (kdev.inc grep_walk)
+        ga.nslots = 0;
+        memset(ga.slot_rule, 0, sizeof(ga.slot_rule)); memset(ga.rule_slot, 0, sizeof(ga.rule_slot));
+        bool fits = !getenv("FLBGPU_GREP_NO_HITS") && f->rules.size() <= (size_t) MAX_RULES;
+        for (size_t i = 0; fits && i < f->rules.size(); i++) {
+            const DevKey &k = f->rules[i].key;
+            int slot = -1;
+            for (int s = 0; s < ga.nslots; s++) {
+                const DevKey &o = f->rules[ga.slot_rule[s]].key;
+                if (o.key_len == k.key_len && memcmp(o.key, k.key, (size_t) k.key_len) == 0) { slot = s; break; }
+            }
+            if (slot < 0) {
+                if (ga.nslots >= GREP_SLOTS) { fits = false; break; }
+                slot = ga.nslots++;
+                ga.slot_rule[slot] = (uint8_t) i;
+            }
+            ga.rule_slot[i] = (uint8_t) slot;
+        }
+        if (!fits) ga.nslots = 0;
+    }
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     total = 0;
