@@ -1114,7 +1114,8 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
         // the rules' distinct top-level keys: one map walk per record finds them all (kdev.inc grep_walk)
         ga.nslots = 0;
         memset(ga.slot_rule, 0, sizeof(ga.slot_rule)); memset(ga.rule_slot, 0, sizeof(ga.rule_slot));
-        bool fits = !getenv("FLBGPU_GREP_NO_HITS") && f->rules.size() <= (size_t) MAX_RULES;
+        // (a single rule keeps its own lookup: one walk either way, and the slot compare costs 19 % there -- 1.79 against 2.13 ms per 10 M)
+        bool fits = !getenv("FLBGPU_GREP_NO_HITS") && f->rules.size() >= 2 && f->rules.size() <= (size_t) MAX_RULES;
         for (size_t i = 0; fits && i < f->rules.size(); i++) {
             const DevKey &k = f->rules[i].key;
             int slot = -1;
