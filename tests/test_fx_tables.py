@@ -365,3 +365,30 @@ def test_tail_skip_equals_the_full_walk():
                 assert list(b1[:n1 + 1]) == list(b2[:n1 + 1]) and list(e1[:n1 + 1]) == list(e2[:n1 + 1]), (name, s)
         L.flbgpu_rx_free(h)
     assert compared > 2500 and skipped > 700 and declined > 20, (compared, skipped, declined)
+
+
+def test_stock_parsers_with_a_tail():
+    """which of the reference's stock regex parsers (conf/parsers.conf, restated here) get a tail in their compact tables, and with
+    which kill bytes: the line feed alone (`.` does not take it; bytes >= 0x80 poison the walk whatever the row)"""
+    L = _lib()
+    L.flbgpu_rx_fx_tail.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    pats = {
+        "apache2": rb'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$',
+        "apache_error": rb'^\[[^ ]* (?<time>[^\]]*)\] \[(?<level>[^\]]*)\](?: \[pid (?<pid>[^\]]*)\])?( \[client (?<client>[^\]]*)\])? (?<message>.*)$',
+        "syslog-rfc5424": rb'^\<(?<pri>[0-9]{1,5})\>1 (?<time>[^ ]+) (?<host>[^ ]+) (?<ident>[^ ]+) (?<pid>[-0-9]+) (?<msgid>[^ ]+) (?<extradata>(\[(.*?)\]|-)) (?<message>.+)$',
+        "cri": rb'^(?<time>[^ ]+) (?<stream>stdout|stderr) (?<logtag>[^ ]*) (?<message>.*)$',
+        "nginx": rb'^(?<remote>[^ ]*) (?<host>[^ ]*) (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^\"]*?)(?: +\S*)?)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>[^\"]*)")',
+        "fields_only": rb'^(?<a>[^ ]*) (?<b>[^ ]*) (?<c>[^ ]*)$',
+    }
+    # kill bytes: the line feed (`.` does not take it); a last field `[^ ]*$` also dies on a space -- such a line is no match either way
+    want_tail = {"apache2": [10], "apache_error": [10], "syslog-rfc5424": [10], "cri": [10], "nginx": None, "fields_only": [10, 32]}
+    for name, pat in pats.items():
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        assert h, (name, err.value)
+        nk = ctypes.c_int(); kill = ctypes.create_string_buffer(4); first = ctypes.c_int()
+        rows = L.flbgpu_rx_fx_tail(h, None, 0, ctypes.byref(nk), kill, ctypes.byref(first))
+        assert (rows > 0) == (want_tail[name] is not None), (name, rows)
+        if rows > 0:
+            assert sorted(kill.raw[:nk.value]) == want_tail[name], (name, list(kill.raw[:nk.value]))
+        L.flbgpu_rx_free(h)
