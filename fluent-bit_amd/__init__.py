@@ -569,6 +569,15 @@ class StreamTask:
             raise RuntimeError(last_error())
         return int(rec.value), self._take(out, sz)
 
+    def select_dev(self, chunk, now=(1, 0)):
+        """a SELECT without aggregation functions, device chunk in -> (records that passed WHERE, DevChunk of the projected records)"""
+        L = lib()
+        L.flbgpu_sp_select_dev.argtypes = [c_void_p, POINTER(DevChunk), c_void_p, ctypes.c_uint32, ctypes.c_uint32, POINTER(DevChunk), POINTER(c_int64)]
+        out = DevChunk(); rec = c_int64()
+        if L.flbgpu_sp_select_dev(self.h, byref(chunk), None, now[0], now[1], byref(out), byref(rec)) != 0:
+            raise RuntimeError(last_error())
+        return int(rec.value), out
+
     def timer(self, now=(1, 0)):
         """the window's timer fires: packaged records of the window, which is then pruned"""
         out = c_void_p(); sz = c_size_t()

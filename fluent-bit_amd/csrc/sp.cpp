@@ -858,9 +858,10 @@ bool package(flbgpu_sp *t, Snapshot &sn, uint32_t now_sec, uint32_t now_nsec, st
 }
 
 // a plain SELECT over one chunk: size pass, scan, emit; what leaves is copied straight into the buffer finish_do hands over
-bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32_t now_sec, uint32_t now_nsec) {
+bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32_t now_sec, uint32_t now_nsec, flbgpu_dev_chunk *dev_out = nullptr) {
     uint64_t n = in->n;
     free(t->sel_out); t->sel_out = nullptr; t->sel_bytes = 0;
+    if (dev_out) memset(dev_out, 0, sizeof(*dev_out));
     t->records = 0;
     if (n == 0) return true;
     // time / record functions: the pair (RECORD_TIME: its key) packed once per call
@@ -912,6 +913,12 @@ bool run_select(flbgpu_sp *t, const flbgpu_dev_chunk *in, hipStream_t st, uint32
     if (!t->d_sout.ensure(total + 16)) return false;
     a.out = t->d_sout.as<uint8_t>();
     { Profile pr(t, 1, st); launch_sp_select(a, true, st); }
+    if (dev_out) {
+        // the projected records stay in HBM: one row per incoming row (empty where nothing leaves), the layout every *_run_dev takes
+        HIPOK(hipStreamSynchronize(st));
+        dev_out->data = t->d_sout.p; dev_out->row_off = t->d_soff.as<uint64_t>(); dev_out->n = n; dev_out->bytes = total;
+        return true;
+    }
     t->sel_out = malloc(total);
     if (!t->sel_out) { set_err("out of memory"); return false; }
     t->sel_bytes = total;
@@ -1235,6 +1242,17 @@ extern "C" int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *
     hipStream_t st = stream ? (hipStream_t) stream : t->stream;
     if (!run_dev(t, in, st, now_sec, now_nsec)) return -1;
     return finish_do(t, now_sec, now_nsec, out_buf, out_size, records);
+}
+
+extern "C" int flbgpu_sp_select_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uint32_t now_sec, uint32_t now_nsec, flbgpu_dev_chunk *out,
+                                    int64_t *records) {
+    if (!t || !in || !out) { set_err("stream processor: null argument"); return -1; }
+    if (!t->q.select_only) { set_err("stream processor: flbgpu_sp_select_dev is for SELECTs without aggregation functions"); return -1; }
+    hipStream_t st = stream ? (hipStream_t) stream : t->stream;
+    if (!run_select(t, in, st, now_sec, now_nsec, out)) return -1;
+    if (records) *records = (int64_t) t->records;
+    t->records = 0;
+    return 0;
 }
 
 extern "C" int flbgpu_sp_do(flbgpu_sp *t, const void *data, size_t bytes, uint32_t now_sec, uint32_t now_nsec, void **out_buf, size_t *out_size,

@@ -353,6 +353,10 @@ int flbgpu_sp_do(flbgpu_sp *t, const void *data, size_t bytes, uint32_t now_sec,
                  int64_t *records);
 int flbgpu_sp_do_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uint32_t now_sec, uint32_t now_nsec, void **out_buf,
                      size_t *out_size, int64_t *records);
+/* a SELECT without aggregation functions whose result stays in HBM: *out = the projected records as a device chunk (one row per incoming
+ * row, empty where nothing leaves; valid until the task's next call), what flbgpu_jsonfmt_run_dev / a further filter chain takes as it is */
+int flbgpu_sp_select_dev(flbgpu_sp *t, const flbgpu_dev_chunk *in, void *stream, uint32_t now_sec, uint32_t now_nsec, flbgpu_dev_chunk *out,
+                         int64_t *records);
 /* the window's timer fired: package (if the window saw records) and prune */
 int flbgpu_sp_timer(flbgpu_sp *t, uint32_t now_sec, uint32_t now_nsec, void **out_buf, size_t *out_size);
 /* WINDOW HOPPING (n unit, ADVANCE BY m unit) -- replaces flb_sp_fd_event's window.fd_hop branch (src/stream_processor/flb_sp.c:2170-2185

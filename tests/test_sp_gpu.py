@@ -391,6 +391,16 @@ def test_select_at_size_device_resident(g):
     L.flbgpu_memcpy_h2d(d_o, off.ctypes.data, off.nbytes)
     ret, out = t.do_dev(g.DevChunk(d_d, d_o, 1_000_000, data.nbytes))
     assert t.do(data.tobytes()) == (ret, out)                         # the host entry point indexes the chunk itself: same answer
+    # and the result as a device chunk (flbgpu_sp_select_dev): the same bytes, one row per incoming row
+    ret_d, dch = t.select_dev(g.DevChunk(d_d, d_o, 1_000_000, data.nbytes))
+    assert ret_d == ret and dch.n == 1_000_000 and dch.bytes == len(out)
+    hb = np.empty(len(out), dtype=np.uint8)
+    L.flbgpu_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.flbgpu_memcpy_d2h(hb.ctypes.data, dch.data, hb.nbytes)
+    assert hb.tobytes() == out
+    ho = np.empty(1_000_001, dtype=np.uint64)
+    L.flbgpu_memcpy_d2h(ho.ctypes.data, dch.row_off, ho.nbytes)
+    assert int(ho[-1]) == len(out) and bool(np.all(np.diff(ho.astype(np.int64)) >= 0)) and int((np.diff(ho.astype(np.int64)) > 0).sum()) == ret
     L.flbgpu_dev_free(d_d); L.flbgpu_dev_free(d_o)
     raw = data.reshape(1_000_000, -1)
     RL = raw.shape[1]
