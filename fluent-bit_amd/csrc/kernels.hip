@@ -673,11 +673,13 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
 
 // copy of the kept records: one wave per record, byte granular
 
-// One wave per 64 rows: the kept rows of the tile are copied one after the other, each by the
-// whole wave with 16 B per lane (unaligned vector loads/stores), so a 275 B record is one load
-// and one store instruction.
+// One wave per 64 rows; the kept rows of the tile are copied FOUR at a time, each by a quarter of the wave with 16 B per lane
+// (unaligned vector loads / stores: a 275 B record is two steps of its sixteen lanes).  Round 1 copied them one after the other with
+// the whole wave -- twelve lanes busy for a 180 B event and up to 64 dependent load -> store round trips per tile (85 % of the wave
+// cycles waiting); now a quarter of the trips, the four rows' loads in flight together.
 __global__ void __launch_bounds__(256) k_gather(GatherArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint8_t sel[4][64];                 // per wave: the lane that holds the j-th kept row of the tile
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, quarter = lane >> 4, ql = lane & 15;
     const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
@@ -687,18 +689,25 @@ __global__ void __launch_bounds__(256) k_gather(GatherArgs a) {
         uint32_t len = 0;
         uint64_t so = 0, dof = 0;
         if (r < a.n) { len = a.keep_len[r]; if (len) { so = a.row_off[r]; dof = a.out_off[r]; } }
-        uint64_t mask = __ballot(len != 0);
-        while (mask) {
-            const int src_lane = __builtin_ctzll(mask);
-            mask &= mask - 1;
+        const uint64_t mask = __ballot(len != 0);
+        const uint32_t nk = (uint32_t) __builtin_popcountll(mask);
+        if (len) sel[wave][__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint8_t) lane;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (uint32_t j0 = 0; j0 < nk; j0 += 4) {
+            const uint32_t j = j0 + quarter;
+            const bool on = j < nk;
+            const int src_lane = on ? (int) sel[wave][j] : 0;
             const uint32_t l = __shfl(len, src_lane, 64);
             const uint8_t *src = a.data + __shfl(so, src_lane, 64);
             uint8_t *dst = a.out + __shfl(dof, src_lane, 64);
-            for (uint32_t o = lane * 16; o < l; o += 64 * 16) {
-                if (o + 16 <= l) *(v4un *) (dst + o) = *(const v4un *) (src + o);
-                else for (uint32_t q = o; q < l; q++) dst[q] = src[q];
+            if (on) {
+                for (uint32_t o = ql * 16; o < l; o += 16 * 16) {
+                    if (o + 16 <= l) *(v4un *) (dst + o) = *(const v4un *) (src + o);
+                    else for (uint32_t q = o; q < l; q++) dst[q] = src[q];
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
