@@ -107,6 +107,8 @@ CodeSet mb_complement(const CodeSet &in) {
     return o;
 }
 
+CodeSet unicode_word_set();           // {cp >= 0x80 : unicode_word(cp)} (defined behind posix_ranges.inc)
+
 struct CC {
     enum Kind { CLASS, ANY, WORD, LIT } kind = CLASS;
     ByteSet bs;
@@ -123,6 +125,7 @@ struct CC {
     ByteSet asc;
     uint32_t lit = 0;                 // LIT: the code point (matched as its exact byte sequence)
     bool any_nl = false;              // ANY: also matches \n  ((?m))
+    bool uni = false;                 // WORD under (?u): OP_WORD instead of OP_ASCII_WORD -- ONIGENC_IS_MBC_WORD on the decoded character
 
     bool has_mb() const { for (auto &x : mb.r) if (x.second >= 0x80 && x.first <= x.second) return true; return false; }
     // dest |= o, o's negation resolved first (regparse.c or_cclass / or_code_range_buf with not1 == 0)
@@ -161,7 +164,7 @@ struct CC {
         switch (kind) {
         case CLASS: return bs.has(b) != neg;
         case ANY: return true;
-        case WORD: return neg;
+        case WORD: return (uni && b < 0xfe && unicode_word((uint32_t) b)) != neg;
         case LIT: return false;
         }
         return false;
@@ -171,7 +174,7 @@ struct CC {
         switch (kind) {
         case CLASS: return (has_mb() ? mb.has((uint32_t) b) : bs.has(b)) != neg;
         case ANY: return true;
-        case WORD: return neg;
+        case WORD: return (uni && unicode_word((uint32_t) b)) != neg;
         case LIT: return false;
         }
         return false;
@@ -197,7 +200,14 @@ struct CC {
             }
             break;
         case ANY: o.add(0x80, MAXCP); break;
-        case WORD: if (neg) o.add(0x80, MAXCP); break;
+        case WORD:
+            if (!uni) { if (neg) o.add(0x80, MAXCP); }
+            else {
+                CodeSet w = unicode_word_set();
+                if (neg) { w = mb_complement(w); w.norm(); for (auto &x : w.r) if (x.first <= MAXCP) o.add(x.first, std::min(x.second, MAXCP)); }
+                else o = w;
+            }
+            break;
         case LIT: if (lit >= 0x80) o.add(lit, lit); break;
         }
         o.norm();
@@ -206,6 +216,14 @@ struct CC {
 };
 
 #include "posix_ranges.inc"
+
+CodeSet unicode_word_set() {
+    CodeSet w;
+    for (uint32_t c : {0xb2u, 0xb3u, 0xb9u, 0xbcu, 0xbdu, 0xbeu}) w.add(c, c);
+    for (int i = 0; i < posix_u_word_n; i++) w.add(posix_u_word[i][0], posix_u_word[i][1]);
+    w.norm();
+    return w;
+}
 
 }  // namespace
 // what \b / \B ask of a character (regexec.c OP_WORD_BOUND: ONIGENC_IS_MBC_WORD -> onigenc_unicode_is_code_ctype): below U+0100
@@ -227,6 +245,18 @@ bool unicode_word(uint32_t cp) {
 const unsigned int (*unicode_word_ranges(int *n))[2] { *n = posix_u_word_n; return posix_u_word; }
 namespace {
 
+// (?a) / (?u) / (?d) (regparse.c:5257-5297): three option bits of the reference, kept as "off" flags so that 0 is Ruby's default
+// (ONIG_OPTION_ASCII_RANGE | POSIX_BRACKET_ALL_RANGE | WORD_BOUND_ALL_RANGE, regcomp.c:5842-5850):
+//   (?a)  ASCII_RANGE on,  POSIX_BRACKET_ALL_RANGE off, WORD_BOUND_ALL_RANGE off
+//   (?u)  ASCII_RANGE off, POSIX_BRACKET_ALL_RANGE off, WORD_BOUND_ALL_RANGE off
+//   (?d)  all three on (the default)
+// \d \s \w \h are ASCII iff ASCII_RANGE; a POSIX bracket iff ASCII_RANGE && !POSIX_BRACKET_ALL_RANGE (regparse.c:4312);
+// \b \B iff ASCII_RANGE && !WORD_BOUND_ALL_RANGE (regparse.c:3437)
+constexpr unsigned OPT_AR_OFF = 8u, OPT_PBA_OFF = 16u, OPT_WBA_OFF = 32u;
+inline bool ctype_is_ascii(unsigned o) { return !(o & OPT_AR_OFF); }
+inline bool posix_is_ascii(unsigned o) { return !(o & OPT_AR_OFF) && (o & OPT_PBA_OFF); }
+inline bool wordb_is_ascii(unsigned o) { return !(o & OPT_AR_OFF) && (o & OPT_WBA_OFF); }
+
 // \d \s \w \h inside or outside brackets: ASCII-range under Ruby syntax (ONIG_OPTION_ASCII_RANGE).  The
 // positive form has no code-range part; the negated form is "ASCII complement + every code point >= 0x80"
 // (regparse.c add_ctype_to_cc with ascii_range)
@@ -238,7 +268,13 @@ void ctype_ascii(ByteSet &bs, char t) {
     case 'h': bs.set_range('0', '9'); bs.set_range('A', 'F'); bs.set_range('a', 'f'); break;
     }
 }
-void add_ctype(CC &cc, char t, bool negated) {
+bool add_posix(CC &cc, const std::string &n, bool negated, bool ascii_range);
+void add_ctype(CC &cc, char t, bool negated, bool unicode = false) {
+    if (unicode) {
+        // (?u): the Unicode property ranges (add_ctype_to_cc without ascii_range = what a POSIX bracket of the same type adds)
+        add_posix(cc, t == 'd' ? "digit" : t == 's' ? "space" : t == 'h' ? "xdigit" : "word", negated, false);
+        return;
+    }
     ByteSet a;
     ctype_ascii(a, t);
     if (t != 'w') { for (int b = 0; b < 0x80; b++) if (a.has(b) != negated) cc.asc.set(b); }
@@ -252,7 +288,7 @@ void add_ctype(CC &cc, char t, bool negated) {
 
 // [[:name:]] / [[:^name:]]: NOT ASCII-range (ONIG_OPTION_POSIX_BRACKET_ALL_RANGE): the code points >= 0x80
 // come from posix_ranges.inc (generated by probing the reference's engine, tools/gen_posix_ranges.py)
-bool add_posix(CC &cc, const std::string &n, bool negated) {
+bool add_posix(CC &cc, const std::string &n, bool negated, bool ascii_range = false) {
     ByteSet a;
     const unsigned int (*u)[2] = nullptr;
     int un = 0;
@@ -275,6 +311,15 @@ bool add_posix(CC &cc, const std::string &n, bool negated) {
 #undef PX
     CodeSet m;
     for (int i = 0; i < un; i++) m.add(u[i][0], u[i][1]);
+    if (ascii_range) {
+        // (?a): add_ctype_to_cc with ascii_range (regparse.c:4153-4180): the members below 0x80; negated: their ASCII complement and
+        // every code point from 0x80 on.  (The shadow class `asc` of (?i) does not get them: regparse.c:4320-4324 `!ascii_range`.)
+        if (!negated) { cc.bs.merge(a); return true; }
+        for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
+        cc.mb.add(0x80, LASTCP); cc.mb.norm();
+        cc.mbx.add(0x80, LASTCP); cc.mbx.norm();
+        return true;
+    }
     if (n != "word" && n != "ascii") { for (int b = 0; b < 0x80; b++) if (a.has(b) != negated) cc.asc.set(b); }
     if (!negated) { cc.bs.merge(a); cc.mb.merge(m); cc.mbx.merge(m); }
     else {
@@ -304,6 +349,14 @@ bool fold_case(CC &cc) {
             if (x.first != x.second || (x.first != 0x212a && x.first != 0x17f)) return false;
         }
     }
+    // A class that holds EVERY code point from 0x80 on ([\D], [\W], a negated ASCII-range bracket ...): the reference's fold pass
+    // (regparse.c i_apply_case_fold: for every fold pair (from, to) with `from` in the class it adds `to` -- into the BIT SET when
+    // to < 0x100) sets the bits of the Latin-1 letters that have a case partner, and the bit set is what a stray byte >= 0x80 -- a
+    // character of its own whose code is the byte -- is tested on: (?i)[\D] takes a lone 0xE9, [\D] does not (probed from the engine)
+    if (cc.has_mb() && !partial) {
+        cc.bs.set(0xb5);
+        for (int b = 0xc0; b <= 0xff; b++) if (b != 0xd7 && b != 0xf7) cc.bs.set(b);
+    }
     // (the letters were closed under ASCII case above, from the members as they were: the shadow class decides for each of the two)
     const bool kx = cc.mb.has(0x212a) || (had_k && cc.asc.has('k')) || (had_K && cc.asc.has('K'));
     const bool sx = cc.mb.has(0x17f) || (had_s && cc.asc.has('s')) || (had_S && cc.asc.has('S'));
@@ -316,7 +369,8 @@ bool fold_case(CC &cc) {
 }
 
 // ---------------------------------------------------------------- AST
-enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB };
+// (A_WORDB_A / A_NWORDB_A: \b \B under (?a) -- OP_ASCII_WORD_BOUND: only [0-9A-Za-z_] are word characters)
+enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB, A_WORDB_A, A_NWORDB_A };
 
 struct Ast {
     enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR } t = EMPTY;
@@ -451,7 +505,7 @@ struct Syntax {
                         const unsigned char *nm = q;
                         while (q < e && *q >= 'a' && *q <= 'z') q++;
                         if (q + 1 < e && q[0] == ':' && q[1] == ']') {
-                            if (!add_posix(s, std::string((const char *) nm, q - nm), pneg)) return fail("unknown POSIX bracket");
+                            if (!add_posix(s, std::string((const char *) nm, q - nm), pneg, posix_is_ascii(opts))) return fail("unknown POSIX bracket");
                             p = q + 2;
                             continue;
                         }
@@ -467,8 +521,8 @@ struct Syntax {
                     p++;
                     if (eof()) return fail("end pattern at escape");
                     int c = *p;
-                    if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c, false); continue; }
-                    if (c == 'D' || c == 'W' || c == 'S' || c == 'H') { p++; add_ctype(s, (char) (c + 32), true); continue; }
+                    if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c, false, !ctype_is_ascii(opts)); continue; }
+                    if (c == 'D' || c == 'W' || c == 'S' || c == 'H') { p++; add_ctype(s, (char) (c + 32), true, !ctype_is_ascii(opts)); continue; }
                     if (c == 'p' || c == 'P' || c == 'R' || c == 'X') return fail("property escapes are not supported");
                     if (escape_cp(lo, true)) { if (failed()) return false; }
                     else if (c >= '1' && c <= '7') {
@@ -583,6 +637,10 @@ struct Syntax {
                         else if (c == 'x') { if (on) o |= OPT_EXTEND; else o &= ~OPT_EXTEND; }
                         else if (c == '-') on = false;
                         else if (c == ')' || c == ':') break;
+                        // (?a) (?u) (?d): regparse.c:5257-5297 (Ruby syntax; not negatable)
+                        else if (c == 'a' && on) { o &= ~OPT_AR_OFF; o |= OPT_PBA_OFF | OPT_WBA_OFF; }
+                        else if (c == 'u' && on) { o |= OPT_AR_OFF | OPT_PBA_OFF | OPT_WBA_OFF; }
+                        else if (c == 'd' && on) { o &= ~(OPT_AR_OFF | OPT_PBA_OFF | OPT_WBA_OFF); }
                         else { fail("undefined group option"); return nullptr; }
                         p++;
                     }
@@ -631,14 +689,15 @@ struct Syntax {
                 // \w \W compile to the word opcodes, \d \s \h (and negations) to a bit-set class whose NOT is
                 // a flag (regparse.c parse_exp TK_CHAR_TYPE)
                 AstP a = mk(Ast::SET);
-                if ((c | 32) == 'w') { a->cc.kind = CC::WORD; a->cc.neg = !(c & 32); }
-                else { ctype_ascii(a->cc.bs, (char) (c | 32)); a->cc.neg = !(c & 32); }
+                if ((c | 32) == 'w') { a->cc.kind = CC::WORD; a->cc.neg = !(c & 32); a->cc.uni = !ctype_is_ascii(opts); }
+                else if (ctype_is_ascii(opts)) { ctype_ascii(a->cc.bs, (char) (c | 32)); a->cc.neg = !(c & 32); }
+                else { add_ctype(a->cc, (char) (c | 32), false, true); a->cc.neg = !(c & 32); }
                 return a;
             }
             if (c == 'A') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BOS; return a; }
             if (c == 'z') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_EOS; return a; }
-            if (c == 'b') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_WORDB; return a; }
-            if (c == 'B') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_NWORDB; return a; }
+            if (c == 'b') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_WORDB_A : A_WORDB; return a; }
+            if (c == 'B') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_NWORDB_A : A_NWORDB; return a; }
             if (c == 'Z') { fail("\\Z is not supported on the GPU path"); return nullptr; }
             if (strchr("GKRXkgpP", c)) { fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') { fail("back-references are not supported on the GPU path"); return nullptr; }
@@ -824,7 +883,9 @@ struct Nfa {
     std::vector<NNode> n;
     int npos = 0;
     int start = -1;
-    bool uses_nl = false, uses_word = false;
+    bool uses_nl = false, uses_word = false;      // uses_word: a Unicode-aware \b / \B (the default)
+    bool uses_aword = false;                      // an ASCII-only \b / \B ((?a))
+    std::vector<const void *> pos_ast;            // character-level automaton (rx_nfa.inc): position -> its character node
     std::string err;
 
     int add(NNode x) {
@@ -939,11 +1000,18 @@ struct Builder {
     Nfa &nfa;
     bool ascii_only;
     const SymbolMap *syms;
+    bool char_level = false;              // rx_nfa.inc: ONE position per character node, whatever the character's encoded length
     Builder(Nfa &n, bool ascii, const SymbolMap *sm) : nfa(n), ascii_only(ascii), syms(sm) {}
 
     // node matching one character accepted by the character node `a`, continuing at `next`
     int build_set(const Ast *a, int next) {
         const CC &cc = a->cc;
+        if (char_level) {
+            ByteSet none;
+            const int nd = nfa.consume(none, next);
+            nfa.pos_ast.push_back(a);
+            return nd;
+        }
         ByteSet single;
         for (int b = 0; b < 0x80; b++) if (cc.ascii(b)) single.set(b);
         std::vector<Seq> seqs;
@@ -1020,6 +1088,7 @@ struct Builder {
             NNode x; x.t = N_ASSERT; x.akind = a->anchor; x.next = next;
             if (a->anchor == A_BOL || a->anchor == A_EOL) nfa.uses_nl = true;
             if (a->anchor == A_WORDB || a->anchor == A_NWORDB) nfa.uses_word = true;
+            if (a->anchor == A_WORDB_A || a->anchor == A_NWORDB_A) nfa.uses_aword = true;
             return nfa.add(x);
         }
         case Ast::REPEAT: {
@@ -1050,7 +1119,19 @@ struct Builder {
 };
 
 // ---------------------------------------------------------------- closure lists
-enum Kind { K_OTHER = 0, K_NL = 1, K_WORD = 2, K_EDGE = 3, NKIND = 4 };
+// K_WORD: an ASCII word byte; K_UWORD: a non-ASCII character that is a Unicode word character (told apart from K_WORD only when the
+// pattern holds both a Unicode-aware and an ASCII-only (?a) word anchor)
+enum Kind { K_OTHER = 0, K_NL = 1, K_WORD = 2, K_EDGE = 3, K_UWORD = 4, NKIND = 5 };
+// canonical kind -> compact index of the kinds this pattern tells apart; returns their number
+int kind_map(const Nfa &nfa, bool any_assert, int *kmap) {
+    int n = 0;
+    kmap[K_OTHER] = n++;
+    kmap[K_NL] = nfa.uses_nl ? n++ : kmap[K_OTHER];
+    kmap[K_WORD] = (nfa.uses_word || nfa.uses_aword) ? n++ : kmap[K_OTHER];
+    kmap[K_EDGE] = any_assert ? n++ : kmap[K_OTHER];
+    kmap[K_UWORD] = (nfa.uses_word && nfa.uses_aword) ? n++ : nfa.uses_word ? kmap[K_WORD] : kmap[K_OTHER];
+    return n;
+}
 constexpr int T_MATCH = -1;
 
 struct Target { int pos; int tagseq; };   // pos == T_MATCH for MATCH
@@ -1091,8 +1172,10 @@ struct Tables {
         case A_EOL: return nk == K_EDGE || nk == K_NL;                     // OP_END_LINE
         case A_BOS: return pk == K_EDGE;
         case A_EOS: return nk == K_EDGE;
-        case A_WORDB: return (pk == K_WORD) != (nk == K_WORD);
-        case A_NWORDB: return (pk == K_WORD) == (nk == K_WORD);
+        case A_WORDB: return (pk == K_WORD || pk == K_UWORD) != (nk == K_WORD || nk == K_UWORD);
+        case A_NWORDB: return (pk == K_WORD || pk == K_UWORD) == (nk == K_WORD || nk == K_UWORD);
+        case A_WORDB_A: return (pk == K_WORD) != (nk == K_WORD);
+        case A_NWORDB_A: return (pk == K_WORD) == (nk == K_WORD);
         }
         return false;
     }
@@ -1232,15 +1315,9 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     bool any_assert = false;
     for (auto &nd : nfa.n) if (nd.t == N_ASSERT) any_assert = true;
     int kmap[NKIND];                         // canonical kind -> compact index
-    {
-        int n = 0;
-        kmap[K_OTHER] = n++;
-        kmap[K_NL] = nfa.uses_nl ? n++ : kmap[K_OTHER];
-        kmap[K_WORD] = nfa.uses_word ? n++ : kmap[K_OTHER];
-        kmap[K_EDGE] = any_assert ? n++ : kmap[K_OTHER];
-        out.NK = n;
-        out.kind_edge = kmap[K_EDGE];
-    }
+    out.NK = kind_map(nfa, any_assert, kmap);
+    out.kind_edge = kmap[K_EDGE];
+    if (out.NK > 4) { err = "pattern mixes (?a) and Unicode word anchors with line anchors: more context kinds than the byte tables hold (needs the NFA engine)"; return false; }
     int kinv[NKIND];                         // compact index -> a canonical kind
     for (int k = NKIND - 1; k >= 0; k--) kinv[kmap[k]] = k;
     // kind of a SYMBOL (rx.hpp TableSet::cls): an ASCII byte by itself; utf8 set with \b / \B: a stray byte / the lead of a cut
@@ -1251,11 +1328,11 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     auto kind_of_byte = [&](int sym) -> int {
         const int b = sym & 255;
         if (nfa.uses_nl && b == '\n') return K_NL;
-        if (!nfa.uses_word) return K_OTHER;
+        if (!nfa.uses_word && !nfa.uses_aword) return K_OTHER;
         if (b < 0x80) return ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_') ? K_WORD : K_OTHER;
-        if (ascii_only) return K_OTHER;
-        for (int k = 0; k < 11; k++) if (SPARE_BYTES[k] == b) return syms.sym_word[k] ? K_WORD : K_OTHER;
-        return sym >= 256 ? K_WORD : K_OTHER;
+        if (ascii_only || !nfa.uses_word) return K_OTHER;
+        for (int k = 0; k < 11; k++) if (SPARE_BYTES[k] == b) return syms.sym_word[k] ? K_UWORD : K_OTHER;
+        return sym >= 256 ? K_UWORD : K_OTHER;
     };
 
     Tables tb(nfa);
@@ -1582,6 +1659,43 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
     return true;
 }
 
+#include "rx_nfa.inc"
+
+// The ascii table set of a pattern whose ASCII automata do not fit either: ONE class, one state, every byte poisons -- the kernels
+// hand every value on to the second engine exactly as they hand on a value with a byte >= 0x80.  (An EMPTY value has no byte to
+// poison the walk: d_final[0] = 2 and TableSet::stub tell the walkers; kdev.inc.)
+void make_ascii_stub(TableSet &t, bool want_capture) {
+    t = TableSet();
+    t.ascii_only = true;
+    t.stub = true;
+    memset(t.cls, 0, sizeof(t.cls));
+    for (int b = 0; b < 256; b++) { t.xl[b] = (uint8_t) b; t.xl[256 + b] = (uint8_t) b; }
+    t.ncls = 1; t.high_cls = 0;
+    t.nD = 1; t.d_init = 0;
+    t.ddelta.assign(1, D_POISON);
+    t.d_final.assign(1, 2);
+    if (!want_capture) return;
+    t.nR = 1; t.r_init = 0;
+    t.rdelta.assign(1, R_POISON);
+    t.r_info.assign(1, 0);
+    t.P = 0; t.VW = 1;
+    t.vmask.assign(1, 0);
+    t.nX = 1; t.NK = 1; t.kind_edge = 0;
+    t.kind_of_cls.assign(1, 0);
+    t.list_off.assign(2, 0);
+    t.fc_shift = 1; t.cls_shift = 0;
+    t.fastc.assign(2, FC_DEAD);
+    t.rdelta_p.assign(2, 1);
+    t.ck.assign(512, 0);
+    t.NKp = 1; t.wsh = 1;
+    t.col.assign(512, 0);
+    t.col_eot = 1;
+    t.ft.assign(4, FT_SPECIAL | (FT_DEAD << 28));
+    t.ft[2] = t.ft[3] = 1;                      // the absorbing row
+    t.tag_off.assign(2, 0);
+    t.has_capture = true;
+}
+
 }  // namespace
 
 bool compile(const char *pattern, size_t len, unsigned options, bool want_captures, Program &out, std::string &err) {
@@ -1607,15 +1721,101 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
                 f++;
             }
     }
-    if (!build_tables(root.get(), true, true, want_captures, out.slot2cap, out.ascii, err)) {
+    // FLBGPU_RX_FORCE_NFA (tests): 1 = the NFA engine stands in for the utf8 table set even when that one builds; 2 = for both sets
+    const char *force_env = std::getenv("FLBGPU_RX_FORCE_NFA");
+    const int force = force_env ? atoi(force_env) : 0;
+    std::string why;
+    bool ascii_ok = force < 2, utf8_ok = force < 1;
+    if (ascii_ok && !build_tables(root.get(), true, true, want_captures, out.slot2cap, out.ascii, why)) {
         // a parser only walks the capture program: the match-only DFA (forward subset construction) may be left out
         // when it alone is over the budget (stock parser `ambassador`); grep rules (no captures) still need it
-        if (!want_captures || err != "match DFA exceeds the state budget") return false;
-        err.clear();
-        out.ascii = TableSet();
-        if (!build_tables(root.get(), true, false, true, out.slot2cap, out.ascii, err)) return false;
+        ascii_ok = false;
+        if (want_captures && why == "match DFA exceeds the state budget") {
+            std::string e2;
+            out.ascii = TableSet();
+            ascii_ok = build_tables(root.get(), true, false, true, out.slot2cap, out.ascii, e2);
+            if (!ascii_ok) why = e2;
+        }
     }
-    if (!build_tables(root.get(), false, false, true, out.slot2cap, out.utf8, err)) return false;
+    // (the utf8 set only grows on the ascii one: not attempted when that one is over the budget)
+    if (ascii_ok && utf8_ok && !build_tables(root.get(), false, false, true, out.slot2cap, out.utf8, why)) utf8_ok = false;
+    if (ascii_ok && utf8_ok) return true;
+    // ---- the second engine (rx.hpp NfaSet)
+    std::string e3;
+    out.utf8 = TableSet();
+    if (!build_nfa(root.get(), out.nfa, e3)) {
+        err = why.empty() ? e3 : why + "; " + e3;
+        return false;
+    }
+    out.utf8_nfa = true;
+    out.why_nfa = why;
+    if (!ascii_ok) { make_ascii_stub(out.ascii, want_captures); out.ascii_stub = true; }
+    return true;
+}
+
+// ---------------------------------------------------------------- test aid: random texts drawn from a pattern
+namespace {
+struct Sampler {
+    uint64_t st;
+    uint32_t next() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t) (st >> 33); }
+    uint32_t below(uint32_t n) { return n ? next() % n : 0; }
+    static void put_cp(std::string &o, uint32_t c) {
+        if (c < 0x80) o.push_back((char) c);
+        else if (c < 0x800) { o.push_back((char) (0xc0 | (c >> 6))); o.push_back((char) (0x80 | (c & 0x3f))); }
+        else if (c < 0x10000) { o.push_back((char) (0xe0 | (c >> 12))); o.push_back((char) (0x80 | ((c >> 6) & 0x3f))); o.push_back((char) (0x80 | (c & 0x3f))); }
+        else { o.push_back((char) (0xf0 | (c >> 18))); o.push_back((char) (0x80 | ((c >> 12) & 0x3f))); o.push_back((char) (0x80 | ((c >> 6) & 0x3f))); o.push_back((char) (0x80 | (c & 0x3f))); }
+    }
+    void set(const CC &cc, std::string &o) {
+        // mostly a printable ASCII member; now and then a non-ASCII one, a control character, or any member at all
+        const uint32_t r = below(16);
+        if (r == 0) {
+            CodeSet v = cc.valid_multibyte();
+            if (!v.r.empty()) {
+                const Range &x = v.r[below((uint32_t) v.r.size())];
+                uint32_t c = x.first + below(std::min<uint32_t>(x.second - x.first + 1, 64));
+                if (c >= 0xd800 && c <= 0xdfff) c = 0xe000;
+                if (c <= MAXCP && v.has(c)) { put_cp(o, c); return; }
+            }
+        }
+        int cand[128], n = 0;
+        const int lo = r == 1 ? 0 : 32, hi = r == 1 ? 128 : 127;
+        for (int b = lo; b < hi; b++) if (cc.ascii(b)) cand[n++] = b;
+        if (!n) for (int b = 0; b < 128; b++) if (cc.ascii(b)) cand[n++] = b;
+        if (n) { o.push_back((char) cand[below((uint32_t) n)]); return; }
+        CodeSet v = cc.valid_multibyte();
+        if (!v.r.empty()) { uint32_t c = v.r[0].first; if (c >= 0xd800 && c <= 0xdfff) c = 0xe000; put_cp(o, c); }
+    }
+    void walk(const Ast *a, std::string &o, int depth) {
+        if (o.size() > 4000) return;
+        switch (a->t) {
+        case Ast::EMPTY: case Ast::ANCHOR: return;
+        case Ast::SET: set(a->cc, o); return;
+        case Ast::CAT: for (auto &k : a->kids) walk(k.get(), o, depth + 1); return;
+        case Ast::ALT: walk(a->kids[below((uint32_t) a->kids.size())].get(), o, depth + 1); return;
+        case Ast::GROUP: walk(a->kids[0].get(), o, depth + 1); return;
+        case Ast::REPEAT: {
+            int span = a->max < 0 ? (below(4) == 0 ? 12 : 4) : std::min(a->max - a->min, 6);
+            const int n = a->min + (int) below((uint32_t) span + 1);
+            for (int i = 0; i < n; i++) walk(a->kids[0].get(), o, depth + 1);
+            return;
+        }
+        }
+    }
+};
+}  // namespace
+
+bool sample(const char *pattern, size_t len, unsigned options, uint64_t seed, std::string &out, std::string &err) {
+    Syntax sx;
+    sx.s = sx.p = (const unsigned char *) pattern;
+    sx.e = sx.s + len;
+    sx.has_named = scan_named(sx.s, sx.e);
+    AstP root = sx.alternation(options & (OPT_IGNORECASE | OPT_EXTEND | OPT_MULTILINE), 0);
+    if (!sx.failed() && !sx.eof()) sx.fail("trailing garbage");
+    if (sx.failed()) { err = sx.err; return false; }
+    Sampler sm;
+    sm.st = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+    out.clear();
+    sm.walk(root.get(), out, 0);
     return true;
 }
 
@@ -1802,8 +2002,171 @@ int run_capture(const TableSet &t, int ngroups, const uint8_t *s, int olen, int 
 
 void debug_stats(long *out) { out[0] = g_stat_fast; out[1] = g_stat_look; out[2] = g_stat_multi; g_stat_fast = g_stat_look = g_stat_multi = 0; }
 
+// ---------------------------------------------------------------- host execution of the NFA set (what kdev.inc nfa_* do)
+namespace {
+
+struct NfaCh { int cls, L; };
+
+int nfa_mb_class(const NfaSet &t, uint32_t cp) {
+    size_t lo = 0, hi = t.mb_lo.size();               // the last interval that starts at or below cp
+    while (hi - lo > 1) {
+        const size_t m = (lo + hi) / 2;
+        if (t.mb_lo[m] <= cp) lo = m; else hi = m;
+    }
+    return t.mb_cls[lo];
+}
+uint32_t nfa_decode(const uint8_t *s, int i, int L) {
+    uint32_t cp = L == 2 ? (uint32_t) (s[i] & 0x1f) : L == 3 ? (uint32_t) (s[i] & 0x0f) : (uint32_t) (s[i] & 0x07);
+    for (int k = 1; k < L; k++) cp = (cp << 6) | (uint32_t) (s[i + k] & 0x3f);
+    return cp;
+}
+// the character that starts at byte i of the walked text (olen: the real length; the walked text ends behind the lead of a cut sequence)
+NfaCh nfa_char_at(const NfaSet &t, const uint8_t *s, int i, int olen) {
+    const int b = s[i];
+    if (b < 0x80) return {t.cls_byte[b], 1};
+    if (b >= 0xc2 && b <= 0xf4) {
+        const int L = utf8_seq_len(s, i, olen);
+        if (L > 1) {
+            if (i + L > olen) return {olen - i >= 2 ? t.cls_byte[256 + b] : t.cls_byte[b], 1};
+            return {nfa_mb_class(t, nfa_decode(s, i, L)), L};
+        }
+    }
+    return {t.cls_byte[b], 1};
+}
+// the character that ends at boundary e of the walked text [0, wlen)
+NfaCh nfa_char_before(const NfaSet &t, const uint8_t *s, int e, int wlen, int olen) {
+    const int i = e - 1, b = s[i];
+    if (b < 0x80) return {t.cls_byte[b], 1};
+    if (b <= 0xbf) {
+        for (int d = 1; d <= 3 && d <= i; d++) {
+            const int c = s[i - d];
+            if (c >= 0x80 && c <= 0xbf) continue;
+            if (c >= 0xc2 && c <= 0xf4) {
+                const int L = utf8_seq_len(s, i - d, olen);
+                if (L == d + 1 && i - d + L <= olen) return {nfa_mb_class(t, nfa_decode(s, i - d, L)), L};
+            }
+            break;
+        }
+        return {t.cls_byte[b], 1};
+    }
+    if (i == wlen - 1 && wlen < olen) return {t.cls_byte[256 + b], 1};      // the lead of the sequence the end of the text cuts
+    return {t.cls_byte[b], 1};
+}
+
+// one step of the reverse walk: the state (V, nk) of boundary e becomes the one of the boundary in front of the character `ch`;
+// *start = a match may start at boundary e (with ch as the character in front of it)
+void nfa_rev_step(const NfaSet &t, const NfaCh &ch, uint32_t *V, int &nk, bool *start) {
+    const int VW = t.VW, P = t.P, k = t.ckind[ch.cls];
+    const size_t kk = (size_t) k * t.NK + nk;
+    const uint32_t *rows = t.pred.data() + kk * (size_t) (P + 2) * VW;
+    uint32_t N[NFA_MAXP / 32];
+    bool st = t.mstart[kk] != 0;
+    for (int w = 0; w < VW; w++) { N[w] = rows[(size_t) P * VW + w]; if (rows[(size_t) (P + 1) * VW + w] & V[w]) st = true; }
+    for (int w = 0; w < VW; w++)
+        for (uint32_t m = V[w]; m; m &= m - 1) {
+            const uint32_t *r = rows + (size_t) (32 * w + __builtin_ctz(m)) * VW;
+            for (int u = 0; u < VW; u++) N[u] |= r[u];
+        }
+    for (int w = 0; w < VW; w++) V[w] = N[w] & t.amask[(size_t) ch.cls * VW + w];
+    nk = k;
+    if (start) *start = st;
+}
+
+}  // namespace
+
+int nfa_run(const NfaSet &t, int ngroups, const uint8_t *s, int olen, int *beg, int *end) {
+    const int VW = t.VW, NK = t.NK, P = t.P;
+    const int wlen = utf8_walk_len(s, olen);
+    // ---- reverse pass: leftmost viable start; the state of the first boundary of every block of NFA_CHK boundaries (from the end) is kept
+    const int CW = VW + 1;
+    std::vector<uint32_t> chk((size_t) (wlen / NFA_CHK + 2) * CW, 0u);
+    uint32_t V[NFA_MAXP / 32];
+    for (int w = 0; w < VW; w++) V[w] = 0;
+    int nk = t.kind_edge, best = -1, e = wlen, last_blk = -1;
+    for (;;) {
+        const int tt = wlen - e, blk = tt / NFA_CHK;
+        if (blk != last_blk) {
+            for (int w = 0; w < VW; w++) chk[(size_t) blk * CW + w] = V[w];
+            chk[(size_t) blk * CW + VW] = (uint32_t) nk | ((uint32_t) (tt % NFA_CHK) << 8);
+            last_blk = blk;
+        }
+        if (e == 0) break;
+        const NfaCh ch = nfa_char_before(t, s, e, wlen, olen);
+        bool st;
+        nfa_rev_step(t, ch, V, nk, &st);
+        if (st) best = e;
+        e -= ch.L;
+    }
+    {
+        // a start at boundary 0: the text edge in front of it
+        const size_t kk = (size_t) t.kind_edge * NK + nk;
+        const uint32_t *rows = t.pred.data() + kk * (size_t) (P + 2) * VW;
+        bool st = t.mstart[kk] != 0;
+        for (int w = 0; w < VW; w++) if (rows[(size_t) (P + 1) * VW + w] & V[w]) st = true;
+        if (st) best = 0;
+    }
+    if (best < 0) return 0;
+    if (!beg) return 1;
+    // ---- forward pass: the first candidate that is viable
+    std::vector<int> slot(2 * (ngroups + 1), -1);
+    slot[0] = best;
+    int j = best, x = P;
+    int pk = j == 0 ? t.kind_edge : t.ckind[nfa_char_before(t, s, j, wlen, olen).cls];
+    for (;;) {
+        NfaCh ch = {0, 1};
+        int nk2 = t.kind_edge;
+        if (j < wlen) { ch = nfa_char_at(t, s, j, olen); nk2 = t.ckind[ch.cls]; }
+        const size_t li = ((size_t) x * NK + pk) * NK + nk2;
+        const uint32_t *am = t.amask.data() + (size_t) ch.cls * VW;
+        uint32_t pick = 0xFFFFFFFFu;
+        int cnt = 0;
+        for (uint32_t q = t.list_off[li]; q < t.list_off[li + 1]; q++) {
+            const uint32_t ent = t.list_ent[q], tg = ent & 0xFFFF;
+            if (tg == NFA_MATCH || (j < wlen && ((am[tg >> 5] >> (tg & 31)) & 1))) { if (!cnt) pick = ent; cnt++; }
+            if (tg == NFA_MATCH) break;
+        }
+        if (cnt == 0) return -2;
+        if (cnt > 1) {
+            // several candidates accept the character: the set V of this boundary decides (replayed from its block's checkpoint)
+            const int blk = (wlen - j) / NFA_CHK;
+            uint32_t Vj[NFA_MAXP / 32];
+            for (int w = 0; w < VW; w++) Vj[w] = chk[(size_t) blk * CW + w];
+            const uint32_t info = chk[(size_t) blk * CW + VW];
+            int nkc = (int) (info & 0xFF), ec = wlen - (blk * NFA_CHK + (int) (info >> 8));
+            while (ec > j) {
+                const NfaCh c2 = nfa_char_before(t, s, ec, wlen, olen);
+                nfa_rev_step(t, c2, Vj, nkc, nullptr);
+                ec -= c2.L;
+            }
+            if (ec != j) return -2;
+            pick = 0xFFFFFFFFu;
+            for (uint32_t q = t.list_off[li]; q < t.list_off[li + 1]; q++) {
+                const uint32_t ent = t.list_ent[q], tg = ent & 0xFFFF;
+                if (tg == NFA_MATCH || ((Vj[tg >> 5] >> (tg & 31)) & 1)) { pick = ent; break; }
+            }
+            if (pick == 0xFFFFFFFFu) return -2;
+        }
+        const uint32_t ts = pick >> 16;
+        for (uint32_t q = t.tag_off[ts]; q < t.tag_off[ts + 1]; q++) slot[t.tag_data[q]] = j;
+        if ((pick & 0xFFFF) == NFA_MATCH) break;
+        x = (int) (pick & 0xFFFF);
+        pk = nk2;
+        j += ch.L;
+        if (j > wlen) return -2;
+    }
+    for (int g = 0; g <= ngroups; g++) {
+        if (slot[2 * g] >= 0 && slot[2 * g + 1] >= 0) {
+            beg[g] = slot[2 * g] == wlen ? olen : slot[2 * g];
+            end[g] = slot[2 * g + 1] == wlen ? olen : slot[2 * g + 1];
+        }
+        else { beg[g] = -1; end[g] = -1; }
+    }
+    return 1;
+}
+
 int simulate_match(const Program &p, const uint8_t *s, int len) {
     const TableSet &t = p.ascii;
+    if (p.ascii_stub) return nfa_run(p.nfa, p.ngroups, s, len, nullptr, nullptr);
     if (t.nD == 0) {                          // no match-only DFA (see compile): the capture program answers
         std::vector<int> b(p.ngroups + 1), e(p.ngroups + 1);
         int r = simulate_capture(p, s, len, b.data(), e.data());
@@ -1814,6 +2177,7 @@ int simulate_match(const Program &p, const uint8_t *s, int len) {
         uint16_t n = t.ddelta[(size_t) st * t.ncls + t.cls[s[i]]];
         if (n == D_ACCEPT) return 1;
         if (n == D_POISON) {
+            if (p.utf8_nfa) return nfa_run(p.nfa, p.ngroups, s, len, nullptr, nullptr);
             std::vector<int> b(p.ngroups + 1), e(p.ngroups + 1);
             int r = run_capture(p.utf8, p.ngroups, s, len, b.data(), e.data());
             return r < 0 ? r : r;
@@ -1824,8 +2188,8 @@ int simulate_match(const Program &p, const uint8_t *s, int len) {
 }
 
 int simulate_capture(const Program &p, const uint8_t *s, int len, int *beg, int *end) {
-    int r = p.ascii.has_capture ? run_capture(p.ascii, p.ngroups, s, len, beg, end) : -3;
-    if (r == -3) r = run_capture(p.utf8, p.ngroups, s, len, beg, end);
+    int r = (p.ascii.has_capture && !p.ascii_stub) ? run_capture(p.ascii, p.ngroups, s, len, beg, end) : -3;
+    if (r == -3) r = p.utf8_nfa ? nfa_run(p.nfa, p.ngroups, s, len, beg, end) : run_capture(p.utf8, p.ngroups, s, len, beg, end);
     if (r == 1) return p.ngroups + 1;
     if (r == 0) return -1;
     return r;

@@ -44,6 +44,7 @@ constexpr uint16_t F_MATCH = 0xFFFF;      // forward list entry: low half == MAT
 // small enough to be staged in LDS.
 struct TableSet {
     bool ascii_only = false;
+    bool stub = false;                        // ascii set that hands EVERY value on (rx.cpp make_ascii_stub: Program::ascii_stub)
     // [symbol] -> class.  Symbols 0 .. 255 are bytes (utf8 set: after the SymbolMap translation); the utf8 set of a pattern
     // with \b / \B has a second half, 256 + b: byte b of a well-formed multi-byte character that IS a word character
     // (the reference's \b is Unicode-aware, ONIG_OPTION_WORD_BOUND_ALL_RANGE: every byte of such a character carries the
@@ -131,6 +132,41 @@ constexpr uint32_t FC_DEAD = 0xFFFFFFFFu;
 constexpr uint32_t FC_TMATCH = 0xFFFu;        // target field value meaning MATCH
 constexpr uint32_t FC_LOOK = 0xFE000000u;     // | m: resolve with fast2[m][next byte class]
 
+// ---- the second engine: a bit-parallel walk over the CHARACTER-level position automaton (rx_nfa.inc).
+// Where the table compiler gives up -- a reverse automaton over the state budget (stock parser `istio-envoy-proxy`), classes whose
+// UTF-8 spelling needs more than 63 byte classes or thousands of byte positions ([[:alpha:]], [[:alnum:]] ...: `http_statement`),
+// bounded repeats like .{0,300} -- the same two passes run on position SETS instead of state ids: the reverse pass keeps the set V
+// of positions from which the rest of the text still matches as VW 32-bit words and steps it per CHARACTER
+//     V' = accept(c) & (pred[k][nk][MATCH] | OR over q in V of pred[k][nk][q])
+// (k, nk: the context kinds of the consumed character and of the one right of it), the forward pass takes the first candidate of
+// list(core, pk, nk) that is in V.  One position per character node of the pattern whatever the character's encoded length: a
+// non-ASCII character is decoded and classified by a search in the merged range table (mb_lo / mb_cls), so [[:alpha:]] costs one
+// position and one range search, not 730 ranges spelled out in UTF-8 bytes.  Ill-formed input follows the engine exactly like the
+// byte tables do (a stray byte / the lead of a sequence cut by the end of the text are characters of their own: cls_byte).
+constexpr int NFA_MAXP = 320;                 // positions (ten 32-bit words per set)
+constexpr int NFA_CHK = 8;                    // the reverse walk keeps its state once per block of 8 byte boundaries (counted from the end)
+constexpr uint32_t NFA_MATCH = 0xFFFFu;       // list entry target: MATCH
+struct NfaSet {
+    bool ok = false;
+    int P = 0, VW = 0;                        // positions, words per set
+    int NK = 1, kind_edge = 0;                // context kinds told apart (compact indices), the one of "no character" (text edge)
+    int ncls = 0;                             // character classes: (accepting positions, kind) signatures
+    std::vector<uint16_t> cls_byte;           // [512]: [b] an ASCII byte or a byte >= 0x80 that is a character of its own;
+                                              //        [256 + b] the lead b of a prefix-valid sequence cut by the end of the text
+    std::vector<uint32_t> mb_lo;              // first code points of the intervals that partition [0x80, 0x10FFFF], ascending
+    std::vector<uint16_t> mb_cls;             // their classes
+    std::vector<uint32_t> amask;              // [ncls][VW] positions that accept a character of the class
+    std::vector<uint8_t> ckind;               // [ncls] its context kind
+    // per context kk = k * NK + nk: rows q < P = the positions whose continuation reaches q, row P = those that reach MATCH,
+    // row P + 1 = what the START core reaches (the forward view of one row, for "may a match start here")
+    std::vector<uint32_t> pred;               // [NK * NK][P + 2][VW]
+    std::vector<uint8_t> mstart;              // [NK * NK] START reaches MATCH
+    std::vector<uint32_t> list_off;           // [((P + 1) * NK + pk) * NK + nk .. + 1] core P = START
+    std::vector<uint32_t> list_ent;           // target position (NFA_MATCH) | tag sequence << 16, priority order
+    std::vector<uint32_t> tag_off;
+    std::vector<uint8_t> tag_data;
+};
+
 struct Program {
     int ngroups = 0;                          // capture groups excluding group 0
     std::vector<std::string> names;           // first-appearance order (onig_foreach_name)
@@ -139,6 +175,11 @@ struct Program {
                                               // the named fields (0xFF: not a named group's slot)
     TableSet ascii;                           // match DFA (+ capture program when requested)
     TableSet utf8;                            // capture program (also answers match-only)
+    // the NFA engine stands in for a table set the compiler could not build:
+    bool utf8_nfa = false;                    // values with a byte >= 0x80 (everything the ascii set hands on) walk `nfa`; utf8 is empty
+    bool ascii_stub = false;                  // the ascii set is a stub that hands EVERY value on (always-poison tables)
+    NfaSet nfa;
+    std::string why_nfa;                      // what the table compiler said when it gave up (diagnostics)
 };
 
 // Compiles `pattern` (already stripped of the /../flags wrapper).  want_captures=false skips the
@@ -158,6 +199,9 @@ void split_flb_pattern(const char *pattern, const char **start, const char **end
 //   exactly as the kernels do.
 int simulate_capture(const Program &p, const uint8_t *s, int len, int *beg, int *end);
 int simulate_match(const Program &p, const uint8_t *s, int len);
+// host execution of the NFA set alone (the algorithm the kernels run: kdev.inc nfa_*): 1 match (spans filled when beg != nullptr),
+// 0 no match, -2 inconsistency
+int nfa_run(const NfaSet &t, int ngroups, const uint8_t *s, int len, int *beg, int *end);
 // UTF-8 sequence length rule shared with the kernels: length (2..4) of the well-formed or
 // end-truncated sequence starting at s[i], else 1
 int utf8_seq_len(const uint8_t *s, int i, int len);
@@ -168,6 +212,9 @@ int utf8_symbol(const uint8_t *xl, const uint8_t *s, int i, int len, int *seqlen
 bool unicode_word(uint32_t cp);
 // the ranges behind unicode_word for code points >= 0x80: {lo, hi} pairs, ascending (uploaded for the device walkers)
 const unsigned int (*unicode_word_ranges(int *n))[2];
+// test aid: a random text drawn from the pattern itself (every alternative / repeat count / class member by a seeded generator;
+// anchors are not looked at, so a text need not match) -- the differentials against the real engine feed on it
+bool sample(const char *pattern, size_t len, unsigned options, uint64_t seed, std::string &out, std::string &err);
 // forward-walk step counters of simulate_capture since the last call: {fast, lookahead, slow}
 void debug_stats(long *out);
 

@@ -46,6 +46,30 @@ void flbgpu_rx_info(void *h, int *info)
 
 void flbgpu_rx_debug_stats(long *out3) { rx::debug_stats(out3); }
 
+/* which engines stand behind the handle: bit 0 the NFA engine answers for values with a byte >= 0x80, bit 1 for every value (the
+ * ascii set is a stub); info[0] = positions, [1] = words per set, [2] = character classes, [3] = context kinds, [4] = list entries,
+ * [5] = code point intervals.  why (may be NULL): what the table compiler said when it gave up. */
+int flbgpu_rx_engine(void *h, int *info6, char *why, int whylen)
+{
+    auto *p = (rx::Program *) h;
+    if (info6) {
+        info6[0] = p->nfa.P; info6[1] = p->nfa.VW; info6[2] = p->nfa.ncls; info6[3] = p->nfa.NK;
+        info6[4] = (int) p->nfa.list_ent.size(); info6[5] = (int) p->nfa.mb_lo.size();
+    }
+    if (why && whylen > 0) { strncpy(why, p->why_nfa.c_str(), whylen - 1); why[whylen - 1] = 0; }
+    return (p->utf8_nfa ? 1 : 0) | (p->ascii_stub ? 2 : 0);
+}
+
+/* test aid: a random text drawn from the pattern (rx::sample); returns its length (cut to cap), -1 when the pattern does not parse */
+int flbgpu_rx_sample(const char *pattern, int len, unsigned options, unsigned long long seed, char *out, int cap)
+{
+    std::string o, e;
+    if (!rx::sample(pattern, (size_t) len, options, seed, o, e)) return -1;
+    const int n = (int) o.size() < cap ? (int) o.size() : cap;
+    memcpy(out, o.data(), (size_t) n);
+    return n;
+}
+
 /* The compact tables of the single-pass tile kernel (fx.cpp) executed on the host with the kernel's rules.
  * >= 0: groups, beg/end of the NAMED groups filled (-1 elsewhere), beg[0] = 0, end[0] = end of the match;
  * -1: the forward walk from boundary 0 does not settle this text (the kernel falls back to the classic walk);

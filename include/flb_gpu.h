@@ -436,6 +436,11 @@ int flbgpu_rx_simulate_fx_walk_all(void *h, const char *s, int len, int *beg, in
 int flbgpu_rx_fx_tail(void *h, const char *s, int len, int *nkill, unsigned char *kill4, int *first);   /* the tables' tail (rows, kill bytes; where a text enters it) */
 int flbgpu_rx_fx_profile(void *h, const char *s, int len, long *out);              /* table sizes, look-ahead / double-write steps over a text */
 void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call: fast, lookahead, slow */
+/* which engine answers: bit 0 = the bit-parallel NFA engine for values with a byte >= 0x80, bit 1 = for every value; info6 = its
+ * positions, words per set, character classes, context kinds, list entries, code point intervals; why = the table compiler's reason */
+int flbgpu_rx_engine(void *h, int *info6, char *why, int whylen);
+/* test aid: a random text drawn from the pattern's own syntax tree (length, cut to cap; -1: the pattern does not parse) */
+int flbgpu_rx_sample(const char *pattern, int len, unsigned options, unsigned long long seed, char *out, int cap);
 
 /* ---- diagnostics: text <-> binary64 (csrc/numconv.hpp) ----------------------------------------
  * strtod() (mode 0) / sscanf("%lf") (mode 1) and printf("%f") / ("%ld") as the kernels compute them;

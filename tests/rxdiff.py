@@ -142,7 +142,10 @@ def rand_input(rng, pat=None, maxlen=24, utf8=False):
     for _ in range(n):
         r = rng.random()
         if utf8 and r < 0.15:
-            out += rng.choice(["é", "ü", "日", "本", "ß", "€", "😀"]).encode()
+            # letters of both cases, a digit, a superscript (a word character for \b, not for [[:word:]]), punctuation, a
+            # blank, a full-width letter, the Kelvin sign, symbols outside every class
+            out += rng.choice(["é", "ü", "日", "本", "ß", "€", "😀", "É", "Ж", "ж", "٣", "²", "¡", "«", "\u00a0", "\u3000", "Ａ", "\u212a", "ǅ", "\u0301",
+                               "\u00ad", "\u2028"]).encode()
         elif r < 0.5:
             out.append(rng.choice(lits))
         else:

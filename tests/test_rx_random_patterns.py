@@ -86,7 +86,13 @@ def gen(rng, depth, names):
 
 
 MORE_ATOMS = [rb"\b", rb"\B", rb"[[:alpha:]]", rb"[[:digit:][:punct:]]", rb"[^[:space:]]", rb"\h", rb"\H", rb"$", rb"^", rb"\A", rb"\z", rb"\Z", rb"\n", rb"A", rb"K",
-              rb"[A-Z]", rb"\x41", rb"\t"]
+              rb"[A-Z]", rb"\x41", rb"\t",
+              # the POSIX brackets with their Unicode members (round 4: through the NFA engine where the byte tables give up)
+              rb"[[:alnum:]]", rb"[[:upper:]]", rb"[[:lower:]]", rb"[[:punct:]]", rb"[[:word:]]", rb"[[:graph:]]", rb"[[:print:]]", rb"[^[:alpha:]]",
+              rb"[[:^lower:]x]", rb"[[:space:][:upper:]]", rb"[[:cntrl:]]", rb"[[:blank:]]", rb"[[:xdigit:]]", rb"[^[:word:]-]"]
+# group options (regparse.c:5257-5297): (?a) ASCII-only \w \d \s, POSIX brackets and \b; (?u) the Unicode ones; (?d) the default
+OPTION_GROUPS = [rb"(?a)", rb"(?u)", rb"(?d)", rb"(?a:\w+\b)", rb"(?u:\w+)", rb"(?u:\d|\s)", rb"(?a:[[:alpha:]]+)", rb"(?u:[\w-]+)", rb"(?a:\B.)", rb"(?u:\h)",
+                 rb"(?u:\W)", rb"(?u:[^\s\d])", rb"(?ia)", rb"(?a-i:x)"]
 
 
 def run(seed, npat, nsub, more=False):
@@ -106,7 +112,15 @@ def run(seed, npat, nsub, more=False):
         if more:
             o = rng.random()
             pat = b"(?i)" + pat if o < 0.2 else b"(?m)" + pat if o < 0.3 else pat
-        if any(n for n in names) and b"(" in pat.replace(b"(?<", b"").replace(b"(?:", b"").replace(b"(?i)", b"").replace(b"(?m)", b""):
+            o = rng.random()
+            if o < 0.25:
+                og = rng.choice(OPTION_GROUPS)
+                k = rng.randrange(3)
+                pat = og + pat if k == 0 else pat + og if k == 1 and not pat.endswith(b"$") else og + pat
+        bare = pat.replace(b"(?<", b"").replace(b"(?:", b"").replace(b"(?i)", b"").replace(b"(?m)", b"")
+        for og in OPTION_GROUPS:
+            bare = bare.replace(og[:og.index(b":") + 1] if b":" in og else og, b"")
+        if any(n for n in names) and b"(" in bare:
             continue                               # named and numbered groups together: ONIG_OPTION_CAPTURE_GROUP off -> plain groups do not capture
         eng = rxdiff.RefRegex(ref, pat)
         if not eng.ok:
