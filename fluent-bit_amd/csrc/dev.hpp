@@ -5,6 +5,22 @@
 
 namespace flbgpu {
 
+// ---- the NFA engine's tables (rx.hpp NfaSet; walked by nfa_dev.inc), as device pointers
+struct DevNfa {
+    const uint16_t *cls_byte;      // [512] class of an ASCII byte / a stray byte (b), of the lead of a cut sequence (256 + b)
+    const uint32_t *mb_lo;         // [nmb] first code points of the intervals over [0x80, 0x10FFFF]
+    const uint16_t *mb_cls;        // [nmb]
+    const uint32_t *amask;         // [ncls][VW]
+    const uint8_t *ckind;          // [ncls]
+    const uint32_t *pred;          // [NK * NK][P + 2][VW]
+    const uint8_t *mstart;         // [NK * NK]
+    const uint32_t *list_off;      // [(P + 1) * NK * NK + 1]
+    const uint32_t *list_ent;
+    const uint32_t *tag_off;
+    const uint8_t *tag_data;
+    int P, VW, NK, kind_edge, ncls, nmb;
+};
+
 // ---- capture tables of one rx::TableSet, as device pointers
 struct DevCap {
     // hot tables (touched once per input byte); stored back to back so that a workgroup can
@@ -31,6 +47,9 @@ struct DevCap {
     const uint8_t *hot_base;
     uint32_t hot_bytes;
     uint32_t off_rdelta, off_ft, off_ft2, off_cls, off_col;   // byte offsets inside the hot block
+    int stub;                      // ascii set only: a stub that hands EVERY value on, the empty one too (rx.cpp make_ascii_stub)
+    int nfa_on;                    // utf8 slot only: the NFA engine stands in for the table set (rx::Program::utf8_nfa); the
+    DevNfa nfa;                    // table pointers above are null then
 };
 
 // ---- compact forward tables of the single-pass tile kernel (k_parser_tile, tile_kernels.inc), built from the ascii
@@ -69,7 +88,8 @@ enum { FXS_END_EOT = 1, FXS_END_MID = 2, FXS_DEAD_EOT = 3, FXS_FAIL = 4 };   // 
 struct DevDfa {
     const uint8_t *cls;            // [256]
     const uint16_t *ddelta;        // [nD][ncls]
-    const uint8_t *d_final;        // [nD]
+    const uint8_t *d_final;        // [nD] the answer at the end of the text AS AN RX_* CODE: 0 no match, 1 match, 2 hand the value on (the stub
+                                   // of a pattern whose ASCII automaton does not fit: an empty text has no byte to poison the walk)
     int ncls, nD, d_init;
     uint32_t lds_bytes;
 };

@@ -104,6 +104,29 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     out.hot_base = d; out.hot_bytes = (uint32_t) hot_end;
     out.off_rdelta = (uint32_t) o_rd; out.off_ft = (uint32_t) o_ft; out.off_ft2 = (uint32_t) o_f2;
     out.off_cls = (uint32_t) o_cls; out.off_col = (uint32_t) o_col;
+    out.stub = t.stub ? 1 : 0;
+    return true;
+}
+
+// what stands behind the ascii set of a pattern: its utf8 table set, or the NFA engine's tables (rx.hpp NfaSet -> dev.hpp DevNfa)
+bool flbgpu::upload_utf8(const rx::Program &prog, TableBlob &blob, DevCap &out) {
+    if (!prog.utf8_nfa) return upload_cap(prog.utf8, blob, out);
+    const rx::NfaSet &t = prog.nfa;
+    std::vector<uint8_t> b;
+    const size_t o_cb = put(b, t.cls_byte), o_ml = put(b, t.mb_lo), o_mc = put(b, t.mb_cls), o_am = put(b, t.amask), o_ck = put(b, t.ckind);
+    const size_t o_pr = put(b, t.pred), o_ms = put(b, t.mstart), o_lo = put(b, t.list_off), o_le = put(b, t.list_ent);
+    const size_t o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
+    HIPOK(hipMalloc(&blob.dev, b.size()));
+    HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
+    const uint8_t *d = (const uint8_t *) blob.dev;
+    memset(&out, 0, sizeof(out));
+    out.nfa_on = 1;
+    DevNfa &n = out.nfa;
+    n.cls_byte = (const uint16_t *) (d + o_cb); n.mb_lo = (const uint32_t *) (d + o_ml); n.mb_cls = (const uint16_t *) (d + o_mc);
+    n.amask = (const uint32_t *) (d + o_am); n.ckind = d + o_ck; n.pred = (const uint32_t *) (d + o_pr); n.mstart = d + o_ms;
+    n.list_off = (const uint32_t *) (d + o_lo); n.list_ent = (const uint32_t *) (d + o_le); n.tag_off = (const uint32_t *) (d + o_to);
+    n.tag_data = d + o_td;
+    n.P = t.P; n.VW = t.VW; n.NK = t.NK; n.kind_edge = t.kind_edge; n.ncls = t.ncls; n.nmb = (int) t.mb_lo.size();
     return true;
 }
 
@@ -292,7 +315,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
             delete p;
             return nullptr;
         }
-        if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_cap(p->prog.utf8, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
+        if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_utf8(p->prog, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
     }
     d.is_json = is_json ? 1 : 0;
     d.ngroups = p->prog.ngroups;
@@ -404,7 +427,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         if (ntime != 1) d.time_field = -1;
     }
     // compact forward tables of the single-pass tile kernel (start-anchored patterns: the forward walk needs no reverse pass)
-    if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE")) {
+    if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE") && !p->prog.ascii_stub) {
         if (!upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx, d.fx)) { delete p; return nullptr; }
         // the same with a cell per pair of byte classes (two steps per table read) when that fits the LDS too
         if (d.fx.ok && !upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx2, d.fx2, true)) { delete p; return nullptr; }
@@ -617,7 +640,7 @@ bool flbgpu::compile_rule(const std::string &ra_field, const char *pattern, Grep
     auto *b1 = new TableBlob(), *b2 = new TableBlob();
     blobs.push_back(b1);
     blobs.push_back(b2);
-    if (!upload_dfa(prog.ascii, *b1, r.dfa) || !upload_cap(prog.utf8, *b2, r.utf8)) { why = flbgpu_last_error(); return false; }
+    if (!upload_dfa(prog.ascii, *b1, r.dfa) || !upload_utf8(prog, *b2, r.utf8)) { why = flbgpu_last_error(); return false; }
     return true;
 }
 
@@ -881,7 +904,14 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         launch_max_row_len(row_off, n, &dm->max_row, st);
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
-        const uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
+        uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
+        // a parser whose non-ASCII side is the NFA engine keeps position SETS, one per NFA_CHK byte boundaries (nfa_dev.inc
+        // nfa_chk_words 32-bit words = twice as many 16-bit slots)
+        for (auto *pp : f->parsers)
+            if (pp->dev.utf8.nfa_on) {
+                const uint32_t need = 2u * (uint32_t) (hm.max_row / rx::NFA_CHK + 2) * (uint32_t) (pp->dev.utf8.nfa.VW + 1) + 2;
+                if (need > gchk_len) gchk_len = need;
+            }
         int ggrid = cus * 8;
         while (ggrid > 1 && (size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t) > ((size_t) 2 << 30)) ggrid /= 2;
         if (!f->d_rid2.ensure((size_t) ggrid * 4 * 64 * gchk_len * sizeof(uint16_t))) return false;
@@ -1173,6 +1203,10 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     const DevParser &d = fp->parsers[0]->dev;
     if (d.is_json || !d.plain_types || d.nfields > 32 || d.nfields == 0 || d.nregs_minus1 <= 0) return false;
     if (fg->rules.empty()) return false;
+    // a rule (or the parser) whose non-ASCII side is the NFA engine: the fused kernels do not carry that walker (it would sit, as a
+    // call, inside the hot single-pass kernel): the unfused kernels take the pair
+    if (d.utf8.nfa_on || d.ascii.stub) return false;
+    for (const GrepRule &r : fg->rules) if (r.utf8.nfa_on) return false;
     return true;
 }
 

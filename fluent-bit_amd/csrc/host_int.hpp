@@ -77,6 +77,7 @@ struct TableBlob {
 };
 
 bool upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out);
+bool upload_utf8(const rx::Program &prog, TableBlob &blob, DevCap &out);
 bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out);
 bool upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out, bool pair = false);
 bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pair = false);

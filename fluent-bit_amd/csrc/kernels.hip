@@ -147,6 +147,12 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
         if (!(flags & RF_CAND)) continue;
         const uint32_t vlen = a.info[2 * a.n + r];
         const uint8_t *val = a.data + a.row_off[r] + a.info[1 * a.n + r];
+        if (ps.ascii.stub) {
+            // no ASCII tables for this pattern (rx.cpp make_ascii_stub): every value, the empty one too, is the second engine's
+            a.info[r] = flags | RF_GENERIC;
+            n_gen++;
+            continue;
+        }
         // phase 0: forward walk from boundary 0 with no reverse pass (start-anchored patterns: a match
         // that starts at 0 is the leftmost one, and every choice the walk makes is forced by the
         // byte / the next byte whenever a match exists); phase 1: reverse pass; phase 2: forward

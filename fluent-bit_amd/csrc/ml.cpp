@@ -158,7 +158,7 @@ static bool ml_compile(flbgpu_ml_parser *p, const std::string &pat, unsigned opt
     if (!rx::compile(pat.data(), pat.size(), opts, false, prog, err)) { set_err("multiline: could not compile regex pattern '%s' for the GPU path: %s", shown, err.c_str()); return false; }
     auto *b1 = new TableBlob(), *b2 = new TableBlob();
     p->blobs.push_back(b1); p->blobs.push_back(b2);
-    if (!upload_dfa(prog.ascii, *b1, gr.dfa) || !upload_cap(prog.utf8, *b2, gr.utf8)) return false;
+    if (!upload_dfa(prog.ascii, *b1, gr.dfa) || !upload_utf8(prog, *b2, gr.utf8)) return false;
     p->rules.push_back(gr);
     p->progs.push_back(std::move(prog));
     return true;
@@ -276,23 +276,16 @@ static bool build_product(flbgpu_ml_parser *p, std::vector<uint8_t> &blob) {
     }
     const int nj = (int) rep.size() + 1;
     for (int b = 0; b < 256; b++) if (jcls[(size_t) b] < 0) jcls[(size_t) b] = nj - 1;
-    // per rule: the states from which a match is still possible over such bytes
+    // per rule: the states from which a match is still possible on the rest of a line.  NOT judged on the bytes < 0x80 alone (ADVICE
+    // round 3): a rule like /^\s+原因/ has no accepting path over them at all, its component would be DEAD from the start, the
+    // product state absorbing, and the walk would stop before it met the byte >= 0x80 that sends the line to the per-rule tables.
+    // rx.cpp's d_live is liveness over texts of any characters (without line feeds).
     std::vector<std::vector<uint8_t>> good((size_t) R);
     for (int r = 0; r < R; r++) {
-        const rx::TableSet &t = p->progs[(size_t) r].ascii;
-        std::vector<uint8_t> &g = good[(size_t) r];
-        g.assign((size_t) t.nD, 0);
-        for (int s = 0; s < t.nD; s++) g[(size_t) s] = t.d_final[(size_t) s] ? 1 : 0;
-        for (bool changed = true; changed;) {
-            changed = false;
-            for (int s = 0; s < t.nD; s++) {
-                if (g[(size_t) s]) continue;
-                for (int c = 0; c + 1 < nj && !g[(size_t) s]; c++) {
-                    const uint16_t n = t.ddelta[(size_t) s * t.ncls + t.cls[rep[(size_t) c]]];
-                    if (n == 0xFFFF || (n < 0xFFF0 && g[n])) { g[(size_t) s] = 1; changed = true; }
-                }
-            }
-        }
+        const rx::Program &pr = p->progs[(size_t) r];
+        if (pr.ascii_stub || pr.ascii.nD == 0 || pr.ascii.d_live.size() != (size_t) pr.ascii.nD) return false;    // (no ASCII automaton: rule by rule)
+        good[(size_t) r] = pr.ascii.d_live;
+        for (int s = 0; s < pr.ascii.nD; s++) if (pr.ascii.d_final[(size_t) s]) good[(size_t) r][(size_t) s] = 1;
     }
     std::map<std::vector<uint16_t>, int> ids;
     std::vector<std::vector<uint16_t>> states;

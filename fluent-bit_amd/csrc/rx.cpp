@@ -893,8 +893,10 @@ struct Nfa {
         n.push_back(std::move(x));
         return (int) n.size() - 1;
     }
+    std::vector<char> pos_hi;                     // ascii set: the position's character node also accepts some character >= 0x80
     int consume(const ByteSet &s, int next) {
         NNode x; x.t = N_CONSUME; x.set = s; x.next = next; x.pos = npos++;
+        pos_hi.push_back(0);
         return add(std::move(x));
     }
     int split(std::vector<int> outs) { NNode x; x.t = N_SPLIT; x.outs = std::move(outs); return add(std::move(x)); }
@@ -1028,6 +1030,11 @@ struct Builder {
         }
         std::vector<int> alts;
         if (!single.empty()) alts.push_back(nfa.consume(single, next));
+        if (ascii_only && !alts.empty()) {
+            bool hi = !cc.valid_multibyte().r.empty();
+            for (int b = 0x80; b < 256 && !hi; b++) hi = cc.invalid_byte(b) || (b >= 0xc2 && b <= 0xf4 && cc.truncated(b));
+            nfa.pos_hi.back() = hi ? 1 : 0;
+        }
         // share continuation chains between sequences with identical tails
         std::map<std::vector<uint8_t>, int> tails;
         // group sequences by (tail signature) so leads with the same tail merge into one CONSUME
@@ -1055,7 +1062,13 @@ struct Builder {
         }
         if (alts.empty()) {
             ByteSet none;
-            return nfa.consume(none, next);      // matches nothing
+            const int nd = nfa.consume(none, next);      // matches nothing (ascii set: nothing below 0x80)
+            if (ascii_only) {
+                bool hi = !cc.valid_multibyte().r.empty();
+                for (int b = 0x80; b < 256 && !hi; b++) hi = cc.invalid_byte(b) || (b >= 0xc2 && b <= 0xf4 && cc.truncated(b));
+                nfa.pos_hi.back() = hi ? 1 : 0;
+            }
+            return nd;
         }
         if (alts.size() == 1) return alts[0];
         return nfa.split(alts);
@@ -1415,6 +1428,53 @@ bool build_tables(const Ast *root, bool ascii_only, bool want_match_dfa, bool wa
             out.d_final.push_back(fin ? 1 : 0);
         }
         out.nD = (int) states.size();
+        // ---- d_live: can a match still follow from this state on a text WITHOUT line feeds, whatever its characters -- the ones
+        // >= 0x80 included, which this set's transitions do not describe?  (The product automaton of the multiline rules,
+        // ml.cpp build_product, may stop reading a line only in states that are dead for real: a rule like /^\s+原因/ has no accepting
+        // path over ASCII bytes at all.)  Over-approximated per (core, previous kind): some next kind has a list entry that is MATCH or a
+        // position that takes a character of that kind and is live behind it.
+        {
+            auto ascii_word = [](int b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || (b >= 'a' && b <= 'z') || b == '_'; };
+            const bool any_word = nfa.uses_word || nfa.uses_aword;
+            std::vector<int> kinds = {K_OTHER};
+            if (any_word) kinds.push_back(K_WORD);
+            if (nfa.uses_word) kinds.push_back(K_UWORD);
+            auto takes = [&](int p, int k) -> bool {
+                const NNode &nd = nfa.n[tb.pos_node[p]];
+                if (nfa.pos_hi[p] && (k == K_OTHER || k == K_UWORD)) return true;
+                for (int b = 0; b < 0x80; b++) {
+                    if (b == '\n' || !nd.set.has(b)) continue;
+                    const int kb = (any_word && ascii_word(b)) ? K_WORD : K_OTHER;
+                    if (kb == k) return true;
+                }
+                return false;
+            };
+            std::vector<char> live((size_t) X * NKIND, 0);
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int x = 0; x < X; x++)
+                    for (int pk = 0; pk < NKIND; pk++) {
+                        if (live[(size_t) x * NKIND + pk]) continue;
+                        bool l = false;
+                        for (const Target &t : tb.list(x, pk, K_EDGE)) if (t.pos == T_MATCH) l = true;
+                        for (size_t ki = 0; ki < kinds.size() && !l; ki++)
+                            for (const Target &t : tb.list(x, pk, kinds[ki])) {
+                                if (t.pos == T_MATCH) { l = true; break; }
+                                if (takes(t.pos, kinds[ki]) && live[(size_t) t.pos * NKIND + kinds[ki]]) { l = true; break; }
+                            }
+                        if (l) { live[(size_t) x * NKIND + pk] = 1; changed = true; }
+                    }
+            }
+            bool restart = false;                                 // the search may start again behind any later character
+            for (int k : kinds) if (live[(size_t) START * NKIND + k]) restart = true;
+            out.d_live.assign((size_t) out.nD, 0);
+            for (int si = 0; si < out.nD; si++) {
+                const int pk = (int) states[(size_t) si][W];
+                bool l = restart;
+                for (int x = 0; x < X && !l; x++) if (bit(states[(size_t) si], x) && live[(size_t) x * NKIND + pk]) l = true;
+                out.d_live[(size_t) si] = l ? 1 : 0;
+            }
+        }
     }
     if (tb.budget > 4000000) { err = "pattern too complex (nested empty loops)"; return false; }
     if (!want_capture) return true;

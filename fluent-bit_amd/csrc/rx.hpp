@@ -61,7 +61,8 @@ struct TableSet {
     // match-only forward DFA (built for the ascii set only)
     int nD = 0, d_init = 0;
     std::vector<uint16_t> ddelta;             // [nD][ncls]
-    std::vector<uint8_t> d_final;             // [nD]
+    std::vector<uint8_t> d_final;             // [nD] (a stub: 2 = hand the value on, dev.hpp DevDfa)
+    std::vector<uint8_t> d_live;              // [nD] a match can still follow on a one-line text of ANY characters (rx.cpp; ml.cpp build_product)
 
     // capture program
     bool has_capture = false;

@@ -24,6 +24,10 @@ SEED_LINES = {
 ATOMS = [(r"^\d+ ", b"12 "), (r"^\[", b"["), (r"^\s+", b"   "), (r"^\s+at ", b"  at "), (r"ERROR", b"ERROR"), (r"^$", b""), (r"end$", b"end"),
          (r"^[A-Z][a-z]+:", b"Caused:"), (r"\bpanic: ", b"panic: "), (r"^--", b"--"), (r"[^\t ]", b"x"), (r"^\S", b"q"), (r"(?i)^warn", b"WaRn"),
          # the documented "not a first line" idiom: a leading look-ahead behind the line anchor
+         # rules that only a character >= 0x80 can satisfy (round 3's advice: the product automaton of the rules must not take such a
+         # rule for dead because no ASCII byte leads to its match), and a POSIX bracket with its Unicode members
+         ("^错误", "错误".encode()), (r"^\s+é", "  é".encode()), ("ü", "grün".encode()), (r"[^\x00-\x7f]$", "tail ж".encode()),
+         (r"^[[:upper:]][[:lower:]]", "Жук".encode()),
          (r"^(?!\d+ ).*", b"zz"), (r"^(?!\[|--)(?:\S+ e|x)", b"qq e"), (r"^(?=\s+at )\s+at [a-z]", b"  at b"), (r"^(?![A-Z][a-z]+:)", b"lower:")]
 STATES = ["s1", "s2", "s3", "s4"]
 

@@ -99,6 +99,7 @@ def run(seed, npat, nsub, more=False):
     global ATOMS
     ref = rxdiff.load_ref()
     L = flbamd_loader.load().lib()
+    ORX = rxdiff.load_orx()
     rng = random.Random(seed)
     tried = accepted = compared = 0
     base = ATOMS
@@ -131,6 +132,8 @@ def run(seed, npat, nsub, more=False):
         if not h:
             continue                               # refused loudly (budget / unsupported construct): not a wrong answer
         accepted += 1
+        # the oracle's engine (oracle/orx.c: what the device is compared with in the -m gpu tests) rides along where it takes the pattern
+        orx = rxdiff.OrxRegex(ORX, pat)
         for k in range(nsub):
             # (round 3: \b / \B are Unicode-aware, POSIX brackets carry their Unicode members -- or the pattern is refused --,
             # (?i) applies the multi-character folds: non-ASCII and ill-formed subjects for every pattern)
@@ -151,6 +154,8 @@ def run(seed, npat, nsub, more=False):
             n = L.flbgpu_rx_simulate_capture(h, s, len(s), beg, end)
             got = None if n == -1 else [(beg[i], end[i]) for i in range(n)]
             assert got == want, (pat, s, got, want)
+            if orx.ok:
+                assert orx.search(s) == want, ("orx", pat, s, orx.search(s), want)
             compared += 1
         L.flbgpu_rx_free(h)
     return tried, accepted, compared

@@ -94,6 +94,24 @@ def compare_one(L, ref, pat, subjects, want_captures=1):
     return matched, eng_bits
 
 
+@pytest.mark.skipif(rxdiff.load_ref() is None, reason="oracle/_ref/libonig_ref.so not built (needs /root/reference)")
+def test_oracle_regex_on_the_stock_regexes():
+    """the oracle's own engine (oracle/orx.c, what the -m gpu parity tests compare the device with) against the real one on the same texts"""
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    orx = rxdiff.load_orx()
+    n = 0
+    for k, it in enumerate(stock()):
+        pat = inner(it["regex"])
+        eng = rxdiff.RefRegex(ref, pat)
+        o = rxdiff.OrxRegex(orx, pat)
+        assert eng.ok and o.ok, (pat, o.err)
+        for s in texts(L, pat, 40, 991 + k):
+            assert o.search(s) == eng.search(s), (pat, s)
+            n += 1
+    assert n > 2000
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "conf")), reason="needs /root/reference")
 def test_fixture_is_the_conf_files():
     import gen_stock_parsers
