@@ -295,6 +295,7 @@ struct ParserMatchArgs {
                                 // while they are cache-hot so that k_parser_finish never touches the chunk
     uint16_t *chk;              // scratch: reverse-DFA state checkpoints [slots][chk_len][64]
     uint32_t chk_len;           // checkpoints per lane (max value length / CHK_STEP + 2)
+    uint32_t chk_nfa_off;       // k_parser_generic: the 16-bit slot the NFA engine's kept states start at (behind the table walkers' slots)
     uint32_t lds_bytes;         // dynamic LDS: parser 0's hot ASCII tables are staged when > 0
     uint32_t caps_lds_off;      // byte offset of the per-thread capture columns inside the dynamic LDS
     uint32_t caps_in_lds;       // 0: spans are written straight to the global row

@@ -846,7 +846,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.data = data; ma.row_off = row_off; ma.n = n; ma.cfg = f->pcfg; ma.parsers = f->d_parsers.as<DevParser>();
     ma.info = f->d_info.as<uint32_t>(); ma.caps = f->d_caps.as<uint32_t>(); ma.caps_stride = f->caps_stride;
     ma.null_mask = f->d_null.as<uint64_t>(); ma.out_len = f->d_len.as<uint32_t>(); ma.chk = f->d_rid.as<uint16_t>();
-    ma.chk_len = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
+    ma.chk_len = chk_len; ma.chk_nfa_off = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
@@ -906,10 +906,11 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         HIPOK(hipStreamSynchronize(st));
         uint32_t gchk_len = (uint32_t) (hm.max_row / CHK_STEP) + 3;
         // a parser whose non-ASCII side is the NFA engine keeps position SETS, one per NFA_CHK byte boundaries (nfa_dev.inc
-        // nfa_chk_words 32-bit words = twice as many 16-bit slots)
+        // nfa_chk_words 32-bit words = twice as many 16-bit slots), in its own part of a lane's scratch: behind the table walkers' slots
+        const uint32_t nfa_off = gchk_len;
         for (auto *pp : f->parsers)
             if (pp->dev.utf8.nfa_on) {
-                const uint32_t need = 2u * (uint32_t) (hm.max_row / rx::NFA_CHK + 2) * (uint32_t) (pp->dev.utf8.nfa.VW + 1) + 2;
+                const uint32_t need = nfa_off + 2u * (uint32_t) (hm.max_row / rx::NFA_CHK + 2) * (uint32_t) (pp->dev.utf8.nfa.VW + 1) + 2;
                 if (need > gchk_len) gchk_len = need;
             }
         int ggrid = cus * 8;
@@ -918,6 +919,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         ParserMatchArgs mg = ma;
         mg.chk = f->d_rid2.as<uint16_t>();
         mg.chk_len = gchk_len;
+        mg.chk_nfa_off = nfa_off;
         { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
         return true;
     };

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
                     ps = t.sec; pn = t.nsec; nk = t.npairs; dm = t.skip;
                 }
                 else
-                last_ok = try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, capg, &ps, &pn, &nk, &dm, 0u);
+                last_ok = try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, a.chk_nfa_off, capg, &ps, &pn, &nk, &dm, 0u);
                 if (last_ok) {
                     have_out = true;
                     ri.val_off = (uint32_t) (vptr - rec); ri.val_len = vlen; ri.parser_idx = q; ri.nkept = nk; ri.drop_mask = dm;
