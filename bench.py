@@ -49,6 +49,50 @@ def _sha16(path):
         return None
 
 
+MIXED_LENS = [80, 120, 160, 256, 400, 600]
+
+
+def mixed_shape_records():
+    """the pool of secondary.mixed_shapes: 60 000 events whose lines are 80 .. 600 bytes long, 10 % with a four-key body (the value is
+    looked up among other keys), 1 % legacy [ts, map] events"""
+    import random as _rnd, re as _re
+    import numpy as np
+    import synth as _synth
+    rng_ = _rnd.Random(0x51ab)
+    lens_ = MIXED_LENS
+    import re as _re
+    cut_ = _re.compile(rb'^(\S+ - \S+ \[[^\]]+\] "\S+ /)(\S*)( HTTP/1.1" \d+ \d+)( ".*)$')
+    pools = []
+    for ll in lens_:
+        d_, o_, _e = _synth.apache_records(10000, line_len=max(ll, 256), seed=0xF1B17 + ll)
+        rec = int(o_[1] - o_[0])
+        arr = np.asarray(d_).reshape(10000, rec)
+        full = [bytes(arr[i, rec - max(ll, 256):]) for i in range(10000)]
+        if ll < 256:                   # shorter lines: the request path cut, no referer / agent (the pattern's optional tail)
+            short = []
+            for ln in full:
+                m_ = cut_.match(ln)
+                keep = max(0, ll - len(m_.group(1)) - len(m_.group(3)))
+                short.append(m_.group(1) + m_.group(2)[:keep] + m_.group(3))
+            full = short
+        pools.append(full)
+    recs_ = []
+    for i in range(60000):
+        line = pools[rng_.randrange(len(lens_))][rng_.randrange(10000)]
+        r_ = rng_.random()
+        sec_ = 1700000000 + i
+        if r_ < 0.01:
+            recs_.append(_synth.legacy_record(_synth.ext_ts(sec_, 5), {"log": line}))
+        elif r_ < 0.11:
+            body = [("stream", "stdout"), ("log", line), ("pod", "api-%d" % rng_.randrange(100)), ("n", rng_.randrange(1000))]
+            rng_.shuffle(body)
+            recs_.append(_synth.v2_record(sec_, 7, dict(body)))
+        else:
+            recs_.append(_synth.v2_record(sec_, 7, {"log": line}))
+
+    return recs_
+
+
 def kernel_source_sha():
     """identity of the headline kernels' sources: the PMC summary is only quoted while it was taken from this build"""
     import hashlib
@@ -549,37 +593,8 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         import numpy as np
         import synth as _synth
         import oracle_binding as _ob
-        rng_ = _rnd.Random(0x51ab)
-        lens_ = [80, 120, 160, 256, 400, 600]
-        import re as _re
-        cut_ = _re.compile(rb'^(\S+ - \S+ \[[^\]]+\] "\S+ /)(\S*)( HTTP/1.1" \d+ \d+)( ".*)$')
-        pools = []
-        for ll in lens_:
-            d_, o_, _e = _synth.apache_records(10000, line_len=max(ll, 256), seed=0xF1B17 + ll)
-            rec = int(o_[1] - o_[0])
-            arr = np.asarray(d_).reshape(10000, rec)
-            full = [bytes(arr[i, rec - max(ll, 256):]) for i in range(10000)]
-            if ll < 256:                   # shorter lines: the request path cut, no referer / agent (the pattern's optional tail)
-                short = []
-                for ln in full:
-                    m_ = cut_.match(ln)
-                    keep = max(0, ll - len(m_.group(1)) - len(m_.group(3)))
-                    short.append(m_.group(1) + m_.group(2)[:keep] + m_.group(3))
-                full = short
-            pools.append(full)
-        recs_ = []
-        for i in range(60000):
-            line = pools[rng_.randrange(len(lens_))][rng_.randrange(10000)]
-            r_ = rng_.random()
-            sec_ = 1700000000 + i
-            if r_ < 0.01:
-                recs_.append(_synth.legacy_record(_synth.ext_ts(sec_, 5), {"log": line}))
-            elif r_ < 0.11:
-                body = [("stream", "stdout"), ("log", line), ("pod", "api-%d" % rng_.randrange(100)), ("n", rng_.randrange(1000))]
-                rng_.shuffle(body)
-                recs_.append(_synth.v2_record(sec_, 7, dict(body)))
-            else:
-                recs_.append(_synth.v2_record(sec_, 7, {"log": line}))
+        lens_ = MIXED_LENS
+        recs_ = mixed_shape_records()
         pool_bytes = b"".join(recs_)
         tiles_ = max(1, min(n, 3_000_000) // len(recs_))
         mdata = pool_bytes * tiles_
@@ -600,18 +615,34 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
             r3_, o3_ = ch3.filter_dev(mch)
         torch.cuda.synchronize()
         dt_x = (time.perf_counter() - t0) / steps
-        # the first 3 000 records through the oracle's two filters: what they keep is the head of the device's output
-        head_ = b"".join(recs_[:3000])
+        # parity at the timed size (round 4): (a) the whole fused output against the unfused kernels (filter_parser's full output through
+        # filter_grep), by hash; (b) four blocks of 1 000 input rows spread over the chunk through the oracle's two filters -- the output
+        # keeps one row per input row, so a block of input rows is a block of output rows
+        import hashlib as _hl
+        fb = np.empty(int(o3_.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(fb.ctypes.data, o3_.data, int(o3_.bytes))
+        foff = np.empty(mn + 1, dtype=np.uint64)
+        L.flbgpu_memcpy_d2h(foff.ctypes.data, o3_.row_off, foff.nbytes)
+        rp_, op_ = f3.filter_dev(mch)
+        ru_, ou_ = g3.filter_dev(op_)
+        ub_ = np.empty(int(ou_.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(ub_.ctypes.data, ou_.data, int(ou_.bytes))
+        sha_f, sha_u = _hl.sha256(memoryview(fb)).hexdigest(), _hl.sha256(memoryview(ub_)).hexdigest()
         po_ = _ob.Parser(regex=APACHE2, time_fmt=TIME_FMT, time_key="time")
-        w1 = _ob.FilterParser("log", [po_]).filter(head_)
-        w2 = _ob.Grep([GREP_RULE]).filter(w1[1] if w1[0] == 1 else head_)
-        want_ = w2[1] if w2[0] == 1 else (w1[1] if w1[0] == 1 else head_)
-        got_ = ctypes.create_string_buffer(max(1, len(want_)))
-        if len(want_):
-            L.flbgpu_memcpy_d2h(got_, o3_.data, len(want_))
+        fo_ = _ob.FilterParser("log", [po_]); go_ = _ob.Grep([GREP_RULE])
+        ok_, rows_ = True, 0
+        blk_ = 1000
+        for start in sorted({0, mn // 3, (2 * mn) // 3, mn - blk_}):
+            blob = bytes(mdata[int(moff[start]): int(moff[start + blk_])])
+            r1_, w1_ = fo_.filter(blob)
+            r2_, w2_ = go_.filter(w1_ if r1_ == _ob.MODIFIED else blob)
+            want_ = w2_ if r2_ == _ob.MODIFIED else (w1_ if r1_ == _ob.MODIFIED else blob)
+            ok_ = ok_ and bytes(fb[int(foff[start]): int(foff[start + blk_])]) == want_
+            rows_ += blk_
         out["mixed_shapes"] = {"records": mn, "chunk_bytes": len(mdata), "line_lengths": lens_, "multi_key_bodies": 0.10, "legacy_events": 0.01,
                                "records_per_s_per_gpu": round(mn / dt_x, 1), "ms_per_step": round(dt_x * 1e3, 3), "chunk_GBps": round(len(mdata) / dt_x / 1e9, 1),
-                               "kept": int(ch3.last_stats()[1]["out_records"]), "head_matches_oracle": bool(got_.raw[:len(want_)] == want_), "head_records": 3000}
+                               "kept": int(ch3.last_stats()[1]["out_records"]), "fused_sha256": sha_f, "fused_equals_unfused": bool(sha_f == sha_u),
+                               "oracle_sample_rows": rows_, "oracle_sample_matches": bool(ok_)}
         f3.close(); g3.close(); p3.close(); L.flbgpu_dev_free(d_md); L.flbgpu_dev_free(d_mo)
     except Exception as e:
         out["mixed_shapes"] = {"error": repr(e)[:300]}

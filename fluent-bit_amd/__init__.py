@@ -87,6 +87,7 @@ def lib():
     L.flbgpu_rx_info.argtypes = [c_void_p, POINTER(c_int)]
     L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
     L.flbgpu_rx_engine.argtypes = [c_void_p, POINTER(c_int), c_char_p, c_int]
+    L.flbgpu_rx_simulate_fx3.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.flbgpu_rx_sample.argtypes = [c_char_p, c_int, c_uint, ctypes.c_ulonglong, c_char_p, c_int]
     L.flbgpu_filter_chain_run.argtypes = [POINTER(c_void_p), c_int, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), c_void_p]
     L.flbgpu_filter_chain_run_dev.argtypes = [POINTER(c_void_p), c_int, POINTER(DevChunk), POINTER(DevChunk), c_void_p]

@@ -319,6 +319,11 @@ struct ParserMatchArgs {
     uint32_t *desc;
     uint32_t dstride;
     uint64_t fix_first;              // k_parser_reg<true>: first flagged row
+    // the rows k_parser_reg<false> leaves to the fix-up launch (another layout: several keys, metadata, legacy events ...), as a LIST:
+    // the fix-up launch takes 64 listed rows per wave instead of looking for flagged rows among all of them (10 % such rows scattered
+    // over the chunk had every wave of it run with six lanes: as long as the main pass, round 4)
+    uint32_t *fix_list;              // [n] row numbers (nullptr: none -- n >= 2^32)
+    unsigned long long *fix_count;   // how many
     // k_parser_reg, staged ingest: a workgroup's waves share stage_nbuf LDS buffers of stage_bytes (+ 32 of slack) each at
     // stage_lds_off; a wave takes one, copies its 64 records (one contiguous range of the chunk) into it with coalesced
     // 16 B / lane loads, every lane pulls header + value into registers, and the buffer goes back (0 buffers: per-lane loads)

@@ -429,8 +429,17 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
     // compact forward tables of the single-pass tile kernel (start-anchored patterns: the forward walk needs no reverse pass)
     if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE") && !p->prog.ascii_stub) {
         if (!upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx, d.fx)) { delete p; return nullptr; }
-        // the same with a cell per pair of byte classes (two steps per table read) when that fits the LDS too
-        if (d.fx.ok && !upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx2, d.fx2, true)) { delete p; return nullptr; }
+        // the same tables without special entries (fx.cpp build_fx3: 8-byte cells, two capture writes per step): what k_parser_reg<.., FX3> walks
+        if (d.fx.ok) {
+            std::vector<uint8_t> b3;
+            if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2)) { delete p; return nullptr; }
+            if (d.fx2.ok) {
+                if (hipMalloc(&p->blob_fx2.dev, b3.size()) != hipSuccess || hipMemcpy(p->blob_fx2.dev, b3.data(), b3.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                    set_err("parser '%s': upload failed", p->name.c_str()); delete p; return nullptr;
+                }
+                d.fx2.base = (const uint8_t *) p->blob_fx2.dev;
+            }
+        }
     }
     return p;
 }
@@ -744,7 +753,7 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[12]; unsigned int ov_count; unsigned int kept_count; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[16]; unsigned int ov_count; unsigned int kept_count; };
 static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FParserCfg's side list
 
 // Pass 1 of filter_parser on a device chunk: every record decoded, located, matched and sized (locate / rx /
@@ -793,8 +802,9 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     // tables; a workgroup's waves share one copy of the tables, every wave owns a record tile + its capture columns
     const char *tmode0 = getenv("FLBGPU_TILE_MODE");
     // (pair cells -- two positions per table read -- are built and tested but measured SLOWER, DESIGN 4.0: off unless FLBGPU_PAIR2=1)
-    const char *pair2 = getenv("FLBGPU_PAIR2");
-    const bool use_fx2 = f->parsers[0]->dev.fx2.ok && !(tmode0 && !strcmp(tmode0, "tile")) && pair2 && pair2[0] == '1';
+    // (fx2 = the tables without special entries, k_parser_reg<.., FX3>; FLBGPU_FX3=0: the tables with look-ahead / pair entries)
+    const char *fx3env = getenv("FLBGPU_FX3");
+    const bool use_fx2 = f->parsers[0]->dev.fx2.ok && !(tmode0 && !strcmp(tmode0, "tile")) && !(fx3env && fx3env[0] == '0');
     const DevFx &fx = use_fx2 ? f->parsers[0]->dev.fx2 : f->parsers[0]->dev.fx;
     bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
     for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
@@ -814,6 +824,8 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         else { rx_threads = waves * 64; caps_bytes = 1; }
     }
     int grid = cus;
+    // (several workgroups per CU: the register kernel's waves beyond the 16 of one workgroup -- FLBGPU_TILE_GRID_MULT, with FLBGPU_TILE_WAVES)
+    if (use_tile && getenv("FLBGPU_TILE_GRID_MULT")) { const int m = atoi(getenv("FLBGPU_TILE_GRID_MULT")); if (m >= 1 && m <= 4) grid = cus * m; }
     uint64_t need_blocks = (n + rx_threads - 1) / rx_threads;
     if ((uint64_t) grid > need_blocks) grid = (int) need_blocks;
     if (!f->d_rid.ensure((size_t) grid * (rx_threads / 64) * 64 * chk_len * sizeof(uint16_t))) return false;
@@ -849,7 +861,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.chk_len = chk_len; ma.chk_nfa_off = chk_len; ma.lds_bytes = lds_bytes; ma.caps_lds_off = tab_bytes; ma.caps_in_lds = caps_bytes ? 1 : 0;
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
-    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
+    ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? 1 : 0;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
@@ -956,6 +968,15 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             ma.tail_buf = f->d_tail.as<uint8_t>(); ma.tail_start = in->bytes - tb;
         }
         if (!f->d_args.ensure(sizeof(ParserMatchArgs)) || !f->hp_args.ensure(sizeof(ParserMatchArgs))) return false;
+        // the list of the rows the fast pass hands to the fix-up launch (dev.hpp ParserMatchArgs::fix_list)
+        if (!tile_in_lds && n < 0xFFFFFFFFull) {
+            // (a region per wave of the launch: what a wave sees at most, rounded up to whole iterations; behind them one count per wave)
+            const uint64_t nw = (uint64_t) grid * (uint64_t) (rx_threads / 64);
+            const uint64_t stride = ((n + nw * 64 - 1) / (nw * 64)) * 64;
+            if (!f->d_fix.ensure((nw * stride + nw) * sizeof(uint32_t))) return false;
+            ma.fix_list = f->d_fix.as<uint32_t>();
+            ma.fix_count = (unsigned long long *) (f->d_fix.as<uint32_t>() + nw * stride);
+        }
         ma.self = f->d_args.as<ParserMatchArgs>();
         memcpy(f->hp_args.p, &ma, sizeof(ma));                   // (page-locked: the copy below is a real asynchronous transfer)
         HIPOK(hipMemcpyAsync(f->d_args.p, f->hp_args.p, sizeof(ma), hipMemcpyHostToDevice, st));
@@ -992,6 +1013,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             ma.fix_first = hm.counts[11] <= n ? n - hm.counts[11] : 0;
             uint64_t fix_blocks = ((n - (ma.fix_first & ~63ull)) + (uint64_t) rx_threads - 1) / (uint64_t) rx_threads;
             if (fix_blocks > (uint64_t) grid) fix_blocks = (uint64_t) grid;
+            if (ma.fix_list) fix_blocks = (uint64_t) grid;                       // the same shape: wave w takes what wave w listed
             { ProfScope ps(f, st, "k_parser_reg_fixup"); launch_parser_reg(ma, (int) fix_blocks, rx_threads, true, st); }
             HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));

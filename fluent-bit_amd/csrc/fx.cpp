@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include "host_int.hpp"
@@ -250,6 +251,153 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
     out.pair_bias = bias; out.ncls1 = stride;
     out.ok = 1;
     return true;
+}
+
+
+// ---- fx3: the compact tables WITHOUT special entries (k_parser_reg<.., FX3>, round 4).
+// In the tables above a step is a table read, a test of the entry's top bit by the whole wave, and -- in two steps of five on access
+// logs -- a second read (the look-ahead cell), a select and a second test (a double capture write): a compare, a scalar branch and
+// often another LDS round trip on the walk's ONE dependent chain.  Here every cell is 8 bytes
+//     lo = address of the next row | (slot B * 128) << 16        hi = slot A * 128
+// and a step is ONE ds_read_b64 and two unconditional capture writes: slot A gets position j - 1, slot B position j.  That second
+// write is what dissolves the special entries:
+//   * look-ahead: the cell "the next byte decides" leads (no write) to a PENDING row P_m; its cell for class c2 holds what the
+//     resolved entry ft2[m][c2] = (row n, slot s) and then the step from n on c2 give together: slot A = s (position j - 1: the byte
+//     the look-ahead stood on), slot B and the next row from ft[n][c2] (which may be another pending row);
+//   * two capture writes at one position: one goes out now (slot B), the other is CARRIED into the next step's slot A -- the
+//     next row is a copy (n, y) of row n whose every cell has slot A = y (written with the next step's j - 1, the same position).
+//     The walk runs one position past the end-of-text column so that a write carried out of that column lands too.
+// What cannot be spelled with two writes per step (a look-ahead that resolves to a double write, a carry into a cell that already
+// carries) goes to the absorbing row with the FAIL slot: the record takes the generic kernel.  No tail, no pair cells: a row's cells
+// are all there is.  Result slots, sentinel byte and poison row are those of the tables above.
+bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out) {
+    memset(&out, 0, sizeof(out));
+    if (!t.has_capture || !t.ascii_only || t.ft.empty() || t.stub) return true;
+    const uint32_t ncol = (uint32_t) t.ncls + 1;                                 // byte classes + the end-of-text column
+    const uint32_t nbase = (uint32_t) t.nX * (uint32_t) t.NKp, ABS = nbase, POI = nbase + 1;
+    const size_t W = (size_t) 1 << t.wsh, ncols2 = (size_t) 1 << t.fc_shift, nm = t.ft2.size() / ncols2;
+    const uint32_t nslots = (uint32_t) ncap + 5;
+    if (nslots > 63) return true;
+    const uint32_t S_END_EOT = (uint32_t) ncap + FXS_END_EOT, S_END_MID = (uint32_t) ncap + FXS_END_MID,
+                   S_DEAD_EOT = (uint32_t) ncap + FXS_DEAD_EOT, S_FAIL = (uint32_t) ncap + FXS_FAIL;
+    // an entry of the kernel tables in the abstract: kind 0 one write (s1), 1 two writes (s1, s2), 2 look-ahead row m
+    struct Ent { int kind; uint32_t next, s1, s2, m; };
+    auto conv = [&](uint32_t e, bool eot) -> Ent {
+        if (e & rx::FT_SPECIAL) {
+            const uint32_t ty = rx::ft_type(e);
+            if (ty == rx::FT_LOOK) { if ((e & 0xFFFFFF) >= nm) return Ent{0, ABS, S_FAIL, 0, 0}; return Ent{2, 0, 0, 0, e & 0xFFFFFF}; }
+            if (ty == rx::FT_MATCH) {
+                const uint32_t a = (e >> 12) & 63, c = (e >> 18) & 63, endslot = eot ? S_END_EOT : S_END_MID;
+                if (a && c) return Ent{0, ABS, S_FAIL, 0, 0};                    // three writes
+                if (a || c) return Ent{1, ABS, a ? a : c, endslot, 0};
+                return Ent{0, ABS, endslot, 0, 0};
+            }
+            if (ty == rx::FT_MULTI) return Ent{0, ABS, S_FAIL, 0, 0};
+            return Ent{0, ABS, eot ? S_DEAD_EOT : 0u, 0, 0};                     // dead end
+        }
+        const uint32_t a = (e >> 12) & 63, c = (e >> 18) & 63;
+        if (a && c) return Ent{1, e & 0xFFF, a, c, 0};
+        return Ent{0, e & 0xFFF, a ? a : c, 0, 0};
+    };
+    auto base_ent = [&](uint32_t r, uint32_t c) -> Ent {                        // row r (base, ABS, POI), column c
+        const bool eot = c == (uint32_t) t.ncls;
+        if (r == ABS) return Ent{0, ABS, 0, 0, 0};
+        if (r == POI) return Ent{0, POI, 0, 0, 0};
+        if (!eot && (int) c == t.high_cls) return Ent{0, POI, 0, 0, 0};
+        const uint32_t kind = eot ? (uint32_t) t.kind_edge : t.kind_of_cls[c];
+        return conv(t.ft[(size_t) r * W + (((size_t) kind << t.fc_shift) | c)], eot);
+    };
+    auto look_ent = [&](uint32_t m, uint32_t c) -> Ent {                        // what look-ahead row m resolves to when the NEXT byte has class c
+        if (c < (uint32_t) t.ncls && (int) c == t.high_cls) return Ent{0, ABS, S_FAIL, 0, 0};      // a byte >= 0x80 follows: the UTF-8 tables decide
+        Ent v = conv(t.ft2[m * ncols2 + c], false);
+        if (v.kind == 2) return Ent{0, ABS, S_FAIL, 0, 0};
+        return v;
+    };
+    // new rows: (base row r | pending row of look m, carried slot y), made on demand
+    struct Key { uint32_t pend, id, carry; bool operator<(const Key &o) const { return pend != o.pend ? pend < o.pend : id != o.id ? id < o.id : carry < o.carry; } };
+    std::map<Key, uint32_t> ids;
+    std::vector<Key> rows;
+    auto row_id = [&](uint32_t pend, uint32_t id, uint32_t carry) -> uint32_t {
+        const Key k{pend, id, carry};
+        auto it = ids.find(k);
+        if (it != ids.end()) return it->second;
+        const uint32_t n = (uint32_t) rows.size();
+        ids.emplace(k, n); rows.push_back(k);
+        return n;
+    };
+    struct Cell { uint32_t next, sa, sb; };
+    std::vector<Cell> cells;
+    const uint32_t start_base = ((uint32_t) t.nX - 1) * (uint32_t) t.NKp + (uint32_t) t.kind_edge;
+    row_id(0, start_base, 0); row_id(0, ABS, 0); row_id(0, POI, 0);              // rows 0, 1, 2: start, absorbing, poison
+    const Cell FAILC{1, 0, S_FAIL};
+    // the step `v` taken with `sa` already owed to position j - 1: where it leads and what it writes
+    auto finish = [&](const Ent &v, uint32_t sa) -> Cell {
+        if (v.kind == 2) return Cell{row_id(1, v.m, 0), sa, 0};
+        if (v.kind == 1) return Cell{row_id(0, v.next, v.s2), sa, v.s1};
+        return Cell{row_id(0, v.next, 0), sa, v.s1};
+    };
+    for (size_t ri = 0; ri < rows.size(); ri++) {
+        if (rows.size() > 4000) return true;
+        const Key k = rows[ri];
+        for (uint32_t c = 0; c < ncol; c++) {
+            Cell out_c;
+            if (!k.pend) out_c = finish(base_ent(k.id, c), k.carry);
+            else {
+                // the look-ahead stood on the byte in front of this one: its resolution's write belongs to position j - 1, then the
+                // step from the resolved row on this byte
+                const Ent r = look_ent(k.id, c);
+                if (r.kind == 1) out_c = FAILC;                                   // two writes at j - 1 and the step's own: three
+                else out_c = finish(base_ent(r.next, c), r.s1);
+            }
+            cells.push_back(out_c);
+        }
+    }
+    const uint32_t nrows = (uint32_t) rows.size();
+    const uint32_t rs = ncol | 1u;                                              // cells per row, odd: rows spread over the LDS banks
+    const uint32_t rowb = rs * 8, at0 = 1024;
+    const uint64_t total64 = (uint64_t) at0 + (uint64_t) nrows * rowb;
+    if (total64 > 60000) return true;
+    std::vector<uint32_t> cls(256);
+    for (int i = 0; i < 256; i++) cls[(size_t) i] = (uint32_t) t.cls[i] * 8u;
+    cls[255] = (uint32_t) t.ncls * 8u;                                          // the end-of-text sentinel
+    b.assign((size_t) ((total64 + 15) & ~15ull), 0);
+    memcpy(b.data(), cls.data(), 1024);
+    for (uint32_t r = 0; r < nrows; r++)
+        for (uint32_t c = 0; c < ncol; c++) {
+            const Cell &x = cells[(size_t) r * ncol + c];
+            const uint32_t lo = (at0 + x.next * rowb) | ((x.sb * 128u) << FX_SLOT_SHIFT), hi = x.sa * 128u;
+            memcpy(b.data() + at0 + (size_t) r * rowb + c * 8, &lo, 4);
+            memcpy(b.data() + at0 + (size_t) r * rowb + c * 8 + 4, &hi, 4);
+        }
+    out.base = nullptr; out.bytes = (uint32_t) b.size();
+    out.off_p2 = 0;
+    out.start_off = at0; out.absorb_off = at0 + rowb; out.poison_off = at0 + 2 * rowb;
+    out.tail_min = out.absorb_off; out.nkill = 0;
+    out.nslots = nslots; out.pair_bias = 0; out.ncls1 = ncol;
+    out.ok = 1;
+    return true;
+}
+
+// k_parser_reg<.., FX3>'s walk on the host: positions 0 .. len + 1, one 8-byte cell per step, two writes
+int flbgpu::simulate_fx3(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps) {
+    auto u32at = [&](uint32_t at) -> uint32_t { uint32_t v; memcpy(&v, b.data() + at, 4); return v; };
+    for (uint32_t i = 0; i < fx.nslots; i++) caps[i] = 0xFFFF;
+    uint32_t e = fx.start_off;
+    for (uint32_t j = 0; j <= len + 1; j++) {
+        const uint32_t at = (e & FX_ROW_MASK) + u32at(4 * (j < len ? s[j] : j == len ? 0xFFu : 0u));      // (behind the sentinel: zero bytes)
+        const uint32_t lo = u32at(at), hi = u32at(at + 4);
+        caps[hi / 128] = (uint16_t) (j - 1);
+        caps[(lo >> FX_SLOT_SHIFT) / 128] = (uint16_t) j;
+        e = lo;
+    }
+    const uint32_t S = e & FX_ROW_MASK;
+    const uint32_t e_eot = caps[ncap + FXS_END_EOT], e_mid = caps[ncap + FXS_END_MID], d_eot = caps[ncap + FXS_DEAD_EOT], failed = caps[ncap + FXS_FAIL];
+    if (S == fx.poison_off) return -2;
+    if (failed != 0xFFFF) return -1;
+    if (e_mid != 0xFFFF) return (int) e_mid;
+    if (e_eot != 0xFFFF) return e_eot == len ? (int) len : -2;
+    if (d_eot != 0xFFFF) return d_eot == len ? -1 : -2;
+    return -1;
 }
 
 

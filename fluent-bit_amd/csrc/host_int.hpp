@@ -82,6 +82,9 @@ bool upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out);
 bool upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out, bool pair = false);
 bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pair = false);
 int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps, bool use_tail = true);
+// fx3: the same tables without special entries (8-byte cells, two capture writes per step; fx.cpp)
+bool build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out);
+int simulate_fx3(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool parse_ra(const char *pat, DevKey &k, std::string &why);
 // "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)
@@ -144,7 +147,7 @@ struct flbgpu_filter {
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec, d_fix;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     flbgpu::PinnedBuf hp_misc, hp_args, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -160,7 +163,7 @@ struct flbgpu_filter {
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec};
+                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
         hp_misc.release(); hp_args.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();

@@ -80,6 +80,32 @@ int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end) {
 int flbgpu_rx_simulate_fx_walk_all(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, false, false); }
 /* the same over the tables with a cell per pair of byte classes (k_parser_reg<PAIR2>: two positions per table read); -4 also when they do not fit */
 int flbgpu_rx_simulate_fx2(void *h, const char *s, int len, int *beg, int *end) { return simulate_fx_tables(h, s, len, beg, end, true); }
+/* the tables without special entries (fx.cpp build_fx3: 8-byte cells, two capture writes per step -- k_parser_reg<.., FX3>); info2
+ * (may be NULL): rows, bytes of the tables */
+int flbgpu_rx_simulate_fx3(void *h, const char *s, int len, int *beg, int *end, int *info2)
+{
+    auto *p = (rx::Program *) h;
+    int ncap = 0;
+    for (uint8_t c : p->slot2cap) if (c != 0xFF) ncap++;
+    if (ncap == 0) return -4;
+    std::vector<uint8_t> blob;
+    flbgpu::DevFx fx;
+    if (!flbgpu::build_fx3(p->ascii, ncap, blob, fx) || !fx.ok) return -4;
+    if (info2) { info2[0] = (int) ((fx.bytes - 1024) / ((fx.ncls1 | 1u) * 8)); info2[1] = (int) fx.bytes; }
+    std::vector<uint16_t> caps(fx.nslots);
+    const int r = flbgpu::simulate_fx3(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
+    if (r < 0) return r;
+    for (int g = 0; g <= p->ngroups; g++) { beg[g] = -1; end[g] = -1; }
+    beg[0] = 0; end[0] = r;
+    for (int g = 1; g <= p->ngroups; g++) {
+        const uint8_t cb = p->slot2cap[2 * (size_t) g], ce = p->slot2cap[2 * (size_t) g + 1];
+        if (cb == 0xFF || ce == 0xFF) continue;
+        const uint16_t b = caps[(size_t) cb + 1], e = caps[(size_t) ce + 1];
+        if (b != 0xFFFF && e != 0xFFFF) { beg[g] = b; end[g] = e; }
+    }
+    return p->ngroups;
+}
+
 static int simulate_fx_tables(void *h, const char *s, int len, int *beg, int *end, bool pair, bool use_tail)
 {
     auto *p = (rx::Program *) h;

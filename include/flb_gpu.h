@@ -433,6 +433,7 @@ uint64_t flbgpu_diag_fused_failures(void);                       /* single passe
 int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end);   /* compact tables of the tile kernel, host execution */
 int flbgpu_rx_simulate_fx2(void *h, const char *s, int len, int *beg, int *end);  /* ... with a cell per pair of byte classes (two positions per read) */
 int flbgpu_rx_simulate_fx_walk_all(void *h, const char *s, int len, int *beg, int *end);   /* flbgpu_rx_simulate_fx without the tail skip */
+int flbgpu_rx_simulate_fx3(void *h, const char *s, int len, int *beg, int *end, int *info2);  /* ... the tables without special entries (8-byte cells, two writes per step) */
 int flbgpu_rx_fx_tail(void *h, const char *s, int len, int *nkill, unsigned char *kill4, int *first);   /* the tables' tail (rows, kill bytes; where a text enters it) */
 int flbgpu_rx_fx_profile(void *h, const char *s, int len, long *out);              /* table sizes, look-ahead / double-write steps over a text */
 void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call: fast, lookahead, slow */

@@ -392,3 +392,71 @@ def test_stock_parsers_with_a_tail():
         if rows > 0:
             assert sorted(kill.raw[:nk.value]) == want_tail[name], (name, list(kill.raw[:nk.value]))
         L.flbgpu_rx_free(h)
+
+
+def test_fx3_tables_give_the_single_steps_answers():
+    """fx.cpp build_fx3 -- 8-byte cells, two unconditional capture writes per step (positions j - 1 and j), look-ahead cells turned
+    into pending rows, double writes carried into the next step: what k_parser_reg<.., FX3> walks without a single test inside the
+    step -- must answer like the tables with special entries: same return, same spans; it may hand a text on (-1) where those settle
+    it (a look-ahead that resolves to a double write), rarely.  Golden corpus, every stock parser on texts drawn from its own
+    pattern, apache lines with every kind of damage."""
+    import random
+    import test_stock_parsers as sp
+    L = _lib()
+    L.flbgpu_rx_simulate_fx_walk_all.argtypes = L.flbgpu_rx_simulate_fx.argtypes
+    L.flbgpu_rx_simulate_fx3.argtypes = list(L.flbgpu_rx_simulate_fx.argtypes) + [ctypes.POINTER(ctypes.c_int)]
+    rng = random.Random(11)
+    stats = {"compared": 0, "handed_on": 0, "patterns": 0}
+
+    def both(h, s):
+        b1 = (ctypes.c_int * 40)(); e1 = (ctypes.c_int * 40)(); b2 = (ctypes.c_int * 40)(); e2 = (ctypes.c_int * 40)()
+        n1 = L.flbgpu_rx_simulate_fx_walk_all(h, s, len(s), b1, e1)
+        n3 = L.flbgpu_rx_simulate_fx3(h, s, len(s), b2, e2, None)
+        if n3 == -4 or n1 == -4:
+            return False
+        if n3 == -1 and n1 != -1:
+            stats["handed_on"] += 1
+            return True
+        assert n1 == n3, (s, n1, n3)
+        if n1 >= 0:
+            assert list(b1[:n1 + 1]) == list(b2[:n1 + 1]) and list(e1[:n1 + 1]) == list(e2[:n1 + 1]), (s, list(b1[:n1 + 1]), list(b2[:n1 + 1]), list(e1[:n1 + 1]), list(e2[:n1 + 1]))
+        stats["compared"] += 1
+        return True
+
+    kat = json.load(open(os.path.join(HERE, "golden", "regex_kat.json")))
+    for ent in kat:
+        pat = base64.b64decode(ent["pattern"])
+        if not ent["compiles"] or not ent["names"] or not (pat.startswith(b"^") or pat.startswith(b"\\A")):
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        if not h:
+            continue
+        texts = [base64.b64decode(s64) for s64, _ in ent["cases"]]
+        alphabet = sorted(set(b"".join(texts) + pat)) or [97]
+        ok = all(both(h, s) for s in texts)
+        for _ in range(150 if ok else 0):
+            base = bytearray(rng.choice(texts)) if texts and rng.random() < 0.7 else bytearray()
+            for _ in range(rng.randrange(0, 6)):
+                if base and rng.random() < 0.5:
+                    base[rng.randrange(len(base))] = rng.choice(alphabet)
+                else:
+                    base.insert(rng.randrange(len(base) + 1), rng.choice(alphabet))
+            both(h, bytes(base))
+        stats["patterns"] += 1 if ok else 0
+        L.flbgpu_rx_free(h)
+    n_kat = stats["compared"]
+    assert stats["patterns"] >= 10 and n_kat > 2000, stats
+    for k, it in enumerate(sp.stock()):
+        pat = sp.inner(it["regex"])
+        if not pat.startswith(b"^") or it["section"] != "PARSER":
+            continue
+        err = ctypes.create_string_buffer(256)
+        h = L.flbgpu_rx_compile(pat, len(pat), 0, 1, err, 256)
+        assert h
+        for s in sp.texts(L, pat, 60, 300 + k):
+            if not both(h, s):
+                break
+        L.flbgpu_rx_free(h)
+    assert stats["compared"] - n_kat > 800, stats
+    assert stats["handed_on"] * 50 < stats["compared"], stats
