@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 from ndjson_synth import GREP32_REGEX, GREP32_EXCLUDE          # noqa: E402  (tests/ is on sys.path)
 
 
-PMC_FILE = os.path.join("profiles", "r3_pmc_hbm_bench_10M.json")
+PMC_FILE = os.path.join("profiles", "r4_pmc_hbm_bench_10M.json")
 
 
 def _sha16(path):
@@ -97,12 +97,40 @@ def kernel_source_sha():
     """identity of the headline kernels' sources: the PMC summary is only quoted while it was taken from this build"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tile_kernels.inc", "fused_kernels.inc", "kdev.inc", "dev.hpp"):
+    for f in ("tile_kernels.inc", "fused_kernels.inc", "kdev.inc", "nfa_dev.inc", "dev.hpp", "fx.cpp"):
         try:
             h.update(open(os.path.join(ROOT, "fluent-bit_amd", "csrc", f), "rb").read())
         except OSError:
             return None
     return h.hexdigest()[:16]
+
+
+def pmc_pass(n, steps=5, warmup=1):
+    """--pmc: HBM traffic of this very build, measured now -- the headline step once more under rocprofv3, one pass per counter
+    (FETCH_SIZE, WRITE_SIZE: separate passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), in child
+    processes.  Returns {kernel base name: {"FETCH_SIZE": KiB, "WRITE_SIZE": KiB}} averaged per launch, or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile, collections
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    tmp = tempfile.mkdtemp(prefix="flbgpu_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--no-cpu", "--no-secondary", "--steps", str(steps), "--warmup", str(warmup), "--records", str(n)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    out[row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    except Exception as e:
+        return None, repr(e)[:160]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (bench.py --pmc; FETCH x 2, WRITE x 1)"
 
 
 def recorded_traffic(kernel, n):
@@ -982,6 +1010,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the log_to_metrics / JSON side measurements")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic now: two more passes of the headline step under rocprofv3 (FETCH_SIZE, WRITE_SIZE)")
     ap.add_argument("--ndjson-lines", type=int, default=100_000_000, help="BASELINE configs[2]: NDJSON lines through JSON -> events -> 32-rule grep (secondary)")
     ap.add_argument("--l2m-records", type=int, default=1_000_000_000, help="BASELINE configs[3]: records through log_to_metrics over all ranks (secondary)")
     args = ap.parse_args()
@@ -1158,6 +1187,17 @@ def main():
         avg_s = ms / 1e3 / max(launches, 1)
         ach = alg_bytes_per_launch.get(dom, in_bytes) / avg_s / 1e9
         traffic, traffic_src = recorded_traffic(dom, n)
+        live = None
+        if args.pmc and world == 1:
+            # the same step twice more under rocprofv3 (children), after this process has finished its own timing
+            live, live_src = pmc_pass(n, args.steps, args.warmup)
+            if live is None:
+                traffic_src = "--pmc: " + live_src + "; " + str(traffic_src)
+            else:
+                hit = live.get(dom) or {}
+                if hit:
+                    traffic = int(hit.get("FETCH_SIZE", 0) * 1024 * 2.0 + hit.get("WRITE_SIZE", 0) * 1024 * 1.0)
+                    traffic_src = live_src
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_s * 1e3, 4), "launches": int(launches),
@@ -1166,7 +1206,13 @@ def main():
         # filter_parser emits + what filter_grep keeps (552 + 275 x keep B/record), over the step's kernel time
         step_bytes = in_bytes + parsed_bytes + kept_bytes
         kern_ms = sum(v[0] for v in prof.values()) / args.steps
-        tr = [recorded_traffic(k, n)[0] for k in prof]
+        def _tr(k):
+            if live is not None:
+                hs = [v for kk, v in live.items() if kk == k or (k.endswith("k_scan") and kk.startswith("k_scan_"))]
+                if hs:
+                    return int(sum(h.get("FETCH_SIZE", 0) * 1024 * 2.0 + h.get("WRITE_SIZE", 0) * 1024 * 1.0 for h in hs))
+            return recorded_traffic(k, n)[0]
+        tr = [_tr(k) for k in prof]
         roof["step"] = {"algorithmic_bytes": int(step_bytes), "kernel_ms": round(kern_ms, 3), "achieved": round(step_bytes / (kern_ms / 1e3) / 1e9, 1),
                         "frac": round(step_bytes / (kern_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": int(sum(tr)) if tr and all(t is not None for t in tr) else None}

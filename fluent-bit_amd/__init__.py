@@ -87,6 +87,12 @@ def lib():
     L.flbgpu_rx_info.argtypes = [c_void_p, POINTER(c_int)]
     L.flbgpu_rx_names.argtypes = [c_void_p, c_char_p, c_int]
     L.flbgpu_rx_engine.argtypes = [c_void_p, POINTER(c_int), c_char_p, c_int]
+    L.flbgpu_rx_corner.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int)]
+    L.flbgpu_l2m_set_sum_order.argtypes = [c_void_p, c_int]
+    L.flbgpu_l2m_seq_sums.restype = c_int64
+    L.flbgpu_l2m_seq_sums.argtypes = [c_void_p, c_uint64, POINTER(c_double)]
+    L.flbgpu_filter_regex_corners.restype = ctypes.c_uint64
+    L.flbgpu_filter_regex_corners.argtypes = [c_void_p]
     L.flbgpu_rx_simulate_fx3.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     L.flbgpu_rx_sample.argtypes = [c_char_p, c_int, c_uint, ctypes.c_ulonglong, c_char_p, c_int]
     L.flbgpu_filter_chain_run.argtypes = [POINTER(c_void_p), c_int, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), c_void_p]
@@ -214,6 +220,10 @@ class _Filter:
         a = c_uint64(); b = c_uint64()
         lib().flbgpu_filter_last_counts(self.h, byref(a), byref(b))
         return a.value, b.value
+
+    def regex_corners(self):
+        """values that met one of the reference's optimizer-dependent regex corners since the filter was created (flb_gpu.h)"""
+        return int(lib().flbgpu_filter_regex_corners(self.h))
 
     def profile(self, enable=True):
         lib().flbgpu_filter_profile(self.h, int(enable))
@@ -787,6 +797,20 @@ class FilterLogToMetrics(_Filter):
         b = (c_double * max(nb.value, 1))()
         lib().flbgpu_l2m_bounds(self.h, b)
         self.bounds = list(b[: nb.value])
+
+    def set_sum_order(self, reference=True):
+        """sum_order reference: also keep the histogram sum as the reference adds it up (one f64 addition per observation in record order)"""
+        if lib().flbgpu_l2m_set_sum_order(self.h, int(bool(reference))) != 0:
+            raise RuntimeError(last_error())
+
+    def seq_sums(self):
+        """the reference-order sums of the series, in snapshot() / export() order"""
+        cap = 1 << 16
+        buf = (c_double * cap)()
+        n = lib().flbgpu_l2m_seq_sums(self.h, cap, buf)
+        if n < 0:
+            raise RuntimeError("no reference-order sums: %s" % last_error())
+        return [buf[i] for i in range(n)]
 
     def set_index_base(self, base):
         lib().flbgpu_l2m_set_index_base(self.h, base)

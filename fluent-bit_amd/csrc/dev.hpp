@@ -48,6 +48,10 @@ struct DevCap {
     uint32_t hot_bytes;
     uint32_t off_rdelta, off_ft, off_ft2, off_cls, off_col;   // byte offsets inside the hot block
     int stub;                      // ascii set only: a stub that hands EVERY value on, the empty one too (rx.cpp make_ascii_stub)
+    // utf8 slot: the optimizer-dependent corners of the reference this pattern can meet (rx::CF_*) and where the walkers count the
+    // values that do (kdev.inc rx_corner_note; one u64 in device memory, read by flbgpu_filter_regex_corners)
+    int corner_flags;
+    unsigned long long *corner_count;
     int nfa_on;                    // utf8 slot only: the NFA engine stands in for the table set (rx::Program::utf8_nfa); the
     DevNfa nfa;                    // table pointers above are null then
 };
@@ -794,6 +798,8 @@ void launch_l2m_generic(const L2mArgs &a, hipStream_t st);
 void launch_l2m_stale(uint32_t *sid_col, uint64_t *val_col, uint64_t n, const unsigned long long *first_bad, uint64_t *tmp, hipStream_t st);
 size_t l2m_stale_tmp_elems(uint64_t n);
 void launch_l2m_aggregate(const L2mAggArgs &a, int cus, hipStream_t st);
+void launch_l2m_seqsum(const uint32_t *sid_col, const uint64_t *val_col, uint64_t n, const unsigned long long *first_bad, double *seq, uint32_t nseries,
+                       hipStream_t st);
 void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
 void launch_json_size(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);

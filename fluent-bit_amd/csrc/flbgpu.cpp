@@ -89,6 +89,7 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     std::vector<uint32_t> wrv;
     if (t.word_variants) for (int i = 0; i < nwr; i++) { wrv.push_back(wr[i][0]); wrv.push_back(wr[i][1]); }
     size_t o_wr = put(b, wrv);
+    const size_t o_cc = put(b, std::vector<uint64_t>{0});          // corner_count (dev.hpp DevCap)
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     const uint8_t *d = (const uint8_t *) blob.dev;
@@ -105,22 +106,29 @@ bool flbgpu::upload_cap(const rx::TableSet &t, TableBlob &blob, DevCap &out) {
     out.off_rdelta = (uint32_t) o_rd; out.off_ft = (uint32_t) o_ft; out.off_ft2 = (uint32_t) o_f2;
     out.off_cls = (uint32_t) o_cls; out.off_col = (uint32_t) o_col;
     out.stub = t.stub ? 1 : 0;
+    out.corner_flags = 0; out.corner_count = (unsigned long long *) (d + o_cc);
     return true;
 }
 
 // what stands behind the ascii set of a pattern: its utf8 table set, or the NFA engine's tables (rx.hpp NfaSet -> dev.hpp DevNfa)
 bool flbgpu::upload_utf8(const rx::Program &prog, TableBlob &blob, DevCap &out) {
-    if (!prog.utf8_nfa) return upload_cap(prog.utf8, blob, out);
+    if (!prog.utf8_nfa) {
+        if (!upload_cap(prog.utf8, blob, out)) return false;
+        out.corner_flags = (int) prog.corner_flags;
+        return true;
+    }
     const rx::NfaSet &t = prog.nfa;
     std::vector<uint8_t> b;
     const size_t o_cb = put(b, t.cls_byte), o_ml = put(b, t.mb_lo), o_mc = put(b, t.mb_cls), o_am = put(b, t.amask), o_ck = put(b, t.ckind);
     const size_t o_pr = put(b, t.pred), o_ms = put(b, t.mstart), o_lo = put(b, t.list_off), o_le = put(b, t.list_ent);
     const size_t o_to = put(b, t.tag_off), o_td = put(b, t.tag_data);
+    const size_t o_cc = put(b, std::vector<uint64_t>{0});
     HIPOK(hipMalloc(&blob.dev, b.size()));
     HIPOK(hipMemcpy(blob.dev, b.data(), b.size(), hipMemcpyHostToDevice));
     const uint8_t *d = (const uint8_t *) blob.dev;
     memset(&out, 0, sizeof(out));
     out.nfa_on = 1;
+    out.corner_flags = (int) prog.corner_flags; out.corner_count = (unsigned long long *) (d + o_cc);
     DevNfa &n = out.nfa;
     n.cls_byte = (const uint16_t *) (d + o_cb); n.mb_lo = (const uint32_t *) (d + o_ml); n.mb_cls = (const uint16_t *) (d + o_mc);
     n.amask = (const uint32_t *) (d + o_am); n.ckind = d + o_ck; n.pred = (const uint32_t *) (d + o_pr); n.mstart = d + o_ms;
@@ -582,6 +590,18 @@ extern "C" int flbgpu_filter_profile_read(flbgpu_filter *f, int max, const char 
         names[n] = k.name; ms[n] = k.ms; launches[n] = k.launches; n++;
     }
     return n;
+}
+
+extern "C" uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f) {
+    if (!f) return 0;
+    uint64_t total = 0;
+    auto add = [&](const DevCap &u) {
+        unsigned long long v = 0;
+        if (u.corner_flags && u.corner_count && hipMemcpy(&v, u.corner_count, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += v;
+    };
+    for (auto *p : f->parsers) if (!p->dev.is_json) add(p->dev.utf8);
+    for (const GrepRule &r : f->rules) add(r.utf8);
+    return total;
 }
 
 extern "C" void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t *out_records) {

@@ -110,6 +110,11 @@ struct L2mState {
     flbgpu::DevBuf d_sid, d_val, d_tmp, d_misc;
     uint64_t idx_base = 0;
     uint64_t last_obs = 0, last_deferred = 0, last_stale = 0, grows = 0;
+    // sum_order reference (flbgpu_l2m_set_sum_order): next to the exact sum, the histogram sum as cmetrics builds it -- one f64
+    // addition per observation in record order (lib/cmetrics/src/cmt_metric_histogram.c:124-137) --, one binary64 per series id
+    int sum_order_ref = 0;
+    flbgpu::DevBuf d_seq;
+    uint32_t seq_cap = 0;
 };
 
 void l2m_state_destroy(L2mState *);

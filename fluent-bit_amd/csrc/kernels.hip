@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(MATCH_BLOCK) k_parser_rx(ParserMatchArgs a) {
                 for (int i = 0; i < a.pg->nrules; i++) named |= a.pg->rule_fmask[i];
                 if (any && !(named & a.pg->time_fields & ~drop)) {
                     struct { const CapLds *c; DEV uint32_t operator[](uint32_t i) const { return c->get(i); } } cv{&capl};
-                    const bool keep = pg_grep_parsed(a.pg->rules, a.pg->nrules, a.pg->logical_op, a.pg->rule_fmask, a.pg->rule_lds_off, drop, val, cv,
+                    const bool keep = pg_grep_parsed<true>(a.pg->rules, a.pg->nrules, a.pg->logical_op, a.pg->rule_fmask, a.pg->rule_lds_off, drop, val, cv,
                                                      (LDS_AS const uint8_t *) pg_lds);
                     pgbits = RF_PGDONE | (keep ? RF_PGKEEP : 0u);
                 }

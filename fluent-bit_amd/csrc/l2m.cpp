@@ -23,7 +23,7 @@ struct L2mMisc { unsigned long long first_bad; unsigned long long counts[3]; };
 void l2m_state_destroy(L2mState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->d_labels, &s->d_value_key, &s->d_bounds, &s->d_slot_hash, &s->d_slot_sid, &s->d_arena, &s->d_key_off,
-                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc};
+                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc, &s->d_seq};
     for (auto *b : all) b->release();
     delete s;
 }
@@ -284,9 +284,52 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
     g.rows = s->d_rows.as<unsigned long long>(); g.W = s->W; g.mode = s->mode; g.nb = s->nb;
     g.bounds = s->d_bounds.as<double>(); g.idx_base = s->idx_base; g.n_series = &s->d_ctr.as<L2mCtr>()->n_series;
     { ProfScope ps(f, st, "k_l2m_aggregate"); launch_l2m_aggregate(g, cus, st); }
+    if (s->sum_order_ref && s->mode == L2M_HISTOGRAM && hc.n_series) {
+        // the reference's own sum next to the exact one (host_int.hpp L2mState::sum_order_ref)
+        if (hc.n_series > s->seq_cap) {
+            uint32_t nc = s->seq_cap ? s->seq_cap : 64;
+            while (nc < hc.n_series) nc *= 2;
+            if (!grow_keep(s->d_seq, (size_t) nc * sizeof(double), (size_t) s->seq_cap * sizeof(double))) return false;
+            s->seq_cap = nc;
+        }
+        ProfScope ps(f, st, "k_l2m_seqsum");
+        launch_l2m_seqsum(g.sid_col, g.val_col, n, g.first_bad, s->d_seq.as<double>(), hc.n_series, st);
+    }
     HIPOK(hipStreamSynchronize(st));
     s->idx_base += n;
     return true;
+}
+
+// sum_order: 0 = the exact sum rounded once (default), 1 = also the reference's sequential sum (flbgpu_l2m_seq_sums)
+extern "C" int flbgpu_l2m_set_sum_order(flbgpu_filter *f, int reference) {
+    if (!f || f->kind != F_L2M) return -1;
+    f->l2m->sum_order_ref = reference ? 1 : 0;
+    return 0;
+}
+
+// the sequential sums of the series flbgpu_l2m_export lists, in its order (first appearance); returns their number, -1 when the
+// filter does not keep them
+extern "C" int64_t flbgpu_l2m_seq_sums(flbgpu_filter *f, uint64_t max_series, double *sums) {
+    if (!f || f->kind != F_L2M || !f->l2m->sum_order_ref || f->l2m->mode != L2M_HISTOGRAM) return -1;
+    L2mState *s = f->l2m;
+    L2mCtr c;
+    if (hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return -1; }
+    const uint32_t ns = c.n_series;
+    std::vector<uint64_t> hrows((size_t) ns * s->W);
+    std::vector<double> hseq(ns, 0.0);
+    if (ns) {
+        if (hipMemcpy(hrows.data(), s->d_rows.p, hrows.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return -1; }
+        const uint32_t have = ns < s->seq_cap ? ns : s->seq_cap;
+        if (have && hipMemcpy(hseq.data(), s->d_seq.p, (size_t) have * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return -1; }
+    }
+    std::vector<uint32_t> live;
+    for (uint32_t i = 0; i < ns; i++) if (hrows[(size_t) i * s->W + L2M_W_FIRST] != 0) live.push_back(i);
+    std::sort(live.begin(), live.end(), [&](uint32_t a, uint32_t b) {
+        return ~hrows[(size_t) a * s->W + L2M_W_FIRST] < ~hrows[(size_t) b * s->W + L2M_W_FIRST];
+    });
+    if (live.size() > max_series) return -(int64_t) live.size() - 2;
+    for (size_t j = 0; j < live.size(); j++) sums[j] = hseq[live[j]];
+    return (int64_t) live.size();
 }
 
 // ------------------------------------------------------------------------------------------ results

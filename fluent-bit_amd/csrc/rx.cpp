@@ -381,6 +381,7 @@ struct Ast {
     bool greedy = true;
     AnchorKind anchor = A_BOL;
     uint32_t ilit = 0;          // SET made from a literal LETTER under (?i): the letter, lower case (multi-character folds, below)
+    bool icase = false;         // SET parsed under (?i) (Program::corner_flags)
 };
 using AstP = std::unique_ptr<Ast>;
 
@@ -571,6 +572,7 @@ struct Syntax {
             a->cc.asc.set((int) c);
             fold_case(a->cc);
             a->ilit = c | 32;
+            a->icase = true;
             return a;
         }
         a->cc.kind = CC::LIT;
@@ -668,6 +670,7 @@ struct Syntax {
             p++;
             AstP a = mk(Ast::SET);
             if (!char_class(a->cc, opts)) return nullptr;
+            a->icase = (opts & OPT_IGNORECASE) != 0;
             return a;
         }
         if (c == '.') {
@@ -1768,6 +1771,21 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
     if (sx.failed()) { err = sx.err; return false; }
     if (sx.ncap > 31) { err = "more than 31 capture groups"; return false; }
     out = Program();
+    {
+        // the two corners where the reference's own answer depends on its search optimizer (DESIGN: deviations): which of them this
+        // pattern can meet at all -- the walkers count the values that could (rx::corner), nothing is answered silently
+        std::vector<const Ast *> st{root.get()};
+        while (!st.empty()) {
+            const Ast *a = st.back(); st.pop_back();
+            if (a->t == Ast::ANCHOR) {
+                if (a->anchor == A_BOL) out.corner_flags |= CF_NL_LOOKBACK;
+                if (a->anchor == A_WORDB || a->anchor == A_NWORDB || a->anchor == A_WORDB_A || a->anchor == A_NWORDB_A) out.corner_flags |= CF_WORD_LOOKBACK;
+            }
+            if (a->t == Ast::SET && a->icase) out.corner_flags |= CF_ICASE_FOLD;
+            for (auto &k : a->kids) st.push_back(k.get());
+        }
+    }
+    const unsigned corner_flags = out.corner_flags;
     out.ngroups = sx.ncap;
     out.names = sx.names;
     out.name_groups = sx.name_groups;
@@ -1799,6 +1817,7 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
     }
     // (the utf8 set only grows on the ascii one: not attempted when that one is over the budget)
     if (ascii_ok && utf8_ok && !build_tables(root.get(), false, false, true, out.slot2cap, out.utf8, why)) utf8_ok = false;
+    (void) corner_flags;
     if (ascii_ok && utf8_ok) return true;
     // ---- the second engine (rx.hpp NfaSet)
     std::string e3;
@@ -1811,6 +1830,39 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
     out.why_nfa = why;
     if (!ascii_ok) { make_ascii_stub(out.ascii, want_captures); out.ascii_stub = true; }
     return true;
+}
+
+// ---------------------------------------------------------------- the optimizer-dependent corners: which texts can meet them
+// (1) `^` / \b / \B looking back at a match start that sits right behind stray continuation bytes: the reference's matcher takes
+//     the stray byte as the previous character, unless its forward search jumped to the start -- then onigenc_get_prev_char_head
+//     left-adjusts over every 10xxxxxx byte (regexec.c:3559, regenc.c:107); which happens depends on the optimisation chosen.
+//     `^` only sees a difference behind "\n" + continuation bytes; a word anchor behind any stray continuation byte.
+// (2) (?i) and a text character whose case fold has another UTF-8 length (U+212A, U+017F, U+00DF, U+1E9E, U+FB00 .. U+FB06): the
+//     engine bounds where a match may start by the byte length of the pattern's prefix; its answer there is not leftmost.
+// The tables / the NFA engine give the leftmost-first answer in both; a value for which the reference MAY answer otherwise is
+// counted (kdev.inc rx_corner, flbgpu_filter_regex_corners) -- never a silent difference.
+bool corner(unsigned flags, const uint8_t *s, int len) {
+    if (!flags) return false;
+    bool hi = false;
+    for (int i = 0; i < len && !hi; i++) hi = s[i] >= 0x80;
+    if (!hi) return false;
+    if (flags & CF_NL_LOOKBACK) for (int i = 0; i + 1 < len; i++) if (s[i] == '\n' && s[i + 1] >= 0x80 && s[i + 1] <= 0xbf) return true;
+    if (flags & CF_WORD_LOOKBACK) {
+        for (int i = 0; i < len;) {
+            const int b = s[i];
+            if (b >= 0xc2 && b <= 0xf4) { const int L = utf8_seq_len(s, i, len); i += (L > 1 && i + L <= len) ? L : 1; continue; }
+            if (b >= 0x80 && b <= 0xbf) return true;
+            i++;
+        }
+    }
+    if (flags & CF_ICASE_FOLD) {
+        for (int i = 0; i + 1 < len; i++) {
+            const int b = s[i], c = s[i + 1], d = i + 2 < len ? s[i + 2] : -1;
+            if ((b == 0xc5 && c == 0xbf) || (b == 0xc3 && c == 0x9f) || (b == 0xe2 && c == 0x84 && d == 0xaa) || (b == 0xe1 && c == 0xba && d == 0x9e) ||
+                (b == 0xef && c == 0xac && d >= 0x80 && d <= 0x86)) return true;
+        }
+    }
+    return false;
 }
 
 // ---------------------------------------------------------------- test aid: random texts drawn from a pattern

@@ -181,7 +181,11 @@ struct Program {
     bool ascii_stub = false;                  // the ascii set is a stub that hands EVERY value on (always-poison tables)
     NfaSet nfa;
     std::string why_nfa;                      // what the table compiler said when it gave up (diagnostics)
+    unsigned corner_flags = 0;                // CF_*: the optimizer-dependent corners of the reference this pattern can meet (rx::corner)
 };
+constexpr unsigned CF_NL_LOOKBACK = 1u, CF_WORD_LOOKBACK = 2u, CF_ICASE_FOLD = 4u;
+// a text for which the reference's answer MAY differ from the leftmost-first one (rx.cpp): counted by the walkers, never silent
+bool corner(unsigned flags, const uint8_t *s, int len);
 
 // Compiles `pattern` (already stripped of the /../flags wrapper).  want_captures=false skips the
 // capture program (grep rules).  Returns false and fills err when the pattern uses a construct

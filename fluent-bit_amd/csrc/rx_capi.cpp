@@ -60,6 +60,15 @@ int flbgpu_rx_engine(void *h, int *info6, char *why, int whylen)
     return (p->utf8_nfa ? 1 : 0) | (p->ascii_stub ? 2 : 0);
 }
 
+/* 1: the text can meet one of the two corners where the reference's own answer depends on its search optimizer (rx::corner): the
+ * filters count such values (flbgpu_filter_regex_corners); info (may be NULL): the pattern's corner flags */
+int flbgpu_rx_corner(void *h, const char *s, int len, int *flags)
+{
+    auto *p = (rx::Program *) h;
+    if (flags) *flags = (int) p->corner_flags;
+    return rx::corner(p->corner_flags, (const uint8_t *) s, len) ? 1 : 0;
+}
+
 /* test aid: a random text drawn from the pattern (rx::sample); returns its length (cut to cap), -1 when the pattern does not parse */
 int flbgpu_rx_sample(const char *pattern, int len, unsigned options, unsigned long long seed, char *out, int cap)
 {

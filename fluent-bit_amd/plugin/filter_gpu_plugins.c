@@ -45,6 +45,8 @@
 #endif
 
 static int gpu_ready = 0;
+static int gpu_corner_warned = 0;
+static unsigned long gpu_calls = 0;
 
 static int ensure_gpu(struct flb_filter_instance *ins)
 {
@@ -133,14 +135,23 @@ static int cb_gpu_filter(const void *data, size_t bytes, const char *tag, int ta
 {
     /* grep_gpu_ctx and parser_gpu_ctx share their first member */
     struct grep_gpu_ctx *ctx = context;
+    int ret;
     (void) tag;
     (void) tag_len;
-    (void) f_ins;
     (void) i_ins;
     (void) config;
     /* FLBGPU_FILTER_MODIFIED/NOTOUCH == FLB_FILTER_MODIFIED/NOTOUCH; the output buffer is
      * malloc'd, the engine releases it with flb_free (src/flb_filter.c:235-237) */
-    return flbgpu_filter_run(ctx->f, data, bytes, out_buf, out_size);
+    ret = flbgpu_filter_run(ctx->f, data, bytes, out_buf, out_size);
+    /* the two regex corners in which the reference's own answer depends on its search optimizer (flb_gpu.h
+     * flbgpu_filter_regex_corners): said once, never silent; looked at every 256 calls (a small device read) */
+    if (!gpu_corner_warned && (++gpu_calls & 255) == 1 && flbgpu_filter_regex_corners(ctx->f) > 0) {
+        gpu_corner_warned = 1;
+        flb_plg_warn(f_ins, "%llu value(s) held ill-formed UTF-8 behind a line / word anchor or a case-fold character whose UTF-8 "
+                     "length differs: Onigmo's answer there depends on its search optimizer, the GPU path answered leftmost-first",
+                     (unsigned long long) flbgpu_filter_regex_corners(ctx->f));
+    }
+    return ret;
 }
 
 static int cb_gpu_exit(void *data, struct flb_config *config)

@@ -135,6 +135,13 @@ int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint64_t *rows,
  * arithmetic on integers only; the sum is the exact sum of the observations rounded once. */
 int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
                             double *sum);
+/* sum_order reference: next to the exact sum (the default, rounded once: flbgpu_l2m_finalize_row), the histogram sum as the
+ * reference builds it -- cmt_metric_hist_sum_add, lib/cmetrics/src/cmt_metric_histogram.c:124-137: one binary64 addition per
+ * observation in record order --, bit for bit.  flbgpu_l2m_set_sum_order(f, 1) before the first record; flbgpu_l2m_seq_sums fills
+ * one sum per series in flbgpu_l2m_export's order and returns their number (-1: the filter does not keep them).  Sharded runs add
+ * the shards' sums in shard order (there is no single record order across shards to reproduce). */
+int flbgpu_l2m_set_sum_order(flbgpu_filter *f, int reference);
+int64_t flbgpu_l2m_seq_sums(flbgpu_filter *f, uint64_t max_series, double *sums);
 /* ---- multi-GPU: the collective of the log_to_metrics aggregates (one process per GPU, records sharded) --------
  * Same configuration on every rank; each rank runs the filter on its own shard (flbgpu_l2m_set_index_base gives
  * the ranks disjoint record index ranges).  flbgpu_l2m_all_reduce makes the label dictionaries identical
@@ -192,6 +199,11 @@ int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nfilters, con
 /* Record accounting of the last run (what flb_filter_do derives with flb_mp_count_log_records,
  * src/flb_filter.c:272): records decoded from the input / records in the output. */
 void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t *out_records);
+/* Values (since the filter was created) that met one of the two documented corners in which the reference's regex answer depends on
+ * its search optimizer (lib/onigmo/regexec.c:3559 forward_search_range / regenc.c:107 onigenc_get_prev_char_head; case folds that
+ * change the byte length): the product answered leftmost-first, the reference MAY have answered otherwise.  Not silent: the plugin
+ * shims warn once when this is non-zero (filter_gpu_plugins.c). */
+uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f);
 
 /* Kernel timing (HIP events recorded on the stream the kernels run on).  When enabled, every
  * run accumulates the duration of each kernel; names[] is a NUL-separated list. */
@@ -440,6 +452,10 @@ void flbgpu_rx_debug_stats(long *out3);   /* forward-walk steps since last call:
 /* which engine answers: bit 0 = the bit-parallel NFA engine for values with a byte >= 0x80, bit 1 = for every value; info6 = its
  * positions, words per set, character classes, context kinds, list entries, code point intervals; why = the table compiler's reason */
 int flbgpu_rx_engine(void *h, int *info6, char *why, int whylen);
+/* 1: for this text the reference's own answer depends on its search optimizer (a match start behind stray continuation bytes under
+ * ^ \b \B; (?i) and a character whose case fold changes the UTF-8 length): the filters count such values, see
+ * flbgpu_filter_regex_corners; flags (may be NULL): which corners the pattern can meet (1 line anchor, 2 word anchor, 4 case folds) */
+int flbgpu_rx_corner(void *h, const char *s, int len, int *flags);
 /* test aid: a random text drawn from the pattern's own syntax tree (length, cut to cap; -1: the pattern does not parse) */
 int flbgpu_rx_sample(const char *pattern, int len, unsigned options, unsigned long long seed, char *out, int cap);
 

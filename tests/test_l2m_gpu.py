@@ -327,3 +327,40 @@ def test_rccl_all_reduce_in_c_single_rank(g):
         assert f.snapshot((keys1, rows1)) == f.snapshot()
         f.close()
     comm.close()
+
+
+def test_histogram_sum_in_reference_order(g):
+    """sum_order reference (flbgpu_l2m_set_sum_order): next to the exact sum the device keeps the sum as cmetrics builds it -- one f64
+    addition per observation in record order (lib/cmetrics/src/cmt_metric_histogram.c:124-137) -- and that one equals the oracle's
+    (= the reference plugin's, tests/test_l2m_refplugin.py) BIT FOR BIT: no tolerance.  Values chosen so that the two sums differ
+    (cancellation, magnitudes 1e-9 .. 1e16, three series, several chunks, a failed parse that keeps the previous value)."""
+    import random
+    rng = random.Random(77)
+    vals = []
+    for i in range(6000):
+        r = rng.random()
+        if r < 0.02:
+            vals.append(rng.choice(["1e16", "-1e16", "9007199254740993", "3e15"]))
+        elif r < 0.04:
+            vals.append(rng.choice(["junk", "", "0x10", "1e-9"]))
+        else:
+            vals.append(repr(rng.uniform(-1000, 1000) * 10 ** rng.randint(-6, 6)))
+    recs = [v2_record(1700000000 + i, 0, {"duration": v, "color": rng.choice(["red", "green", "blue"])}) for i, v in enumerate(vals)]
+    chunks = [b"".join(recs[a:a + 700]) for a in range(0, len(recs), 700)]
+    props = [("label_field", "color"), ("bucket", "0.5"), ("bucket", "10"), ("bucket", "1e6")]
+    o = ob.L2M("histogram", props, value_field="duration")
+    f = g.FilterLogToMetrics("histogram", props, value_field="duration")
+    f.set_sum_order(True)
+    for c in chunks:
+        assert o.filter(c) == f.filter(c)[0]
+    _, _, osn = o.snapshot()
+    gsn = f.snapshot()
+    seq = f.seq_sums()
+    assert [s["labels"] for s in gsn] == [s["labels"] for s in osn] and len(seq) == len(osn) == 3
+    differs = 0
+    for a, b, q in zip(gsn, osn, seq):
+        assert a["buckets"] == b["buckets"] and a["count"] == b["count"]
+        assert same_f64(q, b["sum"]), (a["labels"], q, b["sum"])             # the reference's own bits
+        differs += not same_f64(a["sum"], b["sum"])                             # (the exact sum is another number here)
+    assert differs >= 1
+    f.close()

@@ -129,3 +129,29 @@ def test_posix_brackets_and_group_options_on_device(g):
     for pat in POSIX_PATTERNS:
         kept = run_pattern(g, pat, subj)
         assert kept > 0, pat
+
+
+def test_regex_corners_are_counted_not_silent(g):
+    """The two corners where the reference's own answer depends on its search optimizer (DESIGN.md "deviations"): a value that can
+    meet one is COUNTED by the walkers (flbgpu_filter_regex_corners; the plugin shims warn) -- on the table engine and on the NFA
+    engine, for filter_grep and filter_parser; clean values count nothing."""
+    cases = [
+        (rb"\bfoo", [b"x\x80foo", b"caf\xc3\xa9 foo", b"foo"], 1),              # a stray continuation byte and a word anchor
+        (rb"^bar", [b"a\n\x80bar", b"a\nbar", b"\xc3\xa9\nbar"], 1),              # "\n" + continuation byte in front of a line anchor
+        (rb"(?i)ks", [b"x\xe2\x84\xaas", b"xks", b"\xc3\xa9ks"], 1),            # the Kelvin sign under (?i)
+        (rb"[[:alpha:]]+\b", [b"\xbfa b", b"\xc3\xa9a b"], 1),                    # the same through the NFA engine
+        (rb"plain", [b"pl\x80ain", b"plain \xc3\xa9"], 0),                       # no anchor, no fold: nothing to count
+    ]
+    for pat, subjects, want in cases:
+        blob = b"".join(_rec({"log": s}, 7, i) for i, s in enumerate(subjects))
+        fg = g.FilterGrep([("regex", b"log " + pat)])
+        fg.filter(blob)
+        assert fg.regex_corners() == want, (pat, fg.regex_corners())
+        fg.filter(blob)
+        assert fg.regex_corners() == 2 * want                                  # cumulative
+        fg.close()
+        pg = g.Parser(b"(?<m>" + pat + b")")
+        fp = g.FilterParser("log", [pg])
+        fp.filter(blob)
+        assert fp.regex_corners() == want, (pat, fp.regex_corners())
+        fp.close(); pg.close()
