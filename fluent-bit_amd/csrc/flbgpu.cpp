@@ -160,6 +160,51 @@ bool flbgpu::upload_dfa(const rx::TableSet &t, TableBlob &blob, DevDfa &out) {
     return true;
 }
 
+// The fixed-layout plan once more, COMPILED for the single-pass kernel (tile_kernels.inc time_fast_compiled): instead of an
+// interpreter loop over the ops -- a scalar load, a switch and a register select per op and per byte: a sixth of the kernel's
+// iteration on the apache format -- the literals of the whole text are ONE masked compare per dword, the digit positions ONE SWAR
+// test per dword, and every field sits at an offset the kernel reads from this block.  32 dwords behind the fx3 tables in the LDS:
+//   [0..7] literal mask  [8..15] literal bytes  [16..23] 0x80 at every digit position
+//   [24] offsets mday | hour << 8 | min << 16 | sec << 24        (0xFF: no such field)
+//   [25] offsets mon2 | year << 8 | mon3 << 16 | tz << 24
+//   [26] upper limits, [27] lower limits of [24]'s fields       [28] mon2 upper | lower << 8 | spaces << 16 | length << 24
+//   [29] offsets of up to four whitespace positions              [31] 1: usable
+static void compile_time_plan(const TimePlan &pl, uint32_t out[32]) {
+    memset(out, 0, 32 * sizeof(uint32_t));
+    if (!pl.ok || pl.len > 32) return;
+    uint8_t *lm = (uint8_t *) out, *lv = (uint8_t *) (out + 8), *dm = (uint8_t *) (out + 16);
+    uint8_t off[8] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};     // mday hour min sec mon2 year mon3 tz
+    uint8_t hi[5] = {0, 0, 0, 0, 0}, lo[5] = {0, 0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
+    int nsp = 0;
+    auto take = [&](int f, uint8_t o) -> bool { if (off[f] != 0xFF) return false; off[f] = o; return true; };
+    for (int k = 0; k < pl.nops; k++) {
+        const TimeOp &op = pl.ops[k];
+        switch (op.kind) {
+        case TP_LIT: lm[op.off] = 0xFF; lv[op.off] = op.a; break;
+        case TP_SPACE: if (nsp >= 4) return; sp[nsp++] = op.off; break;
+        case TP_NUM2: {
+            const int f = op.a == TPF_MDAY ? 0 : op.a == TPF_HOUR ? 1 : op.a == TPF_MIN ? 2 : op.a == TPF_SEC ? 3 : 4;
+            if (!take(f, op.off)) return;
+            hi[f] = op.b; lo[f] = pl.lo[k];
+            dm[op.off] = dm[op.off + 1] = 0x80;
+            break;
+        }
+        case TP_YEAR4: if (!take(5, op.off)) return; for (int q = 0; q < 4; q++) dm[op.off + q] = 0x80; break;
+        case TP_MON3: if (!take(6, op.off)) return; break;
+        case TP_TZ5: if (!take(7, op.off)) return; for (int q = 1; q < 5; q++) dm[op.off + q] = 0x80; break;
+        default: return;
+        }
+    }
+    if (off[4] != 0xFF && off[6] != 0xFF) return;                          // two months
+    out[24] = off[0] | (off[1] << 8) | (off[2] << 16) | ((uint32_t) off[3] << 24);
+    out[25] = off[4] | (off[5] << 8) | (off[6] << 16) | ((uint32_t) off[7] << 24);
+    out[26] = hi[0] | (hi[1] << 8) | (hi[2] << 16) | ((uint32_t) hi[3] << 24);
+    out[27] = lo[0] | (lo[1] << 8) | (lo[2] << 16) | ((uint32_t) lo[3] << 24);
+    out[28] = hi[4] | (lo[4] << 8) | ((uint32_t) nsp << 16) | ((uint32_t) pl.len << 24);
+    out[29] = sp[0] | (sp[1] << 8) | (sp[2] << 16) | ((uint32_t) sp[3] << 24);
+    out[31] = 1;
+}
+
 // ------------------------------------------------------------------------------------------ parser
 struct flbgpu_parser {
     std::string name;
@@ -442,6 +487,13 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
             std::vector<uint8_t> b3;
             if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2)) { delete p; return nullptr; }
             if (d.fx2.ok) {
+                // the compiled time plan rides behind the tables (the last 128 bytes of what the kernel stages into the LDS)
+                uint32_t ctp[32];
+                compile_time_plan(d.plan, ctp);
+                const size_t at = b3.size();
+                b3.resize(at + sizeof(ctp));
+                memcpy(b3.data() + at, ctp, sizeof(ctp));
+                d.fx2.bytes = (uint32_t) b3.size();
                 if (hipMalloc(&p->blob_fx2.dev, b3.size()) != hipSuccess || hipMemcpy(p->blob_fx2.dev, b3.data(), b3.size(), hipMemcpyHostToDevice) != hipSuccess) {
                     set_err("parser '%s': upload failed", p->name.c_str()); delete p; return nullptr;
                 }
