@@ -485,7 +485,14 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         // the same tables without special entries (fx.cpp build_fx3: 8-byte cells, two capture writes per step): what k_parser_reg<.., FX3> walks
         if (d.fx.ok) {
             std::vector<uint8_t> b3;
-            if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2)) { delete p; return nullptr; }
+            // the two-position form (fx4) when it fits the LDS beside the capture columns, else one position per read (fx3)
+            const char *fxe = getenv("FLBGPU_FX");
+            const bool want4 = !(fxe && fxe[0] == '3');
+            if (want4 && !build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, true)) { delete p; return nullptr; }
+            if (!want4 || !d.fx2.ok || b3.size() > 48 * 1024) {
+                b3.clear();
+                if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, false)) { delete p; return nullptr; }
+            }
             if (d.fx2.ok) {
                 // the compiled time plan rides behind the tables (the last 128 bytes of what the kernel stages into the LDS)
                 uint32_t ctp[32];
@@ -934,7 +941,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
-    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? 1 : 0;
+    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias ? 4 : 3) : 0;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit

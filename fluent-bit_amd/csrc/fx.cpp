@@ -270,7 +270,7 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
 // What cannot be spelled with two writes per step (a look-ahead that resolves to a double write, a carry into a cell that already
 // carries) goes to the absorbing row with the FAIL slot: the record takes the generic kernel.  No tail, no pair cells: a row's cells
 // are all there is.  Result slots, sentinel byte and poison row are those of the tables above.
-bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out) {
+bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pairs) {
     memset(&out, 0, sizeof(out));
     if (!t.has_capture || !t.ascii_only || t.ft.empty() || t.stub) return true;
     const uint32_t ncol = (uint32_t) t.ncls + 1;                                 // byte classes + the end-of-text column
@@ -352,6 +352,50 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
             cells.push_back(out_c);
         }
     }
+    if (pairs) {
+        // ---- fx4: TWO positions per cell.  The cell of (row R, class of byte j, class of byte j + 1) holds what the two fx3 steps
+        // give together: the row behind both, and four capture slots -- step 1's slot A (position j - 1) and slot B (j), step 2's slot
+        // A (its j - 1 = j) and slot B (j + 1).  One ds_read_b64 per two bytes on the walk's dependent chain.  Rows are the fx3 rows
+        // reachable at EVEN positions; 8 bytes per cell: lo = next row | s0 << 16 | s1 << 22, hi = s2 | s3 << 6 (slot numbers).
+        // Two class tables in front: even positions give class * ncol * 8, odd ones class * 8.
+        std::vector<uint32_t> id4(rows.size(), 0xFFFFFFFFu), order;
+        auto r4 = [&](uint32_t r3) -> uint32_t { if (id4[r3] == 0xFFFFFFFFu) { id4[r3] = (uint32_t) order.size(); order.push_back(r3); } return id4[r3]; };
+        r4(0); r4(1); r4(2);
+        struct C4 { uint32_t next, s0, s1, s2, s3; };
+        std::vector<C4> c4;
+        for (size_t i = 0; i < order.size(); i++) {
+            const uint32_t R = order[i];
+            for (uint32_t c0 = 0; c0 < ncol; c0++)
+                for (uint32_t c1 = 0; c1 < ncol; c1++) {
+                    const Cell &x = cells[(size_t) R * ncol + c0];
+                    const Cell &y = cells[(size_t) x.next * ncol + c1];
+                    c4.push_back(C4{r4(y.next), x.sa, x.sb, y.sa, y.sb});
+                }
+        }
+        const uint32_t n4 = (uint32_t) order.size(), rs4 = (ncol * ncol) | 1u, rowb4 = rs4 * 8, at4 = 2048;
+        const uint64_t tot4 = (uint64_t) at4 + (uint64_t) n4 * rowb4;
+        if (tot4 > 60000) return true;                                           // (the caller keeps fx3)
+        std::vector<uint32_t> ca(256), cb(256);
+        for (int i = 0; i < 256; i++) { ca[(size_t) i] = (uint32_t) t.cls[i] * ncol * 8u; cb[(size_t) i] = (uint32_t) t.cls[i] * 8u; }
+        ca[255] = (uint32_t) t.ncls * ncol * 8u; cb[255] = (uint32_t) t.ncls * 8u;
+        b.assign((size_t) ((tot4 + 15) & ~15ull), 0);
+        memcpy(b.data(), ca.data(), 1024);
+        memcpy(b.data() + 1024, cb.data(), 1024);
+        for (uint32_t r = 0; r < n4; r++)
+            for (uint32_t c = 0; c < ncol * ncol; c++) {
+                const C4 &x = c4[(size_t) r * ncol * ncol + c];
+                const uint32_t lo = (at4 + x.next * rowb4) | (x.s0 << 16) | (x.s1 << 22), hi = x.s2 | (x.s3 << 6);
+                memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8, &lo, 4);
+                memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8 + 4, &hi, 4);
+            }
+        out.base = nullptr; out.bytes = (uint32_t) b.size();
+        out.off_p2 = 0;
+        out.start_off = at4; out.absorb_off = at4 + rowb4; out.poison_off = at4 + 2 * rowb4;
+        out.tail_min = out.absorb_off; out.nkill = 0;
+        out.nslots = nslots; out.pair_bias = 1; out.ncls1 = ncol;              // pair_bias != 0: the two-position form
+        out.ok = 1;
+        return true;
+    }
     const uint32_t nrows = (uint32_t) rows.size();
     const uint32_t rs = ncol | 1u;                                              // cells per row, odd: rows spread over the LDS banks
     const uint32_t rowb = rs * 8, at0 = 1024;
@@ -376,6 +420,31 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
     out.nslots = nslots; out.pair_bias = 0; out.ncls1 = ncol;
     out.ok = 1;
     return true;
+}
+
+// k_parser_reg<.., 4>'s walk on the host: two positions per cell, positions 0 .. len + 1 rounded up to whole pairs
+int flbgpu::simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps) {
+    auto u32at = [&](uint32_t at) -> uint32_t { uint32_t v; memcpy(&v, b.data() + at, 4); return v; };
+    auto byte_at = [&](uint32_t j) -> uint32_t { return j < len ? s[j] : j == len ? 0xFFu : 0u; };
+    for (uint32_t i = 0; i < fx.nslots; i++) caps[i] = 0xFFFF;
+    uint32_t e = fx.start_off;
+    for (uint32_t j = 0; j <= len + 1; j += 2) {
+        const uint32_t at = (e & FX_ROW_MASK) + u32at(4 * byte_at(j)) + u32at(1024 + 4 * byte_at(j + 1));
+        const uint32_t lo = u32at(at), hi = u32at(at + 4);
+        caps[(lo >> 16) & 63] = (uint16_t) (j - 1);
+        caps[(lo >> 22) & 63] = (uint16_t) j;
+        caps[hi & 63] = (uint16_t) j;
+        caps[(hi >> 6) & 63] = (uint16_t) (j + 1);
+        e = lo;
+    }
+    const uint32_t S = e & FX_ROW_MASK;
+    const uint32_t e_eot = caps[ncap + FXS_END_EOT], e_mid = caps[ncap + FXS_END_MID], d_eot = caps[ncap + FXS_DEAD_EOT], failed = caps[ncap + FXS_FAIL];
+    if (S == fx.poison_off) return -2;
+    if (failed != 0xFFFF) return -1;
+    if (e_mid != 0xFFFF) return (int) e_mid;
+    if (e_eot != 0xFFFF) return e_eot == len ? (int) len : -2;
+    if (d_eot != 0xFFFF) return d_eot == len ? -1 : -2;
+    return -1;
 }
 
 // k_parser_reg<.., FX3>'s walk on the host: positions 0 .. len + 1, one 8-byte cell per step, two writes

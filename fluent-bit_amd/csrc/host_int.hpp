@@ -83,8 +83,10 @@ bool upload_fx(const rx::TableSet &t, int ncap, TableBlob &blob, DevFx &out, boo
 bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pair = false);
 int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps, bool use_tail = true);
 // fx3: the same tables without special entries (8-byte cells, two capture writes per step; fx.cpp)
-bool build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out);
+// (pairs: fx4 -- a cell per (row, class of byte j, class of byte j + 1), two positions per table read; out.ok == 0 when that does not fit)
+bool build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pairs = false);
 int simulate_fx3(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
+int simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool parse_ra(const char *pat, DevKey &k, std::string &why);
 // "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)

@@ -99,10 +99,13 @@ int flbgpu_rx_simulate_fx3(void *h, const char *s, int len, int *beg, int *end, 
     if (ncap == 0) return -4;
     std::vector<uint8_t> blob;
     flbgpu::DevFx fx;
-    if (!flbgpu::build_fx3(p->ascii, ncap, blob, fx) || !fx.ok) return -4;
-    if (info2) { info2[0] = (int) ((fx.bytes - 1024) / ((fx.ncls1 | 1u) * 8)); info2[1] = (int) fx.bytes; }
+    // info2[0] < 0 on entry (with info2 given): the two-position form (fx4)
+    const bool pairs = info2 && info2[0] < 0;
+    if (!flbgpu::build_fx3(p->ascii, ncap, blob, fx, pairs) || !fx.ok) return -4;
+    if (info2) { info2[0] = pairs ? (int) ((fx.bytes - 2048) / (((fx.ncls1 * fx.ncls1) | 1u) * 8)) : (int) ((fx.bytes - 1024) / ((fx.ncls1 | 1u) * 8)); info2[1] = (int) fx.bytes; }
     std::vector<uint16_t> caps(fx.nslots);
-    const int r = flbgpu::simulate_fx3(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
+    const int r = pairs ? flbgpu::simulate_fx4(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data())
+                        : flbgpu::simulate_fx3(blob, fx, ncap, (const uint8_t *) s, (uint32_t) len, caps.data());
     if (r < 0) return r;
     for (int g = 0; g <= p->ngroups; g++) { beg[g] = -1; end[g] = -1; }
     beg[0] = 0; end[0] = r;

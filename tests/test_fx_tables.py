@@ -414,6 +414,14 @@ def test_fx3_tables_give_the_single_steps_answers():
         n3 = L.flbgpu_rx_simulate_fx3(h, s, len(s), b2, e2, None)
         if n3 == -4 or n1 == -4:
             return False
+        # fx4 (two positions per cell, the same cells composed): exactly fx3's answer wherever it exists
+        b4 = (ctypes.c_int * 40)(); e4 = (ctypes.c_int * 40)(); inf = (ctypes.c_int * 2)(-1, 0)
+        n4 = L.flbgpu_rx_simulate_fx3(h, s, len(s), b4, e4, inf)
+        if n4 != -4:
+            assert n4 == n3, (s, n3, n4)
+            if n3 >= 0:
+                assert list(b4[:n3 + 1]) == list(b2[:n3 + 1]) and list(e4[:n3 + 1]) == list(e2[:n3 + 1]), (s, list(b4[:n3 + 1]), list(b2[:n3 + 1]))
+            stats["pairs"] = stats.get("pairs", 0) + 1
         if n3 == -1 and n1 != -1:
             stats["handed_on"] += 1
             return True
@@ -460,3 +468,4 @@ def test_fx3_tables_give_the_single_steps_answers():
         L.flbgpu_rx_free(h)
     assert stats["compared"] - n_kat > 800, stats
     assert stats["handed_on"] * 50 < stats["compared"], stats
+    assert stats.get("pairs", 0) > 1500, stats                     # the two-position tables fit for most of these patterns
