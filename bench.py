@@ -926,13 +926,16 @@ def measure_host_level(g, data, off, n):
         nrec = min(nrec, n)
         blob = bytes(data[: int(off[nrec])])
         ch.filter(blob)
-        reps = 20 if nrec < 50000 else 5
+        reps = 40 if nrec < 50000 else 8
+        phases = []
         t0 = time.perf_counter()
         for _ in range(reps):
             ch.filter(blob)
+            phases.append(g.host_phases())
         dt = (time.perf_counter() - t0) / reps
+        med = {k: round(sorted(p[k] for p in phases)[len(phases) // 2], 1) for k in phases[0]}
         out[name] = {"records": nrec, "bytes": len(blob), "ms_per_call": round(dt * 1e3, 3), "records_per_s": round(nrec / dt, 1),
-                     "in_GBps": round(len(blob) / dt / 1e9, 2)}
+                     "in_GBps": round(len(blob) / dt / 1e9, 2), "phases_us_median": med}
     fp.close(); fg.close(); p.close()
     return out
 

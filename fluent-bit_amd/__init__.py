@@ -91,6 +91,8 @@ def lib():
     L.flbgpu_l2m_set_sum_order.argtypes = [c_void_p, c_int]
     L.flbgpu_l2m_seq_sums.restype = c_int64
     L.flbgpu_l2m_seq_sums.argtypes = [c_void_p, c_uint64, POINTER(c_double)]
+    L.flbgpu_host_phases.restype = ctypes.c_int
+    L.flbgpu_host_phases.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     L.flbgpu_filter_regex_corners.restype = ctypes.c_uint64
     L.flbgpu_filter_regex_corners.argtypes = [c_void_p]
     L.flbgpu_rx_simulate_fx3.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
@@ -701,6 +703,16 @@ class FilterChain:
     def last_stats(self):
         return [dict(ret=s.ret, in_records=s.in_records, out_records=s.out_records, out_bytes=s.out_bytes)
                 for s in self.stats[: len(self.filters)]]
+
+
+HOST_PHASES = ("index", "copy_in", "upload_wait", "chain", "download", "malloc", "total")
+
+
+def host_phases():
+    """microseconds of this thread's last host-level call, by phase (flbgpu_host_phases)"""
+    ph = (ctypes.c_double * 8)()
+    k = lib().flbgpu_host_phases(ph, 8)
+    return dict(zip(HOST_PHASES, list(ph)[:k]))
 
 
 def index_host(data):

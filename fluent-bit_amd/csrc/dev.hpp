@@ -367,6 +367,7 @@ struct ParserEmitArgs {
     const uint64_t *out_off;    // exclusive scan of out_len, [n+1]
     uint8_t *out;
     uint64_t bytes;             // chunk size (bounds the wide tail loads)
+    uint64_t out_cap;           // launched ahead of the size (flbgpu.cpp SpecCall): room behind `out`; a larger out_off[n] ends the kernel (0: not checked)
     EmitCfg ec;
 };
 
@@ -491,6 +492,7 @@ struct PgEmitArgs {
     const uint32_t *desc;            // row descriptors of the single pass (ParserMatchArgs::desc), nullptr: columns only
     uint32_t dstride;
     uint64_t bytes;                  // chunk size (bounds the wide tail loads)
+    uint64_t out_cap;                // as in ParserEmitArgs
     EmitCfg ec;
 };
 
@@ -753,6 +755,7 @@ struct GatherArgs {
     const uint32_t *keep_len;
     const uint64_t *out_off;
     uint8_t *out;
+    uint64_t out_cap;                // as in ParserEmitArgs
 };
 
 // progress of the device-side record indexer (index_kernels.inc)
@@ -789,6 +792,12 @@ void launch_pjson_size(const ParserMatchArgs &a, int cus, hipStream_t st);
 void launch_pjson_size_generic(const ParserMatchArgs &a, hipStream_t st);
 void launch_grep_match(const GrepArgs &a, int cus, hipStream_t st);
 void launch_gather(const GatherArgs &a, hipStream_t st);
+// the end of a call launched ahead of its sizes: counters + output size into page-locked host words and, when `sink` is given and the
+// output fits, the output into the page-locked slab -- written by the device, no copy command that would need the size on the host
+void launch_call_prep(void *words, uint32_t words_bytes, uint8_t *tail, uint32_t tail_room, const uint8_t *data, uint64_t bytes, uint32_t tail_bytes,
+                      uint32_t *keep_len, uint64_t n, hipStream_t st);
+void launch_finish_to_host(const uint8_t *out, uint64_t out_cap, const uint64_t *total, uint8_t *sink, uint64_t sink_cap, const void *words, void *host_words,
+                           uint32_t nwords_bytes, uint64_t *host_total, hipStream_t st);
 size_t scan_tmp_elems(uint64_t n);
 // exclusive scan u32 -> u64 (out[n] = total); nonzero (optional) receives the number of non-zero inputs
 void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st, unsigned long long *nonzero = nullptr);

@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include "host_int.hpp"
@@ -842,8 +843,36 @@ static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FP
 // pair mode (filter_grep follows and is evaluated inline): grep's rules for k_parser_rx, keep_len for k_parser_finish
 struct PairCtx { PgInline pg; uint32_t *keep_len; const flbgpu_filter *fg; uint32_t *desc; uint32_t dstride; };
 
+// A call on a small chunk (what the engine appends at a time) is bound by the waits between its launches, not by its kernels: the
+// stages then launch AHEAD of the counters they normally wait for -- the fix-up pass, the rule decisions, the scan and the writer with
+// room for the usual output -- and wait once at the end; kernels guard themselves on the device (fix-up: the per-wave lists,
+// writers: ParserEmitArgs::out_cap).  Whatever the counters then show that the launched kernels did not cover (rows for the generic
+// kernel or the strptime interpreter, a bad record, records for the exact writer, an output over the room) runs the stage again the
+// usual way.  Set around chain_dev by the entry points; off for everything else.
+struct SpecCall {
+    bool on = false;
+    bool last = false;              // the stage being run ends the chain (chain_dev)
+    uint8_t *sink = nullptr;        // host-level call: page-locked slab the last stage's output is written into by the device
+    uint64_t sink_cap = 0;
+    bool sunk = false;              // ... and it is there
+};
+static thread_local SpecCall g_spec;
+struct SpecOff {                    // one stage run the usual way
+    bool was;
+    SpecOff() : was(g_spec.on) { g_spec.on = false; }
+    ~SpecOff() { g_spec.on = was; }
+};
+static const uint64_t SPEC_MAX_RECORDS = 262144, SPEC_MAX_BYTES = 8u << 20;
+static inline bool spec_wanted(uint64_t n, uint64_t bytes) { return n <= SPEC_MAX_RECORDS && bytes <= SPEC_MAX_BYTES && !getenv("FLBGPU_NO_SPEC"); }
+// what parser_size_pass reads from the counters between its launches, for a pass launched ahead: false = run it the usual way
+static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
+    if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
+    if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
+    return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
+}
+
 static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
-                             PairCtx *pair = nullptr) {
+                             PairCtx *pair = nullptr, bool *ahead = nullptr) {
     uint64_t n = in->n;
     if (!f->d_misc.ensure(sizeof(MiscWords))) return false;
     MiscWords *dm = f->d_misc.as<MiscWords>();
@@ -857,7 +886,17 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     // scratch sizing: one state id per byte boundary of the longest record
     memset(&hm, 0, sizeof(hm));
     hm.first_bad = ~0ull;
-    HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+    // (a call launched ahead: the counter block, the tail copy and the pair's keep_len column are set by ONE kernel -- k_call_prep, in
+    // the register kernel's branch below; the other branches issue the commands here)
+    bool prep_pending = g_spec.on;
+    auto prep_now = [&]() -> bool {
+        if (!prep_pending) return true;
+        prep_pending = false;
+        HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+        if (pair) HIPOK(hipMemsetAsync(pair->keep_len, 0xFF, n * sizeof(uint32_t), st));
+        return true;
+    };
+    if (!prep_pending) HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
     // scratch of the fast path: one reverse-DFA state checkpoint per CHK_STEP bytes, per lane, for
     // values up to 4 KiB (longer ones go to the generic kernel, whose scratch is sized from the
     // longest row -- measured only when that kernel is needed)
@@ -1014,6 +1053,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         { ProfScope ps(f, st, "k_parser_generic"); launch_parser_generic(mg, ggrid, st); }
         return true;
     };
+    if ((f->parsers[0]->dev.is_json || !use_tile || tile_in_lds) && !prep_now()) return false;
     if (f->parsers[0]->dev.is_json) {
         // Format json: one size kernel replaces locate / rx / finish
         { ProfScope ps(f, st, "k_pjson_size"); launch_pjson_size(ma, cus, st); }
@@ -1042,8 +1082,15 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             // a zero-padded copy of the chunk's last bytes: the call-free kernel loads 16 bytes at a time without bounds tests
             const size_t T = 4096, tb = in->bytes < T ? (size_t) in->bytes : T;
             if (!f->d_tail.ensure(T + 512)) return false;
-            HIPOK(hipMemsetAsync(f->d_tail.p, 0, T + 512, st));
-            if (tb) HIPOK(hipMemcpyAsync(f->d_tail.p, data + (in->bytes - tb), tb, hipMemcpyDeviceToDevice, st));
+            if (prep_pending) {
+                prep_pending = false;
+                launch_call_prep(dm, (uint32_t) sizeof(hm), f->d_tail.as<uint8_t>(), (uint32_t) (T + 512), data, in->bytes, (uint32_t) tb,
+                                 pair ? pair->keep_len : nullptr, n, st);
+            }
+            else {
+                HIPOK(hipMemsetAsync(f->d_tail.p, 0, T + 512, st));
+                if (tb) HIPOK(hipMemcpyAsync(f->d_tail.p, data + (in->bytes - tb), tb, hipMemcpyDeviceToDevice, st));
+            }
             ma.tail_buf = f->d_tail.as<uint8_t>(); ma.tail_start = in->bytes - tb;
         }
         if (!f->d_args.ensure(sizeof(ParserMatchArgs)) || !f->hp_args.ensure(sizeof(ParserMatchArgs))) return false;
@@ -1073,6 +1120,14 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         }
         if (tile_in_lds) { ProfScope ps(f, st, "k_parser_tile"); launch_parser_tile(ma, grid, rx_threads, st); }
         else { ProfScope ps(f, st, "k_parser_reg"); launch_parser_reg(ma, grid, rx_threads, false, st); }
+        if (ahead && g_spec.on && !tile_in_lds && ma.fix_list && !d_trace) {
+            // launched ahead (SpecCall): the fix-up pass in the main pass's shape, every wave takes what it listed (usually nothing);
+            // *hm_out is not valid before the caller's wait, and ahead_counters_ok is the caller's to ask
+            { ProfScope ps(f, st, "k_parser_reg_fixup"); launch_parser_reg(ma, grid, rx_threads, true, st); }
+            *ahead = true;
+            *n_valid = n;
+            return true;
+        }
         if (d_trace) {
             std::vector<unsigned long long> ht(trace_bytes / sizeof(unsigned long long));
             if (hipMemcpyAsync(ht.data(), d_trace, trace_bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
@@ -1143,7 +1198,8 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     f->last_in = 0; f->last_out = 0;
     if (n == 0) return true;
     MiscWords *dm = nullptr, *hmp = nullptr;
-    if (!parser_size_pass(f, in, st, &dm, &hmp, &n)) return false;
+    bool ahead = false;
+    if (!parser_size_pass(f, in, st, &dm, &hmp, &n, nullptr, &ahead)) return false;
     MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     const uint64_t *row_off = in->row_off;
@@ -1177,6 +1233,32 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     // write offsets + the number of emitted records (what flb_mp_count_log_records would report) in one pass
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st, &dm->counts[1]); }
     total = 0;
+    if (ahead) {
+        // launched ahead (SpecCall): the writer with room for the usual output, counters + size + (host-level call) the output itself
+        // written to page-locked memory by the device, ONE wait
+        if (!f->d_out.ensure(in->bytes * 2 + n * 64 + 65536 + 16)) return false;
+        ParserEmitArgs ea;
+        ea.data = data; ea.row_off = row_off; ea.n = n; ea.cfg = f->pcfg; ea.parsers = f->d_parsers.as<DevParser>();
+        ea.n_cols = in->n; ea.info = f->d_info.as<uint32_t>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
+        ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
+        ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes; ea.out_cap = f->d_out.cap - 16;
+        fill_emit_cfg(f, ea.ec);
+        { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
+        uint8_t *sink = g_spec.last ? g_spec.sink : nullptr;
+        launch_finish_to_host(ea.out, ea.out_cap, ea.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
+        HIPOK(hipStreamSynchronize(st));
+        if (!ahead_counters_ok(f, hm, n) || hm.counts[3] > 0 || hm.ov_count > OV_CAP || total > ea.out_cap) {
+            SpecOff usual;
+            return run_parser_dev(f, in, out, st, ret);
+        }
+        f->last_in = hm.counts[0];
+        if (total == 0) return true;
+        out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
+        f->last_out = hm.counts[1];
+        if (sink && total <= g_spec.sink_cap) g_spec.sunk = true;
+        *ret = FLBGPU_FILTER_MODIFIED;
+        return true;
+    }
     HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
@@ -1191,7 +1273,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     ea.data = data; ea.row_off = row_off; ea.n = n; ea.cfg = f->pcfg; ea.parsers = f->d_parsers.as<DevParser>();
     ea.n_cols = in->n; ea.info = f->d_info.as<uint32_t>(); ea.caps = f->d_caps.as<uint32_t>(); ea.caps_stride = f->caps_stride;
     ea.null_mask = f->d_null.as<uint64_t>(); ea.out_len = f->d_len.as<uint32_t>(); ea.out_off = f->d_off.as<uint64_t>();
-    ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes;
+    ea.out = f->d_out.as<uint8_t>(); ea.bytes = in->bytes; ea.out_cap = 0;
     fill_emit_cfg(f, ea.ec);
     { ProfScope ps(f, st, "k_parser_emit"); launch_parser_emit(ea, cus, st); }
     if (hm.counts[3] > 0) { ProfScope ps(f, st, "k_parser_emit_exact"); launch_parser_emit_exact(ea, st); }
@@ -1268,8 +1350,21 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     total = 0;
-    HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
-    HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    const bool ahead = g_spec.on;
+    uint8_t *sink = ahead && g_spec.last ? g_spec.sink : nullptr;
+    if (ahead) {
+        // launched ahead (SpecCall): the kept records are never more than the chunk -- the gather needs no size; one wait
+        if (!f->d_out.ensure(in->bytes + 32)) return false;
+        GatherArgs ta;
+        ta.data = (const uint8_t *) in->data; ta.row_off = in->row_off; ta.n = n; ta.keep_len = f->d_len.as<uint32_t>();
+        ta.out_off = f->d_off.as<uint64_t>(); ta.out = f->d_out.as<uint8_t>(); ta.out_cap = f->d_out.cap - 16;
+        { ProfScope ps(f, st, "k_gather"); launch_gather(ta, st); }
+        launch_finish_to_host(ta.out, ta.out_cap, ta.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
+    }
+    else {
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipMemcpyAsync(&total, f->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
     HIPOK(hipStreamSynchronize(st));
     f->last_in = hm.counts[0];
     f->last_out = hm.counts[0];
@@ -1280,12 +1375,17 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     if (hm.first_bad != ~0ull || trailing_garbage) return true;
     if (hm.counts[0] == hm.counts[1]) return true;
     f->last_out = hm.counts[1];
-    if (!f->d_out.ensure(total + 16)) return false;
-    GatherArgs ta;
-    ta.data = (const uint8_t *) in->data; ta.row_off = in->row_off; ta.n = n; ta.keep_len = f->d_len.as<uint32_t>();
-    ta.out_off = f->d_off.as<uint64_t>(); ta.out = f->d_out.as<uint8_t>();
-    { ProfScope ps(f, st, "k_gather"); launch_gather(ta, st); }
-    HIPOK(hipStreamSynchronize(st));
+    if (ahead) {
+        if (sink && total <= g_spec.sink_cap) g_spec.sunk = true;
+    }
+    else {
+        if (!f->d_out.ensure(total + 16)) return false;
+        GatherArgs ta;
+        ta.data = (const uint8_t *) in->data; ta.row_off = in->row_off; ta.n = n; ta.keep_len = f->d_len.as<uint32_t>();
+        ta.out_off = f->d_off.as<uint64_t>(); ta.out = f->d_out.as<uint8_t>(); ta.out_cap = 0;
+        { ProfScope ps(f, st, "k_gather"); launch_gather(ta, st); }
+        HIPOK(hipStreamSynchronize(st));
+    }
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     *ret = FLBGPU_FILTER_MODIFIED;
     return true;
@@ -1351,11 +1451,12 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     }
     // filter_parser's pass 1: every record sized (out_len), spans and record columns in HBM; keep_len of the records
     // whose rules could be settled on the spans
-    if (hipMemsetAsync(pc.keep_len, 0xFF, n * sizeof(uint32_t), st) != hipSuccess) return -1;
-    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc)) return -1;
+    if (!g_spec.on && hipMemsetAsync(pc.keep_len, 0xFF, n * sizeof(uint32_t), st) != hipSuccess) return -1;      // (ahead: parser_size_pass, with the counters)
+    bool ahead = false;
+    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc, &ahead)) return -1;
     MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
-    if (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0) return 0;           // (records for k_parser_emit_exact: unfused)
+    if (!ahead && (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0)) return 0;           // (records for k_parser_emit_exact: unfused)
     const int cus = g_cus > 0 ? g_cus : 256;
     PgDecideArgs da;
     memset(&da, 0, sizeof(da));
@@ -1369,9 +1470,45 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     }
     da.keep_len = pc.keep_len; da.counts = dm->counts;
     // rows the inline evaluation left open (unparsed records, records of the generic kernel, rules on a kept time field)
-    if (hm.counts[7] > 0 || hm.counts[2] > 0) { ProfScope ps(fp, st, "k_pg_decide"); launch_pg_decide(da, cus, st); }
+    if (ahead || hm.counts[7] > 0 || hm.counts[2] > 0) { ProfScope ps(fp, st, "k_pg_decide"); launch_pg_decide(da, cus, st); }
     { ProfScope ps(fp, st, "k_scan"); launch_scan(da.keep_len, n, fp->d_scan_tmp.as<uint64_t>(), fp->d_off.as<uint64_t>(), st); }
     total = 0;
+    auto emit_args = [&](PgEmitArgs &ea) {
+        memset(&ea, 0, sizeof(ea));
+        ea.data = da.data; ea.row_off = da.row_off; ea.cfg = fp->pcfg; ea.parsers = fp->d_parsers.as<DevParser>(); ea.n_cols = in->n;
+        ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
+        ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
+        ea.desc = pc.desc; ea.dstride = pc.dstride; ea.bytes = in->bytes;
+        fill_emit_cfg(fp, ea.ec);
+    };
+    if (ahead) {
+        // launched ahead (SpecCall): the writer with room for the usual output, counters + size + (host-level call) the output itself
+        // written to page-locked memory by the device, ONE wait
+        if (!fg->d_out.ensure(in->bytes * 2 + n * 64 + 65536 + 16)) return -1;
+        PgEmitArgs ea;
+        emit_args(ea);
+        ea.out_cap = fg->d_out.cap - 16;
+        { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
+        uint8_t *sink = g_spec.last ? g_spec.sink : nullptr;
+        launch_finish_to_host(ea.out, ea.out_cap, ea.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (!ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
+            SpecOff usual;
+            return run_pair_fused(fp, fg, in, out, stats2);
+        }
+        if (hm.counts[6] == 0 || hm.counts[5] == hm.counts[6]) return 0;
+        fp->last_in = hm.counts[0]; fp->last_out = hm.counts[6];
+        fg->last_in = hm.counts[6]; fg->last_out = hm.counts[5];
+        if (stats2) {
+            stats2[0].ret = FLBGPU_FILTER_MODIFIED; stats2[0].in_records = hm.counts[0]; stats2[0].out_records = hm.counts[6]; stats2[0].out_bytes = hm.counts[4];
+            stats2[1].ret = FLBGPU_FILTER_MODIFIED; stats2[1].in_records = hm.counts[6]; stats2[1].out_records = hm.counts[5]; stats2[1].out_bytes = total;
+        }
+        memset(out, 0, sizeof(*out));
+        if (total == 0) return 1;
+        out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
+        if (sink && total <= g_spec.sink_cap) g_spec.sunk = true;
+        return 1;
+    }
     if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(&total, fp->d_off.as<uint64_t>() + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) return -1;
@@ -1388,12 +1525,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     if (total == 0) return 1;                               // every record dropped: MODIFIED with an empty output
     if (!fg->d_out.ensure(total + 16)) return -1;
     PgEmitArgs ea;
-    memset(&ea, 0, sizeof(ea));
-    ea.data = da.data; ea.row_off = da.row_off; ea.cfg = fp->pcfg; ea.parsers = fp->d_parsers.as<DevParser>(); ea.n_cols = in->n;
-    ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
-    ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
-    ea.desc = pc.desc; ea.dstride = pc.dstride; ea.bytes = in->bytes;
-    fill_emit_cfg(fp, ea.ec);
+    emit_args(ea);
     { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
@@ -1541,6 +1673,7 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
             // the pair in one pass; the parser's stage always answers MODIFIED when this path completes
             flbgpu_chain_stat s2[2];
             memset(s2, 0, sizeof(s2));
+            g_spec.last = i + 2 == n;
             const int fr = run_pair_fused(filters[i], filters[i + 1], &cur, &o, s2);
             if (fr == 1) {
                 if (stats) { stats[i] = s2[0]; stats[i + 1] = s2[1]; }
@@ -1561,6 +1694,7 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
                 return FLBGPU_FILTER_NOTOUCH;
             }
         }
+        g_spec.last = i + 1 == n;
         int ret = run_any_dev(filters[i], &cur, &o, filters[i]->stream, garbage && !modified);
         if (stats) {
             stats[i].ret = ret;
@@ -1588,7 +1722,11 @@ extern "C" int flbgpu_filter_chain_run_dev(flbgpu_filter *const *filters, int nf
     bool garbage = false;
     if (!resolve_raw_chunk(filters[0], in, &r, &garbage)) return FLBGPU_FILTER_NOTOUCH;
     if (in->row_off == nullptr && in->bytes > 0 && r.n == 0) return empty_chunk_result(filters, nfilters, garbage, out);
-    return chain_dev(filters, nfilters, &r, out, garbage, stats);
+    g_spec = SpecCall();
+    g_spec.on = spec_wanted(r.n, r.bytes);
+    const int ret = chain_dev(filters, nfilters, &r, out, garbage, stats);
+    g_spec = SpecCall();
+    return ret;
 }
 
 // ------------------------------------------------------------------------------------------ host indexer
@@ -1599,6 +1737,19 @@ static inline bool h_skip(const uint8_t *d, size_t len, size_t *pos) {
     if (len - p >= 13 && d[p] == 0x92 && d[p + 1] == 0x92 && d[p + 2] == 0xd7) {
         p += 12;
         remaining = 2;
+        // ... and what an input plugin appends for a line of text -- no metadata, {one short key: a str} -- without the loop
+        if (len - p >= 8 && d[p] == 0x80 && d[p + 1] == 0x81 && (d[p + 2] & 0xe0) == 0xa0) {
+            const size_t v = p + 3 + (d[p + 2] & 31);
+            if (len - p >= 3 + (size_t) (d[p + 2] & 31) + 5) {
+                const uint8_t c = d[v];
+                size_t e = 0;
+                if ((c & 0xe0) == 0xa0) e = v + 1 + (c & 31);
+                else if (c == 0xd9) e = v + 2 + d[v + 1];
+                else if (c == 0xda) e = v + 3 + (((size_t) d[v + 1] << 8) | d[v + 2]);
+                else if (c == 0xdb) e = v + 5 + (((size_t) d[v + 1] << 24) | ((size_t) d[v + 2] << 16) | ((size_t) d[v + 3] << 8) | d[v + 4]);
+                if (e && e <= len) { *pos = e; return true; }
+            }
+        }
     }
     while (remaining > 0) {
         if (p >= len) return false;
@@ -1679,6 +1830,23 @@ extern "C" int64_t flbgpu_index_host(const void *data, size_t bytes, uint64_t *r
 
 // ------------------------------------------------------------------------------------------ run (host level)
 static const size_t STAGE_SLAB = 8u << 20;
+
+// Where the wall time of the last host-level call of this thread went, in microseconds (flbgpu_host_phases; bench.py host_level):
+// 0 record boundaries on the host, 1 caller's buffer -> pinned slabs, 2 waiting for the upload, 3 the device chain (launches, kernels
+// and the waits for the sizes between them), 4 output -> pinned slabs -> caller's buffer (with the wait for the copy), 5 malloc of the
+// output, 6 the whole call.
+enum { HP_INDEX, HP_COPY_IN, HP_UPLOAD_WAIT, HP_CHAIN, HP_DOWNLOAD, HP_MALLOC, HP_TOTAL, HP_N };
+static thread_local double g_phase_us[HP_N];
+static inline double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct PhaseScope {
+    int k; double t0;
+    explicit PhaseScope(int k_) : k(k_), t0(wall_us()) {}
+    ~PhaseScope() { g_phase_us[k] += wall_us() - t0; }
+};
+extern "C" int flbgpu_host_phases(double *out, int cap) {
+    for (int i = 0; i < HP_N && i < cap; i++) out[i] = g_phase_us[i];
+    return HP_N;
+}
 
 static bool stage_init(flbgpu_filter *f) {
     for (int i = 0; i < 2; i++) {
@@ -1764,7 +1932,7 @@ CopyPool g_copy;
 // (diagnostics: the slab copy of the host-level calls, for the CPU-only unit test)
 extern "C" void flbgpu_diag_copy(void *dst, const void *src, size_t n) { g_copy.copy(dst, src, n); }
 
-int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off) {
+int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off, bool no_wait) {
     hipStream_t st = f->stream;
     if (!stage_init(f) || !f->h_in_data.ensure(bytes + 16)) return -1;
     bool dev_index = bytes >= DEV_INDEX_MIN && !getenv("FLBGPU_HOST_INDEX");
@@ -1776,14 +1944,32 @@ int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, 
     int64_t n = 0;
     bool stop = false;
     int k = 0;
+    if (no_wait && !dev_index && bytes <= slab) {
+        // a small chunk (SpecCall): the copy is on its way while the host finds the record boundaries, and nothing waits here -- the
+        // stage that follows is on the same stream (the bytes behind the last whole record travel too: nobody reads them)
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;                      // (idle unless an earlier call ended early)
+        { PhaseScope ph(HP_COPY_IN); g_copy.copy(f->hp_stage[0].p, d, bytes); }
+        if (hipMemcpyAsync(f->h_in_data.p, f->hp_stage[0].p, bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipEventRecord(f->ev_stage[0], st) != hipSuccess) return -1;
+        { PhaseScope ph(HP_INDEX); if (!host_index_range(f, d, bytes, bytes, &pos, &n, &cap, &stop)) return -1; }
+        uint64_t *off = f->hp_off.as<uint64_t>();
+        off[n] = pos;
+        *consumed = pos;
+        *row_off = f->h_in_off.as<uint64_t>();
+        if (n == 0) return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
+        if (!f->h_in_off.ensure((size_t) (n + 1) * sizeof(uint64_t))) return -1;
+        *row_off = f->h_in_off.as<uint64_t>();
+        if (hipMemcpyAsync(f->h_in_off.p, off, (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        return n;
+    }
     while (sent < bytes) {
         const size_t end = sent + slab < bytes ? sent + slab : bytes;
-        if (!dev_index && !host_index_range(f, d, bytes, end, &pos, &n, &cap, &stop)) return -1;
+        if (!dev_index) { PhaseScope ph(HP_INDEX); if (!host_index_range(f, d, bytes, end, &pos, &n, &cap, &stop)) return -1; }
         // bytes past the last whole record are never read by the kernels; they are not uploaded
         const size_t upto = stop ? (pos < end ? pos : end) : end;
         if (upto > sent) {
             if (hipEventSynchronize(f->ev_stage[k]) != hipSuccess) return -1;
-            g_copy.copy(f->hp_stage[k].p, d + sent, upto - sent);
+            { PhaseScope ph(HP_COPY_IN); g_copy.copy(f->hp_stage[k].p, d + sent, upto - sent); }
             if (hipMemcpyAsync((uint8_t *) f->h_in_data.p + sent, f->hp_stage[k].p, upto - sent, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipEventRecord(f->ev_stage[k], st) != hipSuccess) return -1;
             k ^= 1;
@@ -1809,6 +1995,7 @@ int64_t flbgpu::staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, 
     *row_off = f->h_in_off.as<uint64_t>();
     if (hipMemcpyAsync(f->h_in_off.p, off, (size_t) (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     // the staging slabs and the offsets are reused by the next call
+    PhaseScope ph(HP_UPLOAD_WAIT);
     if (hipStreamSynchronize(st) != hipSuccess) { set_err("host to device copy failed"); return -1; }
     return n;
 }
@@ -1847,8 +2034,17 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     // through a pinned staging buffer to the device while the next one is being indexed.
     size_t consumed = 0;
     const uint64_t *row_off = nullptr;
-    int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed, &row_off);
+    memset(g_phase_us, 0, sizeof(g_phase_us));
+    PhaseScope ph_all(HP_TOTAL);
+    // a small chunk: everything launched ahead, one wait (SpecCall); the output comes back through the second slab, written by the device
+    bool small = spec_wanted(0, bytes) && f->hp_stage[1].ensure(STAGE_SLAB);
+    int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed, &row_off, small);
     if (n < 0) return FLBGPU_FILTER_NOTOUCH;
+    small = small && spec_wanted((uint64_t) n, bytes);
+    struct SpecScope {
+        SpecScope(bool on, flbgpu_filter *f0) { g_spec = SpecCall(); g_spec.on = on; if (on) { g_spec.sink = (uint8_t *) f0->hp_stage[1].p; g_spec.sink_cap = STAGE_SLAB; } }
+        ~SpecScope() { g_spec = SpecCall(); }
+    } spec_scope(small, f);
     bool garbage = consumed != bytes && !tail_is_clean((const uint8_t *) data, bytes, consumed);
     if (n == 0) {
         flbgpu_dev_chunk o0;
@@ -1859,11 +2055,17 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     flbgpu_dev_chunk in, out;
     in.data = f->h_in_data.p; in.row_off = row_off; in.n = (uint64_t) n; in.bytes = consumed;
     memset(&out, 0, sizeof(out));
-    if (chain_dev(filters, nfilters, &in, &out, garbage, stats) != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
+    {
+        PhaseScope ph(HP_CHAIN);
+        if (chain_dev(filters, nfilters, &in, &out, garbage, stats) != FLBGPU_FILTER_MODIFIED) return FLBGPU_FILTER_NOTOUCH;
+    }
     if (out.bytes == 0) { *out_buf = NULL; *out_size = 0; return FLBGPU_FILTER_MODIFIED; }
-    void *hb = malloc(out.bytes);
+    void *hb;
+    { PhaseScope ph(HP_MALLOC); hb = malloc(out.bytes); }
     if (!hb) return FLBGPU_FILTER_NOTOUCH;
-    if (!staged_download(f, hb, out.data, out.bytes)) {
+    PhaseScope ph_dl(HP_DOWNLOAD);
+    if (g_spec.sunk && out.bytes <= g_spec.sink_cap) g_copy.copy(hb, g_spec.sink, out.bytes);
+    else if (!staged_download(f, hb, out.data, out.bytes)) {
         free(hb);
         set_err("device to host copy failed");
         return FLBGPU_FILTER_NOTOUCH;

@@ -203,7 +203,7 @@ void prof_resolve(flbgpu_filter *f);
 
 namespace flbgpu {
 // host chunk -> device (pinned slabs, record boundaries found on the host or the device); device -> host buffer
-int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off);
+int64_t staged_upload(flbgpu_filter *f, const uint8_t *d, size_t bytes, size_t *consumed, const uint64_t **row_off, bool no_wait = false);
 bool staged_download(flbgpu_filter *f, void *dst, const void *src, size_t bytes);
 // row_off == NULL ("raw chunk bytes" in HBM): the records are found on the device
 bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *resolved, bool *garbage);

@@ -474,6 +474,7 @@ constexpr int EMIT_BLOCK = 256;
 constexpr int EMIT_STG = 18944;             // staging bytes per wave (64 records x 275 B + slack)
 
 __global__ void __launch_bounds__(EMIT_BLOCK) k_parser_emit(ParserEmitArgs a) {
+    if (a.out_cap && a.out_off[a.n] > a.out_cap) return;            // launched ahead of the size and the room was too small: the host runs the call again
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LDS_AS uint8_t *stg = (LDS_AS uint8_t *) g_lds + (size_t) wave * EMIT_STG;
     const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -572,6 +573,7 @@ void launch_parser_dec(const DecArgs &a, int blocks, hipStream_t st) {
 // records whose Types float literal is a hard rounding case (RF_EXACT): rewritten in place with the
 // big-integer conversion, one record per lane straight to global memory (rare)
 __global__ void __launch_bounds__(64) k_parser_emit_exact(ParserEmitArgs a) {
+    if (a.out_cap && a.out_off[a.n] > a.out_cap) return;
     for (uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * blockDim.x) {
         if (!(a.info[r] & RF_EXACT) || a.out_off[r + 1] == a.out_off[r]) continue;
         ByteSink s(a.out + a.out_off[r]);
@@ -684,6 +686,7 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
 // the whole wave -- twelve lanes busy for a 180 B event and up to 64 dependent load -> store round trips per tile (85 % of the wave
 // cycles waiting); now a quarter of the trips, the four rows' loads in flight together.
 __global__ void __launch_bounds__(256) k_gather(GatherArgs a) {
+    if (a.out_cap && a.out_off[a.n] > a.out_cap) return;
     __shared__ uint8_t sel[4][64];                 // per wave: the lane that holds the j-th kept row of the tile
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, quarter = lane >> 4, ql = lane & 15;
     const uint64_t wave_id = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -747,6 +750,44 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t *i
         for (int w = 0; w < SCAN_BLOCK / 64; w++) t += sh[w];
         tile_sums[blockIdx.x] = t;
     }
+}
+
+// n <= SCAN_SMALL: the whole scan in one workgroup (one launch instead of four stream commands: what a 2 MB call is made of)
+constexpr uint32_t SCAN_SMALL = 32768;
+__global__ void __launch_bounds__(1024) k_scan_small(const uint32_t *in, uint32_t n, uint64_t *out, unsigned long long *nonzero) {
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t cnt[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023) / 1024, b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+    uint64_t s = 0;
+    uint32_t c = 0;
+    for (uint32_t i = b; i < e; i++) { const uint32_t v = in[i]; s += v; c += v != 0; }
+    part[t] = s; cnt[t] = c;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint64_t v = t >= o ? part[t - o] : 0;
+        const uint32_t w = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        part[t] += v; cnt[t] += w;
+        __syncthreads();
+    }
+    uint64_t run = part[t] - s;
+    for (uint32_t i = b; i < e; i++) { out[i] = run; run += in[i]; }
+    if (t == 1023) { out[n] = part[1023]; if (nonzero && cnt[1023]) atomicAdd(nonzero, (unsigned long long) cnt[1023]); }
+}
+
+// counters, size and (when it fits) the output itself to page-locked host memory (launch_finish_to_host)
+__global__ void __launch_bounds__(256) k_finish_to_host(const uint8_t *out, uint64_t out_cap, const uint64_t *total, uint8_t *sink, uint64_t sink_cap,
+                                                        const uint32_t *words, uint32_t *host_words, uint32_t nwords, uint64_t *host_total) {
+    const uint64_t t = *total;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) host_words[i] = words[i];
+        if (threadIdx.x == 0) *host_total = t;
+    }
+    if (!sink || t > sink_cap || t > out_cap) return;         // (over out_cap: the writer ended without writing)
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint64_t n16 = (t + 15) / 16;                 // (both buffers end on a whole 16 bytes)
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t) gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(((const v4 *) out)[i], (v4 *) sink + i);
 }
 
 // single block: exclusive scan of the tile sums in place; total written to tile_sums[ntiles]
@@ -903,6 +944,7 @@ size_t scan_tmp_elems(uint64_t n) { const size_t t = (size_t) ((n + SCAN_TILE - 
 void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, hipStream_t st, unsigned long long *nonzero) {
     uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (ntiles == 0) { (void) hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
+    if (n <= SCAN_SMALL) { hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, in, (uint32_t) n, out, nonzero); return; }
     uint32_t *tile_cnt = nullptr;
     if (nonzero) {
         tile_cnt = (uint32_t *) (tmp + ntiles + 2);
@@ -911,6 +953,30 @@ void launch_scan(const uint32_t *in, uint64_t n, uint64_t *tmp, uint64_t *out, h
     hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp, tile_cnt);
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, tmp, ntiles, (const uint32_t *) tile_cnt, nonzero);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(SCAN_BLOCK), 0, st, in, n, tmp, out);
+}
+// the start of a call launched ahead (flbgpu.cpp SpecCall), one launch for what are otherwise four or five copy / fill commands: the
+// counter block zeroed (words[0..1] = first_bad = ~0), the zero-padded copy of the chunk's last bytes the register kernel reads its
+// last rows from, the pair's keep_len column at "undecided"
+__global__ void __launch_bounds__(256) k_call_prep(uint32_t *words, uint32_t nwords, uint8_t *tail, uint32_t tail_room, const uint8_t *data, uint64_t bytes,
+                                                   uint32_t tail_bytes, uint32_t *keep_len, uint64_t n) {
+    const uint64_t gid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, gsz = (uint64_t) gridDim.x * blockDim.x;
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) words[i] = i < 2 ? 0xFFFFFFFFu : 0u;
+    if (tail) for (uint64_t i = gid; i < tail_room; i += gsz) tail[i] = i < tail_bytes ? data[bytes - tail_bytes + i] : (uint8_t) 0;
+    if (keep_len) for (uint64_t i = gid; i < n; i += gsz) keep_len[i] = 0xFFFFFFFFu;
+}
+void launch_call_prep(void *words, uint32_t words_bytes, uint8_t *tail, uint32_t tail_room, const uint8_t *data, uint64_t bytes, uint32_t tail_bytes,
+                      uint32_t *keep_len, uint64_t n, hipStream_t st) {
+    uint64_t blocks = keep_len ? (n + 1023) / 1024 : 1;
+    if (blocks < 4) blocks = 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_call_prep, dim3((unsigned) blocks), dim3(256), 0, st, (uint32_t *) words, words_bytes / 4, tail, tail_room, data, bytes, tail_bytes, keep_len, n);
+}
+void launch_finish_to_host(const uint8_t *out, uint64_t out_cap, const uint64_t *total, uint8_t *sink, uint64_t sink_cap, const void *words, void *host_words,
+                           uint32_t nwords_bytes, uint64_t *host_total, hipStream_t st) {
+    // (the grid for the slab's size: the output's is not known here)
+    unsigned blocks = sink ? 1024u : 1u;
+    hipLaunchKernelGGL(k_finish_to_host, dim3(blocks), dim3(256), 0, st, out, out_cap, total, sink, sink_cap, (const uint32_t *) words, (uint32_t *) host_words,
+                       nwords_bytes / 4, host_total);
 }
 void launch_max_row_len(const uint64_t *row_off, uint64_t n, unsigned long long *out, hipStream_t st) {
     (void) hipMemsetAsync(out, 0, sizeof(unsigned long long), st);

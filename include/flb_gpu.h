@@ -440,6 +440,11 @@ int flbgpu_rx_simulate_capture(void *h, const char *s, int len, int *beg, int *e
 int flbgpu_rx_simulate_match(void *h, const char *s, int len);
 void flbgpu_rx_info(void *h, int *info12);
 int flbgpu_rx_names(void *h, char *buf, int cap);
+/* where the wall time of this thread's last host-level call (flbgpu_filter_run / flbgpu_filter_chain_run) went, microseconds:
+ * [0] record boundaries on the host, [1] caller's buffer -> page-locked slab, [2] waiting for the upload (0 for a small chunk: nothing
+ * waits there), [3] the device chain (launches, kernels, the wait), [4] output -> caller's buffer, [5] malloc of the output, [6] the call.
+ * Returns the number of phases (7); out may hold fewer. */
+int flbgpu_host_phases(double *out, int cap);
 void flbgpu_diag_copy(void *dst, const void *src, size_t n);   /* the threaded slab copy of the host-level calls (unit test) */
 uint64_t flbgpu_diag_fused_failures(void);                       /* single passes over a [parser, grep] pair that failed on the device (the chain then answers NOTOUCH) */
 int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end);   /* compact tables of the tile kernel, host execution */
