@@ -370,10 +370,16 @@ bool fold_case(CC &cc) {
 
 // ---------------------------------------------------------------- AST
 // (A_WORDB_A / A_NWORDB_A: \b \B under (?a) -- OP_ASCII_WORD_BOUND: only [0-9A-Za-z_] are word characters)
-enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB, A_WORDB_A, A_NWORDB_A };
+// (A_SEMI_EOS \Z, A_BEGIN_POS \G and the node kinds LOOK / ATOMIC / BACKREF / KEEP exist only in trees parsed with Syntax::ext -- the
+// product's backtracking matcher, rxbt.inc; the table and NFA builders never see them)
+enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB, A_WORDB_A, A_NWORDB_A, A_SEMI_EOS, A_BEGIN_POS };
 
 struct Ast {
-    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR } t = EMPTY;
+    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR, LOOK, ATOMIC, BACKREF, KEEP } t = EMPTY;
+    bool ahead = true, neg_look = false;   // LOOK
+    std::vector<int> refs;                 // BACKREF: the groups the reference names, in group order
+    bool ref_icase = false;
+    CodeSet btmb;                          // SET, rxbt: the well-formed multi-byte characters it accepts
     CC cc;
     std::vector<std::unique_ptr<Ast>> kids;
     int cap = 0;
@@ -394,6 +400,10 @@ struct Syntax {
     std::string err;
     std::vector<std::string> names;
     std::vector<std::vector<int>> name_groups;
+    bool ext = false;             // accept what only a backtracking matcher can run: look-around, atomic groups, possessive repeats, back-references, \Z \G \K
+    bool nonregular = false;      // ... such a construct was met (with ext off: the reason of the failure)
+    std::vector<std::pair<Ast *, std::string>> named_refs;    // \k<name> met before the end of the pattern: resolved there
+    int max_ref = 0;
 
     bool fail(const char *m) { if (err.empty()) { err = m; err += " (offset " + std::to_string(p - s) + ")"; } return false; }
     bool failed() const { return !err.empty(); }
@@ -609,11 +619,29 @@ struct Syntax {
                     return mk(Ast::EMPTY);
                 }
                 if (c == ':') { p++; g->kids.push_back(alternation(opts, depth + 1)); }
-                else if (c == '=' || c == '!') { fail("look-ahead is not supported on the GPU path"); return nullptr; }
-                else if (c == '>') { fail("atomic groups are not supported on the GPU path"); return nullptr; }
+                else if (c == '=' || c == '!') {
+                    nonregular = true;
+                    if (!ext) { fail("look-ahead is not supported on the GPU path"); return nullptr; }
+                    p++;
+                    g->t = Ast::LOOK; g->ahead = true; g->neg_look = c == '!';
+                    g->kids.push_back(alternation(opts, depth + 1));
+                }
+                else if (c == '>') {
+                    nonregular = true;
+                    if (!ext) { fail("atomic groups are not supported on the GPU path"); return nullptr; }
+                    p++;
+                    g->t = Ast::ATOMIC;
+                    g->kids.push_back(alternation(opts, depth + 1));
+                }
+                else if (c == '<' && p + 1 < e && (p[1] == '=' || p[1] == '!')) {
+                    nonregular = true;
+                    if (!ext) { fail("look-behind is not supported on the GPU path"); return nullptr; }
+                    g->t = Ast::LOOK; g->ahead = false; g->neg_look = p[1] == '!';
+                    p += 2;
+                    g->kids.push_back(alternation(opts, depth + 1));
+                }
                 else if (c == '<' || c == '\'') {
                     int term = c == '<' ? '>' : '\'';
-                    if (c == '<' && p + 1 < e && (p[1] == '=' || p[1] == '!')) { fail("look-behind is not supported on the GPU path"); return nullptr; }
                     p++;
                     const unsigned char *nm = p;
                     while (!eof() && *p != term) {
@@ -701,9 +729,50 @@ struct Syntax {
             if (c == 'z') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_EOS; return a; }
             if (c == 'b') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_WORDB_A : A_WORDB; return a; }
             if (c == 'B') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_NWORDB_A : A_NWORDB; return a; }
-            if (c == 'Z') { fail("\\Z is not supported on the GPU path"); return nullptr; }
-            if (strchr("GKRXkgpP", c)) { fail("unsupported escape"); return nullptr; }
-            if (c >= '1' && c <= '9') { fail("back-references are not supported on the GPU path"); return nullptr; }
+            if (c == 'Z') {
+                nonregular = true;
+                if (!ext) { fail("\\Z is not supported on the GPU path"); return nullptr; }
+                p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_SEMI_EOS; return a;
+            }
+            if (ext && c == 'G') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_BEGIN_POS; return a; }
+            if (ext && c == 'K') { p++; return mk(Ast::KEEP); }
+            if (ext && c == 'k' && p + 1 < e && (p[1] == '<' || p[1] == '\'')) {
+                // \k<name> \k<n> \k<-n>  (regparse.c fetch_token 'k')
+                const int term = p[1] == '<' ? '>' : '\'';
+                p += 2;
+                const unsigned char *nm = p;
+                while (!eof() && *p != term) p++;
+                if (eof() || p == nm) { fail("invalid backref name"); return nullptr; }
+                std::string name((const char *) nm, p - nm);
+                p++;
+                AstP a = mk(Ast::BACKREF);
+                a->ref_icase = (opts & OPT_IGNORECASE) != 0;
+                const bool numeric = (name[0] >= '0' && name[0] <= '9') || (name[0] == '-' && name.size() > 1);
+                if (numeric) {
+                    if (has_named) { fail("numbered backref/call is not allowed. (use name)"); return nullptr; }
+                    int v = 0;
+                    for (size_t i = name[0] == '-' ? 1 : 0; i < name.size(); i++) { if (name[i] < '0' || name[i] > '9' || v > 1000) { fail("invalid backref number/name"); return nullptr; } v = v * 10 + (name[i] - '0'); }
+                    if (name[0] == '-') v = ncap + 1 - v;
+                    if (v <= 0) { fail("invalid backref number/name"); return nullptr; }
+                    a->refs.push_back(v);
+                    max_ref = std::max(max_ref, v);
+                }
+                else named_refs.emplace_back(a.get(), name);
+                return a;
+            }
+            if (strchr("GKRXkgpP", c)) { if (c == 'G' || c == 'K' || c == 'k') nonregular = true; fail("unsupported escape"); return nullptr; }
+            if (c >= '1' && c <= '9') {
+                nonregular = true;
+                if (!ext) { fail("back-references are not supported on the GPU path"); return nullptr; }
+                if (has_named) { fail("numbered backref/call is not allowed. (use name)"); return nullptr; }
+                int v = 0;
+                while (!eof() && *p >= '0' && *p <= '9' && v < 1000) { v = v * 10 + (*p - '0'); p++; }
+                AstP a = mk(Ast::BACKREF);
+                a->ref_icase = (opts & OPT_IGNORECASE) != 0;
+                a->refs.push_back(v);
+                max_ref = std::max(max_ref, v);
+                return a;
+            }
             uint32_t v;
             if (escape_cp(v, false)) { if (failed()) return nullptr; return literal(v, opts); }
             v = take_cp();
@@ -744,13 +813,20 @@ struct Syntax {
                 brace = true;
             }
             else break;
-            if (a->t == Ast::ANCHOR) { fail("target of repeat operator is invalid"); return nullptr; }
+            if (a->t == Ast::ANCHOR || a->t == Ast::KEEP) { fail("target of repeat operator is invalid"); return nullptr; }
             AstP r = mk(Ast::REPEAT);
             r->min = lo; r->max = hi;
             if (!eof() && *p == '?') { p++; r->greedy = false; }
-            else if (!brace && !eof() && *p == '+') { fail("possessive repeats are not supported on the GPU path"); return nullptr; }
+            bool possessive = false;
+            if (r->greedy && !brace && !eof() && *p == '+') {
+                nonregular = true;
+                if (!ext) { fail("possessive repeats are not supported on the GPU path"); return nullptr; }
+                p++;
+                possessive = true;
+            }
             r->kids.push_back(std::move(a));
             a = std::move(r);
+            if (possessive) { AstP at = mk(Ast::ATOMIC); at->kids.push_back(std::move(a)); a = std::move(at); }
         }
         return a;
     }
@@ -1184,6 +1260,7 @@ struct Tables {
 
     static bool assert_ok(AnchorKind a, int pk, int nk) {
         switch (a) {
+        default: break;
         case A_BOL: return pk == K_EDGE || (pk == K_NL && nk != K_EDGE);   // OP_BEGIN_LINE
         case A_EOL: return nk == K_EDGE || nk == K_NL;                     // OP_END_LINE
         case A_BOS: return pk == K_EDGE;
@@ -1768,7 +1845,7 @@ bool compile(const char *pattern, size_t len, unsigned options, bool want_captur
     sx.has_named = scan_named(sx.s, sx.e);
     AstP root = sx.alternation(options & (OPT_IGNORECASE | OPT_EXTEND | OPT_MULTILINE), 0);
     if (!sx.failed() && !sx.eof()) sx.fail(*sx.p == ')' ? "unmatched close parenthesis" : "trailing garbage");
-    if (sx.failed()) { err = sx.err; return false; }
+    if (sx.failed()) { err = sx.err; out = Program(); out.nonregular = sx.nonregular; return false; }
     if (sx.ncap > 31) { err = "more than 31 capture groups"; return false; }
     out = Program();
     {
@@ -1904,7 +1981,9 @@ struct Sampler {
         case Ast::SET: set(a->cc, o); return;
         case Ast::CAT: for (auto &k : a->kids) walk(k.get(), o, depth + 1); return;
         case Ast::ALT: walk(a->kids[below((uint32_t) a->kids.size())].get(), o, depth + 1); return;
-        case Ast::GROUP: walk(a->kids[0].get(), o, depth + 1); return;
+        case Ast::GROUP: case Ast::ATOMIC: walk(a->kids[0].get(), o, depth + 1); return;
+        case Ast::LOOK: case Ast::KEEP: return;
+        case Ast::BACKREF: if (!o.empty() && below(2)) o.push_back(o[below((uint32_t) o.size())]); return;
         case Ast::REPEAT: {
             int span = a->max < 0 ? (below(4) == 0 ? 12 : 4) : std::min(a->max - a->min, 6);
             const int n = a->min + (int) below((uint32_t) span + 1);
@@ -1918,6 +1997,7 @@ struct Sampler {
 
 bool sample(const char *pattern, size_t len, unsigned options, uint64_t seed, std::string &out, std::string &err) {
     Syntax sx;
+    sx.ext = true;
     sx.s = sx.p = (const unsigned char *) pattern;
     sx.e = sx.s + len;
     sx.has_named = scan_named(sx.s, sx.e);
@@ -2275,6 +2355,8 @@ int nfa_run(const NfaSet &t, int ngroups, const uint8_t *s, int olen, int *beg, 
     }
     return 1;
 }
+
+#include "rxbt.inc"
 
 int simulate_match(const Program &p, const uint8_t *s, int len) {
     const TableSet &t = p.ascii;

@@ -181,6 +181,7 @@ struct Program {
     bool ascii_stub = false;                  // the ascii set is a stub that hands EVERY value on (always-poison tables)
     NfaSet nfa;
     std::string why_nfa;                      // what the table compiler said when it gave up (diagnostics)
+    bool nonregular = false;                  // compile() failed on a construct only a backtracking matcher runs (bt_compile takes the pattern)
     unsigned corner_flags = 0;                // CF_*: the optimizer-dependent corners of the reference this pattern can meet (rx::corner)
 };
 constexpr unsigned CF_NL_LOOKBACK = 1u, CF_WORD_LOOKBACK = 2u, CF_ICASE_FOLD = 4u;
@@ -206,6 +207,17 @@ int simulate_capture(const Program &p, const uint8_t *s, int len, int *beg, int 
 int simulate_match(const Program &p, const uint8_t *s, int len);
 // host execution of the NFA set alone (the algorithm the kernels run: kdev.inc nfa_*): 1 match (spans filled when beg != nullptr),
 // 0 no match, -2 inconsistency
+// ---- the backtracking matcher for what is not a regular expression (rxbt.inc): look-around, atomic groups, possessive repeats,
+// back-references, \Z \G \K.  Host only; the filters give it the values of the rules / parsers whose compile() failed with
+// Program::nonregular set.  bt_search: groups + 1 on a match (beg / end may be NULL), -1 no match, -4 the backtrack budget was spent.
+struct BtProgram;
+BtProgram *bt_compile(const char *pattern, size_t len, unsigned options, std::string &err);
+void bt_free(BtProgram *p);
+int bt_ngroups(const BtProgram *p);
+const std::vector<std::string> &bt_names(const BtProgram *p);
+const std::vector<std::vector<int>> &bt_name_groups(const BtProgram *p);
+int bt_search(const BtProgram *p, const uint8_t *s, int len, int *beg, int *end);
+
 int nfa_run(const NfaSet &t, int ngroups, const uint8_t *s, int len, int *beg, int *end);
 // UTF-8 sequence length rule shared with the kernels: length (2..4) of the well-formed or
 // end-truncated sequence starting at s[i], else 1

@@ -24,6 +24,30 @@ void *flbgpu_rx_compile(const char *pattern, int len, unsigned options, int want
 
 void flbgpu_rx_free(void *h) { delete (rx::Program *) h; }
 
+/* the backtracking matcher for look-around, atomic groups, possessive repeats, back-references, \Z \G \K (rxbt.inc): what the filters
+ * run on the host for a rule / parser the GPU engines cannot take.  flbgpu_rxbt_search: groups + 1 on a match (beg / end may be NULL),
+ * -1 no match, -4 the backtrack budget was spent. */
+void *flbgpu_rxbt_compile(const char *pattern, int len, unsigned options, char *err, int errlen)
+{
+    std::string e;
+    rx::BtProgram *p = rx::bt_compile(pattern, (size_t) len, options, e);
+    if (err && errlen > 0) { strncpy(err, e.c_str(), errlen - 1); err[errlen - 1] = 0; }
+    return p;
+}
+void flbgpu_rxbt_free(void *h) { rx::bt_free((rx::BtProgram *) h); }
+int flbgpu_rxbt_search(void *h, const char *s, int len, int *beg, int *end)
+{
+    return rx::bt_search((const rx::BtProgram *) h, (const uint8_t *) s, len, beg, end);
+}
+/* 1: flbgpu_rx_compile refuses the pattern because of such a construct (and flbgpu_rxbt_compile is the one to ask) */
+int flbgpu_rx_is_nonregular(const char *pattern, int len, unsigned options)
+{
+    rx::Program p;
+    std::string e;
+    if (rx::compile(pattern, (size_t) len, options, true, p, e)) return 0;
+    return p.nonregular ? 1 : 0;
+}
+
 int flbgpu_rx_simulate_capture(void *h, const char *s, int len, int *beg, int *end)
 {
     return rx::simulate_capture(*(rx::Program *) h, (const uint8_t *) s, len, beg, end);

@@ -445,6 +445,15 @@ int flbgpu_rx_names(void *h, char *buf, int cap);
  * waits there), [3] the device chain (launches, kernels, the wait), [4] output -> caller's buffer, [5] malloc of the output, [6] the call.
  * Returns the number of phases (7); out may hold fewer. */
 int flbgpu_host_phases(double *out, int cap);
+
+/* The backtracking matcher behind rules / parsers that are not regular expressions (look-around, atomic groups, possessive repeats,
+ * back-references, \Z \G \K; csrc/rxbt.inc -- semantics of lib/onigmo/regexec.c:1431 match_at).  The filters use it by themselves
+ * (flbgpu_filter_host_rules); these entry points are for the differential tests against the real engine.
+ * search: groups + 1 on a match (beg / end may be NULL), -1 no match, -4 the backtrack budget was spent ("no match" to the callers). */
+void *flbgpu_rxbt_compile(const char *pattern, int len, unsigned options, char *err, int errlen);
+void flbgpu_rxbt_free(void *h);
+int flbgpu_rxbt_search(void *h, const char *s, int len, int *beg, int *end);
+int flbgpu_rx_is_nonregular(const char *pattern, int len, unsigned options);
 void flbgpu_diag_copy(void *dst, const void *src, size_t n);   /* the threaded slab copy of the host-level calls (unit test) */
 uint64_t flbgpu_diag_fused_failures(void);                       /* single passes over a [parser, grep] pair that failed on the device (the chain then answers NOTOUCH) */
 int flbgpu_rx_simulate_fx(void *h, const char *s, int len, int *beg, int *end);   /* compact tables of the tile kernel, host execution */

@@ -1,0 +1,211 @@
+"""The product's backtracking matcher (csrc/rxbt.inc: what the filters run on the host for a rule / parser that is not a regular
+expression -- look-around, atomic groups, possessive repeats, back-references, \\Z \\G \\K) against the REAL Onigmo
+(oracle/_ref/libonig_ref.so): known answers, random non-regular patterns over a grammar of those constructs, and -- the same
+matcher, the same semantics underneath -- the regular random patterns of test_rx_random_patterns.py."""
+import ctypes, os, random, sys
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import flbamd_loader
+import rxdiff
+import test_rx_random_patterns as rp
+
+needs_ref = pytest.mark.skipif(rxdiff.load_ref() is None, reason="oracle/_ref/libonig_ref.so not built (needs /root/reference)")
+
+KNOWN = [
+    rb"foo(?=bar)", rb"foo(?!bar)", rb"(?<=foo)bar", rb"(?<!foo)bar", rb"(?<=a|bc)x", rb"(?<!a|bc)x", rb"(?>a+)b", rb"(?>a|ab)c", rb"a*+a", rb"a++b", rb"a?+a",
+    rb"(a+)\1", rb"(?<x>\w+) \k<x>", rb"(\w)(\w)\2\1", rb"(?i)(ab)\1", rb"^(?!.*error).*$", rb"^(?=.*\d)(?=.*[a-z]).{4,}$", rb"\bfoo\b(?! bar)",
+    rb"(?<=\d)(?=(\d{3})+$)", rb"x\Z", rb"\Aab\Z", rb"a\Kb", rb"\Gab", rb"(?<=^|,)[^,]*", rb"(?<![\w.])\d+(?![\w.])", rb"(?<k>a)?\k<k>b", rb"(a)|\1b",
+    rb"(?>a*)a", rb"(?:(?=a)a|b)+", rb"(?!a)(?!b).", rb"(?<=(?<!x)y)z", "(?<=é)x".encode(), "(?<!日)本".encode(), rb"(?<=\s)\S+(?=\s)", rb"(a*)*+b", rb"(?>(a|b)*)c",
+    rb"(?<q>['\"])(?<body>.*?)\k<q>", rb"^(?<host>\S+) (?!-)(?<user>\S+)", rb"(?<n>\d+)-\k<n>", rb"(?=(a+))a*b\1", rb"(?<!\\)\"", rb"(\d+)(?<=5)x", rb"a(?=b|c)(?<=a).",
+]
+
+LOOK_BODY = [rb"a", rb"b", rb"ab", rb"\d", rb"\w", rb"[a-c]", rb" ", rb"x|y", rb"ab|cd", rb"a|bc", rb"\s", rb"[^a]", rb".", "é".encode(), rb"\d\d", rb"^", rb"$", rb"\b"]
+
+
+def gen_nonregular(rng):
+    names = []
+    n_plain = [0]
+
+    def atom():
+        return rng.choice(rp.ATOMS)
+
+    def piece(d):
+        r = rng.random()
+        if r < 0.10:
+            return b"(?=" + rng.choice(LOOK_BODY) + b")"
+        if r < 0.18:
+            return b"(?!" + rng.choice(LOOK_BODY) + b")"
+        if r < 0.26:
+            return b"(?<=" + rng.choice(LOOK_BODY) + b")"
+        if r < 0.33:
+            return b"(?<!" + rng.choice(LOOK_BODY) + b")"
+        if r < 0.41 and d > 0:
+            return b"(?>" + alt(d - 1) + b")" + rng.choice([b"", b"", b"?"])
+        if r < 0.49:
+            return atom() + rng.choice([b"*+", b"++", b"?+"])
+        if r < 0.57 and names:
+            return b"\\k<" + rng.choice(names) + b">"
+        if r < 0.67 and d > 0 and len(names) < 4:
+            nm = b"g%d" % len(names)
+            body = b"(?<" + nm + b">" + alt(d - 1) + b")"
+            names.append(nm)
+            return body + rng.choice([b"", b"", b"?"])
+        if r < 0.70:
+            return rng.choice([rb"\Z", rb"\K", rb"\G", rb"\b"])
+        return atom() + rng.choice(rp.QUANT)
+
+    def seq(d):
+        return b"".join(piece(d) for _ in range(rng.randint(1, 4)))
+
+    def alt(d):
+        out = seq(d)
+        while rng.random() < 0.2:
+            out += b"|" + seq(d)
+        return out
+    p = alt(2)
+    if rng.random() < 0.3:
+        p = b"^" + p
+    if rng.random() < 0.15:
+        p = b"(?i)" + p
+    return p
+
+
+def subjects(L, rng, pat, n):
+    buf = ctypes.create_string_buffer(4096)
+    out = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.45:
+            k = L.flbgpu_rx_sample(pat, len(pat), 0, rng.getrandbits(48), buf, 4096)
+            s = buf.raw[:max(k, 0)]
+            if rng.random() < 0.5 and s:
+                m = bytearray(s)
+                q = rng.randrange(len(m) + 1)
+                m[q:q] = rng.choice([b"a", b" ", b"5", b"\n", b"x", "é".encode(), b"\xe9", b"ab", b"b"])
+                s = bytes(m)
+            if rng.random() < 0.3:
+                s = rxdiff.rand_input(rng, pat, 6) + s + rxdiff.rand_input(rng, pat, 6)
+            out.append(s[:60])
+        elif r < 0.8:
+            out.append(rxdiff.rand_input(rng, pat, 20, utf8=rng.random() < 0.4))
+        else:
+            out.append(rxdiff.rand_input_illformed(rng, pat, 14))
+    return out + [b"", b"a", b"\n"]
+
+
+def bt_compile(L, pat):
+    L.flbgpu_rxbt_compile.restype = ctypes.c_void_p
+    err = ctypes.create_string_buffer(256)
+    h = L.flbgpu_rxbt_compile(pat, len(pat), 0, err, 256)
+    return (ctypes.c_void_p(h) if h else None), err.value
+
+
+def bt_search(L, h, s):
+    beg = (ctypes.c_int * 64)(); end = (ctypes.c_int * 64)()
+    n = L.flbgpu_rxbt_search(h, s, len(s), beg, end)
+    if n < 0:
+        return None if n == -1 else ("budget", n)
+    return [(beg[i], end[i]) for i in range(n)]
+
+
+CORNERS = [0]
+
+
+def corner(pat, s):
+    """the two documented corners where the reference's answer hangs on how it steps BACK over ill-formed UTF-8 (a stray continuation
+    byte in front of ^ \\b \\B or a look-behind) or on a fold that changes a character's length under (?i) (DESIGN: deviations; the
+    table engines count such values, rx::corner)"""
+    if rp.has_stray_continuation(s) and (b"\\b" in pat or b"\\B" in pat or b"^" in pat or b"(?<" in pat):
+        return True
+    if b"(?i)" in pat and rp.FOLD_LENGTH_CHANGERS.search(s) is not None:
+        return True
+    # a defect of the reference that is not reproduced: a pattern that can only match the empty string at the end of the text (nothing
+    # but anchors and look-arounds, \\z or \\Z among them) is searched BACKWARDS from the end with the right limit of the match at the start of
+    # the text (regexec.c onig_search end_buf: start = end - anchor_dmax, then the backward loop's MATCH_AND_RETURN_CHECK(orig_start)),
+    # so every character test inside a look-behind fails its DATA_ENSURE: `(?<=\\d)\\z` does not match "1" there.
+    return (b"\\Z" in pat or b"\\z" in pat) and b"(?<" in pat
+
+
+def compare(L, ref, pat, subj):
+    """-> (compared, matched); raises on a difference"""
+    eng = rxdiff.RefRegex(ref, pat)
+    h, err = bt_compile(L, pat)
+    if not eng.ok:
+        if h:
+            L.flbgpu_rxbt_free(h)
+        return 0, 0
+    if not h and ((b"not supported" in err and b"case-insensitive" in err) or b"target of repeat operator is invalid" in err):
+        return 0, 0                    # (the front end's own limits -- (?i) with non-ASCII members, a repeat of an anchor: refused at create, for every engine)
+    assert h, (pat, err)
+    matched = 0
+    try:
+        for s in subj:
+            want = eng.search(s)
+            got = bt_search(L, h, s)
+            if got != want and corner(pat, s):
+                CORNERS[0] += 1
+                continue
+            assert got == want, (pat, s, got, want)
+            matched += want is not None
+    finally:
+        L.flbgpu_rxbt_free(h)
+    return len(subj), matched
+
+
+@needs_ref
+def test_known_nonregular_patterns():
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(11)
+    total = matched = 0
+    for pat in KNOWN:
+        assert L.flbgpu_rx_is_nonregular(pat, len(pat), 0) == 1, pat            # the GPU engines refuse it -- and say why
+        n, m = compare(L, ref, pat, subjects(L, rng, pat, 120))
+        assert n > 0, pat                                                       # the real engine takes every one of them
+        total += n; matched += m
+    assert total > 4000 and matched > 300, (total, matched)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_nonregular_patterns(seed):
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(seed * 7919)
+    total = matched = pats = 0
+    for _ in range(700):
+        pat = gen_nonregular(rng)
+        n, m = compare(L, ref, pat, subjects(L, rng, pat, 25))
+        total += n; matched += m; pats += n > 0
+    assert pats > 300 and total > 8000 and matched > 800, (pats, total, matched)
+
+
+@needs_ref
+def test_regular_patterns_through_the_backtracker():
+    """the same machine underneath: the random REGULAR patterns must come out as from the real engine, too"""
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(99)
+    total = matched = 0
+    base = rp.ATOMS
+    for i in range(1200):
+        names = []
+        rp.ATOMS = base + rp.MORE_ATOMS if i % 2 else base
+        try:
+            pat = rp.gen(rng, 2, names)
+        finally:
+            rp.ATOMS = base
+        n, m = compare(L, ref, pat, subjects(L, rng, pat, 12))
+        total += n; matched += m
+    assert total > 10000 and matched > 2000, (total, matched)
+
+
+def test_what_stays_refused():
+    """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
+    L = flbamd_loader.load().lib()
+    for pat in [rb"(?~abc)", rb"(?(1)a|b)", rb"\g<1>", rb"\p{Alpha}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>"]:
+        h, err = bt_compile(L, pat)
+        assert h is None and err, pat
