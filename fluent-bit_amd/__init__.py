@@ -93,6 +93,8 @@ def lib():
     L.flbgpu_l2m_seq_sums.argtypes = [c_void_p, c_uint64, POINTER(c_double)]
     L.flbgpu_host_phases.restype = ctypes.c_int
     L.flbgpu_host_phases.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    L.flbgpu_filter_host_rules.restype = ctypes.c_int
+    L.flbgpu_filter_host_rules.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     L.flbgpu_filter_regex_corners.restype = ctypes.c_uint64
     L.flbgpu_filter_regex_corners.argtypes = [c_void_p]
     L.flbgpu_rx_simulate_fx3.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
@@ -226,6 +228,13 @@ class _Filter:
     def regex_corners(self):
         """values that met one of the reference's optimizer-dependent regex corners since the filter was created (flb_gpu.h)"""
         return int(lib().flbgpu_filter_regex_corners(self.h))
+
+    def host_rules(self):
+        """rules / parsers of this filter the host's backtracking matcher answers (patterns that are not regular expressions):
+        dict(rules, values, budget_over, unhandled) -- flbgpu_filter_host_rules"""
+        o = (ctypes.c_uint64 * 4)()
+        lib().flbgpu_filter_host_rules(self.h, o)
+        return dict(rules=int(o[0]), values=int(o[1]), budget_over=int(o[2]), unhandled=int(o[3]))
 
     def profile(self, enable=True):
         lib().flbgpu_filter_profile(self.h, int(enable))

@@ -395,6 +395,11 @@ struct GrepRule {
     DevKey key;
     DevDfa dfa;
     DevCap utf8;
+    // a HOST rule: the pattern is not a regular expression (csrc/rxbt.inc answers it on the host, flbgpu.cpp "host rules").  host_mode 1:
+    // k_grep_match notes the value's place per row (host_io[2r] offset in the row, [2r+1] length; 0xFFFFFFFF: no string value);
+    // 2: host_io is the host's answers, one bit per row.  0: a device rule.
+    uint32_t *host_io;
+    int host_mode;
 };
 
 struct GrepArgs {
@@ -409,6 +414,7 @@ struct GrepArgs {
     uint32_t *status;           // [n] RF_* flags
     unsigned long long *first_bad;
     unsigned long long *counts; // [0] = decoded (non-skipped) records, [1] = kept records
+    int host_collect;           // pass 1 of a filter with host rules (GrepRule::host_mode 1)
     // the rules' match-only DFA blobs (cls | ddelta | d_final: upload_dfa) staged behind the record tiles in LDS: two dependent
     // table reads per byte of a tested value, ~100 cycles from LDS against ~400 through L2
     uint32_t rule_lds_off[MAX_RULES], rule_lds_bytes[MAX_RULES];   // offset 0xFFFFFFFF: not staged

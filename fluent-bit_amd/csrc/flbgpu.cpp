@@ -215,8 +215,9 @@ struct flbgpu_parser {
     flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
     DevDecoders decs;              // Decode_Field / Decode_Field_As (flbgpu_parser_add_decoder), uploaded when a filter takes the parser
     void *d_decs = nullptr;
+    rx::BtProgram *bt = nullptr;   // a HOST parser: the Regex is not a regular expression, the backtracking matcher answers on the host (rxbt.inc)
     flbgpu_parser() { memset(&decs, 0, sizeof(decs)); }
-    ~flbgpu_parser() { if (d_decs) (void) hipFree(d_decs); }
+    ~flbgpu_parser() { if (d_decs) (void) hipFree(d_decs); if (bt) rx::bt_free(bt); }
 };
 
 // One rule of a parser's decoder list: "Decode_Field[_As] <backend> <key> [try_next|do_next]" (conf/parsers.conf, parsed by
@@ -365,11 +366,29 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         rx::split_flb_pattern(regex, &s, &e, &opts);
         std::string err;
         if (!rx::compile(s, (size_t) (e - s), opts, true, p->prog, err)) {
-            set_err("parser '%s': cannot compile regex for the GPU path: %s", p->name.c_str(), err.c_str());
-            delete p;
-            return nullptr;
+            // not a regular expression (look-around, back-references, ...): a HOST parser -- the device does everything but the
+            // capture search, which the backtracking matcher runs on the located values (host_parser_rx below)
+            std::string e2;
+            if (p->prog.nonregular && !getenv("FLBGPU_NO_HOST_RULES")) p->bt = rx::bt_compile(s, (size_t) (e - s), opts, e2);
+            if (p->bt && rx::bt_ngroups(p->bt) > 31) { e2 = "more than 31 capture groups"; rx::bt_free(p->bt); p->bt = nullptr; }
+            if (!p->bt) {
+                set_err("parser '%s': cannot compile regex for the GPU path: %s%s%s", p->name.c_str(), err.c_str(), e2.empty() ? "" : "; on the host: ", e2.c_str());
+                delete p;
+                return nullptr;
+            }
+            p->prog = rx::Program();
+            p->prog.ngroups = rx::bt_ngroups(p->bt);
+            p->prog.names = rx::bt_names(p->bt);
+            p->prog.name_groups = rx::bt_name_groups(p->bt);
+            p->prog.slot2cap.assign(2 * (size_t) (p->prog.ngroups + 1), 0xFF);
+            int fi = 0;
+            for (size_t i = 0; i < p->prog.names.size(); i++)
+                for (int g : p->prog.name_groups[i]) {
+                    if (fi < 120) { p->prog.slot2cap[2 * g] = (uint8_t) (2 * fi); p->prog.slot2cap[2 * g + 1] = (uint8_t) (2 * fi + 1); }
+                    fi++;
+                }
         }
-        if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_utf8(p->prog, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
+        else if (!upload_cap(p->prog.ascii, p->blob_ascii, d.ascii) || !upload_utf8(p->prog, p->blob_utf8, d.utf8)) { delete p; return nullptr; }
     }
     d.is_json = is_json ? 1 : 0;
     d.ngroups = p->prog.ngroups;
@@ -481,7 +500,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         if (ntime != 1) d.time_field = -1;
     }
     // compact forward tables of the single-pass tile kernel (start-anchored patterns: the forward walk needs no reverse pass)
-    if (!is_json && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE") && !p->prog.ascii_stub) {
+    if (!is_json && !p->bt && d.fwd_first && d.nregs_minus1 > 0 && d.nfields > 0 && !getenv("FLBGPU_NO_TILE") && !p->prog.ascii_stub) {
         if (!upload_fx(p->prog.ascii, 2 * d.nfields, p->blob_fx, d.fx)) { delete p; return nullptr; }
         // the same tables without special entries (fx.cpp build_fx3: 8-byte cells, two capture writes per step): what k_parser_reg<.., FX3> walks
         if (d.fx.ok) {
@@ -714,7 +733,7 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
     return f;
 }
 
-bool flbgpu::compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why) {
+bool flbgpu::compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why, bool *nonregular) {
     std::string w2;
     if (!parse_ra(ra_field.c_str(), r.key, w2)) { why = "invalid record accessor? '" + ra_field + "': " + w2; return false; }
     const char *ps, *pe;
@@ -724,6 +743,7 @@ bool flbgpu::compile_rule(const std::string &ra_field, const char *pattern, Grep
     std::string err;
     if (!rx::compile(ps, (size_t) (pe - ps), opts, false, prog, err)) {
         why = std::string("could not compile regex pattern '") + pattern + "' for the GPU path: " + err;
+        if (nonregular) *nonregular = prog.nonregular;
         return false;
     }
     auto *b1 = new TableBlob(), *b2 = new TableBlob();
@@ -765,9 +785,24 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
         std::string field(v, sp - v);
         if (field[0] != '$') field = "$" + field;
         std::string why;
-        if (!compile_rule(field, sp + 1, r, f->rule_blobs, why)) { set_err("filter_grep: %s", why.c_str()); delete f; return nullptr; }
-        if ((int) f->rules.size() >= MAX_RULES) { set_err("filter_grep: more than %d rules", MAX_RULES); delete f; return nullptr; }
+        bool nonregular = false;
+        rx::BtProgram *bt = nullptr;
+        if (!compile_rule(field, sp + 1, r, f->rule_blobs, why, &nonregular)) {
+            // not a regular expression: a HOST rule -- the device finds the value, the backtracking matcher answers (grep_host_pass)
+            std::string e2;
+            if (nonregular && !getenv("FLBGPU_NO_HOST_RULES")) {
+                const char *ps, *pe;
+                unsigned opts;
+                rx::split_flb_pattern(sp + 1, &ps, &pe, &opts);
+                bt = rx::bt_compile(ps, (size_t) (pe - ps), opts, e2);
+            }
+            if (!bt) { set_err("filter_grep: %s%s%s", why.c_str(), e2.empty() ? "" : "; on the host: ", e2.c_str()); delete f; return nullptr; }
+            memset(&r.dfa, 0, sizeof(r.dfa)); memset(&r.utf8, 0, sizeof(r.utf8));
+            f->has_host_rules = true;
+        }
+        if ((int) f->rules.size() >= MAX_RULES) { set_err("filter_grep: more than %d rules", MAX_RULES); if (bt) rx::bt_free(bt); delete f; return nullptr; }
         f->rules.push_back(r);
+        f->host_rx.push_back(bt);
         rule_field.push_back(field);
         rule_pat.push_back(sp + 1);
     }
@@ -775,7 +810,7 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
     // match" -- so the rules that test the SAME field are one search for the alternation of their patterns, one automaton
     // pass over the value instead of one per rule (BASELINE configs[2]: 16 + 16 rules on five fields).  Each pattern keeps
     // its own /../imx options as an inline group; a group whose automaton would exceed the table budget is split in halves.
-    if (f->logical_op == OP_OR && f->rules.size() >= 2 && !getenv("FLBGPU_NO_MERGE")) {
+    if (f->logical_op == OP_OR && f->rules.size() >= 2 && !f->has_host_rules && !getenv("FLBGPU_NO_MERGE")) {
         std::vector<std::string> keys;
         std::vector<std::vector<int>> members;
         for (size_t i = 0; i < f->rules.size(); i++) {
@@ -813,6 +848,7 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
         };
         for (size_t k = 0; k < keys.size(); k++) merge(keys[k], members[k]);
         f->rules.swap(out);
+        f->host_rx.assign(f->rules.size(), nullptr);
     }
     if (!filter_common_init(f) || !f->d_rules.ensure(std::max<size_t>(1, f->rules.size()) * sizeof(GrepRule))) { delete f; return nullptr; }
     if (!f->rules.empty() &&
@@ -825,6 +861,18 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
 }
 
 extern "C" void flbgpu_filter_destroy(flbgpu_filter *f) { delete f; }
+
+// host rules of a filter (see "host rules" below): out[0] = how many of its rules / parsers run on the host's backtracking matcher,
+// out[1] = values it has searched so far, out[2] = of these, searches that ended on the backtrack budget (answered "no match", as the
+// reference answers its own limit), out[3] = records a host parser did not take (duplicate Key_Name entries, values >= 64 KB)
+extern "C" int flbgpu_filter_host_rules(flbgpu_filter *f, uint64_t *out4) {
+    if (!f || !out4) return -1;
+    uint64_t k = 0;
+    for (auto *b : f->host_rx) if (b) k++;
+    for (auto *p : f->parsers) if (p->bt) k++;
+    out4[0] = k; out4[1] = f->host_values; out4[2] = f->host_budget_over; out4[3] = f->host_unhandled;
+    return 0;
+}
 
 extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
     if (!p) return;
@@ -842,6 +890,45 @@ static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FP
 // error, hm the counters.  The emit pass (or the fused pair's decide + emit) follows.
 // pair mode (filter_grep follows and is evaluated inline): grep's rules for k_parser_rx, keep_len for k_parser_finish
 struct PairCtx { PgInline pg; uint32_t *keep_len; const flbgpu_filter *fg; uint32_t *desc; uint32_t dstride; };
+
+// ------------------------------------------------------------------------------------------ host rules
+// A Regex / Parser entry that is not a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K)
+// would abort start-up in the reference's place (src/flb_filter.c:691-697) if the filter refused it.  It does not: the DEVICE still
+// decodes every record, resolves the keys, evaluates the other rules, times, sizes and writes the records; only the search of that
+// one pattern runs on the host -- the product's own backtracking matcher (rxbt.inc; nothing under oracle/) over the values the device
+// located -- and its answers go back as one bit per row (filter_grep) or as the capture columns k_parser_rx would have written
+// (filter_parser).  Two passes over the chunk and a round trip through host memory: a correct slow path, counted
+// (flbgpu_filter_host_rules), never the timed one.
+//
+// the caller's copy of the chunk a host-level call uploaded (the values are read from it instead of a copy back)
+struct HostView { const void *dev = nullptr; const uint8_t *host = nullptr; size_t bytes = 0; };
+static thread_local HostView g_hostview;
+
+template <class F> static void parallel_rows(uint64_t n, F fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (n < 4096 || nt < 2) { fn((uint64_t) 0, n); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = ((n + nt - 1) / nt + 63) & ~63ull;           // (whole words of a bit column per thread)
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t a = (uint64_t) t * per, b = a + per < n ? a + per : n;
+        if (a < b) th.emplace_back([=]() { fn(a, b); });
+    }
+    for (auto &t : th) t.join();
+}
+
+// the chunk's bytes and row offsets on the host
+static bool host_chunk(const flbgpu_dev_chunk *in, hipStream_t st, std::vector<uint8_t> &copy, const uint8_t **data, std::vector<uint64_t> &off) {
+    off.resize((size_t) in->n + 1);
+    if (hipMemcpyAsync(off.data(), in->row_off, ((size_t) in->n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (g_hostview.dev == in->data && g_hostview.host && g_hostview.bytes >= in->bytes) *data = g_hostview.host;
+    else {
+        copy.resize((size_t) in->bytes + 16);
+        if (hipMemcpyAsync(copy.data(), in->data, (size_t) in->bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        *data = copy.data();
+    }
+    return hipStreamSynchronize(st) == hipSuccess;
+}
 
 // A call on a small chunk (what the engine appends at a time) is bound by the waits between its launches, not by its kernels: the
 // stages then launch AHEAD of the counters they normally wait for -- the fix-up pass, the rule decisions, the scan and the writer with
@@ -869,6 +956,63 @@ static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n)
     if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
     if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
     return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
+}
+
+// k_parser_rx's part for a host parser: the capture search of parser 0 on the values k_parser_locate found, by the backtracking
+// matcher; writes what that kernel writes -- the span columns, RF_RXOK, the time text column
+static bool host_parser_rx(flbgpu_filter *f, const flbgpu_dev_chunk *in, const ParserMatchArgs &ma, hipStream_t st) {
+    const uint64_t n = ma.n;
+    const flbgpu_parser *hp = f->parsers[0];
+    const DevParser &d = hp->dev;
+    const int ncap = 2 * d.nfields;
+    std::vector<uint32_t> info(3 * (size_t) n);
+    HIPOK(hipMemcpyAsync(info.data(), ma.info, info.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> copy;
+    std::vector<uint64_t> off;
+    const uint8_t *hd = nullptr;
+    if (!host_chunk(in, st, copy, &hd, off)) { set_err("filter_parser: copying the chunk back for the host parser failed"); return false; }
+    std::vector<uint32_t> caps((size_t) ncap * n, 0u), tbuf((size_t) TBUF_WORDS * n, 0u);
+    std::atomic<uint64_t> over{0}, vals{0}, unhandled{0};
+    const uint64_t total_bytes = in->bytes;
+    const int ng = rx::bt_ngroups(hp->bt);
+    parallel_rows(n, [&](uint64_t a, uint64_t b) {
+        std::vector<int> beg((size_t) ng + 1), end((size_t) ng + 1);
+        uint64_t ov = 0, nv = 0, un = 0;
+        for (uint64_t r = a; r < b; r++) {
+            uint32_t fl = info[r];
+            if (fl & RF_GENERIC) { info[r] = fl & ~(uint32_t) RF_GENERIC; un++; continue; }     // (duplicate Key_Name entries, a value of 64 KB or more: not taken)
+            if (!(fl & RF_CAND)) continue;
+            const uint32_t vo = info[(size_t) n + r], vlen = info[2 * (size_t) n + r];
+            if (off[r] + vo + (uint64_t) vlen > total_bytes) continue;
+            const uint8_t *val = hd + off[r] + vo;
+            const int res = rx::bt_search(hp->bt, val, (int) vlen, beg.data(), end.data());
+            nv++;
+            if (res == -4) ov++;
+            if (res <= 0) continue;
+            for (int q = 0; q < d.nfields; q++) {
+                const int g = d.field_group[q];
+                caps[(size_t) (2 * q) * n + r] = beg[(size_t) g] >= 0 ? (uint32_t) beg[(size_t) g] : CAP_UNSET;
+                caps[(size_t) (2 * q + 1) * n + r] = end[(size_t) g] >= 0 ? (uint32_t) end[(size_t) g] : CAP_UNSET;
+            }
+            info[r] = fl | RF_RXOK;
+            if (d.time_field >= 0) {
+                const uint32_t tb = caps[(size_t) (2 * d.time_field) * n + r], te = caps[(size_t) (2 * d.time_field + 1) * n + r];
+                if (tb != CAP_UNSET && te != CAP_UNSET && te >= tb && te - tb <= 4 * TBUF_WORDS) {
+                    uint8_t tx[4 * TBUF_WORDS];
+                    memset(tx, 0, sizeof(tx));
+                    memcpy(tx, val + tb, te - tb);
+                    for (int k = 0; k < TBUF_WORDS; k++) { uint32_t w; memcpy(&w, tx + 4 * k, 4); tbuf[(size_t) k * n + r] = w; }
+                }
+            }
+        }
+        over += ov; vals += nv; unhandled += un;
+    });
+    f->host_budget_over += over.load(); f->host_values += vals.load(); f->host_unhandled += unhandled.load();
+    HIPOK(hipMemcpyAsync(ma.caps, caps.data(), caps.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPOK(hipMemcpyAsync(ma.info, info.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (ma.tbuf) HIPOK(hipMemcpyAsync(ma.tbuf, tbuf.data(), tbuf.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPOK(hipStreamSynchronize(st));            // (the vectors above are the source of the copies)
+    return true;
 }
 
 static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
@@ -1054,7 +1198,18 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         return true;
     };
     if ((f->parsers[0]->dev.is_json || !use_tile || tile_in_lds) && !prep_now()) return false;
-    if (f->parsers[0]->dev.is_json) {
+    if (f->parsers[0]->bt) {
+        // a HOST parser (the Regex is not a regular expression): locate on the device, the capture search on the host, finish on the
+        // device.  Every single candidate is located as one (no length limit of a device walker applies).
+        ParserMatchArgs ml = ma;
+        ml.caps_in_lds = 1; ml.chk_len = 0x7FFFFFFFu;
+        { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ml, cus, st); }
+        if (!host_parser_rx(f, in, ma, st)) return false;
+        { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+    }
+    else if (f->parsers[0]->dev.is_json) {
         // Format json: one size kernel replaces locate / rx / finish
         { ProfScope ps(f, st, "k_pjson_size"); launch_pjson_size(ma, cus, st); }
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
@@ -1347,6 +1502,63 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
         }
         if (!fits) ga.nslots = 0;
     }
+    ga.host_collect = 0;
+    if (f->has_host_rules) {
+        // host rules, pass 1: where their values sit; the host's matcher answers; the answers go back as one bit per row
+        const size_t words = (size_t) ((n + 31) / 32);
+        size_t nh = 0;
+        for (auto *b : f->host_rx) if (b) nh++;
+        if (!f->d_hspans.ensure(nh * n * 2 * sizeof(uint32_t)) || !f->d_hbits.ensure(nh * words * sizeof(uint32_t))) return false;
+        HIPOK(hipMemsetAsync(f->d_hspans.p, 0xFF, nh * n * 2 * sizeof(uint32_t), st));
+        std::vector<GrepRule> rr = f->rules;
+        {
+            size_t k = 0;
+            for (size_t i = 0; i < rr.size(); i++) if (f->host_rx[i]) { rr[i].host_mode = 1; rr[i].host_io = f->d_hspans.as<uint32_t>() + k * n * 2; k++; }
+        }
+        HIPOK(hipStreamSynchronize(st));
+        HIPOK(hipMemcpy(f->d_rules.p, rr.data(), rr.size() * sizeof(GrepRule), hipMemcpyHostToDevice));
+        ga.host_collect = 1;
+        { ProfScope ps(f, st, "k_grep_match(values for the host rules)"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
+        ga.host_collect = 0;
+        std::vector<uint32_t> spans(nh * n * 2);
+        HIPOK(hipMemcpyAsync(spans.data(), f->d_hspans.p, spans.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        std::vector<uint8_t> copy;
+        std::vector<uint64_t> off;
+        const uint8_t *hd = nullptr;
+        if (!host_chunk(in, st, copy, &hd, off)) { set_err("filter_grep: copying the chunk back for the host rules failed"); return false; }
+        std::vector<uint32_t> bits(nh * words, 0u);
+        std::atomic<uint64_t> over{0}, vals{0};
+        size_t k = 0;
+        for (size_t i = 0; i < rr.size(); i++) {
+            if (!f->host_rx[i]) continue;
+            const uint32_t *sp = spans.data() + k * n * 2;
+            uint32_t *bw = bits.data() + k * words;
+            const rx::BtProgram *bt = f->host_rx[i];
+            const uint64_t total_bytes = in->bytes;
+            parallel_rows(n, [&, sp, bw, bt, total_bytes](uint64_t a, uint64_t b) {
+                uint64_t ov = 0, nv = 0;
+                for (uint64_t r = a; r < b; r++) {
+                    const uint32_t len = sp[2 * r + 1], o = sp[2 * r];
+                    if (len == 0xFFFFFFFFu || off[r] + o + (uint64_t) len > total_bytes || len > 0x7FFFFFF0u) continue;
+                    const int res = rx::bt_search(bt, hd + off[r] + o, (int) len, nullptr, nullptr);
+                    nv++;
+                    if (res == -4) ov++;
+                    if (res > 0) bw[r >> 5] |= 1u << (r & 31);
+                }
+                over += ov; vals += nv;
+            });
+            rr[i].host_mode = 2;
+            rr[i].host_io = f->d_hbits.as<uint32_t>() + k * words;
+            k++;
+        }
+        f->host_budget_over += over.load(); f->host_values += vals.load();
+        HIPOK(hipMemcpy(f->d_hbits.p, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(f->d_rules.p, rr.data(), rr.size() * sizeof(GrepRule), hipMemcpyHostToDevice));
+        // (what pass 1 counted is dropped)
+        memset(&hm, 0, sizeof(hm));
+        hm.first_bad = ~0ull;
+        HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
+    }
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     total = 0;
@@ -1410,6 +1622,7 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     // call, inside the hot single-pass kernel): the unfused kernels take the pair
     if (d.utf8.nfa_on || d.ascii.stub) return false;
     for (const GrepRule &r : fg->rules) if (r.utf8.nfa_on) return false;
+    if (fp->parsers[0]->bt || fg->has_host_rules) return false;                 // (host rules: the unfused kernels)
     return true;
 }
 
@@ -2041,6 +2254,10 @@ extern "C" int flbgpu_filter_chain_run(flbgpu_filter *const *filters, int nfilte
     int64_t n = staged_upload(f, (const uint8_t *) data, bytes, &consumed, &row_off, small);
     if (n < 0) return FLBGPU_FILTER_NOTOUCH;
     small = small && spec_wanted((uint64_t) n, bytes);
+    struct ViewScope {
+        ViewScope(const void *dev, const void *host, size_t bytes) { g_hostview.dev = dev; g_hostview.host = (const uint8_t *) host; g_hostview.bytes = bytes; }
+        ~ViewScope() { g_hostview = HostView(); }
+    } view_scope(f->h_in_data.p, data, bytes);                 // (host rules read the values from the caller's copy)
     struct SpecScope {
         SpecScope(bool on, flbgpu_filter *f0) { g_spec = SpecCall(); g_spec.on = on; if (on) { g_spec.sink = (uint8_t *) f0->hp_stage[1].p; g_spec.sink_cap = STAGE_SLAB; } }
         ~SpecScope() { g_spec = SpecCall(); }

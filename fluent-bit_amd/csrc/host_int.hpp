@@ -90,7 +90,7 @@ int simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
 bool parse_ra(const char *pat, DevKey &k, std::string &why);
 // "<field> <regex>" rule of filter_grep / filter_log_to_metrics -> device rule (tables uploaded into blobs)
-bool compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why);
+bool compile_rule(const std::string &ra_field, const char *pattern, GrepRule &r, std::vector<TableBlob *> &blobs, std::string &why, bool *nonregular = nullptr);
 
 }  // namespace flbgpu
 
@@ -146,6 +146,13 @@ struct flbgpu_filter {
     // filter_grep (and the rule gate of filter_log_to_metrics)
     std::vector<flbgpu::GrepRule> rules;
     std::vector<flbgpu::TableBlob *> rule_blobs;
+    // host rules (flbgpu.cpp): rules[i] whose pattern is not a regular expression -- host_rx[i] is the backtracking matcher's program
+    // (rx.hpp bt_compile), nullptr for a device rule; values the matcher gave up on (its backtrack budget); filter_parser: records the
+    // host parser did not take (duplicate Key_Name entries, values of 64 KB and more)
+    std::vector<rx::BtProgram *> host_rx;
+    bool has_host_rules = false;
+    flbgpu::DevBuf d_hspans, d_hbits;
+    uint64_t host_budget_over = 0, host_unhandled = 0, host_values = 0;
     flbgpu::DevBuf d_rules;
     int logical_op = 0;
     // filter_log_to_metrics
@@ -169,6 +176,8 @@ struct flbgpu_filter {
         for (auto &p : pending) { (void) hipEventDestroy(p.e0); (void) hipEventDestroy(p.e1); }
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
+        for (auto *b : host_rx) if (b) rx::bt_free(b);
+        d_hspans.release(); d_hbits.release();
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                                  &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix};
         for (auto *b : all) b->release();

@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(GREP_BLOCK) k_grep_match(GrepArgs a) {
                 bool keep = false;
                 if (!(ev.flags & (RF_BAD | RF_SKIP))) {
                     bool valid = false;
-                    keep = grep_decide(a, ev, &valid, a.rules_lds_total ? (LDS_AS const uint8_t *) lds_rules : (LDS_AS const uint8_t *) nullptr);
+                    keep = grep_decide(a, ev, &valid, a.rules_lds_total ? (LDS_AS const uint8_t *) lds_rules : (LDS_AS const uint8_t *) nullptr, r, rec);
                     if (!valid) valid = mp_skip(ev.body, rec_end, 1) == rec_end;  // no rule walked the map
                     if (!valid) ev.flags = RF_BAD;
                 }

@@ -1,0 +1,183 @@
+"""Rules / parsers that are not regular expressions (look-around, atomic groups, possessive repeats, back-references) do not abort
+start-up: the device does everything but the search of that pattern, the product's backtracking matcher (csrc/rxbt.inc) answers on
+the host (flbgpu.cpp "host rules").  Checked against the REAL Onigmo's decisions on the same values (oracle/_ref/libonig_ref.so travels
+with the snapshot) and against the oracle's filters run with an equivalent regular expression."""
+import ctypes, os, random, sys
+import numpy as np
+import pytest
+import oracle_binding as ob
+import synth
+import flbamd_loader
+import rxdiff
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(rxdiff.load_ref() is None, reason="oracle/_ref/libonig_ref.so not built")
+APACHE2 = r'^(?<host>[^ ]*) [^ ]* (?<user>[^ ]*) \[(?<time>[^\]]*)\] "(?<method>\S+)(?: +(?<path>[^ ]*) +\S*)?" (?<code>[^ ]*) (?<size>[^ ]*)(?: "(?<referer>[^\"]*)" "(?<agent>.*)")?$'
+TF = "%d/%b/%Y:%H:%M:%S %z"
+
+
+@pytest.fixture(scope="module")
+def g():
+    m = flbamd_loader.load()
+    m.init(0)
+    return m
+
+
+WORDS = ["GET /health 200", "GET /ping 200", "POST /api/v1/items 201", "error: disk full", "warn: retry 3", "user=alice id=alice", "user=bob id=carol",
+         "'quoted' text", '"double" quoted"', "abcabc", "abcabd", "price 100 USD", "price 100USD", "tail\n", "", "é=é", "x" * 300, "aaa", "aab", "#comment", "k=v"]
+
+
+def records(n, seed, keys=("log",), extra=True):
+    rng = random.Random(seed)
+    recs, vals = [], []
+    for i in range(n):
+        body = {}
+        v = {}
+        for k in keys:
+            t = rng.choice(WORDS) + (" %d" % rng.randrange(1000) if rng.random() < 0.5 else "")
+            body[k] = t
+            v[k] = t
+        if extra and rng.random() < 0.2:
+            body["n"] = i
+        if rng.random() < 0.05:
+            body[keys[0]] = i                     # not a string: no rule matches it
+            v[keys[0]] = None
+        recs.append(synth.v2_record(1700000000 + i, i % 1000, body))
+        vals.append(v)
+    return recs, vals
+
+
+def ref_match(ref, pat, value):
+    if value is None:
+        return False
+    eng = rxdiff.RefRegex(ref, pat.encode() if isinstance(pat, str) else pat)
+    assert eng.ok
+    return eng.search(value.encode() if isinstance(value, str) else value) is not None
+
+
+HOST_PATTERNS = [r"^(?!.*(?:health|ping)).*\d$", r"(?<=user=)(\w+) id=\1", r"(?>a+)b", r"^(['\"]).*\1", r"\d+(?! ?USD)\b", r"(abc)\1", r"error(?=:)|warn(?=:)", r"a++b"]
+
+
+@needs_ref
+@pytest.mark.parametrize("pat", HOST_PATTERNS)
+def test_grep_host_rule_against_the_real_engine(g, pat):
+    ref = rxdiff.load_ref()
+    recs, vals = records(6000, 5)
+    blob = b"".join(recs)
+    for kind in ("regex", "exclude"):
+        f = g.FilterGrep([(kind, "log " + pat)])
+        assert f.host_rules()["rules"] == 1
+        r, out = f.filter(blob)
+        keep = [ref_match(ref, pat, v["log"]) == (kind == "regex") for v in vals]
+        want = b"".join(x for x, k in zip(recs, keep) if k)
+        if all(keep):
+            assert r == ob.NOTOUCH
+        else:
+            assert r == ob.MODIFIED and out == want
+        st = f.host_rules()
+        assert st["values"] > 0 and st["budget_over"] == 0
+        # the device-level call: no host copy of the chunk at hand, the values come back from the device
+        data = np.frombuffer(blob, dtype=np.uint8)
+        n, off, cons = g.index_host(blob)
+        L = g.lib()
+        offs = np.array(off, dtype=np.uint64)
+        d_data = L.flbgpu_dev_alloc(data.nbytes); d_off = L.flbgpu_dev_alloc(offs.nbytes)
+        L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, data.nbytes); L.flbgpu_memcpy_h2d(d_off, offs.ctypes.data, offs.nbytes)
+        chunk = g.DevChunk(d_data, d_off, n, data.nbytes)
+        r2, o2 = f.filter_dev(chunk)
+        if all(keep):
+            assert r2 == ob.NOTOUCH
+        else:
+            got = np.empty(int(o2.bytes), dtype=np.uint8)
+            L.flbgpu_memcpy_d2h(got.ctypes.data, o2.data, int(o2.bytes))
+            assert r2 == ob.MODIFIED and got.tobytes() == want
+        L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+        f.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("op", [None, "and", "or"])
+def test_host_and_device_rules_together(g, op):
+    """a host rule between device rules, every Logical_Op: the loop's order and its early ends are the device's"""
+    ref = rxdiff.load_ref()
+    recs, vals = records(5000, 8, keys=("log", "msg"))
+    blob = b"".join(recs)
+    rules = [("regex", r"log \d"), ("regex", r"msg ^(?!.*(?:health|ping))"), ("regex", r"log [a-z]")] if op else \
+            [("exclude", r"log ^#"), ("regex", r"msg (?<![a-z])\d+$"), ("exclude", r"log USD"), ("regex", r"log (\w)\1")]
+    f = g.FilterGrep(rules, op)
+    assert f.host_rules()["rules"] == (1 if op else 2)
+    r, out = f.filter(blob)
+
+    def rule(i, v):
+        kind, kv = rules[i]
+        key, pat = kv.split(" ", 1)
+        return ref_match(ref, pat, v[key])
+    keep = []
+    for v in vals:
+        if op is None:
+            k = True
+            for i, (kind, _) in enumerate(rules):
+                m = rule(i, v)
+                if not m:
+                    if kind == "regex":
+                        k = False
+                        break
+                else:
+                    k = kind != "exclude"
+                    break
+            keep.append(k)
+        else:
+            found = False
+            for i in range(len(rules)):
+                found = rule(i, v)
+                if (op == "or" and found) or (op == "and" and not found):
+                    break
+            keep.append(found)
+    want = b"".join(x for x, k in zip(recs, keep) if k)
+    assert r == ob.MODIFIED and out == want
+    f.close()
+
+
+def test_host_parser_equals_an_equivalent_regular_one(g):
+    """the same captures by construction: a look-ahead that only repeats what the next atom demands, an atomic group / a possessive
+    repeat where nothing could be given back anyway -- against the oracle's filter_parser with the plain pattern"""
+    data, off, ep = synth.apache_records(20000)
+    blob = bytes(data)
+    host_rx = APACHE2.replace(r"^(?<host>[^ ]*) ", r"^(?=[^ ]* )(?<host>[^ ]*+) ").replace(r'(?<code>[^ ]*) ', r'(?<code>(?>[^ ]*)) ')
+    assert host_rx != APACHE2
+    p = g.Parser(host_rx, time_fmt=TF, time_key="time")
+    f = g.FilterParser("log", [p])
+    assert f.host_rules()["rules"] == 1
+    r, out = f.filter(blob)
+    ro, oo = ob.FilterParser("log", [ob.Parser(regex=APACHE2, time_fmt=TF, time_key="time")]).filter(blob)
+    assert r == ro == ob.MODIFIED and out == oo
+    st = f.host_rules()
+    assert st["values"] == 20000 and st["unhandled"] == 0 and st["budget_over"] == 0
+    # ... and in a chain in front of a device grep
+    ch = g.FilterChain([f, g.FilterGrep([("regex", r"code ^5\d\d$")])])
+    r2, o2 = ch.filter(blob)
+    r3, o3 = ob.Grep([("regex", r"code ^5\d\d$")]).filter(oo)
+    assert r2 == r3 == ob.MODIFIED and o2 == o3
+
+
+def test_host_parser_that_rejects_lines(g):
+    recs, vals = records(8000, 21)
+    blob = b"".join(recs)
+    p = g.Parser(r"^(?!#)(?<key>[^=]+)=(?<val>.*)$")
+    f = g.FilterParser("log", [p], True, False)
+    r, out = f.filter(blob)
+    ro, oo = ob.FilterParser("log", [ob.Parser(regex=r"^(?<key>[^#=][^=]*)=(?<val>.*)$")], True, False).filter(blob)
+    assert r == ro and out == oo
+
+
+def test_refused_when_asked_to(g):
+    os.environ["FLBGPU_NO_HOST_RULES"] = "1"
+    try:
+        with pytest.raises(Exception):
+            g.FilterGrep([("regex", r"log a(?=b)")])
+        with pytest.raises(Exception):
+            g.Parser(r"^(?<a>x)(?=y)")
+    finally:
+        del os.environ["FLBGPU_NO_HOST_RULES"]
+    with pytest.raises(Exception):
+        g.FilterGrep([("regex", r"log (?~abc)")])             # what the host's matcher does not take either is still refused
