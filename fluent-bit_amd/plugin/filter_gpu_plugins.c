@@ -67,6 +67,18 @@ struct grep_gpu_ctx {
     struct flb_filter_instance *ins;
 };
 
+
+/* a pattern that is not a regular expression (look-around, back-references, ...) does not fail the filter: the host's backtracking
+ * matcher answers it (include/flb_gpu.h flbgpu_filter_host_rules) -- a slow path, said at start-up */
+static void gpu_note_host_rules(struct flb_filter_instance *f_ins, flbgpu_filter *f)
+{
+    uint64_t hr[4] = {0, 0, 0, 0};
+    if (flbgpu_filter_host_rules(f, hr) == 0 && hr[0] > 0) {
+        flb_plg_warn(f_ins, "%llu pattern(s) of this filter are not regular expressions (look-around, atomic groups, back-references): "
+                     "their values are searched on the host, everything else stays on the GPU", (unsigned long long) hr[0]);
+    }
+}
+
 #ifdef FLBGPU_WITH_GREP
 static int cb_grep_gpu_init(struct flb_filter_instance *f_ins, struct flb_config *config, void *data)
 {
@@ -122,6 +134,7 @@ static int cb_grep_gpu_init(struct flb_filter_instance *f_ins, struct flb_config
         flb_free(ctx);
         return -1;
     }
+    gpu_note_host_rules(f_ins, ctx->f);
     flb_filter_set_context(f_ins, ctx);
     return 0;
 }
@@ -355,6 +368,7 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
         flb_plg_error(f_ins, "%s", flbgpu_last_error());
         goto error;
     }
+    gpu_note_host_rules(f_ins, ctx->f);
     flb_filter_set_context(f_ins, ctx);
     return 0;
 
