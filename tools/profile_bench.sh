@@ -5,7 +5,6 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 O=$R/gpurun_out/profile
 rm -rf $O; mkdir -p $O
-python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 CMD="python $R/bench.py --no-cpu --no-secondary --steps 5 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats_run.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_fetch -- $CMD > /dev/null 2>&1
@@ -34,5 +33,8 @@ json.dump({"command": "python bench.py --no-cpu --no-secondary --steps 5 --warmu
 for k, v in out.items():
     if "parser" in k or "grep" in k or "k_pg" in k: print(k, {c: round(x / 1e6, 3) for c, x in v.items()})
 PY
+# the default bench line LAST: it reads the PMC summary of the same kernel sources for roofline.traffic
+cp $O/pmc_summary.json $R/$(python -c "import sys; sys.path.insert(0,'$R'); import bench; print(bench.PMC_FILE)")
+python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 head -12 $O/kernel_stats.csv | cut -c1-160
 cat $O/bench_default.json | cut -c1-2600
