@@ -264,7 +264,10 @@ static int add_decoders(flbgpu_parser *g, struct flb_parser *p)
         mk_list_foreach(r_head, &dec->rules) {
             rule = mk_list_entry(r_head, struct flb_parser_dec_rule, _head);
             if (rule->backend < 0 || rule->backend > 3) {
-                return -1;
+                /* (flbgpu_last_error would show an older message: say it here) */
+                flb_error("[gpu] parser '%s': decoder backend %d of key '%s' is not one of json / escaped / escaped_utf8 / mysql_quoted",
+                          p->name ? p->name : "", rule->backend, dec->key ? dec->key : "");
+                return -2;
             }
             if (flbgpu_parser_add_decoder(g, rule->type == FLB_PARSER_DEC_AS, backends[rule->backend], dec->key,
                                           rule->action == FLB_PARSER_ACT_TRY_NEXT ? "try_next" :
