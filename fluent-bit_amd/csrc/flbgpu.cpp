@@ -1079,9 +1079,13 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         tile_wave_bytes = tile_in_lds ? (uint32_t) TILE_BYTES + fx.nslots * 128u : fx.nslots * 128u + 64u * (4 * TBUF_WORDS + 4);
         if (pair) for (int i = 0; i < pair->pg.nrules; i++) if (tile_pg_room + ((pair->pg.rule_lds_bytes[i] + 15) & ~15u) <= 8192) tile_pg_room += (pair->pg.rule_lds_bytes[i] + 15) & ~15u;
         int waves = (int) ((lds_cap - 64 - fx.bytes - tile_pg_room) / tile_wave_bytes);
-        const int wmax = tile_in_lds ? 8 : 16;
+        // the register kernel: 12 waves per CU with the compact tables (the build without spills, tile_kernels.inc), 16 on request
+        // (FLBGPU_TILE_WAVES=16) and for the older table form
+        const int wcap = tile_in_lds ? 8 : 16;
+        int wmax = tile_in_lds ? 8 : (use_fx2 ? 12 : 16);
+        if (waves > wcap) waves = wcap;
+        if (getenv("FLBGPU_TILE_WAVES")) { int w = atoi(getenv("FLBGPU_TILE_WAVES")); if (w >= 1 && w <= wcap) wmax = w; }
         if (waves > wmax) waves = wmax;
-        if (getenv("FLBGPU_TILE_WAVES")) { int w = atoi(getenv("FLBGPU_TILE_WAVES")); if (w >= 1 && w < waves) waves = w; }
         if (waves < 2) use_tile = false;
         else { rx_threads = waves * 64; caps_bytes = 1; }
     }
