@@ -289,10 +289,9 @@ static bool expand_time_fmt(const char *fmt, std::string &out, std::string &why)
         case 'R': out += "%H:%M%\x01"; break;
         case 'r': out += "%I:%M:%S %p%\x01"; break;
         case 'c': out += "%a %b %e %H:%M:%S %Y%\x01"; break;
-        case 'Z': why = "%Z (time zone abbreviations) is not supported on the GPU path"; return false;
         case '\0': why = "dangling % in time format"; return false;
         default:
-            if (!strchr("%AaBbhCedkHlIjMmpSsUWVwugGYyznt", *p)) { why = std::string("unsupported time directive %") + *p; return false; }
+            if (!strchr("%AaBbhCedkHlIjMmpSsUWVwugGYyzZnt", *p)) { why = std::string("unsupported time directive %") + *p; return false; }
             out += '%'; out += *p;
         }
     }

@@ -9,7 +9,7 @@
 #include "mlo.hpp"
 
 using namespace flbgpu;
-static const int ML_TRUNC_ROUNDS = 256;      // truncating continuations settled per read (flbgpu_ml_append_dev)
+static const int ML_TRUNC_ROUNDS = 4096;     // truncating continuations settled per read (flbgpu_ml_append_dev): ~0.15 ms each, so a read stalls 0.6 s at worst
 
 struct MlRuleSrc { std::vector<std::string> from; std::string regex, to; bool start = false; };
 struct MlPending { int rule; std::string pat, shown; unsigned opts; bool neg; };
@@ -652,7 +652,7 @@ extern "C" int flbgpu_ml_append_dev(flbgpu_ml_stream *s, const void *d_text, uin
         // One truncating continuation is settled per round (the lines behind it are met in another state, so what overflows behind it is
         // only known after the pass), each round a full pass + a wait: a read with K of them costs K passes.  Reads are bounded -- past
         // ML_TRUNC_ROUNDS the call fails like a read the list path turns down, and the caller keeps THIS read on the CPU's flb_ml (a
-        // buffer_limit so small that hundreds of lines of one read overflow it is a configuration, not a log burst) -- ADVICE r3.
+        // buffer_limit so small that thousands of lines of one read overflow it is a configuration, not a log burst) -- ADVICE r3.
         if (round >= ML_TRUNC_ROUNDS || round > nl) {
             set_err("multiline: more than %d lines of one read overflow buffer_limit (%llu bytes): this read is not taken (keep it on the CPU path)", ML_TRUNC_ROUNDS, (unsigned long long) a.p.buffer_limit);
             return -1;

@@ -6,7 +6,7 @@
  * setlocale, so they are the C-locale English names).  The reference keeps century / relyear /
  * fields in function statics (src/flb_strptime.c:261); this restatement keeps them in a
  * per-call state, which is observably identical for the single-threaded call pattern.
- * The tzname fallback of %Z (:575-615) is not restated (returns NULL).
+ * The tzname fallback of %Z (:630-650) is restated for a process whose zone is UTC.
  */
 #define _GNU_SOURCE
 #include <ctype.h>
@@ -288,7 +288,12 @@ literal:
                 if (strncmp((const char *) bp, "GMT", 3) == 0 || strncmp((const char *) bp, "UTC", 3) == 0) {
                     tm->tm.tm_isdst = 0; tm->gmtoff = 0; bp += 3;
                 }
-                else return NULL;   /* tzname fallback not restated */
+                else if (strncasecmp((const char *) bp, "UTC", 3) == 0) {
+                    /* the last resort (:630-650): the names of the PROCESS's zone, tzname[], without case -- restated for a process
+                     * whose zone is UTC (TZ unset, what a container has: tzname = {"UTC", "UTC"}, timezone = 0) */
+                    tm->tm.tm_isdst = 0; tm->gmtoff = 0; bp += 3;
+                }
+                else return NULL;
             }
             continue;
         }

@@ -15,9 +15,28 @@ TEXTS = ["10/Oct/2000:13:55:36 -0700", "2017-11-01T22:25:21", "2017-11-01 22:25:
          "0000-01-01T00:00:00", "9999-12-31T23:59:59", "69-01-01", "68-12-31", "2017-1-1 1:1:1", "2017-11-01T22:25:21 +9999", "2017-11-01T22:25:21 -0", "Sept 1 2017"]
 
 
+# %Z (round 4: on the device too): every abbreviation of the reference's table in three spellings, abbreviations with a letter or a digit
+# behind them, the exact-case GMT / UTC last resort, names no table holds (the tzname[] resort depends on the process's TZ: UTC here)
+ZONE_FORMATS = ["%Y-%m-%d %H:%M:%S %Z", "%Z %Y", "%H:%M %Z|%Y", "%Y%Z"]
+ZONES = ["GMT", "UTC", "Z", "UT", "EST", "EDT", "CST", "CDT", "MST", "MDT", "PST", "PDT", "AKST", "AKDT", "HST", "HADT", "AST", "ADT", "NST", "NDT", "WET", "WEST",
+         "CET", "CEST", "EET", "EEST", "MSK", "MSD", "ART", "BRT", "BRST", "CLT", "CLST", "AEST", "AEDT", "ACST", "ACDT", "AWST", "NZST", "NZDT", "JST", "KST", "SGT", "IST",
+         "GST", "ICT", "WIB", "WITA", "WIT", "MYT", "BDT", "NPT", "WAT", "CAT", "EAT", "SAST", "A", "B", "J", "K", "M", "N", "Y", "XYZ", "GMTx", "UTC5", "GMT+1", "UTCZ",
+         "ESTx", "EST5", "WITAX", "WITA.", "", "é", "Zulu", "gm", "ut", "utcx"]
+
+
+def zone_cases():
+    out = []
+    for f in ZONE_FORMATS:
+        for z in ZONES:
+            for sp in (z, z.lower(), z.capitalize()):
+                t = f.replace("%Y-%m-%d %H:%M:%S", "2017-11-01 22:25:21").replace("%H:%M", "22:25").replace("%Y", "2017").replace("%Z", sp)
+                out.append((f, t))
+    return sorted(set(out))
+
+
 def corpus(seed=20260921, extra=4000):
     rng = random.Random(seed)
-    out = [(f, t) for f in FORMATS for t in TEXTS]
+    out = [(f, t) for f in FORMATS for t in TEXTS] + zone_cases()
     alpha = "0123456789 :-/+TZaApPmMeEoOcCtTnNvVdDbBuUgGsS.%\t"
     for _ in range(extra):
         f = rng.choice(FORMATS)

@@ -108,7 +108,7 @@ def test_strptime_kat_on_device(g):
                 try:
                     pg = g.Parser(**kw)
                 except ValueError:
-                    refused += 1                        # %Z: refused at create, never a silent difference
+                    refused += 1                        # (a directive the device does not take: refused at create, never a silent difference)
                     continue
                 fpg = g.FilterParser("log", [pg])
                 x, y = ob.FilterParser("log", [po]).filter(blob), fpg.filter(blob)
