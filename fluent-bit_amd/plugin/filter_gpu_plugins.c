@@ -248,6 +248,8 @@ static char *types_to_str(struct flb_parser *p)
 /* the parser's Decode_Field / Decode_Field_As rules (struct flb_parser.decoders: one struct flb_parser_dec per key with its rules
  * in configuration order, src/flb_parser_decoder.c:593-776) handed to the device parser in the same order */
 #include <fluent-bit/flb_parser_decoder.h>
+static char gpu_shim_err[256];      /* what add_decoders refused (flbgpu_last_error would show an older message) */
+
 static int add_decoders(flbgpu_parser *g, struct flb_parser *p)
 {
     static const char *backends[] = { "json", "escaped", "escaped_utf8", "mysql_quoted" };
@@ -264,9 +266,8 @@ static int add_decoders(flbgpu_parser *g, struct flb_parser *p)
         mk_list_foreach(r_head, &dec->rules) {
             rule = mk_list_entry(r_head, struct flb_parser_dec_rule, _head);
             if (rule->backend < 0 || rule->backend > 3) {
-                /* (flbgpu_last_error would show an older message: say it here) */
-                flb_error("[gpu] parser '%s': decoder backend %d of key '%s' is not one of json / escaped / escaped_utf8 / mysql_quoted",
-                          p->name ? p->name : "", rule->backend, dec->key ? dec->key : "");
+                snprintf(gpu_shim_err, sizeof(gpu_shim_err), "parser '%s': decoder backend %d of key '%s' is not one of json / escaped / "
+                         "escaped_utf8 / mysql_quoted", p->name ? p->name : "", rule->backend, dec->key ? dec->key : "");
                 return -2;
             }
             if (flbgpu_parser_add_decoder(g, rule->type == FLB_PARSER_DEC_AS, backends[rule->backend], dec->key,
@@ -283,6 +284,7 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
 {
     char *types;
     char off[16];
+    int ret;
     struct mk_list *head;
     struct flb_kv *kv;
     struct flb_parser *p;
@@ -354,8 +356,9 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             flb_plg_error(f_ins, "%s", flbgpu_last_error());
             goto error;
         }
-        if (add_decoders(ctx->parsers[ctx->n_parsers], p) != 0) {
-            flb_plg_error(f_ins, "%s", flbgpu_last_error());
+        ret = add_decoders(ctx->parsers[ctx->n_parsers], p);
+        if (ret != 0) {
+            flb_plg_error(f_ins, "%s", ret == -2 ? gpu_shim_err : flbgpu_last_error());
             ctx->n_parsers++;
             goto error;
         }
