@@ -449,6 +449,68 @@ static int n_twins = 0;
 static unsigned long twin_clock = 0;
 static pthread_mutex_t twins_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* The signature (every option, as text) is what makes two parsers the same twin -- built with malloc + snprintf.  A call for the parser
+ * a thread used last skips it: the parser's address, a fingerprint of the same options computed without allocating (FNV-1a over the
+ * strings, the numbers, the Types entries and the decoder rules) and the generation of the twin table (bumped whenever a slot is given
+ * to another parser) say the slot it found then is still the one. */
+static __thread struct { const struct flb_parser *p; uint64_t fp; unsigned gen; int slot; } twin_hit = { NULL, 0, 0, -1 };
+static unsigned twin_gen = 1;
+
+static uint64_t fnv_str(uint64_t h, const char *s)
+{
+    if (!s) {
+        return (h ^ 0xfe) * 0x100000001b3ULL;
+    }
+    while (*s) {
+        h = (h ^ (unsigned char) *s++) * 0x100000001b3ULL;
+    }
+    return (h ^ 0xff) * 0x100000001b3ULL;
+}
+
+static uint64_t fnv_int(uint64_t h, long v)
+{
+    int i;
+
+    for (i = 0; i < 8; i++) {
+        h = (h ^ (unsigned char) (v >> (8 * i))) * 0x100000001b3ULL;
+    }
+    return h;
+}
+
+static uint64_t twin_fingerprint(struct flb_parser *parser)
+{
+    int i;
+    uint64_t h = 0xcbf29ce484222325ULL;
+    struct mk_list *head;
+    struct mk_list *r_head;
+    struct flb_parser_dec *dec;
+    struct flb_parser_dec_rule *rule;
+
+    h = fnv_str(h, parser->name);
+    h = fnv_str(h, parser->p_regex);
+    h = fnv_str(h, parser->time_fmt_full);
+    h = fnv_str(h, parser->time_key);
+    h = fnv_int(h, parser->skip_empty);
+    h = fnv_int(h, parser->time_offset);
+    h = fnv_int(h, parser->time_keep);
+    h = fnv_int(h, parser->time_strict);
+    for (i = 0; i < parser->types_len; i++) {
+        h = fnv_str(h, parser->types[i].key);
+        h = fnv_int(h, parser->types[i].type);
+    }
+    if (parser->decoders) {
+        mk_list_foreach(head, parser->decoders) {
+            dec = mk_list_entry(head, struct flb_parser_dec, _head);
+            mk_list_foreach(r_head, &dec->rules) {
+                rule = mk_list_entry(r_head, struct flb_parser_dec_rule, _head);
+                h = fnv_str(h, dec->key);
+                h = fnv_int(h, rule->type * 10000 + rule->backend * 100 + rule->action);
+            }
+        }
+    }
+    return h;
+}
+
 static char *twin_signature(struct flb_parser *parser, const char *types)
 {
     size_t len;
@@ -501,24 +563,33 @@ int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
     int64_t sec = 0;
     int64_t nsec = 0;
     char off[16];
-    char *types;
-    char *sig;
+    char *types = NULL;
+    char *sig = NULL;
+    uint64_t fp;
     flbgpu_parser *g = NULL;
 
     if (parser->type != FLB_PARSER_REGEX || parser->time_zone != NULL || parser->time_system_timezone) {
         return -1;
     }
-    types = types_to_str(parser);
-    sig = twin_signature(parser, types);
-    if (!sig) {
-        flb_free(types);
-        return -1;
-    }
+    fp = twin_fingerprint(parser);
     pthread_mutex_lock(&twins_mu);
-    for (i = 0; i < n_twins; i++) {
-        if (twins[i].sig && strcmp(twins[i].sig, sig) == 0) {
-            slot = i;
-            break;
+    if (twin_hit.p == parser && twin_hit.fp == fp && twin_hit.gen == twin_gen && twin_hit.slot >= 0 && twin_hit.slot < n_twins) {
+        slot = twin_hit.slot;
+    }
+    else {
+        pthread_mutex_unlock(&twins_mu);
+        types = types_to_str(parser);
+        sig = twin_signature(parser, types);
+        if (!sig) {
+            flb_free(types);
+            return -1;
+        }
+        pthread_mutex_lock(&twins_mu);
+        for (i = 0; i < n_twins; i++) {
+            if (twins[i].sig && strcmp(twins[i].sig, sig) == 0) {
+                slot = i;
+                break;
+            }
         }
     }
     if (slot < 0) {
@@ -554,6 +625,7 @@ int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
             }
             flbgpu_parser_destroy(twins[slot].g);
             flb_free(twins[slot].sig);
+            twin_gen++;                                /* (what a thread remembers of this slot is another parser's now) */
         }
         twins[slot].g = g;
         twins[slot].sig = sig;
@@ -563,6 +635,7 @@ int flb_parser_do_gpu(struct flb_parser *parser, const char *buf, size_t length,
     twins[slot].users++;
     twins[slot].stamp = ++twin_clock;
     g = twins[slot].g;
+    twin_hit.p = parser; twin_hit.fp = fp; twin_hit.gen = twin_gen; twin_hit.slot = slot;
     pthread_mutex_unlock(&twins_mu);
     flb_free(types);
     flb_free(sig);
