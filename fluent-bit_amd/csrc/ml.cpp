@@ -498,6 +498,10 @@ static int mlo_phase2(flbgpu_ml_stream *s, flbgpu_dev_chunk *out, uint64_t *reco
     memset(hmisc, 0, sizeof(hmisc));
     hmisc[0] = 0xFFFFFFFFu;
     auto fill_groups = [&]() { mlo_fill_groups(s, a); };
+    // (a read that fails below leaves the stream as it found it: the names this read added go again -- the carried buffers are only
+    // switched at the very end anyway; ADVICE r3.  A caller that then hands the file to the CPU path first takes what the stream still
+    // holds with a flush call of no bytes: flbgpu_ml_append(s, NULL, 0, ..., flush = 1).)
+    struct NamesBack { std::vector<std::string> &v; size_t n; bool keep = false; ~NamesBack() { if (!keep) v.resize(n); } } names_back{s->gnames, s->gnames.size()};
     // group names the stream has not seen yet join its dictionary in the order they appear (flb_ml_stream_group_get creates them so)
     for (int round = 0;; round++) {
         launch_mlo_gid(a, st);
@@ -552,6 +556,7 @@ static int mlo_phase2(flbgpu_ml_stream *s, flbgpu_dev_chunk *out, uint64_t *reco
         s->gc_content_len[g] = hmisc[2 + g]; s->gc_map_len[g] = hmisc[6 + g]; s->gc_sec[g] = hmisc[10 + g]; s->gc_nsec[g] = hmisc[14 + g];
     }
     s->truncations += hmisc[18];
+    names_back.keep = true;
     *records = R;
     out->data = s->d_out.p; out->row_off = s->o_off.as<uint64_t>(); out->n = R; out->bytes = total;
     return 0;
