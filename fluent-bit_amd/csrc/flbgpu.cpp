@@ -1272,7 +1272,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             if (iters > 0 && iters <= 4096) {
                 trace_bytes = (size_t) grid * (rx_threads / 64) * (size_t) iters * 8 * sizeof(unsigned long long);
                 if (hipMalloc(&d_trace, trace_bytes) == hipSuccess && hipMemsetAsync(d_trace, 0, trace_bytes, st) == hipSuccess) {
-                    ma.trace = (unsigned long long *) d_trace; ma.trace_iters = (uint32_t) iters;
+                    ma.trace = (unsigned long long *) d_trace; ma.trace_iters = (uint32_t) iters | (getenv("FLBGPU_TRACE_FIXUP") ? 0x80000000u : 0u);
                 }
             }
         }
@@ -1286,17 +1286,19 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             *n_valid = n;
             return true;
         }
-        if (d_trace) {
+        auto trace_out = [&]() {
             std::vector<unsigned long long> ht(trace_bytes / sizeof(unsigned long long));
             if (hipMemcpyAsync(ht.data(), d_trace, trace_bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
                 if (FILE *tf = fopen(getenv("FLBGPU_TRACE_FILE"), "wb")) {
-                    const uint32_t hdr[4] = {(uint32_t) grid, (uint32_t) (rx_threads / 64), ma.trace_iters, 8};
+                    const uint32_t hdr[4] = {(uint32_t) grid, (uint32_t) (rx_threads / 64), ma.trace_iters & 0x7FFFFFFFu, 8};
                     fwrite(hdr, sizeof(hdr), 1, tf); fwrite(ht.data(), 1, trace_bytes, tf); fclose(tf);
                 }
             }
             (void) hipFree(d_trace);
+            d_trace = nullptr;
             ma.trace = nullptr; ma.trace_iters = 0;
-        }
+        };
+        if (d_trace && !(ma.trace_iters >> 31)) trace_out();
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
         if (!tile_in_lds && hm.counts[10] > 0) {
@@ -1307,6 +1309,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             if (fix_blocks > (uint64_t) grid) fix_blocks = (uint64_t) grid;
             if (ma.fix_list) fix_blocks = (uint64_t) grid;                       // the same shape: wave w takes what wave w listed
             { ProfScope ps(f, st, "k_parser_reg_fixup"); launch_parser_reg(ma, (int) fix_blocks, rx_threads, true, st); }
+            if (d_trace) trace_out();
             HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
             // when most of the data is of that kind the phase kernels (tiled, general) are the better choice from now on
@@ -1314,6 +1317,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         }
         // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when
         // that is the rule for this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on
+        if (d_trace) trace_out();
         if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
         if (hm.counts[8] > 0) {
             // rows whose time text needs the strptime interpreter, sizes that depend on the record's bytes, ...
