@@ -3,4 +3,4 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
 timeout 300 python tools/perf_host_phases.py
-timeout 300 python tools/perf_reg.py 10000000 16 0
+timeout 300 python tools/perf_reg.py 10000000 12 0
