@@ -1076,6 +1076,8 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     const bool tile_in_lds = tmode && !strcmp(tmode, "tile");
     if (use_tile) {
         tile_wave_bytes = tile_in_lds ? (uint32_t) TILE_BYTES + fx.nslots * 128u : fx.nslots * 128u + 64u * (4 * TBUF_WORDS + 4);
+        // (the two-position tables: a block of 68 bytes of capture slots per lane, tile_kernels.inc CAP_STEP)
+        if (!tile_in_lds && use_fx2 && fx.pair_bias && tile_wave_bytes < 64u * 68u) tile_wave_bytes = 64u * 68u;
         if (pair) for (int i = 0; i < pair->pg.nrules; i++) if (tile_pg_room + ((pair->pg.rule_lds_bytes[i] + 15) & ~15u) <= 8192) tile_pg_room += (pair->pg.rule_lds_bytes[i] + 15) & ~15u;
         int waves = (int) ((lds_cap - 64 - fx.bytes - tile_pg_room) / tile_wave_bytes);
         // the register kernel: 12 waves per CU with the compact tables (the build without spills, tile_kernels.inc), 16 on request

@@ -372,6 +372,7 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
                     c4.push_back(C4{r4(y.next), x.sa, x.sb, y.sa, y.sb});
                 }
         }
+        if (nslots > 34) return true;                                            // (a lane's block of capture slots is 68 bytes: the caller keeps fx3)
         const uint32_t n4 = (uint32_t) order.size(), rs4 = (ncol * ncol) | 1u, rowb4 = rs4 * 8, at4 = 2048;
         const uint64_t tot4 = (uint64_t) at4 + (uint64_t) n4 * rowb4;
         if (tot4 > 60000) return true;                                           // (the caller keeps fx3)
@@ -384,7 +385,9 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
         for (uint32_t r = 0; r < n4; r++)
             for (uint32_t c = 0; c < ncol * ncol; c++) {
                 const C4 &x = c4[(size_t) r * ncol * ncol + c];
-                const uint32_t lo = (at4 + x.next * rowb4) | (x.s0 << 16) | (x.s1 << 22), hi = x.s2 | (x.s3 << 6);
+                // lo = next row | slot 0's and slot 1's BYTE offsets in a lane's block of capture slots (slot * 2), hi = slot 2's and 3's:
+                // the kernel adds a selected byte to the lane's block address -- one operation per write (tile_kernels.inc REG_SLOT)
+                const uint32_t lo = (at4 + x.next * rowb4) | ((x.s0 * 2) << 16) | ((x.s1 * 2) << 24), hi = (x.s2 * 2) | ((x.s3 * 2) << 8);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8, &lo, 4);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8 + 4, &hi, 4);
             }
@@ -431,10 +434,10 @@ int flbgpu::simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int nca
     for (uint32_t j = 0; j <= len + 1; j += 2) {
         const uint32_t at = (e & FX_ROW_MASK) + u32at(4 * byte_at(j)) + u32at(1024 + 4 * byte_at(j + 1));
         const uint32_t lo = u32at(at), hi = u32at(at + 4);
-        caps[(lo >> 16) & 63] = (uint16_t) (j - 1);
-        caps[(lo >> 22) & 63] = (uint16_t) j;
-        caps[hi & 63] = (uint16_t) j;
-        caps[(hi >> 6) & 63] = (uint16_t) (j + 1);
+        caps[((lo >> 16) & 255) / 2] = (uint16_t) (j - 1);
+        caps[((lo >> 24) & 255) / 2] = (uint16_t) j;
+        caps[(hi & 255) / 2] = (uint16_t) j;
+        caps[((hi >> 8) & 255) / 2] = (uint16_t) (j + 1);
         e = lo;
     }
     const uint32_t S = e & FX_ROW_MASK;
