@@ -385,9 +385,10 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
         for (uint32_t r = 0; r < n4; r++)
             for (uint32_t c = 0; c < ncol * ncol; c++) {
                 const C4 &x = c4[(size_t) r * ncol * ncol + c];
-                // lo = next row | slot 0's and slot 1's BYTE offsets in a lane's block of capture slots (slot * 2), hi = slot 2's and 3's:
-                // the kernel adds a selected byte to the lane's block address -- one operation per write (tile_kernels.inc REG_SLOT)
-                const uint32_t lo = (at4 + x.next * rowb4) | ((x.s0 * 2) << 16) | ((x.s1 * 2) << 24), hi = (x.s2 * 2) | ((x.s3 * 2) << 8);
+                // lo = the next row, nothing else (the next cell's address is ONE three-operand addition: row + the two class offsets);
+                // hi = the four slots' BYTE offsets in a lane's block of capture slots (slot * 2): the kernel adds a selected byte to the
+                // lane's block address -- one operation per write (tile_kernels.inc REG_SLOT)
+                const uint32_t lo = at4 + x.next * rowb4, hi = (x.s0 * 2) | ((x.s1 * 2) << 8) | ((x.s2 * 2) << 16) | ((x.s3 * 2) << 24);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8, &lo, 4);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8 + 4, &hi, 4);
             }
@@ -434,10 +435,10 @@ int flbgpu::simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int nca
     for (uint32_t j = 0; j <= len + 1; j += 2) {
         const uint32_t at = (e & FX_ROW_MASK) + u32at(4 * byte_at(j)) + u32at(1024 + 4 * byte_at(j + 1));
         const uint32_t lo = u32at(at), hi = u32at(at + 4);
-        caps[((lo >> 16) & 255) / 2] = (uint16_t) (j - 1);
-        caps[((lo >> 24) & 255) / 2] = (uint16_t) j;
-        caps[(hi & 255) / 2] = (uint16_t) j;
-        caps[((hi >> 8) & 255) / 2] = (uint16_t) (j + 1);
+        caps[(hi & 255) / 2] = (uint16_t) (j - 1);
+        caps[((hi >> 8) & 255) / 2] = (uint16_t) j;
+        caps[((hi >> 16) & 255) / 2] = (uint16_t) j;
+        caps[((hi >> 24) & 255) / 2] = (uint16_t) (j + 1);
         e = lo;
     }
     const uint32_t S = e & FX_ROW_MASK;
