@@ -477,6 +477,33 @@ struct Syntax {
         return false;
     }
 
+    // \p{Name} \p{^Name} \P{Name} (regparse.c fetch_token 'p' -> TK_CHAR_PROPERTY; enc/unicode.c onigenc_unicode_property_name_to_ctype:
+    // the name without blanks, '-' and '_', any case).  The fourteen names that are the POSIX brackets' ctypes are taken -- the same sets
+    // as [[:name:]], never ASCII-range (parse_char_property passes ascii_range 0) --; scripts, general categories, ages are refused.
+    // p stands on the 'p' / 'P'; on success behind the '}'.
+    // as_flag (an atom outside brackets): the positive set goes in and the NOT is a flag of the class (regparse.c parse_exp
+    // TK_CHAR_PROPERTY: NCCLASS_SET_NOT) -- it decides what an ill-formed byte matches; inside brackets the complement is added.
+    bool property(CC &cc, bool *as_flag = nullptr) {
+        const bool upper = *p == 'P';
+        p++;
+        if (eof() || *p != '{') return fail("invalid character property name {...}");
+        p++;
+        bool neg = upper;
+        if (!eof() && *p == '^') { neg = !neg; p++; }
+        std::string nm;
+        while (!eof() && *p != '}') {
+            const int ch = *p++;
+            if (ch == ' ' || ch == '-' || ch == '_') continue;
+            nm += (char) ((ch >= 'A' && ch <= 'Z') ? ch + 32 : ch);
+        }
+        if (eof()) return fail("invalid character property name {...}");
+        p++;
+        if (as_flag) { *as_flag = neg; neg = false; }
+        // (\p{Punct} is the Unicode category P -- without $ + < = > ^ ` | ~, which [[:punct:]] has: not the bracket's set, not taken)
+        if (nm == "punct" || !add_posix(cc, nm, neg, false)) return fail(("the character property \\p{" + nm + "} is not supported (scripts, categories, ages: only the POSIX bracket names are)").c_str());
+        return true;
+    }
+
     void skip_extended(unsigned opts) {
         if (!(opts & OPT_EXTEND)) return;
         while (!eof()) {
@@ -534,7 +561,8 @@ struct Syntax {
                     int c = *p;
                     if (c == 'd' || c == 'w' || c == 's' || c == 'h') { p++; add_ctype(s, (char) c, false, !ctype_is_ascii(opts)); continue; }
                     if (c == 'D' || c == 'W' || c == 'S' || c == 'H') { p++; add_ctype(s, (char) (c + 32), true, !ctype_is_ascii(opts)); continue; }
-                    if (c == 'p' || c == 'P' || c == 'R' || c == 'X') return fail("property escapes are not supported");
+                    if (c == 'p' || c == 'P') { if (!property(s)) return false; continue; }
+                    if (c == 'R' || c == 'X') return fail("\\R / \\X are not supported");
                     if (escape_cp(lo, true)) { if (failed()) return false; }
                     else if (c >= '1' && c <= '7') {
                         uint32_t v = 0; int n = 0;
@@ -729,6 +757,16 @@ struct Syntax {
             if (c == 'z') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = A_EOS; return a; }
             if (c == 'b') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_WORDB_A : A_WORDB; return a; }
             if (c == 'B') { p++; AstP a = mk(Ast::ANCHOR); a->anchor = wordb_is_ascii(opts) ? A_NWORDB_A : A_NWORDB; return a; }
+            if (c == 'p' || c == 'P') {
+                AstP a = mk(Ast::SET);
+                bool not_flag = false;
+                if (!property(a->cc, &not_flag)) return nullptr;
+                a->cc.neg = not_flag;
+                a->cc.mb.norm(); a->cc.mbx.norm();
+                if ((opts & OPT_IGNORECASE) && !fold_case(a->cc)) { fail("case-insensitive classes with non-ASCII members are not supported"); return nullptr; }
+                a->icase = (opts & OPT_IGNORECASE) != 0;
+                return a;
+            }
             if (c == 'Z') {
                 nonregular = true;
                 if (!ext) { fail("\\Z is not supported on the GPU path"); return nullptr; }
@@ -760,7 +798,7 @@ struct Syntax {
                 else named_refs.emplace_back(a.get(), name);
                 return a;
             }
-            if (strchr("GKRXkgpP", c)) { if (c == 'G' || c == 'K' || c == 'k') nonregular = true; fail("unsupported escape"); return nullptr; }
+            if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k') nonregular = true; fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') {
                 nonregular = true;
                 if (!ext) { fail("back-references are not supported on the GPU path"); return nullptr; }
