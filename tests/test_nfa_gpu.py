@@ -111,6 +111,10 @@ POSIX_PATTERNS = [
     rb"^(?<a>(?a:\w+\b))(?<b>.*\b.)",
     rb"(?<x>.{0,40}x)$",
     rb"^(?<h>[[:xdigit:]]{2,})(?<s>[[:blank:]]*)(?<c>[[:cntrl:]]?)",
+    # \p{..} with the POSIX bracket names (the NOT of an atom outside brackets is the class's flag)
+    rb"^(?<w>\p{Alpha}+)(?<r>\P{Alpha}*)",
+    rb"(?<u>\p{Upper}\p{Lower}*) (?<rest>[\p{Word}\P{ASCII}]*)",
+    rb"^(?<t>\p{^Space}+)\p{Space}(?<d>\p{Digit}*)",
 ]
 WORDS = ["abc", "Été", "Жук", "日本", "x", "naïve", "ǅ", "Ａ", "١٢٣", "42", "²", "_", "foo_bar", "\u212a", "ß", "«q»", "¡", "\u00a0", "\u3000", "0xFF", "dead", "-", "=",
          "😀", "e\u0301"]
