@@ -375,7 +375,7 @@ bool fold_case(CC &cc) {
 enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB, A_WORDB_A, A_NWORDB_A, A_SEMI_EOS, A_BEGIN_POS };
 
 struct Ast {
-    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR, LOOK, ATOMIC, BACKREF, KEEP } t = EMPTY;
+    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR, LOOK, ATOMIC, BACKREF, KEEP, COND } t = EMPTY;   // COND: (?(refs)kids[0]|kids[1])
     bool ahead = true, neg_look = false;   // LOOK
     std::vector<int> refs;                 // BACKREF: the groups the reference names, in group order
     bool ref_icase = false;
@@ -683,7 +683,43 @@ struct Syntax {
                     p++;
                     g->kids.push_back(alternation(opts, depth + 1));
                 }
-                else if (c == '~' || c == '(' || c == '&' || c == 'P') { fail("unsupported group construct"); return nullptr; }
+                else if (c == '(' && ext) {
+                    // (?(cond)yes|no): cond = a group number or <name> / 'name' (regparse.c parse_enclose '(': OP_CONDITION)
+                    nonregular = true;
+                    p++;
+                    g->t = Ast::COND;
+                    g->ref_icase = false;
+                    if (eof()) { fail("end pattern in group"); return nullptr; }
+                    if (*p >= '0' && *p <= '9') {
+                        int v = 0;
+                        while (!eof() && *p >= '0' && *p <= '9' && v < 1000) { v = v * 10 + (*p - '0'); p++; }
+                        if (has_named) { fail("numbered backref/call is not allowed. (use name)"); return nullptr; }
+                        if (v <= 0) { fail("invalid backref number/name"); return nullptr; }
+                        g->refs.push_back(v);
+                        max_ref = std::max(max_ref, v);
+                    }
+                    else if (*p == '<' || *p == '\'') {
+                        const int term = *p == '<' ? '>' : '\'';
+                        p++;
+                        const unsigned char *nm = p;
+                        while (!eof() && *p != term) p++;
+                        if (eof() || p == nm) { fail("invalid backref name"); return nullptr; }
+                        named_refs.emplace_back(g.get(), std::string((const char *) nm, p - nm));
+                        p++;
+                    }
+                    else { fail("invalid conditional pattern"); return nullptr; }
+                    if (eof() || *p != ')') { fail("invalid conditional pattern"); return nullptr; }
+                    p++;
+                    AstP body = alternation(opts, depth + 1);
+                    if (failed()) return nullptr;
+                    if (body && body->t == Ast::ALT) {
+                        if (body->kids.size() > 2) { fail("invalid conditional pattern"); return nullptr; }
+                        g->kids.push_back(std::move(body->kids[0]));
+                        g->kids.push_back(std::move(body->kids[1]));
+                    }
+                    else { g->kids.push_back(std::move(body)); g->kids.push_back(mk(Ast::EMPTY)); }
+                }
+                else if (c == '~' || c == '(' || c == '&' || c == 'P') { if (c == '(') nonregular = true; fail("unsupported group construct"); return nullptr; }
                 else {
                     unsigned o = opts;
                     bool on = true;
@@ -798,6 +834,24 @@ struct Syntax {
                 else named_refs.emplace_back(a.get(), name);
                 return a;
             }
+            if (c == 'R' && ext) {
+                // \R: (?>\x0D\x0A|[\x0A-\x0D\x{85}\x{2028}\x{2029}])  (regparse.c node_linebreak)
+                p++;
+                AstP crlf = mk(Ast::CAT);
+                crlf->kids.push_back(literal(0x0D, 0));
+                crlf->kids.push_back(literal(0x0A, 0));
+                AstP one = mk(Ast::SET);
+                one->cc.add_cp(0x0A, 0x0D); one->cc.add_cp(0x85, 0x85); one->cc.add_cp(0x2028, 0x2029);
+                one->cc.mb.norm(); one->cc.mbx.norm();
+                AstP alt = mk(Ast::ALT);
+                alt->kids.push_back(std::move(crlf));
+                alt->kids.push_back(std::move(one));
+                AstP at = mk(Ast::ATOMIC);
+                at->kids.push_back(std::move(alt));
+                nonregular = true;
+                return at;
+            }
+            if (c == 'R') nonregular = true;
             if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k') nonregular = true; fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') {
                 nonregular = true;
@@ -2021,6 +2075,7 @@ struct Sampler {
         case Ast::ALT: walk(a->kids[below((uint32_t) a->kids.size())].get(), o, depth + 1); return;
         case Ast::GROUP: case Ast::ATOMIC: walk(a->kids[0].get(), o, depth + 1); return;
         case Ast::LOOK: case Ast::KEEP: return;
+        case Ast::COND: walk(a->kids[below(2)].get(), o, depth + 1); return;
         case Ast::BACKREF: if (!o.empty() && below(2)) o.push_back(o[below((uint32_t) o.size())]); return;
         case Ast::REPEAT: {
             int span = a->max < 0 ? (below(4) == 0 ? 12 : 4) : std::min(a->max - a->min, 6);

@@ -19,6 +19,7 @@ KNOWN = [
     rb"(a+)\1", rb"(?<x>\w+) \k<x>", rb"(\w)(\w)\2\1", rb"(?i)(ab)\1", rb"^(?!.*error).*$", rb"^(?=.*\d)(?=.*[a-z]).{4,}$", rb"\bfoo\b(?! bar)",
     rb"(?<=\d)(?=(\d{3})+$)", rb"x\Z", rb"\Aab\Z", rb"a\Kb", rb"\Gab", rb"(?<=^|,)[^,]*", rb"(?<![\w.])\d+(?![\w.])", rb"(?<k>a)?\k<k>b", rb"(a)|\1b",
     rb"(?>a*)a", rb"(?:(?=a)a|b)+", rb"(?!a)(?!b).", rb"(?<=(?<!x)y)z", "(?<=é)x".encode(), "(?<!日)本".encode(), rb"(?<=\s)\S+(?=\s)", rb"(a*)*+b", rb"(?>(a|b)*)c",
+    rb"(a)?(?(1)b|c)", rb"^(?<q>\")?\w+(?(<q>)\")$", rb"(\()?[^()]+(?(1)\))", rb"(?<x>x)?(?(<x>)y)z", rb"a\Rb", rb"\R+", rb"^.*\R",
     rb"(?<q>['\"])(?<body>.*?)\k<q>", rb"^(?<host>\S+) (?!-)(?<user>\S+)", rb"(?<n>\d+)-\k<n>", rb"(?=(a+))a*b\1", rb"(?<!\\)\"", rb"(\d+)(?<=5)x", rb"a(?=b|c)(?<=a).",
 ]
 
@@ -54,7 +55,9 @@ def gen_nonregular(rng):
             names.append(nm)
             return body + rng.choice([b"", b"", b"?"])
         if r < 0.70:
-            return rng.choice([rb"\Z", rb"\K", rb"\G", rb"\b"])
+            return rng.choice([rb"\Z", rb"\K", rb"\G", rb"\b", rb"\R"])
+        if r < 0.74 and names:
+            return b"(?(<" + rng.choice(names) + b">)" + atom() + rng.choice([b"", b"|" + atom()]) + b")"
         return atom() + rng.choice(rp.QUANT)
 
     def seq(d):
@@ -206,6 +209,6 @@ def test_regular_patterns_through_the_backtracker():
 def test_what_stays_refused():
     """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
     L = flbamd_loader.load().lib()
-    for pat in [rb"(?~abc)", rb"(?(1)a|b)", rb"\g<1>", rb"\p{Han}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>"]:
+    for pat in [rb"(?~abc)", rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Han}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>"]:
         h, err = bt_compile(L, pat)
         assert h is None and err, pat
