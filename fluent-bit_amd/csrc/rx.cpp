@@ -368,6 +368,27 @@ bool fold_case(CC &cc) {
     return true;
 }
 
+// [x&&y]: the members both operands have (regparse.c and_cclass over two classes without their own NOT: the bit sets and'ed, the code
+// ranges and'ed)
+CodeSet mb_intersect(const CodeSet &x0, const CodeSet &y0) {
+    CodeSet x = x0, y = y0, o;
+    x.norm(); y.norm();
+    size_t i = 0, j = 0;
+    while (i < x.r.size() && j < y.r.size()) {
+        const uint32_t lo = std::max(x.r[i].first, y.r[j].first), hi = std::min(x.r[i].second, y.r[j].second);
+        if (lo <= hi) o.add(lo, hi);
+        if (x.r[i].second < y.r[j].second) i++; else j++;
+    }
+    return o;
+}
+CC cc_and(const CC &a, const CC &b) {
+    CC o;
+    for (int i = 0; i < 4; i++) { o.bs.w[i] = a.bs.w[i] & b.bs.w[i]; o.asc.w[i] = a.asc.w[i] & b.asc.w[i]; }
+    o.mb = mb_intersect(a.mb, b.mb);
+    o.mbx = mb_intersect(a.mbx, b.mbx);
+    return o;
+}
+
 // ---------------------------------------------------------------- AST
 // (A_WORDB_A / A_NWORDB_A: \b \B under (?a) -- OP_ASCII_WORD_BOUND: only [0-9A-Za-z_] are word characters)
 // (A_SEMI_EOS \Z, A_BEGIN_POS \G and the node kinds LOOK / ATOMIC / BACKREF / KEEP exist only in trees parsed with Syntax::ext -- the
@@ -522,8 +543,8 @@ struct Syntax {
 
     // '[' already consumed; fills `out` (empty on entry) with the class up to the matching ']'
     bool char_class(CC &out, unsigned opts) {
-        bool neg = false, first = true;
-        CC s;
+        bool neg = false, first = true, have_acc = false;
+        CC s, acc;
         if (!eof() && *p == '^') { neg = true; p++; }
         for (;;) {
             uint32_t lo = 0, hi;
@@ -554,7 +575,15 @@ struct Syntax {
                     s.merge_class(t);
                     continue;
                 }
-                if (*p == '&' && p + 1 < e && p[1] == '&') return fail("class intersection (&&) is not supported");
+                if (*p == '&' && p + 1 < e && p[1] == '&') {
+                    // x&&y&&z: what stands left of the operator so far is one operand (regparse.c parse_char_class CC_AND)
+                    p += 2;
+                    s.mb.norm(); s.mbx.norm();
+                    acc = have_acc ? cc_and(acc, s) : s;
+                    have_acc = true;
+                    s = CC();
+                    continue;
+                }
                 if (*p == '\\') {
                     p++;
                     if (eof()) return fail("end pattern at escape");
@@ -594,6 +623,7 @@ struct Syntax {
             s.add_cp(lo, hi);
         }
         s.mb.norm();
+        if (have_acc) { s.mbx.norm(); s = cc_and(acc, s); s.mb.norm(); s.mbx.norm(); }
         if ((opts & OPT_IGNORECASE) && !fold_case(s)) return fail("case-insensitive classes with non-ASCII members are not supported");
         s.neg = neg;
         out = s;

@@ -92,7 +92,7 @@ MORE_ATOMS = [rb"\b", rb"\B", rb"[[:alpha:]]", rb"[[:digit:][:punct:]]", rb"[^[:
               rb"[[:^lower:]x]", rb"[[:space:][:upper:]]", rb"[[:cntrl:]]", rb"[[:blank:]]", rb"[[:xdigit:]]", rb"[^[:word:]-]",
               # \p{..} with the POSIX bracket names (round 4): the same sets, never ASCII-range
               rb"\p{Alpha}", rb"\P{Alpha}", rb"\p{^Digit}", rb"\p{Upper}", rb"\p{lower}", rb"\p{Word}", rb"\p{Space}", rb"[\p{Alnum}_-]", rb"[^\p{Space}\d]",
-              rb"\p{Graph}", rb"\p{X_Digit}", rb"\p{Blank}", rb"\P{Print}", rb"\p{Cntrl}", rb"\p{ASCII}"]
+              rb"[a-z&&[^aeiou]]", rb"[\w&&[^\d]]", rb"[^a-c&&\S]", rb"\p{Graph}", rb"\p{X_Digit}", rb"\p{Blank}", rb"\P{Print}", rb"\p{Cntrl}", rb"\p{ASCII}"]
 # group options (regparse.c:5257-5297): (?a) ASCII-only \w \d \s, POSIX brackets and \b; (?u) the Unicode ones; (?d) the default
 OPTION_GROUPS = [rb"(?a)", rb"(?u)", rb"(?d)", rb"(?a:\w+\b)", rb"(?u:\w+)", rb"(?u:\d|\s)", rb"(?a:[[:alpha:]]+)", rb"(?u:[\w-]+)", rb"(?a:\B.)", rb"(?u:\h)",
                  rb"(?u:\W)", rb"(?u:[^\s\d])", rb"(?ia)", rb"(?a-i:x)"]
