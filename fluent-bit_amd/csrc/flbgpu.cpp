@@ -870,6 +870,7 @@ extern "C" int flbgpu_filter_host_rules(flbgpu_filter *f, uint64_t *out4) {
     for (auto *b : f->host_rx) if (b) k++;
     for (auto *p : f->parsers) if (p->bt) k++;
     out4[0] = k; out4[1] = f->host_values; out4[2] = f->host_budget_over; out4[3] = f->host_unhandled;
+    if (f->l2m_gate) { for (auto *b : f->l2m_gate->host_rx) if (b) out4[0]++; out4[1] += f->l2m_gate->host_values; out4[2] += f->l2m_gate->host_budget_over; }
     return 0;
 }
 
@@ -1609,6 +1610,25 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     }
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     *ret = FLBGPU_FILTER_MODIFIED;
+    return true;
+}
+
+// the rule gate of a filter_log_to_metrics whose rules run on the host (host_int.hpp flbgpu_filter::l2m_gate)
+bool l2m_gate_dev(flbgpu_filter *gate, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *kept, hipStream_t st) {
+    const bool last0 = g_spec.last;
+    g_spec.last = false;                                   // (its output is no stage's output: nothing goes to the caller's slab)
+    int ret = FLBGPU_FILTER_NOTOUCH;
+    memset(kept, 0, sizeof(*kept));
+    const bool ok = run_grep_dev(gate, in, kept, st, &ret, false);
+    g_spec.last = last0;
+    if (!ok) return false;
+    if (gate->hp_misc.p && gate->hp_misc.as<MiscWords>()->first_bad != ~0ull) {
+        // (grep answers NOTOUCH on a decoder error; the reference's log_to_metrics counts the records in front of it -- with the rules
+        // on the host that prefix is not rebuilt: the chunk is not counted, loudly)
+        set_err("log_to_metrics: a record of the chunk does not decode and the filter's rules run on the host: the chunk is not counted");
+        return false;
+    }
+    if (ret != FLBGPU_FILTER_MODIFIED) *kept = *in;         // every record passes
     return true;
 }
 

@@ -157,6 +157,9 @@ struct flbgpu_filter {
     int logical_op = 0;
     // filter_log_to_metrics
     L2mState *l2m = nullptr;
+    // filter_log_to_metrics whose regex / exclude rules hold a pattern that is not a regular expression: the rules live in this hidden
+    // filter_grep (host rules, flbgpu.cpp) and run in FRONT of the metric kernels, which then see the kept records and no rules
+    flbgpu_filter *l2m_gate = nullptr;
     // msgpack -> JSON output formatter (packfmt.cpp)
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
@@ -177,6 +180,7 @@ struct flbgpu_filter {
         if (l2m) l2m_state_destroy(l2m);
         for (auto *b : rule_blobs) delete b;
         for (auto *b : host_rx) if (b) rx::bt_free(b);
+        delete l2m_gate;
         d_hspans.release(); d_hbits.release();
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                                  &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix};
@@ -220,3 +224,6 @@ bool resolve_raw_chunk(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_
 
 // filter_log_to_metrics entry used by flbgpu_filter_run / flbgpu_filter_run_dev
 bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, int *ret);
+// (flbgpu.cpp) the hidden gate of a log_to_metrics filter: grep's legacy rule loop over `in`; *kept = the chunk the metric kernels take
+// (`in` itself when every record passes); false: failure, or a decoder error inside the chunk (flbgpu_last_error says which)
+bool l2m_gate_dev(flbgpu_filter *gate, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *kept, hipStream_t st);

@@ -171,10 +171,43 @@ extern "C" flbgpu_filter *flbgpu_filter_l2m_create(const char *metric_mode, int 
         int st = parse_first_part(field.c_str(), k, why);
         if (st < 0) return fail("log_to_metrics: invalid record accessor? %s", "'" + field + "': " + why);
         // compile_rule parses an accessor itself: hand it a placeholder and patch the key in
-        if (!compile_rule("$k", sp + 1, r, f->rule_blobs, why)) return fail("log_to_metrics: %s", why);
+        bool nonregular = false;
+        rx::BtProgram *bt = nullptr;
+        if (!compile_rule("$k", sp + 1, r, f->rule_blobs, why, &nonregular)) {
+            // not a regular expression: a host rule (flbgpu.cpp "host rules") -- the whole rule list then runs as a hidden filter_grep
+            // in front of the metric kernels (plugins/filter_log_to_metrics/log_to_metrics.c:314-353 grep_filter_data is grep's legacy loop)
+            std::string e2;
+            if (nonregular && !getenv("FLBGPU_NO_HOST_RULES")) {
+                const char *ps, *pe;
+                unsigned opts;
+                rx::split_flb_pattern(sp + 1, &ps, &pe, &opts);
+                bt = rx::bt_compile(ps, (size_t) (pe - ps), opts, e2);
+            }
+            if (!bt) return fail("log_to_metrics: %s", why + (e2.empty() ? "" : "; on the host: " + e2));
+            memset(&r.dfa, 0, sizeof(r.dfa)); memset(&r.utf8, 0, sizeof(r.utf8));
+            f->has_host_rules = true;
+        }
         r.key = k;
-        if ((int) f->rules.size() >= MAX_RULES) return fail("log_to_metrics: too many rules%s", "");
+        if ((int) f->rules.size() >= MAX_RULES) { if (bt) rx::bt_free(bt); return fail("log_to_metrics: too many rules%s", ""); }
         f->rules.push_back(r);
+        f->host_rx.push_back(bt);
+    }
+    if (f->has_host_rules) {
+        auto *g = new flbgpu_filter();
+        g->kind = F_GREP;
+        g->logical_op = OP_LEGACY;
+        g->rules.swap(f->rules);
+        g->host_rx.swap(f->host_rx);
+        g->rule_blobs.swap(f->rule_blobs);
+        g->has_host_rules = true;
+        f->has_host_rules = false;
+        f->l2m_gate = g;
+        if (!filter_common_init(g) || !g->d_rules.ensure(g->rules.size() * sizeof(GrepRule)) ||
+            hipMemcpy(g->d_rules.p, g->rules.data(), g->rules.size() * sizeof(GrepRule), hipMemcpyHostToDevice) != hipSuccess) {
+            if (!*flbgpu_last_error()) set_err("log_to_metrics: device setup failed");
+            delete f;
+            return nullptr;
+        }
     }
     // set_labels :355-497
     auto add_label = [&](const std::string &name, const char *accessor) {
@@ -241,6 +274,13 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
     *ret = s->discard_logs ? FLBGPU_FILTER_MODIFIED : FLBGPU_FILTER_NOTOUCH;
     f->last_in = n; f->last_out = s->discard_logs ? 0 : n;
     if (n == 0) return true;
+    flbgpu_dev_chunk kept;
+    if (f->l2m_gate) {
+        // the rules in front (a hidden filter_grep with host rules): the metric kernels take what it keeps
+        if (!l2m_gate_dev(f->l2m_gate, in, &kept, st)) return false;
+        if (kept.bytes == 0) return true;                   // nothing passes the rules
+        in = &kept;
+    }
     if (!s->d_sid.ensure(n * 4) || !s->d_misc.ensure(sizeof(L2mMisc)) || !s->d_tmp.ensure(l2m_stale_tmp_elems(n) * 8)) return false;
     if (s->mode != L2M_COUNTER && !s->d_val.ensure(n * 8)) return false;
     L2mMisc hm;

@@ -866,6 +866,7 @@ static int cb_l2m_gpu_init(struct flb_filter_instance *f_ins, struct flb_config 
         flb_free(ctx);
         return -1;
     }
+    gpu_note_host_rules(f_ins, ctx->f);
     flbgpu_l2m_info(ctx->f, &ctx->mode, &ctx->label_count, &ctx->nbuckets, &ctx->row_words);
 
     /* cmetrics context (:825-850); an empty subsystem defaults to the mode name (:769-776) */

@@ -206,8 +206,8 @@ void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t 
 uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f);
 /* Rules / parsers whose pattern is NOT a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K)
  * do not fail the create calls: the device does everything but the search of that pattern, which the product's backtracking matcher
- * (csrc/rxbt.inc) runs on the host over the values the device located -- filter_grep rules and single-parser filter_parser lists; the
- * fused pair, log_to_metrics and multiline rules still refuse them.  out4: [0] host rules / parsers of this filter, [1] values searched
+ * (csrc/rxbt.inc) runs on the host over the values the device located -- filter_grep rules, filter_log_to_metrics rules (run as a
+ * filter_grep in front of the metric kernels) and single-parser filter_parser lists; the fused pair and multiline rules still refuse them.  out4: [0] host rules / parsers of this filter, [1] values searched
  * on the host so far, [2] searches that ended on the backtrack budget ("no match"), [3] records a host parser did not take (duplicate
  * Key_Name entries, values of 64 KB and more: passed on unparsed).  FLBGPU_NO_HOST_RULES=1: refuse such patterns at create as before. */
 int flbgpu_filter_host_rules(flbgpu_filter *f, uint64_t *out4);

@@ -181,3 +181,57 @@ def test_refused_when_asked_to(g):
         del os.environ["FLBGPU_NO_HOST_RULES"]
     with pytest.raises(Exception):
         g.FilterGrep([("regex", r"log (?~abc)")])             # what the host's matcher does not take either is still refused
+
+
+def l2m_same(a, b, mode="counter"):
+    assert [s["labels"] for s in a] == [s["labels"] for s in b]
+    for x, y in zip(a, b):
+        if mode == "histogram":
+            assert x["buckets"] == y["buckets"] and x["count"] == y["count"] and x["sum"] == y["sum"], (x, y)      # (integer observations: the sequential sum is exact)
+        else:
+            assert x["value"] == y["value"], (x, y)
+
+
+L2M_EQUIV = [(r"^(?!#).", r"^[^#]"), (r"(?>a+)b", r"a+b"), (r"error(?=:)|warn(?=:)", r"(error|warn):"), (r"price \d++(?= ?USD)", r"price \d+ ?USD")]
+
+
+@pytest.mark.parametrize("host,plain", L2M_EQUIV)
+def test_log_to_metrics_host_rule_equals_an_equivalent_regular_one(g, host, plain):
+    """filter_log_to_metrics: the rules run as a hidden filter_grep in front of the metric kernels (l2m.cpp l2m_gate) -- against the
+    oracle's filter with a regular expression that decides the same"""
+    chunks = [b"".join(records(5000, s, keys=("log", "msg"))[0]) for s in (31, 32)]
+    for mode, vf, extra in (("counter", None, [("exclude", "msg USD")]), ("histogram", "n", [("regex", "msg .")]), ("gauge", "n", [])):
+        props = lambda p: [("regex", "log " + p)] + extra + [("label_field", "msg"), ("add_label", "app demo")]
+        f = g.FilterLogToMetrics(mode, props(host), value_field=vf)
+        o = ob.L2M(mode, props(plain), value_field=vf)
+        assert f.host_rules()["rules"] == 1
+        for c in chunks:
+            ro = o.filter(c)
+            rg, out = f.filter(c)
+            assert ro == rg == ob.NOTOUCH
+        okeys, obounds, osn = o.snapshot()
+        assert okeys == f.label_keys and len(osn) > 10
+        l2m_same(f.snapshot(), osn, mode)
+        assert f.host_rules()["values"] > 0 and f.host_rules()["budget_over"] == 0
+        f.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", ["regex", "exclude"])
+def test_log_to_metrics_host_rule_against_the_real_engine(g, kind):
+    """a back-reference: no regular equivalent -- the oracle's filter without rules over the records the REAL engine keeps"""
+    ref = rxdiff.load_ref()
+    pat = r"(?<=user=)(\w+) id=\1"
+    recs, vals = records(6000, 41)
+    keep = [ref_match(ref, pat, v["log"]) == (kind == "regex") for v in vals]
+    assert 0 < sum(keep) < len(keep)
+    f = g.FilterLogToMetrics("counter", [(kind, "log " + pat), ("label_field", "log")], discard_logs=True)
+    o = ob.L2M("counter", [("label_field", "log")], discard_logs=True)
+    rg, out = f.filter(b"".join(recs))
+    ro = o.filter(b"".join(x for x, k in zip(recs, keep) if k))
+    assert rg == ro == ob.MODIFIED and out == b""
+    l2m_same(f.snapshot(), o.snapshot()[2])
+    # nothing passes: nothing counted, the series stay
+    f2 = g.FilterLogToMetrics("counter", [("regex", r"log (zz)\1(?!z)"), ("label_field", "log")])
+    assert f2.filter(b"".join(recs))[0] == ob.NOTOUCH and f2.snapshot() == []
+    f.close(); f2.close()
