@@ -16,3 +16,7 @@ g++ -O1 -g -std=c++17 -fPIC -shared -w -fsanitize=address,undefined -fno-sanitiz
 cd ../..
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
     python tools/sanitize_rx.py "$@"
+# ... and the matcher's reentrancy (flbgpu.cpp parallel_rows searches one program from up to 16 threads) under TSan
+(cd fluent-bit_amd/csrc && g++ -O1 -g -std=c++17 -fPIC -shared -w -fsanitize=thread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I. -I../../include \
+    rx.cpp fx.cpp rx_capi.cpp /tmp/san/stub.cpp -o /tmp/san/librx_tsan.so)
+TSAN_OPTIONS=halt_on_error=1:report_signal_unsafe=0 LD_PRELOAD="$(gcc -print-file-name=libtsan.so)" python tools/tsan_rx.py
