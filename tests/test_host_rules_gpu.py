@@ -235,3 +235,45 @@ def test_log_to_metrics_host_rule_against_the_real_engine(g, kind):
     f2 = g.FilterLogToMetrics("counter", [("regex", r"log (zz)\1(?!z)"), ("label_field", "log")])
     assert f2.filter(b"".join(recs))[0] == ob.NOTOUCH and f2.snapshot() == []
     f.close(); f2.close()
+
+
+def test_log_to_metrics_host_rule_in_a_chain_on_a_device_chunk_and_without_the_ahead_launch(g):
+    recs, vals = records(7000, 51, keys=("log", "msg"))
+    blob = b"".join(recs)
+    host, plain = r"(?>a+)b|price(?= )", r"a+b|price "
+    props = lambda p: [("regex", "log " + p), ("label_field", "msg")]
+    pre = [("exclude", "msg ^#")]
+    ro, oo = ob.Grep(pre).filter(blob)
+    assert ro == ob.MODIFIED
+    o = ob.L2M("counter", props(plain))
+    assert o.filter(oo) == ob.NOTOUCH
+    want = o.snapshot()[2]
+    assert len(want) > 5
+    # a device grep in front: the gate reads the values from a copy back of the grep's output
+    fm = g.FilterLogToMetrics("counter", props(host))
+    ch = g.FilterChain([g.FilterGrep(pre), fm])
+    r, out = ch.filter(blob)
+    assert r == ob.MODIFIED and out == oo
+    l2m_same(fm.snapshot(), want)
+    # the device-level call
+    o2 = ob.L2M("counter", props(plain))
+    assert o2.filter(blob) == ob.NOTOUCH
+    f2 = g.FilterLogToMetrics("counter", props(host))
+    data = np.frombuffer(blob, dtype=np.uint8)
+    n, off, cons = g.index_host(blob)
+    L = g.lib()
+    offs = np.array(off, dtype=np.uint64)
+    d_data = L.flbgpu_dev_alloc(data.nbytes); d_off = L.flbgpu_dev_alloc(offs.nbytes)
+    L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, data.nbytes); L.flbgpu_memcpy_h2d(d_off, offs.ctypes.data, offs.nbytes)
+    r2, _ = f2.filter_dev(g.DevChunk(d_data, d_off, n, data.nbytes))
+    assert r2 == ob.NOTOUCH
+    l2m_same(f2.snapshot(), o2.snapshot()[2])
+    L.flbgpu_dev_free(d_data); L.flbgpu_dev_free(d_off)
+    # the host-level call the usual way (a wait per counter)
+    os.environ["FLBGPU_NO_SPEC"] = "1"
+    try:
+        f3 = g.FilterLogToMetrics("counter", props(host))
+        assert f3.filter(blob)[0] == ob.NOTOUCH
+        l2m_same(f3.snapshot(), o2.snapshot()[2])
+    finally:
+        del os.environ["FLBGPU_NO_SPEC"]
