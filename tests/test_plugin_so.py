@@ -164,3 +164,13 @@ def test_log_to_metrics_plugin_runs_through_the_host():
         # discard_logs: MODIFIED with an empty output (log_to_metrics.c:1143-1150)
         r = _host(so, "filter_log_to_metrics_gpu_plugin", "run", fin, fout, "metric_mode=counter", "metric_name=n", "metric_description=n", "tag=t", "discard_logs=true")
         assert r.returncode == 0 and "cb_filter=1 out_size=0" in r.stdout, r.stdout + r.stderr
+        # a rule that is not a regular expression (a look-ahead): cb_init does not fail, the rule runs on the host
+        r = _host(so, "filter_log_to_metrics_gpu_plugin", "run", fin, fout, "metric_mode=counter", "metric_name=errs", "metric_description=n",
+                  "tag=metrics", "regex=code ^(?=5)\\d+$", "label_field=method")
+        assert r.returncode == 0 and "cb_init=0" in r.stdout and "cb_filter=2" in r.stdout, r.stdout + r.stderr
+        o = ob.L2M("counter", [("regex", "code ^5\\d*$"), ("label_field", "method")])
+        assert o.filter(parsed) == ob.NOTOUCH
+        want = o.snapshot()[2]
+        got = series(r.stdout, 1)
+        assert want and [g[0] for g in got] == [w["labels"] for w in want]
+        assert [float(g[1]["value"]) for g in got] == [w["value"] for w in want]
