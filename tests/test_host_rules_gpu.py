@@ -277,3 +277,19 @@ def test_log_to_metrics_host_rule_in_a_chain_on_a_device_chunk_and_without_the_a
         l2m_same(f3.snapshot(), o2.snapshot()[2])
     finally:
         del os.environ["FLBGPU_NO_SPEC"]
+
+
+@pytest.mark.parametrize("reserve,preserve", [(False, False), (True, True)])
+def test_host_parser_with_types_time_keep_and_the_reserve_options(g, reserve, preserve):
+    """everything behind the capture search is the device's as always: Types casts, Time_Keep, Reserve_Data / Preserve_Key"""
+    data, off, ep = synth.apache_records(6000)
+    blob = bytes(data)
+    host_rx = APACHE2.replace(r"^(?<host>[^ ]*) ", r"^(?=[^ ]* )(?<host>[^ ]*+) ")
+    types = "code:integer size:integer"
+    p = g.Parser(host_rx, time_fmt=TF, time_key="time", time_keep=True, types=types)
+    f = g.FilterParser("log", [p], reserve, preserve)
+    assert f.host_rules()["rules"] == 1
+    r, out = f.filter(blob)
+    ro, oo = ob.FilterParser("log", [ob.Parser(regex=APACHE2, time_fmt=TF, time_key="time", time_keep=True, types=types)], reserve, preserve).filter(blob)
+    assert r == ro == ob.MODIFIED and out == oo
+    assert f.host_rules()["unhandled"] == 0
