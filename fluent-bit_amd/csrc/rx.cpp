@@ -895,7 +895,7 @@ struct Syntax {
                 max_ref = std::max(max_ref, v);
                 return a;
             }
-            uint32_t v;
+            uint32_t v = 0;
             if (escape_cp(v, false)) { if (failed()) return nullptr; return literal(v, opts); }
             v = take_cp();
             return literal(v, opts);
@@ -1327,6 +1327,10 @@ struct Builder {
             for (int i = 0; i < a->min; i++) cur = build(body, cur);
             return cur;
         }
+        default:
+            // (look-around, atomic groups, back-references, \K, conditionals: compile() refuses them in front of every table builder)
+            nfa.err = "not a regular expression";
+            return next;
         }
         return next;
     }
