@@ -55,6 +55,9 @@ def lib():
     L.flbgpu_parser_create_kv.argtypes = [c_char_p, c_char_p, c_char_p, c_char_p, c_char_p, c_int, c_int, c_int, c_char_p]
     L.flbgpu_parser_destroy.argtypes = [c_void_p]
     L.flbgpu_parser_add_decoder.argtypes = [c_void_p, c_int, c_char_p, c_char_p, c_char_p]
+    L.flbgpu_parser_set_time_zone.argtypes = [c_void_p, c_char_p]
+    L.flbgpu_parser_set_system_timezone.argtypes = [c_void_p, c_int]
+    L.flbgpu_tz_tm2time.argtypes = [c_char_p, c_int64, POINTER(c_int64)]
     L.flbgpu_parser_do.argtypes = [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int64), POINTER(c_int64)]
     L.flbgpu_filter_parser_create.restype = c_void_p
     L.flbgpu_filter_parser_create.argtypes = [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]
@@ -168,7 +171,8 @@ class Parser:
     flb_parser_create.  Defaults are the parsers-file defaults (src/flb_parser.c:1277-1304)."""
 
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex", no_bare_keys=False, decoders=None):
+                 time_strict=True, skip_empty=True, types=None, name="parser", format="regex", no_bare_keys=False, decoders=None,
+                 time_zone=None, time_system_timezone=False):
         if format in ("logfmt", "ltsv"):
             self.h = lib().flbgpu_parser_create_kv(_b(name), _b(format), _b(time_fmt), _b(time_key), _b(time_offset), int(time_keep),
                                                    int(time_strict), int(no_bare_keys), _b(types))
@@ -184,6 +188,13 @@ class Parser:
         for d in decoders or []:
             if lib().flbgpu_parser_add_decoder(self.h, int(bool(d[0])), _b(d[1]), _b(d[2]), _b(d[3] if len(d) > 3 else None)) != 0:
                 raise ValueError("flbgpu_parser_add_decoder: " + last_error())
+        # Time_Zone <IANA name> / Time_System_Timezone On (src/flb_parser.c:986-1022)
+        if time_system_timezone and lib().flbgpu_parser_set_system_timezone(self.h, 1) != 0:
+            err = last_error(); self.close()
+            raise ValueError("flbgpu_parser_set_system_timezone: " + err)
+        if time_zone and lib().flbgpu_parser_set_time_zone(self.h, _b(time_zone)) != 0:
+            err = last_error(); self.close()
+            raise ValueError("flbgpu_parser_set_time_zone: " + err)
 
     def do(self, buf):
         out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()

@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <atomic>
+#include "tzif.hpp"
 
 namespace flbgpu {
 
@@ -182,6 +183,14 @@ struct DevParser {
     DevFx fx;
     DevFx fx2;                     // the same tables with a pair section per row (two steps per read); ok = 0: does not fit                            // compact forward tables of the tile kernel (ok == 0: none)
     const DevDecoders *decs;             // Decode_Field / Decode_Field_As rules (device memory; nullptr: none) -- dec_dev.inc
+    // Time_Zone / Time_System_Timezone (src/flb_parser.c:685-696 flb_parser_tm2time_parser; tzif.hpp).  zone_mode 0: timegm - gmtoff;
+    // 1: the zone's TZif table decides (when the format carries no zone of its own); 2: the process's zone, which is UTC
+    // (mktime == timegm, whatever offset the text named).  Parsers with a mode take the time interpreter (plan.ok == 0).
+    int zone_mode, time_offset_given;
+    int tz_timecnt, tz_typecnt, tz_default;
+    const int64_t *tz_trans;             // device memory, owned by the flbgpu_parser
+    const int32_t *tz_gmtoff;
+    const uint8_t *tz_ttype;
 };
 
 // ---- record accessor / key

@@ -207,6 +207,9 @@ static void compile_time_plan(const TimePlan &pl, uint32_t out[32]) {
 }
 
 // ------------------------------------------------------------------------------------------ parser
+// what tzif_parse_data keeps of a zone's file (tzif.hpp)
+struct TzTable { std::vector<int64_t> trans; std::vector<uint8_t> ttype; std::vector<int32_t> gmtoff; int default_type = 0; };
+
 struct flbgpu_parser {
     std::string name;
     rx::Program prog;
@@ -216,9 +219,122 @@ struct flbgpu_parser {
     DevDecoders decs;              // Decode_Field / Decode_Field_As (flbgpu_parser_add_decoder), uploaded when a filter takes the parser
     void *d_decs = nullptr;
     rx::BtProgram *bt = nullptr;   // a HOST parser: the Regex is not a regular expression, the backtracking matcher answers on the host (rxbt.inc)
+    TzTable zone;                  // Time_Zone (flbgpu_parser_set_time_zone), uploaded when a filter takes the parser
+    void *d_zone = nullptr;
     flbgpu_parser() { memset(&decs, 0, sizeof(decs)); }
-    ~flbgpu_parser() { if (d_decs) (void) hipFree(d_decs); if (bt) rx::bt_free(bt); }
+    ~flbgpu_parser() { if (d_decs) (void) hipFree(d_decs); if (d_zone) (void) hipFree(d_zone); if (bt) rx::bt_free(bt); }
 };
+
+// ---- Time_Zone / Time_System_Timezone (src/flb_parser.c:805-1049 flb_parser_create_with_time_zone)
+// The zone's TZif file read the way tzif_load / tzif_parse_data do (src/flb_parser.c:452-537, 359-450): $TZDIR or
+// /usr/share/zoneinfo, the 64-bit block of a version 2+ file, else the 32-bit one; the footer string is not read.
+static uint32_t tz_be32(const unsigned char *b) { return ((uint32_t) b[0] << 24) | ((uint32_t) b[1] << 16) | ((uint32_t) b[2] << 8) | b[3]; }
+static bool tz_block(const unsigned char *buf, size_t size, int time_size, TzTable &z) {
+    if (size < 44) return false;
+    const uint32_t timecnt = tz_be32(buf + 32), typecnt = tz_be32(buf + 36);
+    if (typecnt == 0 || timecnt > 0x7FFFFFFFu || typecnt > 0x7FFFFFFFu) return false;
+    size_t off = 44;
+    if (off + (size_t) timecnt * time_size + timecnt + (size_t) typecnt * 6 > size) return false;
+    z.trans.resize(timecnt); z.ttype.resize(timecnt); z.gmtoff.resize(typecnt);
+    for (uint32_t i = 0; i < timecnt; i++, off += time_size) {
+        if (time_size == 8) z.trans[i] = (int64_t) (((uint64_t) tz_be32(buf + off) << 32) | tz_be32(buf + off + 4));
+        else z.trans[i] = (int32_t) tz_be32(buf + off);
+    }
+    for (uint32_t i = 0; i < timecnt; i++) { z.ttype[i] = buf[off + i]; if (z.ttype[i] >= typecnt) return false; }
+    off += timecnt;
+    z.default_type = 0;
+    bool have_std = false;
+    for (uint32_t i = 0; i < typecnt; i++, off += 6) {
+        z.gmtoff[i] = (int32_t) tz_be32(buf + off);
+        if (!have_std && buf[off + 4] == 0) { z.default_type = (int) i; have_std = true; }
+    }
+    // the lookups index the types with a byte and walk all of them per record
+    return typecnt <= 256;
+}
+static bool tz_load(const char *iana_zone, TzTable &z, std::string &why) {
+    const char *tzdir = getenv("TZDIR");
+    if (!tzdir || !tzdir[0]) tzdir = "/usr/share/zoneinfo";
+    const std::string path = std::string(tzdir) + "/" + iana_zone;
+    if (path.size() >= 4096) { why = "path too long"; return false; }
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { why = "invalid or unavailable time_zone (no " + path + ")"; return false; }
+    std::vector<unsigned char> buf;
+    unsigned char chunk[4096];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof(chunk), fp)) > 0) { buf.insert(buf.end(), chunk, chunk + got); if (buf.size() > (1u << 24)) break; }
+    fclose(fp);
+    why = "could not load time_zone";
+    if (buf.size() < 44 || memcmp(buf.data(), "TZif", 4) != 0) return false;
+    const unsigned char version = buf[4];
+    if (version == '2' || version == '3' || version == '4') {
+        const uint32_t isutcnt = tz_be32(&buf[20]), isstdcnt = tz_be32(&buf[24]), leapcnt = tz_be32(&buf[28]), timecnt = tz_be32(&buf[32]),
+                       typecnt = tz_be32(&buf[36]), charcnt = tz_be32(&buf[40]);
+        const size_t block = (size_t) timecnt * 4 + timecnt + (size_t) typecnt * 6 + charcnt + (size_t) leapcnt * 8 + isstdcnt + isutcnt;
+        if (44 + block + 44 > buf.size() || memcmp(&buf[44 + block], "TZif", 4) != 0) return false;
+        return tz_block(&buf[44 + block], buf.size() - 44 - block, 8, z);
+    }
+    return tz_block(buf.data(), buf.size(), 4, z);
+}
+
+// Time_Zone <IANA name> on a parser with a Time_Format (src/flb_parser.c:988-1022): refused together with Time_Offset or
+// Time_System_Timezone, refused when the zone's file is not there.  The records of such a parser take the interpreter
+// for the time text (no compiled plan): the seconds come from tz::tm2time over the table (tzif.hpp).
+extern "C" int flbgpu_parser_set_time_zone(flbgpu_parser *p, const char *iana_zone) {
+    if (!p) { set_err("parser time_zone: missing argument"); return -1; }
+    if (!iana_zone || !iana_zone[0]) return 0;
+    if (!p->dev.has_time) { set_err("parser '%s': time_zone requires time_format", p->name.c_str()); return -1; }
+    if (p->dev.zone_mode == 2) { set_err("parser '%s': time_zone cannot be combined with time_system_timezone", p->name.c_str()); return -1; }
+    if (p->dev.time_offset_given) { set_err("parser '%s': time_zone cannot be combined with time_offset", p->name.c_str()); return -1; }
+    // validate_time_zone (:606-638): the name has to be one of the reference's built-in zone index before its file is looked for
+    static const char *const known[] = {
+#include "tz_names.inc"
+    };
+    size_t lo = 0, hi = sizeof(known) / sizeof(known[0]);
+    bool listed = false;
+    while (lo < hi && !listed) {
+        const size_t mid = (lo + hi) / 2;
+        const int c = strcmp(iana_zone, known[mid]);
+        if (c == 0) listed = true;
+        else if (c < 0) hi = mid;
+        else lo = mid + 1;
+    }
+    if (!listed) { set_err("parser '%s': invalid or unavailable time_zone '%s' (not a name of the zone index)", p->name.c_str(), iana_zone); return -1; }
+    TzTable z;
+    std::string why;
+    if (!tz_load(iana_zone, z, why)) { set_err("parser '%s': %s '%s'", p->name.c_str(), why.c_str(), iana_zone); return -1; }
+    p->zone = z;
+    p->dev.zone_mode = 1;
+    p->dev.plan.ok = 0;
+    if (p->d_zone) { (void) hipFree(p->d_zone); p->d_zone = nullptr; }
+    if (p->self_filter) { delete p->self_filter; p->self_filter = nullptr; }
+    return 0;
+}
+
+// Time_System_Timezone On (src/flb_parser.c:986, include/fluent-bit/flb_parser.h:80-94: mktime() of the fields with
+// tm_isdst = -1, whatever zone the text itself named).  Taken when the process's zone is UTC without rules -- mktime is
+// timegm then; any other process zone is refused (mktime's choice inside gaps and overlaps is the C library's).
+extern "C" int flbgpu_parser_set_system_timezone(flbgpu_parser *p, int on) {
+    if (!p) { set_err("parser time_system_timezone: missing argument"); return -1; }
+    if (!on) return 0;
+    if (p->dev.zone_mode == 1) { set_err("parser '%s': time_zone cannot be combined with time_system_timezone", p->name.c_str()); return -1; }
+    tzset();
+    if (timezone != 0 || daylight != 0) { set_err("parser '%s': Time_System_Timezone with a process zone that is not UTC is not supported", p->name.c_str()); return -1; }
+    p->dev.zone_mode = 2;
+    p->dev.time_offset = 0;                                 // (src/flb_parser.c:1027: the fixed offset is not applied)
+    p->dev.plan.ok = 0;
+    if (p->self_filter) { delete p->self_filter; p->self_filter = nullptr; }
+    return 0;
+}
+
+// CPU test hook: tzif_tm2time (src/flb_parser.c:560-590) of `local_epoch` = timegm() of the parsed fields, over the
+// zone's file -- the same tz::tm2time text the kernels run.  Returns 0, -1 when the zone does not load.
+extern "C" int flbgpu_tz_tm2time(const char *iana_zone, int64_t local_epoch, int64_t *out) {
+    TzTable z;
+    std::string why;
+    if (!iana_zone || !out || !tz_load(iana_zone, z, why)) { set_err("time_zone: %s '%s'", why.c_str(), iana_zone ? iana_zone : ""); return -1; }
+    *out = tz::tm2time(z.trans.data(), z.ttype.data(), z.gmtoff.data(), (int) z.trans.size(), (int) z.gmtoff.size(), z.default_type, local_epoch);
+    return 0;
+}
 
 // One rule of a parser's decoder list: "Decode_Field[_As] <backend> <key> [try_next|do_next]" (conf/parsers.conf, parsed by
 // src/flb_parser_decoder.c:593-776 flb_parser_decoder_list_create): rules of one key are kept together in configuration order,
@@ -422,6 +538,7 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
             int diff = 0;
             if (tzone_offset(time_offset, (int) strlen(time_offset), &diff) == -1) { set_err("parser '%s': invalid Time_Offset", p->name.c_str()); delete p; return nullptr; }
             d.time_offset = diff;
+            d.time_offset_given = 1;
         }
     }
     // Types: src/flb_parser.c:1130-1182
@@ -710,6 +827,25 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
     std::vector<DevParser> dp;
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
+        parsers[i]->dev.tz_trans = nullptr; parsers[i]->dev.tz_gmtoff = nullptr; parsers[i]->dev.tz_ttype = nullptr;
+        if (parsers[i]->dev.zone_mode == 1) {
+            // one block: transitions (8 bytes each), offsets (4), transition types (1)
+            const TzTable &z = parsers[i]->zone;
+            const size_t nt = z.trans.size(), ny = z.gmtoff.size(), bytes = nt * 8 + ny * 4 + nt + 16;
+            if (!parsers[i]->d_zone) {
+                std::vector<uint8_t> blk(bytes, 0);
+                if (nt) memcpy(blk.data(), z.trans.data(), nt * 8);
+                memcpy(blk.data() + nt * 8, z.gmtoff.data(), ny * 4);
+                if (nt) memcpy(blk.data() + nt * 8 + ny * 4, z.ttype.data(), nt);
+                if (hipMalloc(&parsers[i]->d_zone, bytes) != hipSuccess ||
+                    hipMemcpy(parsers[i]->d_zone, blk.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                    set_err("device copy of the time zone table failed"); delete f; return nullptr;
+                }
+            }
+            const uint8_t *b = (const uint8_t *) parsers[i]->d_zone;
+            parsers[i]->dev.tz_trans = (const int64_t *) b; parsers[i]->dev.tz_gmtoff = (const int32_t *) (b + nt * 8); parsers[i]->dev.tz_ttype = b + nt * 8 + ny * 4;
+            parsers[i]->dev.tz_timecnt = (int) nt; parsers[i]->dev.tz_typecnt = (int) ny; parsers[i]->dev.tz_default = z.default_type;
+        }
         parsers[i]->dev.decs = nullptr;
         if (parsers[i]->decs.n > 0) {
             if (!parsers[i]->d_decs &&

@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         uint64_t null_mask = 0;
         if (!a.cfg.key.is_ra) null_note(a.cfg, r, key_index, null_mask);
         int64_t tsec = a.info[4 * n + r], tnsec = a.info[5 * n + r];
-        if (fl0 & RF_BADTS) { tsec = -1; tnsec = 0; }                        // the event time was out of range
+        if (fl0 & RF_BADTS) { tsec = -3; tnsec = 0; }                        // the event time was out of range
         int64_t psec = sec, pnsec = (int64_t) (frac * 1000000000);
         bool have_parsed_time = ((uint64_t) psec * 1000000000ull + (uint64_t) pnsec) != 0;
         if (have_parsed_time) { tsec = psec; tnsec = pnsec; }
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         a.info[11 * n + r] = kept;
         a.info[12 * n + r] = drop;
         // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
-        if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
+        if (encoder_refuses_time(tsec, tnsec)) {
             a.info[r] = flags | RF_BADTS;
             a.out_len[r] = 0;
             if (a.pg_keep_len) a.pg_keep_len[r] = 0;
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
         }
         if (have_out && last_ok) ri.flags |= RF_PARSED;
         // encoder timestamp check (src/flb_log_event_encoder.c:345-363)
-        if (tsec < 0 || (uint64_t) tsec > 0xffffffffull || tnsec < 0 || tnsec >= 1000000000LL) {
+        if (encoder_refuses_time(tsec, tnsec)) {
             ri.flags |= RF_BADTS;
             rec_store(a.info, a.n, r, ri); a.out_len[r] = 0; a.null_mask[r] = null_mask;
             continue;

@@ -286,6 +286,42 @@ void add_ctype(CC &cc, char t, bool negated, bool unicode = false) {
     cc.mbx.norm();
 }
 
+// \p{Name} beyond the POSIX bracket names: general categories, scripts, binary properties, blocks (regparse.c parse_char_property /
+// parse_char_class TK_CHAR_PROPERTY -> add_ctype_to_cc(cc, ctype, not, 0): the property's code ranges, the ASCII ones included, never
+// ASCII-range; inside brackets the (?i) shadow class gets them too).  Members: unicode_props.inc, generated by probing the
+// reference's engine on every code point (tools/gen_unicode_props.py); `n` as the engine normalises a name.
+#include "unicode_props.inc"
+bool add_uniprop(CC &cc, const std::string &n, bool negated) {
+    size_t lo = 0, hi = sizeof(uprop_names) / sizeof(uprop_names[0]);
+    int set = -1;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        const int c = strcmp(n.c_str(), uprop_names[mid].name);
+        if (c == 0) { set = (int) uprop_names[mid].set; break; }
+        if (c < 0) hi = mid;
+        else lo = mid + 1;
+    }
+    if (set < 0) return false;
+    ByteSet a;
+    CodeSet m;
+    const unsigned int first = uprop_sets[set][0], cnt = uprop_sets[set][1];
+    for (unsigned int i = first; i < first + cnt; i++) {
+        const unsigned int l = uprop_ranges[i][0], h = uprop_ranges[i][1];
+        for (unsigned int b = l; b <= h && b < 0x80; b++) a.set((int) b);
+        if (h >= 0x80) m.add(l < 0x80 ? 0x80 : l, h);
+    }
+    for (int b = 0; b < 0x80; b++) if (a.has(b) != negated) cc.asc.set(b);
+    if (!negated) { cc.bs.merge(a); cc.mb.merge(m); cc.mbx.merge(m); }
+    else {
+        for (int b = 0; b < 0x80; b++) if (!a.has(b)) cc.bs.set(b);
+        CodeSet c = mb_complement(m);
+        cc.mb.merge(c);
+        cc.mbx.merge(c);
+    }
+    cc.mb.norm(); cc.mbx.norm();
+    return true;
+}
+
 // [[:name:]] / [[:^name:]]: NOT ASCII-range (ONIG_OPTION_POSIX_BRACKET_ALL_RANGE): the code points >= 0x80
 // come from posix_ranges.inc (generated by probing the reference's engine, tools/gen_posix_ranges.py)
 bool add_posix(CC &cc, const std::string &n, bool negated, bool ascii_range = false) {
@@ -520,9 +556,11 @@ struct Syntax {
         if (eof()) return fail("invalid character property name {...}");
         p++;
         if (as_flag) { *as_flag = neg; neg = false; }
-        // (\p{Punct} is the Unicode category P -- without $ + < = > ^ ` | ~, which [[:punct:]] has: not the bracket's set, not taken)
-        if (nm == "punct" || !add_posix(cc, nm, neg, false)) return fail(("the character property \\p{" + nm + "} is not supported (scripts, categories, ages: only the POSIX bracket names are)").c_str());
-        return true;
+        // (\p{Punct} is the Unicode category P -- without $ + < = > ^ ` | ~, which [[:punct:]] has: the property table's set, not the bracket's)
+        if (nm != "punct" && add_posix(cc, nm, neg, false)) return true;
+        if (add_uniprop(cc, nm, neg)) return true;
+        if (nm.compare(0, 4, "age=") == 0) return fail(("the character property \\p{" + nm + "} is not supported (Unicode ages are not in the property table)").c_str());
+        return fail(("invalid character property name {" + nm + "}").c_str());
     }
 
     void skip_extended(unsigned opts) {

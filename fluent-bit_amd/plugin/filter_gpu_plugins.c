@@ -322,11 +322,9 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
             flb_plg_error(f_ins, "requested parser '%s' not found", kv->val);
             continue;
         }
-        if ((p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON && p->type != FLB_PARSER_LOGFMT &&
-             p->type != FLB_PARSER_LTSV) ||
-            p->time_zone != NULL || p->time_system_timezone) {
-            flb_plg_error(f_ins, "parser '%s': only Format regex / json / logfmt / ltsv without time zones "
-                          "is on the GPU path", kv->val);
+        if (p->type != FLB_PARSER_REGEX && p->type != FLB_PARSER_JSON && p->type != FLB_PARSER_LOGFMT &&
+            p->type != FLB_PARSER_LTSV) {
+            flb_plg_error(f_ins, "parser '%s': only Format regex / json / logfmt / ltsv is on the GPU path", kv->val);
             goto error;
         }
         if (ctx->n_parsers >= MAX_GPU_PARSERS) {
@@ -354,6 +352,13 @@ static int cb_parser_gpu_init(struct flb_filter_instance *f_ins, struct flb_conf
         flb_free(types);
         if (!ctx->parsers[ctx->n_parsers]) {
             flb_plg_error(f_ins, "%s", flbgpu_last_error());
+            goto error;
+        }
+        /* Time_System_Timezone / Time_Zone (src/flb_parser.c:986-1022): the twin reads the zone's file the way the parser did */
+        if (flbgpu_parser_set_system_timezone(ctx->parsers[ctx->n_parsers], p->time_system_timezone) != 0 ||
+            flbgpu_parser_set_time_zone(ctx->parsers[ctx->n_parsers], p->time_zone) != 0) {
+            flb_plg_error(f_ins, "%s", flbgpu_last_error());
+            ctx->n_parsers++;
             goto error;
         }
         ret = add_decoders(ctx->parsers[ctx->n_parsers], p);

@@ -79,6 +79,20 @@ flbgpu_parser *flbgpu_parser_create_kv(const char *name, const char *format, con
  * the filter exactly where flb_parser_decoder_do (:215-550) runs inside flb_parser_do (regex / logfmt / ltsv: on the packed
  * map; Format json: before the time lookup).  0, or -1 with flbgpu_last_error(). */
 int flbgpu_parser_add_decoder(flbgpu_parser *p, int as, const char *backend, const char *key, const char *action);
+/* The parser section's Time_Zone line -- an IANA name, the `time_zone` argument of flb_parser_create_with_time_zone
+ * (src/flb_parser.c:805-1049, :988-1022): a Time_Format without %z / %Z reads its fields as local time of that zone,
+ * the seconds come from the zone's TZif table under $TZDIR (default /usr/share/zoneinfo) exactly as tzif_load :452-537
+ * reads it and tzif_tm2time :560-590 walks it (flb_parser_tm2time_parser :685-696).  NULL / "": nothing.  Refused like the
+ * reference refuses: without a Time_Format, together with Time_Offset or Time_System_Timezone, for a zone whose file is not
+ * there.  Call before the parser is handed to a filter.  0, or -1 with flbgpu_last_error(). */
+int flbgpu_parser_set_time_zone(flbgpu_parser *p, const char *iana_zone);
+/* Time_System_Timezone On (`time_system_timezone`, src/flb_parser.c:986; include/fluent-bit/flb_parser.h:80-94: mktime() of the
+ * parsed fields).  Accepted when the process's zone is UTC (mktime is timegm then; the offset a text names is ignored as mktime
+ * ignores it), refused for any other process zone.  0, or -1 with flbgpu_last_error(). */
+int flbgpu_parser_set_system_timezone(flbgpu_parser *p, int on);
+/* Test hook without a device: tzif_tm2time (src/flb_parser.c:560-590) of local_epoch = timegm() of the parsed fields in the
+ * named zone -- the routine the kernels run, on the host.  0 with *out set, -1 when the zone's file does not load. */
+int flbgpu_tz_tm2time(const char *iana_zone, int64_t local_epoch, int64_t *out);
 void flbgpu_parser_destroy(flbgpu_parser *p);
 /* flb_parser_do(): one value in host memory -> malloc()'d msgpack map.  Returns the last byte
  * consumed (>= 0: the end of the last named group that took part in the match, src/flb_regex.c:52-54)

@@ -109,6 +109,12 @@ typedef struct oflb_parser {
     int types_len;
     struct odec *decs;       /* Decode_Field / Decode_Field_As (src/flb_parser_decoder.c), one entry per key */
     int ndecs;
+    /* Time_Zone (struct tzif, src/flb_parser.c:217-229) / Time_System_Timezone */
+    int has_zone, system_tz;
+    int tz_timecnt, tz_typecnt, tz_default;
+    int64_t *tz_trans;
+    unsigned char *tz_ttype;
+    int32_t *tz_gmtoff;
 } oflb_parser;
 
 /* include/fluent-bit/flb_parser_decoder.h:28-59 */
@@ -367,11 +373,111 @@ static int time_lookup(const char *time_str, size_t tsize, time_t now, oflb_pars
     return 0;
 }
 
-/* include/fluent-bit/flb_parser.h:80-94 (use_system_timezone == FALSE) */
-static time_t tm2time(const struct otm *src)
+/* src/flb_parser.c:539-558 tzif_type_at_utc, said the long way round: the type of the LAST transition at or before `utc`
+ * (the reference bisects; the transitions of a TZif file ascend, so the last one that is <= utc is the same entry) */
+static int zone_type_at(const oflb_parser *p, int64_t utc)
+{
+    int i, at = -1;
+    for (i = 0; i < p->tz_timecnt; i++) {
+        if (p->tz_trans[i] <= utc) at = i;
+        else break;
+    }
+    if (at < 0) return p->tz_default;
+    return p->tz_ttype[at];
+}
+
+/* src/flb_parser.c:560-590 tzif_tm2time */
+static time_t zone_tm2time(const oflb_parser *p, const struct otm *src)
 {
     struct tm tmp = src->tm;
+    int64_t local_epoch, cand;
+    int i, ty;
+    tmp.tm_isdst = 0;
+    local_epoch = (int64_t) timegm(&tmp);
+    for (i = 0; i < p->tz_typecnt; i++) {
+        cand = local_epoch - (int64_t) p->tz_gmtoff[i];
+        ty = zone_type_at(p, cand);
+        if (ty >= 0 && ty < p->tz_typecnt && p->tz_gmtoff[ty] == p->tz_gmtoff[i]) return (time_t) cand;
+    }
+    ty = zone_type_at(p, local_epoch);
+    if (ty < 0 || ty >= p->tz_typecnt) return (time_t) -1;
+    return (time_t) (local_epoch - (int64_t) p->tz_gmtoff[ty]);
+}
+
+/* src/flb_parser.c:685-696 flb_parser_tm2time_parser over include/fluent-bit/flb_parser.h:80-94 flb_parser_tm2time */
+static time_t tm2time(const oflb_parser *parser, const struct otm *src)
+{
+    struct tm tmp = src->tm;
+    if (parser && parser->has_zone && !parser->time_with_tz) return zone_tm2time(parser, src);
+    if (parser && parser->system_tz) { tmp.tm_isdst = -1; return mktime(&tmp); }
     return timegm(&tmp) - src->gmtoff;
+}
+
+static uint32_t be32(const unsigned char *b) { return ((uint32_t) b[0] << 24) | ((uint32_t) b[1] << 16) | ((uint32_t) b[2] << 8) | b[3]; }
+
+/* The `time_zone` / `time_system_timezone` arguments of flb_parser_create_with_time_zone (src/flb_parser.c:986-1022) on a parser made by
+ * oflb_parser_create*: the zone's file read as tzif_load :452-537 + tzif_parse_data :359-450 read it.  -1 where the reference
+ * returns NULL (no Time_Format :894, both at once :989, with Time_Offset :995 -- `had_offset` says the create call was given
+ * one --, no such file :1003, a file that does not parse :1015). */
+int oflb_parser_set_time_zone(oflb_parser *p, const char *zone, int system_tz, int had_offset)
+{
+    const char *tzdir = getenv("TZDIR");
+    char path[4096];
+    FILE *fp;
+    unsigned char *buf, *h;
+    long fsz;
+    size_t size, off;
+    int time_size = 4, i;
+    uint32_t timecnt, typecnt;
+    if (system_tz) { p->system_tz = 1; p->time_offset = 0; }
+    if (!zone || !zone[0]) return 0;
+    if (!p->time_fmt || system_tz || had_offset) return -1;
+    {
+        /* validate_time_zone :606-638: a name outside the built-in index (src/flb_time_tz.c) is refused before its file is looked for */
+        static const char *const known[] = {
+#include "tz_names.inc"
+        };
+        int found = 0;
+        for (i = 0; i < (int) (sizeof(known) / sizeof(known[0])); i++) if (!strcmp(known[i], zone)) found = 1;
+        if (!found) return -1;
+    }
+    if (!tzdir || !tzdir[0]) tzdir = "/usr/share/zoneinfo";
+    if (snprintf(path, sizeof(path), "%s/%s", tzdir, zone) >= (int) sizeof(path)) return -1;
+    fp = fopen(path, "rb");
+    if (!fp) return -1;
+    fseek(fp, 0, SEEK_END); fsz = ftell(fp); rewind(fp);
+    if (fsz <= 0) { fclose(fp); return -1; }
+    buf = malloc((size_t) fsz);
+    if (fread(buf, 1, (size_t) fsz, fp) != (size_t) fsz) { fclose(fp); free(buf); return -1; }
+    fclose(fp);
+    if (fsz < 44 || memcmp(buf, "TZif", 4) != 0) { free(buf); return -1; }
+    h = buf; size = (size_t) fsz;
+    if (buf[4] == '2' || buf[4] == '3' || buf[4] == '4') {
+        /* tzif_data_size :318-345: the length of the 32-bit block, whose 64-bit twin follows it */
+        size_t block = (size_t) be32(buf + 32) * 4 + be32(buf + 32) + (size_t) be32(buf + 36) * 6 + be32(buf + 40) +
+                       (size_t) be32(buf + 28) * 8 + be32(buf + 24) + be32(buf + 20);
+        if (44 + block + 44 > (size_t) fsz || memcmp(buf + 44 + block, "TZif", 4) != 0) { free(buf); return -1; }
+        h = buf + 44 + block; size = (size_t) fsz - 44 - block; time_size = 8;
+    }
+    timecnt = be32(h + 32); typecnt = be32(h + 36);
+    if (typecnt == 0 || timecnt > 0x7fffffffu || typecnt > 0x7fffffffu ||
+        44 + (size_t) timecnt * time_size + timecnt + (size_t) typecnt * 6 > size) { free(buf); return -1; }
+    p->tz_trans = calloc(timecnt + 1, sizeof(int64_t)); p->tz_ttype = calloc(timecnt + 1, 1); p->tz_gmtoff = calloc(typecnt, sizeof(int32_t));
+    off = 44;
+    for (i = 0; i < (int) timecnt; i++, off += time_size)
+        p->tz_trans[i] = time_size == 8 ? (int64_t) (((uint64_t) be32(h + off) << 32) | be32(h + off + 4)) : (int64_t) (int32_t) be32(h + off);
+    memcpy(p->tz_ttype, h + off, timecnt);
+    off += timecnt;
+    for (i = 0; i < (int) timecnt; i++) if (p->tz_ttype[i] >= typecnt) { free(buf); return -1; }
+    p->tz_default = -1;
+    for (i = 0; i < (int) typecnt; i++, off += 6) {
+        p->tz_gmtoff[i] = (int32_t) be32(h + off);
+        if (p->tz_default < 0 && h[off + 4] == 0) p->tz_default = i;
+    }
+    if (p->tz_default < 0) p->tz_default = 0;
+    p->tz_timecnt = (int) timecnt; p->tz_typecnt = (int) typecnt; p->has_zone = 1;
+    free(buf);
+    return 0;
 }
 
 /* src/flb_parser.c:2067-2164 */
@@ -494,7 +600,7 @@ static int oflb_parser_json_do(oflb_parser *parser, const char *buf, size_t leng
         time_lookup_v = 0;
         skip = map_size;
     }
-    else time_lookup_v = tm2time(&tm);
+    else time_lookup_v = tm2time(parser, &tm);
     omp_buf_init(&nb);
     omp_pack_map(&nb, (!parser->time_keep && skip < map_size) ? map_size - 1 : map_size);
     for (i = 0; i < map_size; i++) {
@@ -708,7 +814,7 @@ static int kv_walk(oflb_parser *parser, const char *in_buf, size_t in_size, omp_
             if (parser->time_fmt && key_len == time_key_len && value_len > 0 && !strncmp((const char *) key, time_key, key_len)) {
                 if (pck) {
                     if (time_lookup((const char *) value, value_len, 0, parser, &tm, tmfrac) == -1) return -1;
-                    *time_out = tm2time(&tm);
+                    *time_out = tm2time(parser, &tm);
                 }
                 time_found = 1;
             }
@@ -1033,7 +1139,7 @@ static int parser_do_inner(oflb_parser *parser, const char *buf, size_t length, 
                     }
                     else {
                         time_frac = frac;
-                        time_lookup_v = tm2time(&tm);
+                        time_lookup_v = tm2time(parser, &tm);
                         if (!parser->time_keep) { num_skipped++; done = 1; }
                     }
                 }
@@ -1471,7 +1577,9 @@ int oflb_fparser_filter(oflb_fparser *ctx, const char *data, size_t bytes, char 
         }
 
         /* encoder: begin_record / set_timestamp / set_metadata_from_msgpack_object */
-        if (!valid_eventtime(&tm)) encoder_ok = 0;   /* src/flb_log_event_encoder.c:345-363 */
+        /* src/flb_log_event_encoder.c:345-363: outside the EventTime range the record fails -- except for the two values of the group
+         * markers (-1 s, -2 s, no nanoseconds), which set_timestamp takes from anyone */
+        if (!valid_eventtime(&tm) && !(tm.nsec == 0 && (tm.sec == -1 || tm.sec == -2))) encoder_ok = 0;
 
         if (out_buf != NULL && parse_ret >= 0) {
             if (append_arr != NULL && append_arr_len > 0) {
@@ -1937,7 +2045,7 @@ int oflb_time_lookup(oflb_parser *p, const char *s, size_t len, int64_t now, int
     if (toff_enc >= 0) p->time_offset = toff_enc - (1 << 20);
     r = time_lookup(s, len, (time_t) now, p, &tm, frac);
     p->time_offset = saved;
-    if (r == 0) *sec = (int64_t) tm2time(&tm);
+    if (r == 0) *sec = (int64_t) tm2time(p, &tm);
     return r;
 }
 

@@ -15,7 +15,7 @@
  * Protocol (stdin -> stdout, binary, one case after the other):
  *   u32 kind (1 grep, 2 parser, 3 bench-pair), u32 nprops, nprops x (u32 klen, key, u32 vlen, val),
  *   u32 nparsers, nparsers x 9 strings (name, format, regex, time_fmt, time_key, time_offset, types, skip_empty "0/1",
- *   flags "time_keep time_strict[|decode_field[_as] backend field [action]]..."), u64 data_len, data        [kind 3: u32 iterations first]
+ *   flags "time_keep time_strict[ tz=<zone>][ systz][|decode_field[_as] backend field [action]]..."), u64 data_len, data        [kind 3: u32 iterations first]
  *   kind 4 (in_tail's line packing): props = key, path_key, path, offset_key, stream_offset, skip_empty_lines, sec, nsec; data = text:
  *   the loop of process_content (plugins/in_tail/tail_file.c:783-786,840-1000, plain path) restated here, every line packed by the
  *   REAL encoder through flb_tail_file_pack_line's call sequence (:552-604); answer ret = lines, out = records, then u64 processed
@@ -532,8 +532,20 @@ int main(void)
                 flb_utils_split_free(split);
             }
             decoders = make_decoders(strchr(f[8], '|'));
-            flb_parser_create(f[0], f[1], f[2][0] ? f[2] : NULL, atoi(f[7]), f[3][0] ? f[3] : NULL, f[4][0] ? f[4] : NULL, f[5][0] ? f[5] : NULL,
-                              time_keep, time_strict, FLB_FALSE, FLB_FALSE, types, types_len, decoders, config);
+            {
+                /* "... tz=<IANA name>" / "... systz" in front of the first '|': the parser section's Time_Zone / Time_System_Timezone */
+                char zone[256] = "";
+                int systz = FLB_FALSE;
+                char *bar = strchr(f[8], '|'), *z;
+                if (bar) *bar = 0;
+                z = strstr(f[8], " tz=");
+                if (z) { sscanf(z + 4, "%255s", zone); }
+                if (strstr(f[8], " systz")) systz = FLB_TRUE;
+                if (bar) *bar = '|';
+                flb_parser_create_with_time_zone(f[0], f[1], f[2][0] ? f[2] : NULL, atoi(f[7]), f[3][0] ? f[3] : NULL, f[4][0] ? f[4] : NULL,
+                                                 f[5][0] ? f[5] : NULL, time_keep, time_strict, systz, zone[0] ? zone : NULL, FLB_FALSE,
+                                                 types, types_len, decoders, config);
+            }
         }
         if (!rd(&dlen, 8)) break;
         data = malloc(dlen + 1);

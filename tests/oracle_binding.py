@@ -68,7 +68,8 @@ class Parser:
     time_keep, time_strict, ..., types) -- include/fluent-bit/flb_parser.h:99-110.
     Defaults are the conf-file defaults (src/flb_parser.c:1277-1304)."""
     def __init__(self, regex=None, time_fmt=None, time_key=None, time_offset=None, time_keep=False,
-                 time_strict=True, skip_empty=True, types=None, format="regex", no_bare_keys=False, decoders=None):
+                 time_strict=True, skip_empty=True, types=None, format="regex", no_bare_keys=False, decoders=None,
+                 time_zone=None, time_system_timezone=False):
         e = lambda s: s.encode() if isinstance(s, str) else s
         if format == "json":
             regex = None                      # Format json (src/flb_parser_json.c)
@@ -87,6 +88,11 @@ class Parser:
         for d in decoders or []:
             if lib().oflb_parser_add_decoder(self.h, int(bool(d[0])), e(d[1]), e(d[2]), e(d[3]) if len(d) > 3 and d[3] else None) != 0:
                 raise ValueError("oracle: unknown decoder backend")
+        # Time_Zone / Time_System_Timezone (flb_parser_create_with_time_zone, src/flb_parser.c:986-1022)
+        if time_zone or time_system_timezone:
+            lib().oflb_parser_set_time_zone.argtypes = [c_void_p, c_char_p, c_int, c_int]
+            if lib().oflb_parser_set_time_zone(self.h, e(time_zone), int(bool(time_system_timezone)), int(bool(time_offset))) != 0:
+                raise ValueError("oracle: time_zone refused")
     def do(self, buf):
         out = c_void_p(); sz = c_size_t(); sec = c_int64(); nsec = c_int64()
         r = lib().oflb_parser_do(self.h, buf, len(buf), byref(out), byref(sz), byref(sec), byref(nsec))

@@ -21,6 +21,7 @@ def _parser_fields(name, p):
     fmt = p.get("format") or "regex"
     return [name, fmt, p.get("regex") or "", p.get("time_fmt") or "", p.get("time_key") or "", p.get("time_offset") or "", p.get("types") or "",
             "1" if p.get("skip_empty", True) else "0", "%d %d" % (1 if p.get("time_keep") else 0, 1 if p.get("time_strict", True) else 0) +
+            (" tz=%s" % p["time_zone"] if p.get("time_zone") else "") + (" systz" if p.get("time_system_timezone") else "") +
             "".join("|%s %s %s%s" % ("decode_field_as" if d[0] else "decode_field", d[1], d[2], " " + d[3] if len(d) > 3 and d[3] else "")
                     for d in (p.get("decoders") or []))]
 

@@ -209,6 +209,6 @@ def test_regular_patterns_through_the_backtracker():
 def test_what_stays_refused():
     """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
     L = flbamd_loader.load().lib()
-    for pat in [rb"(?~abc)", rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Han}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>"]:
+    for pat in [rb"(?~abc)", rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Age=6.0}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>"]:
         h, err = bt_compile(L, pat)
         assert h is None and err, pat
