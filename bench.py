@@ -105,7 +105,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_pass(n, steps=5, warmup=1):
+def pmc_pass(n, steps=5, warmup=1, timeout=900):
     """--pmc: HBM traffic of this very build, measured now -- the headline step once more under rocprofv3, one pass per counter
     (FETCH_SIZE, WRITE_SIZE: separate passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), in child
     processes.  Returns {kernel base name: {"FETCH_SIZE": KiB, "WRITE_SIZE": KiB}} averaged per launch, or (None, reason)."""
@@ -118,9 +118,9 @@ def pmc_pass(n, steps=5, warmup=1):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--no-cpu", "--no-secondary", "--steps", str(steps), "--warmup", str(warmup), "--records", str(n)]
+                   "--no-cpu", "--no-secondary", "--no-pmc", "--steps", str(steps), "--warmup", str(warmup), "--records", str(n)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -1013,6 +1013,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="records timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the log_to_metrics / JSON side measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="never start the rocprofv3 passes (roofline.traffic stays null when the committed summary is stale)")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic now: two more passes of the headline step under rocprofv3 (FETCH_SIZE, WRITE_SIZE)")
     ap.add_argument("--ndjson-lines", type=int, default=100_000_000, help="BASELINE configs[2]: NDJSON lines through JSON -> events -> 32-rule grep (secondary)")
     ap.add_argument("--l2m-records", type=int, default=1_000_000_000, help="BASELINE configs[3]: records through log_to_metrics over all ranks (secondary)")
@@ -1191,9 +1192,14 @@ def main():
         ach = alg_bytes_per_launch.get(dom, in_bytes) / avg_s / 1e9
         traffic, traffic_src = recorded_traffic(dom, n)
         live = None
-        if args.pmc and world == 1:
+        # --pmc, or by itself when the committed summary was recorded from other kernel sources than this tree's (an edit since the
+        # last profile): the traffic of THIS build is measured now rather than left null (--no-pmc keeps it null)
+        auto_pmc = traffic is None and not args.no_pmc and not args.pmc and world == 1
+        if (args.pmc or auto_pmc) and world == 1:
             # the same step twice more under rocprofv3 (children), after this process has finished its own timing
-            live, live_src = pmc_pass(n, args.steps, args.warmup)
+            live, live_src = pmc_pass(n, min(args.steps, 3) if auto_pmc else args.steps, args.warmup, timeout=200 if auto_pmc else 900)
+            if auto_pmc and live is not None:
+                live_src += " -- run by itself: " + str(traffic_src)
             if live is None:
                 traffic_src = "--pmc: " + live_src + "; " + str(traffic_src)
             else:
