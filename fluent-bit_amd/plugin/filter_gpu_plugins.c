@@ -45,8 +45,15 @@
 #endif
 
 static int gpu_ready = 0;
-static int gpu_corner_warned = 0;
-static unsigned long gpu_calls = 0;
+
+/* per instance (no process-wide statics shared by instances and threads; one call at a time per instance,
+ * SURVEY 8b "Threading"): what has been said already about the regex corners and the host matcher's limits */
+struct gpu_watch {
+    unsigned long calls;
+    int corner_warned;
+    uint64_t host_over;        /* flbgpu_filter_host_rules [2]: searches ended by the backtrack budget, last seen */
+    uint64_t host_unhandled;   /* [3]: records a host parser did not take, last seen */
+};
 
 static int ensure_gpu(struct flb_filter_instance *ins)
 {
@@ -65,6 +72,7 @@ static int ensure_gpu(struct flb_filter_instance *ins)
 struct grep_gpu_ctx {
     flbgpu_filter *f;
     struct flb_filter_instance *ins;
+    struct gpu_watch w;               /* f, ins, w: the head every context of this file starts with */
 };
 
 
@@ -76,6 +84,35 @@ static void gpu_note_host_rules(struct flb_filter_instance *f_ins, flbgpu_filter
     if (flbgpu_filter_host_rules(f, hr) == 0 && hr[0] > 0) {
         flb_plg_warn(f_ins, "%llu pattern(s) of this filter are not regular expressions (look-around, atomic groups, back-references): "
                      "their values are searched on the host, everything else stays on the GPU", (unsigned long long) hr[0]);
+    }
+}
+
+/* After a run: what must never be silent.  (1) the two regex corners in which the reference's own answer depends on its search
+ * optimizer (flb_gpu.h flbgpu_filter_regex_corners): said once per instance; looked at every 256 calls (a small device read).
+ * (2) the host matcher's own limits (csrc/rxbt.inc: a backtrack budget the reference does not have; records a host parser did not
+ * take): a search that ended on the budget was answered "no match", which is NOT what Onigmo would say -- warned every time the
+ * counters grow (host counters: no device read). */
+static void gpu_watch_after_run(struct flb_filter_instance *f_ins, flbgpu_filter *f, struct gpu_watch *w)
+{
+    uint64_t hr[4] = {0, 0, 0, 0};
+    if (!w->corner_warned && (++w->calls & 255) == 1 && flbgpu_filter_regex_corners(f) > 0) {
+        w->corner_warned = 1;
+        flb_plg_warn(f_ins, "%llu value(s) held ill-formed UTF-8 behind a line / word anchor or a case-fold character whose UTF-8 "
+                     "length differs: Onigmo's answer there depends on its search optimizer, the GPU path answered leftmost-first",
+                     (unsigned long long) flbgpu_filter_regex_corners(f));
+    }
+    if (flbgpu_filter_host_rules(f, hr) == 0 && hr[0] > 0) {
+        if (hr[2] > w->host_over) {
+            flb_plg_warn(f_ins, "%llu search(es) of a pattern that is not a regular expression spent the host matcher's backtrack "
+                         "budget and were answered 'no match' (Onigmo has no such budget: these records may be filtered differently)",
+                         (unsigned long long) (hr[2] - w->host_over));
+            w->host_over = hr[2];
+        }
+        if (hr[3] > w->host_unhandled) {
+            flb_plg_warn(f_ins, "%llu record(s) were passed on unparsed by a parser that is not a regular expression",
+                         (unsigned long long) (hr[3] - w->host_unhandled));
+            w->host_unhandled = hr[3];
+        }
     }
 }
 
@@ -156,14 +193,7 @@ static int cb_gpu_filter(const void *data, size_t bytes, const char *tag, int ta
     /* FLBGPU_FILTER_MODIFIED/NOTOUCH == FLB_FILTER_MODIFIED/NOTOUCH; the output buffer is
      * malloc'd, the engine releases it with flb_free (src/flb_filter.c:235-237) */
     ret = flbgpu_filter_run(ctx->f, data, bytes, out_buf, out_size);
-    /* the two regex corners in which the reference's own answer depends on its search optimizer (flb_gpu.h
-     * flbgpu_filter_regex_corners): said once, never silent; looked at every 256 calls (a small device read) */
-    if (!gpu_corner_warned && (++gpu_calls & 255) == 1 && flbgpu_filter_regex_corners(ctx->f) > 0) {
-        gpu_corner_warned = 1;
-        flb_plg_warn(f_ins, "%llu value(s) held ill-formed UTF-8 behind a line / word anchor or a case-fold character whose UTF-8 "
-                     "length differs: Onigmo's answer there depends on its search optimizer, the GPU path answered leftmost-first",
-                     (unsigned long long) flbgpu_filter_regex_corners(ctx->f));
-    }
+    gpu_watch_after_run(f_ins, ctx->f, &ctx->w);
     return ret;
 }
 
@@ -209,6 +239,7 @@ struct flb_filter_plugin filter_grep_gpu_plugin = {
 struct parser_gpu_ctx {
     flbgpu_filter *f;                       /* must stay first (cb_gpu_filter) */
     struct flb_filter_instance *ins;
+    struct gpu_watch w;
     flbgpu_parser *parsers[MAX_GPU_PARSERS];
     int n_parsers;
     flb_sds_t key_name;
@@ -688,7 +719,9 @@ fail_locked:
 struct l2m_gpu_ctx {
     flbgpu_filter *f;                 /* first member: shared with cb_gpu_filter's view */
     struct flb_filter_instance *ins;
+    struct gpu_watch w;
     int mode, label_count, nbuckets, row_words;
+    int sum_reference;                /* sum_order reference (the default): the histogram sum is cmetrics' sequential sum */
     struct cmt *cmt;
     struct cmt_counter *c;
     struct cmt_gauge *g;
@@ -699,7 +732,7 @@ struct l2m_gpu_ctx {
     int new_data;
     /* config map targets */
     flb_sds_t mode_name, value_field, metric_name, metric_namespace, metric_subsystem, metric_description;
-    flb_sds_t tag, emitter_name;
+    flb_sds_t tag, emitter_name, sum_order;
     size_t emitter_mem_buf_limit;
     int kubernetes_mode, discard_logs;
     int flush_interval_sec, flush_interval_nsec;
@@ -719,6 +752,7 @@ static int l2m_gpu_publish(struct l2m_gpu_ctx *ctx)
     uint64_t *buckets = NULL;
     char *keys = NULL;
     char **labels = NULL;
+    double *seq = NULL;
     uint64_t ts = cfl_time_now();
 
     for (;;) {
@@ -744,6 +778,16 @@ static int l2m_gpu_publish(struct l2m_gpu_ctx *ctx)
     }
     labels = flb_calloc(ctx->label_count ? ctx->label_count : 1, sizeof(char *));
     buckets = flb_calloc(ctx->nbuckets + 1, sizeof(uint64_t));
+    if (ctx->mode == 2 && ctx->sum_reference && n > 0) {
+        /* sum_order reference: the sums exactly as cmt_metric_hist_sum_add builds them (one f64 addition per observation in record
+         * order, lib/cmetrics/src/cmt_metric_histogram.c:124-137), in flbgpu_l2m_export's series order */
+        seq = flb_malloc(n * sizeof(double));
+        if (!seq || flbgpu_l2m_seq_sums(ctx->f, (uint64_t) n, seq) != n) {
+            flb_plg_error(ctx->ins, "sum_order reference: %s", flbgpu_last_error());
+            flb_free(seq); flb_free(labels); flb_free(buckets); flb_free(rows); flb_free(koff); flb_free(keys);
+            return -1;
+        }
+    }
     for (s = 0; s < n && labels && buckets; s++) {
         double value;
         double sum;
@@ -755,6 +799,9 @@ static int l2m_gpu_publish(struct l2m_gpu_ctx *ctx)
             p += strlen(p) + 1;
         }
         flbgpu_l2m_finalize_row(ctx->mode, ctx->nbuckets, rows + s * ctx->row_words, &value, buckets, &count, &sum);
+        if (seq) {
+            sum = seq[s];
+        }
         if (ctx->mode == 0) {
             cmt_counter_set(ctx->c, ts, value, ctx->label_count, labels);
         }
@@ -765,7 +812,7 @@ static int l2m_gpu_publish(struct l2m_gpu_ctx *ctx)
             cmt_histogram_set_default(ctx->h, ts, buckets, sum, count, ctx->label_count, labels);
         }
     }
-    flb_free(labels); flb_free(buckets); flb_free(rows); flb_free(koff); flb_free(keys);
+    flb_free(seq); flb_free(labels); flb_free(buckets); flb_free(rows); flb_free(koff); flb_free(keys);
     return flb_input_metrics_append(ctx->emitter, ctx->tag, flb_sds_len(ctx->tag), ctx->cmt);
 }
 
@@ -788,6 +835,7 @@ static int cb_l2m_gpu_filter(const void *data, size_t bytes, const char *tag, in
     (void) tag; (void) tag_len; (void) f_ins; (void) i_ins; (void) config;
 
     ret = flbgpu_filter_run(ctx->f, data, bytes, out_buf, out_size);
+    gpu_watch_after_run(ctx->ins, ctx->f, &ctx->w);
     if (ctx->timer_mode) {
         ctx->new_data = FLB_TRUE;
     }
@@ -826,6 +874,7 @@ static int cb_l2m_gpu_init(struct flb_filter_instance *f_ins, struct flb_config 
     double *bounds;
     const char *alias;
     char alias_buf[256];
+    char limit_buf[32];
     struct mk_list *head;
     struct flb_kv *kv;
     struct l2m_gpu_ctx *ctx;
@@ -873,6 +922,26 @@ static int cb_l2m_gpu_init(struct flb_filter_instance *f_ins, struct flb_config 
     }
     gpu_note_host_rules(f_ins, ctx->f);
     flbgpu_l2m_info(ctx->f, &ctx->mode, &ctx->label_count, &ctx->nbuckets, &ctx->row_words);
+    /* sum_order: "reference" (default) = the histogram sum is the reference plugin's own bits (sequential f64 additions in record
+     * order); "exact" = the exact sum of the observations rounded once (order-independent: what a sharded multi-GPU run can merge) */
+    if (!ctx->sum_order || strcasecmp(ctx->sum_order, "reference") == 0) {
+        ctx->sum_reference = FLB_TRUE;
+    }
+    else if (strcasecmp(ctx->sum_order, "exact") == 0) {
+        ctx->sum_reference = FLB_FALSE;
+    }
+    else {
+        flb_plg_error(f_ins, "sum_order must be 'reference' or 'exact'");
+        flbgpu_filter_destroy(ctx->f);
+        flb_free(ctx);
+        return -1;
+    }
+    if (ctx->mode == 2 && ctx->sum_reference && flbgpu_l2m_set_sum_order(ctx->f, 1) != 0) {
+        flb_plg_error(f_ins, "%s", flbgpu_last_error());
+        flbgpu_filter_destroy(ctx->f);
+        flb_free(ctx);
+        return -1;
+    }
 
     /* cmetrics context (:825-850); an empty subsystem defaults to the mode name (:769-776) */
     label_keys = flb_calloc(ctx->label_count ? ctx->label_count : 1, sizeof(char *));
@@ -924,7 +993,14 @@ static int cb_l2m_gpu_init(struct flb_filter_instance *f_ins, struct flb_config 
         return -1;
     }
     if (ctx->emitter_mem_buf_limit > 0) {
-        ctx->emitter->mem_buf_limit = ctx->emitter_mem_buf_limit;
+        /* the reference writes input_ins->mem_buf_limit (:913-915): the same value through the property, so that no struct offset
+         * behind an #ifdef of flb_input.h (FLB_HAVE_CHUNK_TRACE) is touched from a separately built object */
+        snprintf(limit_buf, sizeof(limit_buf), "%zu", ctx->emitter_mem_buf_limit);
+        if (flb_input_set_property(ctx->emitter, "mem_buf_limit", limit_buf) == -1) {
+            flb_plg_error(f_ins, "cannot set the emitter's mem_buf_limit");
+            cb_l2m_gpu_exit(ctx, config);
+            return -1;
+        }
     }
     if (flb_input_instance_init(ctx->emitter, config) == -1 ||
         flb_storage_input_create(config->cio, ctx->emitter) == -1) {
@@ -968,6 +1044,8 @@ static struct flb_config_map l2m_config_map[] = {
     { FLB_CONFIG_MAP_INT, "flush_interval_sec", "0", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, flush_interval_sec), "Timer interval (s); 0/0 = emit immediately." },
     { FLB_CONFIG_MAP_INT, "flush_interval_nsec", "0", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, flush_interval_nsec), "Timer interval (ns part)." },
     { FLB_CONFIG_MAP_BOOL, "discard_logs", "false", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, discard_logs), "Drop the logs after processing." },
+    { FLB_CONFIG_MAP_STR, "sum_order", "reference", 0, FLB_TRUE, offsetof(struct l2m_gpu_ctx, sum_order),
+      "Histogram sum: 'reference' = cmetrics' sequential f64 sum, bit for bit (default); 'exact' = the exact sum rounded once." },
     {0}
 };
 

@@ -102,75 +102,7 @@ const char *flb_filter_get_property(const char *key, struct flb_filter_instance 
 const char *flb_filter_name(struct flb_filter_instance *ins) { return ins->alias ? ins->alias : ins->name; }
 
 /* ---- src/record_accessor/ra.l + ra.y by hand (see the header of this file) */
-typedef void *yyscan_t;
-typedef void *YY_BUFFER_STATE;
-int flb_ra_lex_init(yyscan_t *s) { *s = NULL; return 0; }
-int flb_ra_lex_destroy(yyscan_t s) { (void) s; return 0; }
-YY_BUFFER_STATE flb_ra__scan_string(const char *str, yyscan_t s) { (void) s; return (YY_BUFFER_STATE) str; }
-void flb_ra__delete_buffer(YY_BUFFER_STATE b, yyscan_t s) { (void) b; (void) s; }
-
-static void ra_ws(const char **p) { while (**p == ' ' || **p == '\t' || **p == '\n') (*p)++; }
-static int ra_ident_start(int c) { return c == '_' || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
-static int ra_ident_char(int c) { return ra_ident_start(c) || (c >= '0' && c <= '9') || c == '.' || c == '-' || c == '/'; }
-
-int flb_ra_parse(struct flb_ra_parser *rp, const char *str, void *scanner)
-{
-    const char *p = str;
-    void *key;
-    (void) scanner;
-    ra_ws(&p);
-    if (*p != '$') return 1;
-    p++;
-    ra_ws(&p);
-    if (!ra_ident_start((unsigned char) *p)) return 1;
-    {
-        const char *b = p;
-        char *id;
-        while (ra_ident_char((unsigned char) *p)) p++;
-        id = flb_strndup(b, p - b);
-        /* the subkeys are reduced before the key in the grammar (record_subkey is to the right of IDENTIFIER and its
-         * actions run first); flb_ra_parser_key_add only stores the name, so the order does not show */
-        rp->type = FLB_RA_PARSER_KEYMAP;
-        key = flb_ra_parser_key_add(rp, id);
-        if (key) rp->key = key;
-        flb_free(id);
-    }
-    for (;;) {
-        ra_ws(&p);
-        if (*p == '\0') return 0;
-        if (*p != '[') return 1;
-        p++;
-        ra_ws(&p);
-        if (*p == '\'') {
-            /* \'([^']|'{2})*\' with '' -> ' */
-            const char *b = ++p;
-            char *s;
-            size_t n = 0, i;
-            for (;;) {
-                if (*p == '\0') return 1;
-                if (*p == '\'') { if (p[1] == '\'') { p += 2; continue; } break; }
-                p++;
-            }
-            s = flb_malloc((size_t) (p - b) + 1);
-            for (i = 0; b + i < p; i++) { s[n++] = b[i]; if (b[i] == '\'') i++; }
-            s[n] = '\0';
-            p++;
-            flb_ra_parser_subentry_add_string(rp, s);
-            flb_free(s);
-        }
-        else if (*p >= '0' && *p <= '9') {
-            /* [1-9][0-9]*|0 */
-            const char *b = p;
-            if (*p == '0') p++;
-            else while (*p >= '0' && *p <= '9') p++;
-            flb_ra_parser_subentry_add_array_id(rp, atoi(b));
-        }
-        else return 1;
-        ra_ws(&p);
-        if (*p != ']') return 1;
-        p++;
-    }
-}
+#include "grammar_ra.inc"
 
 /* ---- protocol helpers */
 static int rd(void *p, size_t n) { return fread(p, 1, n, stdin) == n; }

@@ -66,386 +66,7 @@ int __wrap_flb_time_get(struct flb_time *tm) { *tm = g_now; return 0; }
 time_t __wrap_time(time_t *t) { if (t) *t = g_now.tm.tv_sec; return g_now.tm.tv_sec; }
 
 /* ---- parser/sql.l + sql.y by hand (see the header of this file) */
-typedef void *yyscan_t;
-typedef void *YY_BUFFER_STATE;
-int flb_sp_lex_init(yyscan_t *s) { *s = NULL; return 0; }
-int flb_sp_lex_destroy(yyscan_t s) { (void) s; return 0; }
-YY_BUFFER_STATE flb_sp__scan_string(const char *str, yyscan_t s) { (void) s; return (YY_BUFFER_STATE) str; }
-void flb_sp__delete_buffer(YY_BUFFER_STATE b, yyscan_t s) { (void) b; (void) s; }
-
-enum { T_EOF = 0, T_IDENT, T_INT, T_FLOAT, T_STRING, T_BOOL, T_KW, T_CH, T_NEQ, T_LT, T_LTE, T_GT, T_GTE, T_BAD };
-struct tok { int t; char *s; int i; float f; int ch; };
-struct lex { const char *p; struct tok cur; };
-
-static const char *KW[] = { "CREATE", "FLUSH", "STREAM", "SNAPSHOT", "WITH", "SELECT", "AS", "FROM", "WHERE", "AND", "OR", "NOT", "WINDOW",
-    "LIMIT", "IS", "NULL", "SUM", "AVG", "COUNT", "MIN", "MAX", "TIMESERIES_FORECAST", "CONTAINS", "TIME", "TUMBLING", "HOPPING",
-    "HOUR", "MINUTE", "SECOND", "NOW", "UNIX_TIMESTAMP", "RECORD_TAG", "RECORD_TIME", NULL };
-
-static int ci_prefix(const char *p, const char *w)
-{
-    while (*w) { if (toupper((unsigned char) *p) != *w) return 0; p++; w++; }
-    return 1;
-}
-static int is_ident_char(int c) { return isalnum(c) || c == '_' || c == '.'; }
-
-/* flex picks the longest match, the earlier rule on a tie: a keyword only when the identifier rule does not match longer */
-static void lex_next(struct lex *L)
-{
-    const char *p = L->p;
-    struct tok *t = &L->cur;
-    memset(t, 0, sizeof(*t));
-    while (*p == ' ' || *p == '\t' || *p == '\n') p++;
-    if (!*p) { t->t = T_EOF; L->p = p; return; }
-    if (ci_prefix(p, "GROUP BY")) { t->t = T_KW; t->s = "GROUP BY"; L->p = p + 8; return; }
-    if (ci_prefix(p, "ADVANCE BY")) { t->t = T_KW; t->s = "ADVANCE BY"; L->p = p + 10; return; }
-    if (ci_prefix(p, "STREAM:")) { t->t = T_KW; t->s = "STREAM:"; L->p = p + 7; return; }
-    if (ci_prefix(p, "TAG:")) { t->t = T_KW; t->s = "TAG:"; L->p = p + 4; return; }
-    if (ci_prefix(p, "@RECORD")) { t->t = T_KW; t->s = "@RECORD"; L->p = p + 7; return; }
-    if (*p == '_' || isalpha((unsigned char) *p)) {
-        const char *q = p;
-        size_t n;
-        int k;
-        while (is_ident_char((unsigned char) *q)) q++;
-        n = q - p;
-        for (k = 0; KW[k]; k++) {
-            if (strlen(KW[k]) == n && ci_prefix(p, KW[k])) { t->t = T_KW; t->s = (char *) KW[k]; L->p = q; return; }
-        }
-        if (n == 4 && ci_prefix(p, "TRUE")) { t->t = T_BOOL; t->i = 1; L->p = q; return; }
-        if (n == 5 && ci_prefix(p, "FALSE")) { t->t = T_BOOL; t->i = 0; L->p = q; return; }
-        t->t = T_IDENT; t->s = flb_strndup(p, n); L->p = q;
-        return;
-    }
-    if (isdigit((unsigned char) *p) || (*p == '-' && p[1] >= '1' && p[1] <= '9')) {
-        const char *q = p;
-        if (*q == '-') q++;
-        if (*q == '0') q++;
-        else while (isdigit((unsigned char) *q)) q++;
-        if (*q == '.' && isdigit((unsigned char) q[1])) {
-            q++;
-            while (isdigit((unsigned char) *q)) q++;
-            t->t = T_FLOAT; t->f = atof(p); L->p = q;
-            return;
-        }
-        t->t = T_INT; t->i = atoi(p); L->p = q;
-        return;
-    }
-    if (*p == '\'') {
-        const char *q = p + 1;
-        char *s;
-        size_t j = 0;
-        for (;;) {
-            if (!*q) { t->t = T_BAD; L->p = q; return; }
-            if (*q == '\'') { if (q[1] == '\'') { q += 2; continue; } break; }
-            q++;
-        }
-        s = flb_malloc(q - p);
-        for (const char *r = p + 1; r < q; r++) { s[j++] = *r; if (*r == '\'') r++; }
-        s[j] = 0;
-        t->t = T_STRING; t->s = s; L->p = q + 1;
-        return;
-    }
-    if (p[0] == '!' && p[1] == '=') { t->t = T_NEQ; L->p = p + 2; return; }
-    if (p[0] == '<' && p[1] == '>') { t->t = T_NEQ; L->p = p + 2; return; }
-    if (p[0] == '<' && p[1] == '=') { t->t = T_LTE; L->p = p + 2; return; }
-    if (p[0] == '>' && p[1] == '=') { t->t = T_GTE; L->p = p + 2; return; }
-    if (p[0] == '<') { t->t = T_LT; L->p = p + 1; return; }
-    if (p[0] == '>') { t->t = T_GT; L->p = p + 1; return; }
-    if (strchr("*,=()[].;", *p)) { t->t = T_CH; t->ch = *p; L->p = p + 1; return; }
-    t->t = T_BAD; L->p = p + 1;
-}
-static int is_kw(struct lex *L, const char *w) { return L->cur.t == T_KW && !strcmp(L->cur.s, w); }
-static int is_ch(struct lex *L, int c) { return L->cur.t == T_CH && L->cur.ch == c; }
-static int eat_kw(struct lex *L, const char *w) { if (is_kw(L, w)) { lex_next(L); return 1; } return 0; }
-static int eat_ch(struct lex *L, int c) { if (is_ch(L, c)) { lex_next(L); return 1; } return 0; }
-
-/* record_subkey: '[' STRING ']' ... -> cmd->tmp_subkeys */
-static int p_subkeys(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    while (is_ch(L, '[')) {
-        lex_next(L);
-        if (L->cur.t != T_STRING) return -1;
-        flb_slist_add(cmd->tmp_subkeys, L->cur.s);
-        flb_free(L->cur.s);
-        lex_next(L);
-        if (!eat_ch(L, ']')) return -1;
-    }
-    return 0;
-}
-static int p_alias(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    if (eat_kw(L, "AS")) {
-        if (L->cur.t != T_IDENT) return -1;
-        flb_sp_cmd_alias_add(cmd, L->cur.s);
-        lex_next(L);
-    }
-    return 0;
-}
-static int func_code(const char *kw)
-{
-    if (!strcmp(kw, "AVG")) return FLB_SP_AVG;
-    if (!strcmp(kw, "SUM")) return FLB_SP_SUM;
-    if (!strcmp(kw, "COUNT")) return FLB_SP_COUNT;
-    if (!strcmp(kw, "MIN")) return FLB_SP_MIN;
-    if (!strcmp(kw, "MAX")) return FLB_SP_MAX;
-    if (!strcmp(kw, "TIMESERIES_FORECAST")) return FLB_SP_FORECAST;
-    if (!strcmp(kw, "NOW")) return FLB_SP_NOW;
-    if (!strcmp(kw, "UNIX_TIMESTAMP")) return FLB_SP_UNIX_TIMESTAMP;
-    if (!strcmp(kw, "RECORD_TAG")) return FLB_SP_RECORD_TAG;
-    if (!strcmp(kw, "RECORD_TIME")) return FLB_SP_RECORD_TIME;
-    return -1;
-}
-static int p_record_key(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    if (eat_ch(L, '*')) return flb_sp_cmd_key_add(cmd, -1, NULL);
-    if (L->cur.t == T_IDENT) {
-        char *name = L->cur.s;
-        int ret;
-        lex_next(L);
-        if (p_subkeys(L, cmd) || p_alias(L, cmd)) return -1;
-        ret = flb_sp_cmd_key_add(cmd, -1, name);
-        flb_free(name);
-        return ret;
-    }
-    if (L->cur.t == T_KW) {
-        int code = func_code(L->cur.s);
-        if (code < 0) return -1;
-        lex_next(L);
-        if (!eat_ch(L, '(')) return -1;
-        if (code >= FLB_SP_NOW) {                       /* time_record_func '(' ')' key_alias */
-            if (!eat_ch(L, ')') || p_alias(L, cmd)) return -1;
-            return flb_sp_cmd_key_add(cmd, code, NULL);
-        }
-        if (code == FLB_SP_COUNT && eat_ch(L, '*')) {
-            if (!eat_ch(L, ')') || p_alias(L, cmd)) return -1;
-            return flb_sp_cmd_key_add(cmd, code, NULL);
-        }
-        if (L->cur.t != T_IDENT) return -1;
-        {
-            char *name = L->cur.s;
-            int ret;
-            lex_next(L);
-            if (code == FLB_SP_FORECAST) {
-                int secs;
-                if (!eat_ch(L, ',') || L->cur.t != T_INT) return -1;
-                secs = L->cur.i;
-                lex_next(L);
-                if (!eat_ch(L, ')') || p_alias(L, cmd)) return -1;
-                ret = flb_sp_cmd_timeseries_forecast(cmd, code, name, secs);
-            }
-            else {
-                if (p_subkeys(L, cmd) || !eat_ch(L, ')') || p_alias(L, cmd)) return -1;
-                ret = flb_sp_cmd_key_add(cmd, code, name);
-            }
-            flb_free(name);
-            return ret;
-        }
-    }
-    return -1;
-}
-static struct flb_exp *p_key(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    struct flb_exp *e;
-    char *name = L->cur.s;
-    lex_next(L);
-    if (p_subkeys(L, cmd)) return NULL;
-    e = flb_sp_cmd_condition_key(cmd, name);
-    flb_free(name);
-    return e;
-}
-static struct flb_exp *p_value(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    struct flb_exp *e = NULL;
-    if (L->cur.t == T_INT) e = flb_sp_cmd_condition_integer(cmd, L->cur.i);
-    else if (L->cur.t == T_FLOAT) e = flb_sp_cmd_condition_float(cmd, L->cur.f);
-    else if (L->cur.t == T_STRING) { e = flb_sp_cmd_condition_string(cmd, L->cur.s); flb_free(L->cur.s); }
-    else if (L->cur.t == T_BOOL) e = flb_sp_cmd_condition_boolean(cmd, L->cur.i ? true : false);
-    else return NULL;
-    lex_next(L);
-    return e;
-}
-static int is_value(struct lex *L) { return L->cur.t == T_INT || L->cur.t == T_FLOAT || L->cur.t == T_STRING || L->cur.t == T_BOOL; }
-
-static struct flb_exp *p_condition(struct lex *L, struct flb_sp_cmd *cmd);
-
-/* comparison | key | value | '(' condition ')' */
-static struct flb_exp *p_primary(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    struct flb_exp *left = NULL, *v;
-    int plain_key = 0;
-    if (eat_ch(L, '(')) {
-        struct flb_exp *e = p_condition(L, cmd);
-        if (!e || !eat_ch(L, ')')) return NULL;
-        return flb_sp_cmd_operation(cmd, e, NULL, FLB_EXP_PAR);
-    }
-    if (is_value(L)) {
-        v = p_value(L, cmd);
-        return v ? flb_sp_cmd_operation(cmd, NULL, v, FLB_EXP_OR) : NULL;
-    }
-    if (is_kw(L, "@RECORD")) {
-        lex_next(L);
-        if (!eat_ch(L, '.')) return NULL;
-        if (eat_kw(L, "CONTAINS")) {
-            struct flb_exp *k;
-            if (!eat_ch(L, '(') || L->cur.t != T_IDENT) return NULL;
-            k = p_key(L, cmd);
-            if (!k || !eat_ch(L, ')')) return NULL;
-            left = flb_sp_record_function_add(cmd, "contains", k);
-        }
-        else if (eat_kw(L, "TIME")) {
-            if (!eat_ch(L, '(') || !eat_ch(L, ')')) return NULL;
-            left = flb_sp_record_function_add(cmd, "time", NULL);
-        }
-        else return NULL;
-    }
-    else if (L->cur.t == T_IDENT) {
-        left = p_key(L, cmd);
-        plain_key = 1;
-    }
-    if (!left) return NULL;
-    if (plain_key && eat_kw(L, "IS")) {
-        int neg = eat_kw(L, "NOT");
-        struct flb_exp *c;
-        if (!eat_kw(L, "NULL")) return NULL;
-        c = flb_sp_cmd_comparison(cmd, left, flb_sp_cmd_condition_null(cmd), FLB_EXP_EQ);
-        return neg ? flb_sp_cmd_operation(cmd, c, NULL, FLB_EXP_NOT) : c;
-    }
-    {
-        int op = -1, neg = 0;
-        if (is_ch(L, '=')) op = FLB_EXP_EQ;
-        else if (L->cur.t == T_NEQ) { op = FLB_EXP_EQ; neg = 1; }
-        else if (L->cur.t == T_LT) op = FLB_EXP_LT;
-        else if (L->cur.t == T_LTE) op = FLB_EXP_LTE;
-        else if (L->cur.t == T_GT) op = FLB_EXP_GT;
-        else if (L->cur.t == T_GTE) op = FLB_EXP_GTE;
-        if (op < 0) {
-            /* a bare key is "condition: key" (an OR with nothing); a bare record function compares with true */
-            if (plain_key) return flb_sp_cmd_operation(cmd, left, NULL, FLB_EXP_OR);
-            return flb_sp_cmd_comparison(cmd, left, flb_sp_cmd_condition_boolean(cmd, true), FLB_EXP_EQ);
-        }
-        lex_next(L);
-        v = p_value(L, cmd);
-        if (!v) return NULL;
-        left = flb_sp_cmd_comparison(cmd, left, v, op);
-        return neg ? flb_sp_cmd_operation(cmd, left, NULL, FLB_EXP_NOT) : left;
-    }
-}
-static struct flb_exp *p_condition(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    struct flb_exp *left, *right;
-    if (eat_kw(L, "NOT")) {
-        left = p_condition(L, cmd);
-        return left ? flb_sp_cmd_operation(cmd, left, NULL, FLB_EXP_NOT) : NULL;
-    }
-    left = p_primary(L, cmd);
-    if (!left) return NULL;
-    if (is_kw(L, "AND") || is_kw(L, "OR")) {
-        int op = is_kw(L, "AND") ? FLB_EXP_AND : FLB_EXP_OR;
-        lex_next(L);
-        right = p_condition(L, cmd);
-        return right ? flb_sp_cmd_operation(cmd, left, right, op) : NULL;
-    }
-    return left;
-}
-static int p_time_unit(struct lex *L)
-{
-    if (eat_kw(L, "SECOND")) return FLB_SP_TIME_SECOND;
-    if (eat_kw(L, "MINUTE")) return FLB_SP_TIME_MINUTE;
-    if (eat_kw(L, "HOUR")) return FLB_SP_TIME_HOUR;
-    return -1;
-}
-static int p_select(struct lex *L, struct flb_sp_cmd *cmd)
-{
-    if (!eat_kw(L, "SELECT")) return -1;
-    do { if (p_record_key(L, cmd)) return -1; } while (eat_ch(L, ','));
-    if (!eat_kw(L, "FROM")) return -1;
-    if (eat_kw(L, "STREAM:")) {
-        if (L->cur.t != T_IDENT) return -1;
-        flb_sp_cmd_source(cmd, FLB_SP_STREAM, L->cur.s);
-        flb_free(L->cur.s);
-        lex_next(L);
-    }
-    else if (eat_kw(L, "TAG:")) {
-        if (L->cur.t != T_STRING) return -1;
-        flb_sp_cmd_source(cmd, FLB_SP_TAG, L->cur.s);
-        flb_free(L->cur.s);
-        lex_next(L);
-    }
-    else return -1;
-    if (eat_kw(L, "WINDOW")) {
-        int size, unit, adv = 0, adv_unit = 0, type;
-        if (eat_kw(L, "TUMBLING")) type = FLB_SP_WINDOW_TUMBLING;
-        else if (eat_kw(L, "HOPPING")) type = FLB_SP_WINDOW_HOPPING;
-        else return -1;
-        if (!eat_ch(L, '(') || L->cur.t != T_INT) return -1;
-        size = L->cur.i;
-        lex_next(L);
-        if ((unit = p_time_unit(L)) < 0) return -1;
-        if (type == FLB_SP_WINDOW_HOPPING) {
-            if (!eat_ch(L, ',') || !eat_kw(L, "ADVANCE BY") || L->cur.t != T_INT) return -1;
-            adv = L->cur.i;
-            lex_next(L);
-            if ((adv_unit = p_time_unit(L)) < 0) return -1;
-        }
-        if (!eat_ch(L, ')')) return -1;
-        flb_sp_cmd_window(cmd, type, size, unit, adv, adv_unit);
-    }
-    if (eat_kw(L, "WHERE")) {
-        struct flb_exp *e = p_condition(L, cmd);
-        if (!e) return -1;
-        flb_sp_cmd_condition_add(cmd, e);
-    }
-    if (eat_kw(L, "GROUP BY")) {
-        do {
-            char *name;
-            if (L->cur.t != T_IDENT) return -1;
-            name = L->cur.s;
-            lex_next(L);
-            if (p_subkeys(L, cmd)) return -1;
-            flb_sp_cmd_gb_key_add(cmd, name);
-            flb_free(name);
-        } while (eat_ch(L, ','));
-    }
-    if (eat_kw(L, "LIMIT")) {
-        if (L->cur.t != T_INT) return -1;
-        flb_sp_cmd_limit_add(cmd, L->cur.i);
-        lex_next(L);
-    }
-    if (!eat_ch(L, ';')) return -1;
-    cmd->type = FLB_SP_SELECT;
-    return 0;
-}
-int flb_sp_parse(struct flb_sp_cmd *cmd, const char *query, void *scanner)
-{
-    struct lex L;
-    (void) scanner;
-    L.p = query;
-    lex_next(&L);
-    if (eat_kw(&L, "CREATE")) {
-        char *name;
-        if (!eat_kw(&L, "STREAM") || L.cur.t != T_IDENT) return 1;       /* snapshots: not on this path */
-        name = L.cur.s;
-        lex_next(&L);
-        if (eat_kw(&L, "WITH")) {
-            if (!eat_ch(&L, '(')) return 1;
-            do {
-                char *k;
-                if (L.cur.t != T_IDENT) return 1;
-                k = L.cur.s;
-                lex_next(&L);
-                if (!eat_ch(&L, '=') || L.cur.t != T_STRING) return 1;
-                flb_sp_cmd_stream_prop_add(cmd, k, L.cur.s);
-                flb_free(k); flb_free(L.cur.s);
-                lex_next(&L);
-            } while (eat_ch(&L, ','));
-            if (!eat_ch(&L, ')')) return 1;
-        }
-        if (!eat_kw(&L, "AS") || p_select(&L, cmd)) return 1;
-        flb_sp_cmd_stream_new(cmd, name);
-        flb_free(name);
-    }
-    else if (p_select(&L, cmd)) return 1;
-    return L.cur.t == T_EOF ? 0 : 1;
-}
+#include "grammar_sql.inc"
 
 /* ---- the driver */
 static void on_segv(int sig)
