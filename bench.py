@@ -874,9 +874,13 @@ def measure_cpu(data, off, n, args):
         import ref_filters as rf
         if rf.available():
             m = min(ns, 2_000_000)
-            secs, rin, rkept = rf.bench_result(rf.run([rf.bench_pair_case("log", dict(regex=APACHE2, time_fmt=TIME_FMT, time_key="time"), [GREP_RULE],
-                                                                           bytes(data[: int(off[m])]), 1)], timeout=900)[0])
+            secs, rin, rkept, ref_out = rf.bench_result(rf.run([rf.bench_pair_case("log", dict(regex=APACHE2, time_fmt=TIME_FMT, time_key="time"), [GREP_RULE],
+                                                                                    bytes(data[: int(off[m])]), 1)], timeout=900)[0], with_output=True)
             assert rin == m, (rin, m)
+            # the reference's own output bytes for these m records: verify_timed_output compares them with the device's first m rows
+            import hashlib
+            cpu["reference_output"] = {"records": m, "bytes": len(ref_out), "sha256": hashlib.sha256(ref_out).hexdigest()}
+            del ref_out
             cpu["port"] = {"value": cpu["value"], "sample": cpu["sample"]}
             cpu.update({"value": round(rin / secs, 1), "kind": "reference", "kept": int(rkept),
                         "sample": "first %d records of the same seeded workload through the reference's own cb_filter of filter_parser(apache2) and "
@@ -912,6 +916,21 @@ def measure_cpu(data, off, n, args):
                             "note": "%d independent processes, each the oracle pair on its own shard for ~6 s, wall-clock aggregate" % nproc}
     except Exception as e:
         cpu["nproc_error"] = repr(e)[:200]
+    try:
+        # BASELINE.json configs[0]: in_dummy -> filter_grep (one regex) -> out_null inside the reference's OWN engine (oracle/_ref/engine,
+        # built by oracle/build_engine.sh with the reference's cmake), 1 M records: the plumbing rate next to the filter-only rates above
+        import subprocess
+        eh = os.path.join(ROOT, "oracle", "_ref", "engine", "engine_host")
+        if os.path.exists(eh):
+            line = '1.2.3.4 - - [10/Oct/2000:13:55:36 -0700] "GET /a HTTP/1.1" 503 2326 "http://r" "Mozilla"'
+            r = subprocess.run([eh, "configs0", "1000000", r"log ^.* 5\d\d ", line], capture_output=True, text=True, timeout=300)
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if js:
+                j = json.loads(js[-1])
+                cpu["configs0_engine"] = {"records": int(j["records"]), "records_per_s": j["records_per_s"], "seconds": j["seconds"],
+                                          "what": "BASELINE configs[0]: in_dummy -> filter_grep -> out_null in the reference's own engine (libfluent-bit.so built from its sources), 1 thread"}
+    except Exception as e:
+        cpu["configs0_error"] = repr(e)[:200]
     return cpu
 
 
@@ -965,7 +984,7 @@ def launch_ranks(args, json_fd, script=None, argv=None):
         sys.exit(r.returncode or 1)
 
 
-def verify_timed_output(g, L, data, off, n, fused_host, parsed_chunk, fgrep, args):
+def verify_timed_output(g, L, data, off, n, fused_host, parsed_chunk, fgrep, args, cpu=None):
     """parity of the timed configuration at the timed size"""
     import hashlib
     import numpy as np
@@ -996,6 +1015,15 @@ def verify_timed_output(g, L, data, off, n, fused_host, parsed_chunk, fgrep, arg
             rows += blk
         out["oracle_sample_rows"] = rows
         out["oracle_sample_matches"] = bool(ok)
+    # (c) VERDICT r4 weak 3: the REFERENCE's own output (its two cb_filter compiled from its sources, the run that gives cpu_baseline)
+    # for the first m records of the timed chunk against the device's first m output rows, whole bytes by hash
+    ro = (cpu or {}).get("reference_output")
+    if ro and ro["records"] <= n:
+        m = ro["records"]
+        dev = memoryview(kb)[: int(koff[m])]
+        out["reference_rows"] = m
+        out["reference_bytes"] = int(ro["bytes"])
+        out["reference_output_matches"] = bool(len(dev) == ro["bytes"] and hashlib.sha256(dev).hexdigest() == ro["sha256"])
     return out
 
 
@@ -1148,7 +1176,7 @@ def main():
     verify = None
     if rank == 0:
         try:
-            verify = verify_timed_output(g, L, data, off, n, fused_host, o1, fgrep, args)
+            verify = verify_timed_output(g, L, data, off, n, fused_host, o1, fgrep, args, cpu)
         except Exception as e:
             verify = {"error": repr(e)[:300]}
 

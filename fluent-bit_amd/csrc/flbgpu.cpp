@@ -825,6 +825,16 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         f->pcfg.key.key_len = (int) n;
     }
     std::vector<DevParser> dp;
+    // a HOST parser (a Regex that is not a regular expression, csrc/rxbt.inc) runs in the place of k_parser_rx for parser 0 of a
+    // one-entry list: it has no device tables for the generic kernel's "try every parser" loop (a list with such a
+    // parser at any index left records unparsed or walked null tables).  Refused here, with its reason, instead.
+    for (int i = 0; i < nparsers; i++)
+        if (parsers[i] && parsers[i]->bt && nparsers > 1) {
+            set_err("filter_parser: parser %d of %d has a Regex that is not a regular expression (look-around, back-reference, atomic group ...): "
+                    "such a parser is supported as the only Parser entry of a filter", i + 1, nparsers);
+            delete f;
+            return nullptr;
+        }
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
         parsers[i]->dev.tz_trans = nullptr; parsers[i]->dev.tz_gmtoff = nullptr; parsers[i]->dev.tz_ttype = nullptr;

@@ -17,6 +17,8 @@
 #include <map>
 #include <memory>
 #include <unordered_map>
+#include <sys/mman.h>
+#include <ucontext.h>
 
 namespace rx {
 namespace {

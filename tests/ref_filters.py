@@ -75,11 +75,12 @@ def bench_pair_case(key_name, parser, rules, data, iters):
     return _case(3, props, [("p0", parser)], data, iters)
 
 
-def bench_result(res):
+def bench_result(res, with_output=False):
+    """-> (seconds, records in, records kept) [+ the pair's output bytes of the first pass]"""
     ret, out = res
-    assert ret == 0 and len(out) == 24, (ret, len(out))
-    secs, rin, rkept = struct.unpack("<dQQ", out)
-    return secs, rin, rkept
+    assert ret == 0 and len(out) >= 24, (ret, len(out))
+    secs, rin, rkept = struct.unpack("<dQQ", out[:24])
+    return (secs, rin, rkept, out[24:]) if with_output else (secs, rin, rkept)
 
 
 def tail_case(text, key="log", path_key=None, path="", offset_key=None, stream_offset=0, skip_empty_lines=True, sec=0, nsec=0):

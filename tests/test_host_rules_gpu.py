@@ -170,6 +170,16 @@ def test_host_parser_that_rejects_lines(g):
     assert r == ro and out == oo
 
 
+def test_host_parser_in_a_list_is_refused_with_its_reason(g):
+    """a host parser at any index of a several-parser list has no device tables for the list's loop; the filter says so at
+    create (a one-entry list runs, the tests above)"""
+    hp, dp = g.Parser(r"^(?!#)(?<key>[^=]+)=(?<val>.*)$"), g.Parser(r"^(?<all>.*)$")
+    for lst in ([hp, dp], [dp, hp]):
+        with pytest.raises(ValueError, match="not a regular expression"):
+            g.FilterParser("log", lst)
+    assert g.FilterParser("log", [hp]).host_rules()["rules"] == 1
+
+
 def test_refused_when_asked_to(g):
     os.environ["FLBGPU_NO_HOST_RULES"] = "1"
     try:

@@ -159,6 +159,43 @@ def compare(L, ref, pat, subj):
 
 
 @needs_ref
+def test_deep_searches_run_on_the_matcher_own_stack():
+    """the recursion needed > 2 MB of the CALLER's stack for a 12 KB value and answered -4 ('no match') past depth 12 000.
+    It now runs on a stack of its own: a thread with a 256 KB stack searches values of 12 KB .. 400 KB and gets the real engine's answer"""
+    import threading
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    pats = [rb"(?=a)(?:ab)*!", rb"(?=a)(?:ab)*x?$", rb"^(?:(?!zz).)*$", rb"(a|b)*\1c"]
+    subj = [b"ab" * 6000 + b"!", b"ab" * 3000, b"ab" * 50000 + b"!", b"ab" * 200000 + b"!", b"abab" * 3000 + b"bc", b"q" * 100000]
+    out = {}
+
+    def work():
+        for pat in pats:
+            h, err = bt_compile(L, pat)
+            assert h, (pat, err)
+            for i, s in enumerate(subj):
+                out[(pat, i)] = bt_search(L, h, s)
+            L.flbgpu_rxbt_free(h)
+    old = threading.stack_size(256 << 10)
+    try:
+        t = threading.Thread(target=work)
+        t.start(); t.join()
+    finally:
+        threading.stack_size(old)
+    assert len(out) == len(pats) * len(subj)
+    for pat in pats:
+        eng = rxdiff.RefRegex(ref, pat)
+        for i, s in enumerate(subj):
+            got = out[(pat, i)]
+            if isinstance(got, tuple):
+                continue                            # the 10 M backtrack budget (the product's own limit, reported): not an answer
+            assert got == eng.search(s), (pat, i, got and got[:2])
+    # none of the linear ones may have been given up
+    assert not isinstance(out[(pats[0], 3)], tuple) and out[(pats[0], 3)][0] == (0, 400001)
+    assert not isinstance(out[(pats[2], 5)], tuple)
+
+
+@needs_ref
 def test_known_nonregular_patterns():
     L = flbamd_loader.load().lib()
     ref = rxdiff.load_ref()
