@@ -213,7 +213,8 @@ struct TzTable { std::vector<int64_t> trans; std::vector<uint8_t> ttype; std::ve
 struct flbgpu_parser {
     std::string name;
     rx::Program prog;
-    TableBlob blob_ascii, blob_utf8, blob_fx, blob_fx2;
+    TableBlob blob_ascii, blob_utf8, blob_fx, blob_fx2, blob_fx2b;
+    DevFx fx2b;                       // the four-port pair tables behind the three-port ones (dev.fx2): a filter falls back to them (flbgpu_filter::fx5_off)
     DevParser dev;                 // host copy (device pointers inside)
     flbgpu_filter *self_filter = nullptr;   // lazily created for flbgpu_parser_do
     DevDecoders decs;              // Decode_Field / Decode_Field_As (flbgpu_parser_add_decoder), uploaded when a filter takes the parser
@@ -622,12 +623,18 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         if (d.fx.ok) {
             std::vector<uint8_t> b3;
             // the two-position form (fx4) when it fits the LDS beside the capture columns, else one position per read (fx3)
+            // (round 5) ... with THREE capture-write ports per cell (fx5) when no cell of the pattern needs two writes at one position,
+            // else with four (fx4).  FLBGPU_FX=3 / 4 selects the older forms.
             const char *fxe = getenv("FLBGPU_FX");
             const bool want4 = !(fxe && fxe[0] == '3');
-            if (want4 && !build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, true)) { delete p; return nullptr; }
+            if (want4 && !(fxe && fxe[0] == '4')) {
+                if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, 2)) { delete p; return nullptr; }
+                if (!d.fx2.ok || b3.size() > 48 * 1024) { b3.clear(); memset(&d.fx2, 0, sizeof(d.fx2)); }
+            }
+            if (want4 && !d.fx2.ok && !build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, 1)) { delete p; return nullptr; }
             if (!want4 || !d.fx2.ok || b3.size() > 48 * 1024) {
                 b3.clear();
-                if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, false)) { delete p; return nullptr; }
+                if (!build_fx3(p->prog.ascii, 2 * d.nfields, b3, d.fx2, 0)) { delete p; return nullptr; }
             }
             if (d.fx2.ok) {
                 // the compiled time plan rides behind the tables (the last 128 bytes of what the kernel stages into the LDS)
@@ -641,6 +648,24 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
                     set_err("parser '%s': upload failed", p->name.c_str()); delete p; return nullptr;
                 }
                 d.fx2.base = (const uint8_t *) p->blob_fx2.dev;
+                memset(&p->fx2b, 0, sizeof(p->fx2b));
+                if (d.fx2.pair_bias == 2) {
+                    // fx5 sends a record with two capture writes at one even position (an EMPTY field, `""`) to the generic kernel.  Data full
+                    // of such records is better served by the four-port cells: both forms are uploaded, a filter switches when it sees
+                    // the fast walk hand on more than 1 row in 64 (parser_size_pass, note_fx5)
+                    std::vector<uint8_t> b4;
+                    if (build_fx3(p->prog.ascii, 2 * d.nfields, b4, p->fx2b, 1) && p->fx2b.ok && b4.size() <= 48 * 1024) {
+                        const size_t at4 = b4.size();
+                        b4.resize(at4 + sizeof(ctp));
+                        memcpy(b4.data() + at4, ctp, sizeof(ctp));
+                        p->fx2b.bytes = (uint32_t) b4.size();
+                        if (hipMalloc(&p->blob_fx2b.dev, b4.size()) != hipSuccess || hipMemcpy(p->blob_fx2b.dev, b4.data(), b4.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                            set_err("parser '%s': upload failed", p->name.c_str()); delete p; return nullptr;
+                        }
+                        p->fx2b.base = (const uint8_t *) p->blob_fx2b.dev;
+                    }
+                    else p->fx2b.ok = 0;
+                }
             }
         }
     }
@@ -1098,7 +1123,13 @@ struct SpecOff {                    // one stage run the usual way
 static const uint64_t SPEC_MAX_RECORDS = 262144, SPEC_MAX_BYTES = 8u << 20;
 static inline bool spec_wanted(uint64_t n, uint64_t bytes) { return n <= SPEC_MAX_RECORDS && bytes <= SPEC_MAX_BYTES && !getenv("FLBGPU_NO_SPEC"); }
 // what parser_size_pass reads from the counters between its launches, for a pass launched ahead: false = run it the usual way
+// fx5 (three write ports) hands a record with an empty field at an even position to the generic kernel: when the fast walk does not
+// settle more than 1 row in 64 of a chunk, this filter takes the four-port tables from the next call on (both are on the device)
+static void note_fx5(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
+    if (!f->fx5_off && n >= 1024 && hm.counts[9] * 64 > n && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok) f->fx5_off = true;
+}
 static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
+    note_fx5(f, hm, n);
     if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
     if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
     return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
@@ -1213,7 +1244,13 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     // (fx2 = the tables without special entries, k_parser_reg<.., FX3>; FLBGPU_FX3=0: the tables with look-ahead / pair entries)
     const char *fx3env = getenv("FLBGPU_FX3");
     const bool use_fx2 = f->parsers[0]->dev.fx2.ok && !(tmode0 && !strcmp(tmode0, "tile")) && !(fx3env && fx3env[0] == '0');
-    const DevFx &fx = use_fx2 ? f->parsers[0]->dev.fx2 : f->parsers[0]->dev.fx;
+    const bool fx5_fallback = use_fx2 && f->fx5_off && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok;
+    if (fx5_fallback && !f->fx5_off_uploaded) {
+        // this filter's device copy of parser 0 gets the four-port tables in the place of the three-port ones
+        HIPOK(hipMemcpyAsync((uint8_t *) f->d_parsers.as<DevParser>() + offsetof(DevParser, fx2), &f->parsers[0]->fx2b, sizeof(DevFx), hipMemcpyHostToDevice, st));
+        f->fx5_off_uploaded = true;
+    }
+    const DevFx &fx = use_fx2 ? (fx5_fallback ? f->parsers[0]->fx2b : f->parsers[0]->dev.fx2) : f->parsers[0]->dev.fx;
     bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
     for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
     uint32_t tile_wave_bytes = 0, tile_pg_room = 0;
@@ -1276,7 +1313,8 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
-    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias ? 4 : 3) : 0;
+    ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
+    { const char *ha = getenv("FLBGPU_FX5_ASM"); ma.fx_hiasm = (ha && ha[0] == '1') ? 1 : 0; }
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
@@ -1467,6 +1505,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when
         // that is the rule for this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on
         if (d_trace) trace_out();
+        note_fx5(f, hm, n);
         if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
         if (hm.counts[8] > 0) {
             // rows whose time text needs the strptime interpreter, sizes that depend on the record's bytes, ...

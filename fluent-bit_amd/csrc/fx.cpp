@@ -270,7 +270,7 @@ bool flbgpu::build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, 
 // What cannot be spelled with two writes per step (a look-ahead that resolves to a double write, a carry into a cell that already
 // carries) goes to the absorbing row with the FAIL slot: the record takes the generic kernel.  No tail, no pair cells: a row's cells
 // are all there is.  Result slots, sentinel byte and poison row are those of the tables above.
-bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pairs) {
+bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, int pairs) {
     memset(&out, 0, sizeof(out));
     if (!t.has_capture || !t.ascii_only || t.ft.empty() || t.stub) return true;
     const uint32_t ncol = (uint32_t) t.ncls + 1;                                 // byte classes + the end-of-text column
@@ -363,15 +363,23 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
         r4(0); r4(1); r4(2);
         struct C4 { uint32_t next, s0, s1, s2, s3; };
         std::vector<C4> c4;
+        uint32_t n_conflict = 0;
         for (size_t i = 0; i < order.size(); i++) {
             const uint32_t R = order[i];
             for (uint32_t c0 = 0; c0 < ncol; c0++)
                 for (uint32_t c1 = 0; c1 < ncol; c1++) {
                     const Cell &x = cells[(size_t) R * ncol + c0];
                     const Cell &y = cells[(size_t) x.next * ncol + c1];
-                    c4.push_back(C4{r4(y.next), x.sa, x.sb, y.sa, y.sb});
+                    C4 v{r4(y.next), x.sa, x.sb, y.sa, y.sb};
+                    // pairs == 2 (fx5, round 5): THREE write ports per cell -- positions j - 1, j, j + 1 --: the two writes at position j
+                    // (step 1's slot B, step 2's slot A) share one port.  A cell that needs both (apache2: cells no well-formed line
+                    // reaches -- 0 of 258 k steps over 2 000 lines) goes to the absorbing row with the FAIL slot like everything else the
+                    // cells cannot spell: the record takes the generic kernel.
+                    if (pairs == 2 && v.s1 && v.s2) { n_conflict++; v = C4{r4(1), 0, S_FAIL, 0, 0}; }
+                    c4.push_back(v);
                 }
         }
+        if (getenv("FLBGPU_FX_DEBUG")) fprintf(stderr, "fx pairs=%d: %zu rows, %u cells with two writes at one position\n", pairs, order.size(), n_conflict);
         if (nslots > 34) return true;                                            // (a lane's block of capture slots is 68 bytes: the caller keeps fx3)
         const uint32_t n4 = (uint32_t) order.size(), rs4 = (ncol * ncol) | 1u, rowb4 = rs4 * 8, at4 = 2048;
         const uint64_t tot4 = (uint64_t) at4 + (uint64_t) n4 * rowb4;
@@ -388,7 +396,9 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
                 // lo = the next row, nothing else (the next cell's address is ONE three-operand addition: row + the two class offsets);
                 // hi = the four slots' BYTE offsets in a lane's block of capture slots (slot * 2): the kernel adds a selected byte to the
                 // lane's block address -- one operation per write (tile_kernels.inc REG_SLOT)
-                const uint32_t lo = at4 + x.next * rowb4, hi = (x.s0 * 2) | ((x.s1 * 2) << 8) | ((x.s2 * 2) << 16) | ((x.s3 * 2) << 24);
+                const uint32_t lo = at4 + x.next * rowb4,
+                               hi = pairs == 2 ? (x.s0 * 2) | (((x.s1 ? x.s1 : x.s2) * 2) << 8) | ((x.s3 * 2) << 16)
+                                               : (x.s0 * 2) | ((x.s1 * 2) << 8) | ((x.s2 * 2) << 16) | ((x.s3 * 2) << 24);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8, &lo, 4);
                 memcpy(b.data() + at4 + (size_t) r * rowb4 + c * 8 + 4, &hi, 4);
             }
@@ -396,7 +406,7 @@ bool flbgpu::build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b,
         out.off_p2 = 0;
         out.start_off = at4; out.absorb_off = at4 + rowb4; out.poison_off = at4 + 2 * rowb4;
         out.tail_min = out.absorb_off; out.nkill = 0;
-        out.nslots = nslots; out.pair_bias = 1; out.ncls1 = ncol;              // pair_bias != 0: the two-position form
+        out.nslots = nslots; out.pair_bias = pairs == 2 ? 2 : 1; out.ncls1 = ncol;     // pair_bias != 0: the two-position form (2: three write ports)
         out.ok = 1;
         return true;
     }
@@ -437,8 +447,11 @@ int flbgpu::simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int nca
         const uint32_t lo = u32at(at), hi = u32at(at + 4);
         caps[(hi & 255) / 2] = (uint16_t) (j - 1);
         caps[((hi >> 8) & 255) / 2] = (uint16_t) j;
-        caps[((hi >> 16) & 255) / 2] = (uint16_t) j;
-        caps[((hi >> 24) & 255) / 2] = (uint16_t) (j + 1);
+        if (fx.pair_bias == 2) caps[((hi >> 16) & 255) / 2] = (uint16_t) (j + 1);      // fx5: three ports
+        else {
+            caps[((hi >> 16) & 255) / 2] = (uint16_t) j;
+            caps[((hi >> 24) & 255) / 2] = (uint16_t) (j + 1);
+        }
         e = lo;
     }
     const uint32_t S = e & FX_ROW_MASK;

@@ -84,7 +84,7 @@ bool build_fx(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &o
 int simulate_fx(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps, bool use_tail = true);
 // fx3: the same tables without special entries (8-byte cells, two capture writes per step; fx.cpp)
 // (pairs: fx4 -- a cell per (row, class of byte j, class of byte j + 1), two positions per table read; out.ok == 0 when that does not fit)
-bool build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, bool pairs = false);
+bool build_fx3(const rx::TableSet &t, int ncap, std::vector<uint8_t> &b, DevFx &out, int pairs = 0);      // pairs: 0 fx3, 1 fx4 (four write ports), 2 fx5 (three)
 int simulate_fx3(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
 int simulate_fx4(const std::vector<uint8_t> &b, const DevFx &fx, int ncap, const uint8_t *s, uint32_t len, uint16_t *caps);
 // grammar: src/record_accessor/ra.l:54-67, ra.y:60-99
@@ -142,6 +142,7 @@ struct flbgpu_filter {
     flbgpu::DevBuf d_parsers;
     uint32_t caps_stride = 0;
     bool tile_declined = false;       // k_parser_tile sent too many values through its fallback: phase kernels from now on
+    bool fx5_off = false, fx5_off_uploaded = false;   // the three-port pair tables handed on too many rows: the four-port ones from now on (flbgpu.cpp note_fx5)
     bool has_decoders = false;        // a parser of the list has Decode_Field / Decode_Field_As rules (dec_dev.inc: k_parser_dec)
     // filter_grep (and the rule gate of filter_log_to_metrics)
     std::vector<flbgpu::GrepRule> rules;

@@ -123,8 +123,8 @@ int flbgpu_rx_simulate_fx3(void *h, const char *s, int len, int *beg, int *end, 
     if (ncap == 0) return -4;
     std::vector<uint8_t> blob;
     flbgpu::DevFx fx;
-    // info2[0] < 0 on entry (with info2 given): the two-position form (fx4)
-    const bool pairs = info2 && info2[0] < 0;
+    // info2[0] < 0 on entry (with info2 given): the two-position form (-1: fx4, four write ports; -2: fx5, three)
+    const int pairs = info2 && info2[0] < 0 ? (info2[0] == -2 ? 2 : 1) : 0;
     if (!flbgpu::build_fx3(p->ascii, ncap, blob, fx, pairs) || !fx.ok) return -4;
     if (info2) { info2[0] = pairs ? (int) ((fx.bytes - 2048) / (((fx.ncls1 * fx.ncls1) | 1u) * 8)) : (int) ((fx.bytes - 1024) / ((fx.ncls1 | 1u) * 8)); info2[1] = (int) fx.bytes; }
     std::vector<uint16_t> caps(fx.nslots);

@@ -422,6 +422,15 @@ def test_fx3_tables_give_the_single_steps_answers():
             if n3 >= 0:
                 assert list(b4[:n3 + 1]) == list(b2[:n3 + 1]) and list(e4[:n3 + 1]) == list(e2[:n3 + 1]), (s, list(b4[:n3 + 1]), list(b2[:n3 + 1]))
             stats["pairs"] = stats.get("pairs", 0) + 1
+        # fx5 (round 5: the pairs with THREE write ports -- positions j - 1, j, j + 1; build_fx3 pairs = 2): exists only for a pattern
+        # none of whose cells needs two writes at one position, and is then exactly fx4
+        b5 = (ctypes.c_int * 40)(); e5 = (ctypes.c_int * 40)(); inf5 = (ctypes.c_int * 2)(-2, 0)
+        n5 = L.flbgpu_rx_simulate_fx3(h, s, len(s), b5, e5, inf5)
+        if n5 != -4:
+            assert n4 != -4 and n5 == n4, (s, n4, n5)
+            if n5 >= 0:
+                assert list(b5[:n5 + 1]) == list(b4[:n5 + 1]) and list(e5[:n5 + 1]) == list(e4[:n5 + 1]), (s, list(b5[:n5 + 1]), list(b4[:n5 + 1]))
+            stats["ports3"] = stats.get("ports3", 0) + 1
         if n3 == -1 and n1 != -1:
             stats["handed_on"] += 1
             return True
@@ -469,3 +478,5 @@ def test_fx3_tables_give_the_single_steps_answers():
     assert stats["compared"] - n_kat > 800, stats
     assert stats["handed_on"] * 50 < stats["compared"], stats
     assert stats.get("pairs", 0) > 1500, stats                     # the two-position tables fit for most of these patterns
+    assert stats.get("ports3", 0) > 600, stats                     # ... and the three-port form exists for a good part of them (apache2 among them)
+    print(stats)

@@ -142,3 +142,44 @@ def test_three_builds_with_keep_options(g):
             assert got[0] == want[0] and got[1] == want[1], (mode, extra, reserve, preserve)
             fp.close(); p.close()
     _set_mode("reg")
+
+
+def test_empty_fields_and_the_two_pair_table_forms(g):
+    """round 5: the three-port pair tables (fx5, the default) send a record with two capture writes at one even position -- an EMPTY
+    field, `""` -- to the generic kernel; a filter that sees more than 1 row in 64 go that way takes the four-port tables (fx4) from its
+    next call on.  Same bytes as the oracle before and after the switch, and with either form forced."""
+    rng = random.Random(23)
+    data, off, _ = synth.apache_records(4000)
+    blob = bytes(data)
+    lines = [blob[int(off[i]) + 21:int(off[i + 1])] for i in range(4000)]
+    recs = []
+    for i, ln in enumerate(lines):
+        r = rng.random()
+        if r < 0.3:
+            # empty referer / agent / user / size, at every alignment (a pad of 0 .. 3 bytes in front)
+            q = ln.split(b'"')
+            if len(q) >= 6:
+                if rng.random() < 0.6: q[3] = b""
+                if rng.random() < 0.3: q[5] = b""
+            ln = b'"'.join(q)
+            ln = ln.replace(b" - - [", b" -  [", 1) if rng.random() < 0.3 else ln
+            ln = b"1" * rng.randrange(0, 4) + ln
+        recs.append(_rec({"log": ln}, sec=1700000000 + i, nsec=i))
+    chunk = b"".join(recs)
+    pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    want = ob.FilterParser("log", [ob.Parser(**pargs)]).filter(chunk)
+    rules = [("regex", r"code ^[45]\d\d$")]
+    want2 = ob.Grep(rules).filter(want[1])
+    _set_mode("reg")
+    for env in ({}, {"FLBGPU_FX": "4"}, {"FLBGPU_FX": "3"}):
+        os.environ.pop("FLBGPU_FX", None)
+        os.environ.update(env)
+        p = g.Parser(**pargs)
+        fp = g.FilterParser("log", [p]); fg = g.FilterGrep(rules); ch = g.FilterChain([fp, fg])
+        for call in range(3):                                   # (the default form switches after its first call on this data)
+            got = fp.filter(chunk)
+            assert got == want, (env, call, "parser")
+            r3, o3 = ch.filter(chunk)
+            assert r3 == ob.MODIFIED and o3 == want2[1], (env, call, "pair")
+        fg.close(); fp.close(); p.close()
+    os.environ.pop("FLBGPU_FX", None)
