@@ -325,7 +325,6 @@ struct ParserMatchArgs {
     // k_parser_tile: dynamic LDS layout = fx tables | rule DFAs (pg_lds_off) | per wave: record tile + capture columns
     uint32_t tile_lds_off;           // first wave's area
     uint32_t use_fx2;                // parsers[0].fx2 (pair cells) instead of .fx: k_parser_reg<.., PAIR2>
-    uint32_t fx_hiasm;               // fx5: the build whose high-half capture stores are ds_write_b16_d16_hi by hand (FLBGPU_FX5_ASM)
     uint32_t tile_wave_bytes;        // bytes per wave (tile + capture columns)
     // pair mode: one descriptor of dstride dwords per ROW, written for the rows the single pass keeps -- ONE aligned store
     // of whole 64-byte sectors instead of 34 column stores of 4 bytes (each of which costs a sector write):

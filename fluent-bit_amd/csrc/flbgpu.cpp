@@ -1314,7 +1314,6 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
-    { const char *ha = getenv("FLBGPU_FX5_ASM"); ma.fx_hiasm = (ha && ha[0] == '1') ? 1 : 0; }
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
