@@ -1165,7 +1165,12 @@ def main():
                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achieved": round((in_bytes + parsed_bytes) / dtp / 1e9, 1),
                                     "frac": round((in_bytes + parsed_bytes) / dtp / 8e12, 4)}}
 
+    per_rank = None
     if dist is not None:
+        # every rank's own clock next to the maximum the line is computed from (a slow rank shows up by name)
+        mine = {"rank": rank, "device": dev, "seconds": round(dt, 6), "records_per_s": round(n * args.steps / dt, 1), "kept_records": kept_records}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -1272,7 +1277,7 @@ def main():
                                   "raw bytes is secondary.record_indexer",
                    "seed": synth.SEED, "parallelism": "shard%d" % world, "gen_seconds": round(gen_s, 1)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "verify": verify, "secondary": secondary,
-        "rccl_ranks": world if (dist is not None and not shared_gpu) else 0,
+        "rccl_ranks": world if (dist is not None and not shared_gpu) else 0, "per_rank": per_rank,
         "collective_backend": None if dist is None else ("gloo (ranks share a GPU: RCCL refuses duplicate devices)" if shared_gpu else "rccl"),
     }
     if dist is not None:

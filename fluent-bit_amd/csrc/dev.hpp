@@ -239,6 +239,8 @@ enum {
     RF_NEEDLOC = 4096,     // k_parser_reg<false> left the row to the fix-up launch (another layout, the end of the chunk)
     RF_DEC = 8192,         // the winning parser has decoders: sized and written by k_parser_dec (dec_dev.inc), skipped by k_parser_emit
     RF_DESC = 2048,        // pair mode: the kept record's fields are in its descriptor (PgEmitArgs::desc), not in the columns
+    RF_TIMEPEND = 16384,   // pair mode, RF_DESC rows: the time text has not been looked up yet -- k_pg_emit does it for the records that are
+                           // kept (TileCfg::defer_time); the descriptor carries the event's own time
 };
 constexpr uint32_t PG_UNDECIDED = 0xFFFFFFFFu;   // keep_len of a row whose rules k_pg_decide still has to evaluate
 
@@ -287,6 +289,12 @@ struct TileCfg {
     int pg_fast;                         // every rule is in rule[] (at most TILE_RULES, DFAs staged in the LDS)
     uint32_t pg_static_drop, pg_time_fields, pg_named;
     TileRule rule[TILE_RULES];
+    // pair mode (round 5): the time lookup of a record is left to k_pg_emit, which only sees the records grep keeps.  What the pass
+    // still has to know of a record it drops is whether the encoder would have refused its parsed time (the record then never
+    // reached grep: flb_filter_do's counts) -- the four year digits at their place in the fixed layout, 1971 .. 2105, rule that out;
+    // any other text takes the lookup here, as before.
+    int defer_time;
+    uint32_t year_off;                   // offset of the plan's %Y digits in the time text
 };
 
 constexpr uint32_t STAGE_MAXK = 20;              // 1 KiB pieces of a staging buffer (ParserMatchArgs::stage_bytes <= 20 KiB)
@@ -509,6 +517,9 @@ struct PgEmitArgs {
     uint64_t bytes;                  // chunk size (bounds the wide tail loads)
     uint64_t out_cap;                // as in ParserEmitArgs
     EmitCfg ec;
+    uint32_t ctp[32];                // the parser's compiled time plan (flbgpu.cpp compile_time_plan; [31] = 0: none, RF_TIMEPEND rows cannot occur)
+    unsigned long long *counts;      // [13]: RF_TIMEPEND rows whose time text the fixed-layout plan does not settle (the host repeats the
+                                     // call with the lookup inside the single pass, and keeps it there for this filter)
 };
 
 // ---- filter_log_to_metrics (plugins/filter_log_to_metrics/log_to_metrics.c)

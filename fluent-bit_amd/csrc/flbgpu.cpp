@@ -1199,7 +1199,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     MiscWords *dm = f->d_misc.as<MiscWords>();
     // host mirror of the counters + the output size, page-locked so that the small copies are real
     // asynchronous DMA transfers
-    if (!f->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return false;
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + 2 * sizeof(uint64_t))) return false;
     MiscWords &hm = *f->hp_misc.as<MiscWords>();
     *dm_out = dm; *hm_out = &hm;
     const uint64_t *row_off = in->row_off;
@@ -1349,6 +1349,17 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             tc.pg_on = 1; tc.pg_nrules = pair->pg.nrules; tc.pg_logical_op = pair->pg.logical_op;
             tc.pg_static_drop = pair->pg.static_drop; tc.pg_time_fields = pair->pg.time_fields;
             tc.pg_fast = pair->pg.nrules <= TILE_RULES ? 1 : 0;
+            // the time lookup left to k_pg_emit (dev.hpp TileCfg::defer_time; FLBGPU_DEFER_TIME=0: in the single pass, as before round 5)
+            if (pair->desc && d0.time_field >= 0 && d0.plan.ok && !d0.time_keep && d0.plan.len <= 4 * TBUF_WORDS && !f->defer_time_off &&
+                !(getenv("FLBGPU_DEFER_TIME") && getenv("FLBGPU_DEFER_TIME")[0] == '0')) {
+                int nyear = 0;
+                for (int k = 0; k < d0.plan.nops; k++) if (d0.plan.ops[k].kind == TP_YEAR4) { nyear++; tc.year_off = d0.plan.ops[k].off; }
+                uint32_t ntime = 0;
+                for (int q = 0; q < d0.nfields; q++) ntime += d0.field_is_time[q] ? 1u : 0u;
+                uint32_t ctp[32];
+                compile_time_plan(d0.plan, ctp);                       // (k_pg_emit reads the text through the compiled form)
+                tc.defer_time = nyear == 1 && ntime == 1 && ctp[31] ? 1 : 0;
+            }
             for (int i = 0; i < pair->pg.nrules; i++) {
                 tc.pg_named |= pair->pg.rule_fmask[i];
                 if (pair->pg.rule_lds_off[i] == 0xFFFFFFFFu) tc.pg_fast = 0;
@@ -1603,7 +1614,7 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
         f->last_in = hm.counts[0];
         if (total == 0) return true;
         out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
-        f->last_out = hm.counts[1];
+        f->last_out = hm.counts[1] - (hm.counts[14] < hm.counts[1] ? hm.counts[14] : hm.counts[1]);   // (see below)
         if (sink && total <= g_spec.sink_cap) g_spec.sunk = true;
         *ret = FLBGPU_FILTER_MODIFIED;
         return true;
@@ -1634,7 +1645,10 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     HIPOK(hipStreamSynchronize(st));
     if (f->has_decoders && hm.counts[10] > 0) { set_err("filter_parser: a decoded field outgrew the decoders' scratch (%llu records)", hm.counts[10]); return false; }
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
-    f->last_out = hm.counts[1];   // rows with length 0 (dropped/skipped) remain as empty rows
+    // rows with length 0 (dropped/skipped) remain as empty rows; a record whose PARSED time reads as a group marker to the decoder
+    // (ff ff ff ff / fe: -1 s, -2 s, 2106-02-07 06:28:14 / :15) is written but not counted: flb_filter_do re-counts the filter's output
+    // with the log event decoder (src/flb_filter.c:272, src/flb_mp.c:49-71), which hides it
+    f->last_out = hm.counts[1] - (hm.counts[14] < hm.counts[1] ? hm.counts[14] : hm.counts[1]);
     *ret = FLBGPU_FILTER_MODIFIED;
     return true;
 }
@@ -1649,7 +1663,7 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     MiscWords *dm = f->d_misc.as<MiscWords>();
     // host mirror of the counters + the output size, page-locked so that the small copies are real
     // asynchronous DMA transfers
-    if (!f->hp_misc.ensure(sizeof(MiscWords) + sizeof(uint64_t))) return false;
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + 2 * sizeof(uint64_t))) return false;
     MiscWords &hm = *f->hp_misc.as<MiscWords>();
     uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     memset(&hm, 0, sizeof(hm));
@@ -1882,7 +1896,8 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc, &ahead)) return -1;
     MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
-    if (!ahead && (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0)) return 0;           // (records for k_parser_emit_exact: unfused)
+    // (counts[14]: a parsed time filter_grep's decoder would read as a group marker -- the unfused kernels restate that, the pair does not)
+    if (!ahead && (n == 0 || hm.counts[3] > 0 || hm.ov_count > 0 || hm.counts[14] > 0)) return 0;           // (records for k_parser_emit_exact: unfused)
     const int cus = g_cus > 0 ? g_cus : 256;
     PgDecideArgs da;
     memset(&da, 0, sizeof(da));
@@ -1905,7 +1920,15 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
         ea.info = da.info; ea.caps = da.caps; ea.null_mask = fp->d_null.as<uint64_t>();
         ea.keep_len = da.keep_len; ea.n = n; ea.out_off = fp->d_off.as<uint64_t>(); ea.out = fg->d_out.as<uint8_t>();
         ea.desc = pc.desc; ea.dstride = pc.dstride; ea.bytes = in->bytes;
+        ea.counts = dm->counts;
         fill_emit_cfg(fp, ea.ec);
+    };
+    // RF_TIMEPEND rows k_pg_emit could not settle (a time text the fixed-layout plan refuses, a time the encoder refuses): the call
+    // is repeated with the lookup inside the single pass, where the strptime interpreter stands behind the plan -- and stays there
+    auto defer_failed = [&](unsigned long long c13) -> bool {
+        if (c13 == 0 || fp->defer_time_off) return false;
+        fp->defer_time_off = true;
+        return true;
     };
     if (ahead) {
         // launched ahead (SpecCall): the writer with room for the usual output, counters + size + (host-level call) the output itself
@@ -1918,7 +1941,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
         uint8_t *sink = g_spec.last ? g_spec.sink : nullptr;
         launch_finish_to_host(ea.out, ea.out_cap, ea.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
-        if (!ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
+        if (defer_failed(hm.counts[13]) || !ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.counts[14] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
             SpecOff usual;
             return run_pair_fused(fp, fg, in, out, stats2);
         }
@@ -1940,7 +1963,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
         hipStreamSynchronize(st) != hipSuccess) return -1;
     // a parser that emits nothing (NOTOUCH: grep would see the ORIGINAL chunk) or a grep that keeps everything
     // (NOTOUCH: the chain's output is the parser's): the unfused kernels
-    if (hm.counts[6] == 0 || hm.counts[5] == hm.counts[6]) return 0;
+    if (hm.counts[6] == 0 || hm.counts[5] == hm.counts[6] || hm.counts[14] > 0) return 0;
     fp->last_in = hm.counts[0]; fp->last_out = hm.counts[6];
     fg->last_in = hm.counts[6]; fg->last_out = hm.counts[5];
     if (stats2) {
@@ -1953,7 +1976,11 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     PgEmitArgs ea;
     emit_args(ea);
     { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
+    unsigned long long &c13 = *(unsigned long long *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords) + sizeof(uint64_t));
+    c13 = 0;
+    if (hipMemcpyAsync(&c13, &dm->counts[13], sizeof(c13), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (defer_failed(c13)) return run_pair_fused(fp, fg, in, out, stats2);
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     return 1;
 }

@@ -307,6 +307,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         }
         a.info[r] = flags;
         a.info[4 * n + r] = (uint32_t) tsec; a.info[5 * n + r] = (uint32_t) tnsec;
+        // a parsed time the next decoder reads as a group marker (tile_kernels.inc k_parser_reg): counted
+        if ((uint32_t) tsec >= 0xfffffffeu) atomicAdd(&a.counts[14], 1ull);
         if (size_from_columns) {
             // 92 92 d7 00 ts(8) + metadata + map header (width of the ORIGINAL count) + fields
             const uint32_t n0 = (uint32_t) ps.nregs_minus1;
@@ -445,6 +447,7 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
             continue;
         }
         ri.ts_sec = (uint32_t) tsec; ri.ts_nsec = (uint32_t) tnsec;
+        if ((ri.flags & RF_PARSED) && (uint32_t) tsec >= 0xfffffffeu) atomicAdd(&a.counts[14], 1ull);     // (a group marker to the next decoder: tile_kernels.inc k_parser_reg)
         CountSink cs;
         const bool json_won = (ri.flags & RF_PARSED) && a.parsers[ri.parser_idx].is_json && !a.parsers[ri.parser_idx].kv_format;
         if (json_won) {

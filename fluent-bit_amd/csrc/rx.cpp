@@ -434,7 +434,8 @@ CC cc_and(const CC &a, const CC &b) {
 enum AnchorKind { A_BOL, A_EOL, A_BOS, A_EOS, A_WORDB, A_NWORDB, A_WORDB_A, A_NWORDB_A, A_SEMI_EOS, A_BEGIN_POS };
 
 struct Ast {
-    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR, LOOK, ATOMIC, BACKREF, KEEP, COND } t = EMPTY;   // COND: (?(refs)kids[0]|kids[1])
+    enum T { EMPTY, SET, CAT, ALT, GROUP, REPEAT, ANCHOR, LOOK, ATOMIC, BACKREF, KEEP, COND, ABSENT, CALL } t = EMPTY;   // COND: (?(refs)kids[0]|kids[1])
+    const Ast *target = nullptr;           // CALL (\g<..>): the group it runs (refs[0] = its number, 0 = the whole pattern); set by bt_compile
     bool ahead = true, neg_look = false;   // LOOK
     std::vector<int> refs;                 // BACKREF: the groups the reference names, in group order
     bool ref_icase = false;
@@ -462,9 +463,11 @@ struct Syntax {
     bool ext = false;             // accept what only a backtracking matcher can run: look-around, atomic groups, possessive repeats, back-references, \Z \G \K
     bool nonregular = false;      // ... such a construct was met (with ext off: the reason of the failure)
     std::vector<std::pair<Ast *, std::string>> named_refs;    // \k<name> met before the end of the pattern: resolved there
+    std::vector<Ast *> calls;                                  // \g<..> nodes: their groups are looked up when the pattern is complete
     int max_ref = 0;
 
     bool fail(const char *m) { if (err.empty()) { err = m; err += " (offset " + std::to_string(p - s) + ")"; } return false; }
+    bool fail(const std::string &m) { return fail(m.c_str()); }
     bool failed() const { return !err.empty(); }
     bool eof() const { return p >= e; }
 
@@ -789,7 +792,15 @@ struct Syntax {
                     }
                     else { g->kids.push_back(std::move(body)); g->kids.push_back(mk(Ast::EMPTY)); }
                 }
-                else if (c == '~' || c == '(' || c == '&' || c == 'P') { if (c == '(') nonregular = true; fail("unsupported group construct"); return nullptr; }
+                else if (c == '~') {
+                    // (?~X) the absent operator (regparse.c parse_enclose '~': OP_PUSH_ABSENT_POS / OP_ABSENT / OP_ABSENT_END)
+                    nonregular = true;
+                    if (!ext) { fail("the absent operator is not supported on the GPU path"); return nullptr; }
+                    p++;
+                    g->t = Ast::ABSENT;
+                    g->kids.push_back(alternation(opts, depth + 1));
+                }
+                else if (c == '(' || c == '&' || c == 'P') { if (c == '(') nonregular = true; fail("unsupported group construct"); return nullptr; }
                 else {
                     unsigned o = opts;
                     bool on = true;
@@ -904,6 +915,30 @@ struct Syntax {
                 else named_refs.emplace_back(a.get(), name);
                 return a;
             }
+            if (ext && c == 'g' && p + 1 < e && (p[1] == '<' || p[1] == '\'')) {
+                // \g<name> \g<n> \g<-n> \g<+n> \g<0>: a subexpression call (regparse.c fetch_token 'g', TK_CALL)
+                const int term = p[1] == '<' ? '>' : '\'';
+                p += 2;
+                const unsigned char *nm = p;
+                while (!eof() && *p != term) p++;
+                if (eof() || p == nm) { fail("invalid group name <>"); return nullptr; }
+                std::string name((const char *) nm, p - nm);
+                p++;
+                AstP a = mk(Ast::CALL);
+                const bool numeric = (name[0] >= '0' && name[0] <= '9') || ((name[0] == '-' || name[0] == '+') && name.size() > 1);
+                if (numeric) {
+                    int v = 0;
+                    for (size_t i = (name[0] == '-' || name[0] == '+') ? 1 : 0; i < name.size(); i++) { if (name[i] < '0' || name[i] > '9' || v > 1000) { fail("invalid group name <" + name + ">"); return nullptr; } v = v * 10 + (name[i] - '0'); }
+                    if (has_named && !(v == 0 && name[0] != '-' && name[0] != '+')) { fail("numbered backref/call is not allowed. (use name)"); return nullptr; }
+                    if (name[0] == '-') { v = ncap + 1 - v; if (v <= 0) { fail("invalid backref number/name"); return nullptr; } }
+                    else if (name[0] == '+') { if (v <= 0) { fail("invalid backref number/name"); return nullptr; } v = ncap + v; }
+                    a->refs.push_back(v);
+                    calls.push_back(a.get());
+                }
+                else { named_refs.emplace_back(a.get(), name); calls.push_back(a.get()); }
+                nonregular = true;
+                return a;
+            }
             if (c == 'R' && ext) {
                 // \R: (?>\x0D\x0A|[\x0A-\x0D\x{85}\x{2028}\x{2029}])  (regparse.c node_linebreak)
                 p++;
@@ -922,7 +957,7 @@ struct Syntax {
                 return at;
             }
             if (c == 'R') nonregular = true;
-            if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k') nonregular = true; fail("unsupported escape"); return nullptr; }
+            if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k' || c == 'g') nonregular = true; fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') {
                 nonregular = true;
                 if (!ext) { fail("back-references are not supported on the GPU path"); return nullptr; }

@@ -55,7 +55,9 @@ def ref_match(ref, pat, value):
     return eng.search(value.encode() if isinstance(value, str) else value) is not None
 
 
-HOST_PATTERNS = [r"^(?!.*(?:health|ping)).*\d$", r"(?<=user=)(\w+) id=\1", r"(?>a+)b", r"^(['\"]).*\1", r"\d+(?! ?USD)\b", r"(abc)\1", r"error(?=:)|warn(?=:)", r"a++b"]
+HOST_PATTERNS = [r"^(?!.*(?:health|ping)).*\d$", r"(?<=user=)(\w+) id=\1", r"(?>a+)b", r"^(['\"]).*\1", r"\d+(?! ?USD)\b", r"(abc)\1", r"error(?=:)|warn(?=:)", r"a++b",
+                 # round 5: the absent operator and subexpression calls
+                 r"^(?~ \d)$", r"/(?~/)/(?~/)$", r"(?<w>[a-z]+)=\g<w>", r"^(?<q>'(?:[^']|\g<q>)*')"]
 
 
 @needs_ref
@@ -190,7 +192,7 @@ def test_refused_when_asked_to(g):
     finally:
         del os.environ["FLBGPU_NO_HOST_RULES"]
     with pytest.raises(Exception):
-        g.FilterGrep([("regex", r"log (?~abc)")])             # what the host's matcher does not take either is still refused
+        g.FilterGrep([("regex", r"log \X+")])                # what the host's matcher does not take either is still refused
 
 
 def l2m_same(a, b, mode="counter"):

@@ -183,3 +183,67 @@ def test_empty_fields_and_the_two_pair_table_forms(g):
             assert r3 == ob.MODIFIED and o3 == want2[1], (env, call, "pair")
         fg.close(); fp.close(); p.close()
     os.environ.pop("FLBGPU_FX", None)
+
+
+def test_time_lookup_left_to_the_emit_pass(g):
+    """round 5 (dev.hpp TileCfg::defer_time): the pair's single pass leaves the time lookup of a fixed-layout Time_Format to k_pg_emit,
+    which only sees the records grep keeps.  Everything a time text can change is compared with the oracle's two filters: the kept
+    records' timestamps, a record the encoder refuses because its parsed time is out of range (it never reaches grep: the parser's
+    record / byte counts of flb_filter_do), a text the plan does not settle (strptime's own reading: one-digit day, full month name,
+    or no time at all), an event whose OWN time is bad and whose parsed time repairs it -- among the records grep keeps (the emit
+    pass reports, the call is repeated with the lookup in the single pass) and among those it drops (the year test of the single
+    pass).  Same answers with the lookup forced into the single pass (FLBGPU_DEFER_TIME=0)."""
+    import re
+    rng = random.Random(31)
+    data, off, _ = synth.apache_records(3000)
+    blob = bytes(data)
+    lines = [blob[int(off[i]) + 21:int(off[i + 1])] for i in range(3000)]
+    odd = [b"10/Mar/1960:08:34:03 +0900", b"10/Mar/2150:08:34:03 +0900", b"10/Foo/2024:08:34:03 +0900", b"5/March/2024:8:34:03 +0900",
+           b"31/Dec/1969:23:59:59 +0000", b"01/Jan/1970:00:00:00 +0100", b"10/Mar/2024:08:34:03 +09x0", b"10/Mar/20x4:08:34:03 +0900",
+           b"10/Mar/2106:08:34:03 +0900", b"07/Feb/2106:06:28:15 +0000", b"07/Feb/2106:06:28:16 +0000", b"                          ", b"-"]
+    pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    rules = [("regex", r"code ^5\d\d$")]
+
+    markers = (b"31/Dec/1969:23:59:59 +0000", b"07/Feb/2106:06:28:15 +0000")    # -1 s and 0xFFFFFFFF s: group markers to the NEXT decoder
+
+    def build(where, with_markers):
+        """where: 'dropped' / 'kept' / 'both' -- which records get the odd time texts"""
+        odd_ = [t for t in odd if with_markers or t not in markers]
+        recs = []
+        for i, ln in enumerate(lines):
+            is5 = re.search(rb'" 5\d\d ', ln) is not None
+            sec, nsec = 1700000000 + i, i
+            if rng.random() < 0.04 and (where == "both" or (where == "kept") == is5):
+                ln = re.sub(rb"\[[^\]]*\]", b"[" + rng.choice(odd_) + b"]", ln, count=1)
+                if rng.random() < 0.3:
+                    sec, nsec = 0xFFFFFFFF, 0                        # (an event time the encoder refuses, next to a parsed one that may not be)
+            recs.append(_rec({"log": ln}, sec=sec, nsec=nsec))
+        return b"".join(recs)
+
+    _set_mode("reg")
+    for where, with_markers in (("dropped", False), ("kept", False), ("both", False), ("both", True)):
+        chunk = build(where, with_markers)
+        want1 = ob.FilterParser("log", [ob.Parser(**pargs)]).filter(chunk)
+        want2 = ob.Grep(rules).filter(want1[1])
+        assert want1[0] == ob.MODIFIED and want2[0] == ob.MODIFIED
+        # what flb_filter_do counts behind filter_parser: the records the log event decoder shows (src/flb_filter.c:272, src/flb_mp.c:49-71) --
+        # a parsed time of ff ff ff ff / ff ff ff fe seconds is a group marker to it
+        nrec, offs, _ = g.index_host(want1[1])
+        n1 = sum(1 for i in range(nrec) if want1[1][int(offs[i]) + 4:int(offs[i]) + 8] not in (b"\xff\xff\xff\xff", b"\xff\xff\xff\xfe"))
+        assert (n1 < nrec) == with_markers                           # (the corner is in the data when asked for: the pair then takes the unfused kernels)
+        for env in (None, "0"):
+            os.environ.pop("FLBGPU_DEFER_TIME", None)
+            if env is not None:
+                os.environ["FLBGPU_DEFER_TIME"] = env
+            p = g.Parser(**pargs)
+            fp, fg = g.FilterParser("log", [p]), g.FilterGrep(rules)
+            ch = g.FilterChain([fp, fg])
+            for rep in range(2):                                     # (the second call: after a repeat the filter keeps the lookup in the single pass)
+                r3, o3 = ch.filter(chunk)
+                assert r3 == g.MODIFIED and o3 == want2[1], (where, env, rep, len(o3), len(want2[1]))
+                st = ch.last_stats()
+                assert int(st[0]["out_bytes"]) == len(want1[1]), (where, env, rep, int(st[0]["out_bytes"]), len(want1[1]))
+                assert int(st[1]["out_bytes"]) == len(want2[1]) and int(st[0]["out_records"]) == int(st[1]["in_records"])
+                assert int(st[0]["out_records"]) == n1, (where, env, rep, int(st[0]["out_records"]), n1)
+            fg.close(); fp.close(); p.close()
+    os.environ.pop("FLBGPU_DEFER_TIME", None)

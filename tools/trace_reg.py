@@ -15,6 +15,8 @@ d_data = L.flbgpu_dev_alloc(data.nbytes); d_off = L.flbgpu_dev_alloc(off.nbytes)
 L.flbgpu_memcpy_h2d(d_data, data.ctypes.data, data.nbytes); L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
 chunk = g.DevChunk(d_data, d_off, n, data.nbytes)
 NAMES = ["row offsets", "ingest (header + value -> registers)", "decode + shift", "walk", "fields + rules", "time", "stores"]
+if "fine" in os.environ.get("FLBGPU_LIB", ""):       # tools/variant.sh fine "-DREG_TRACE_FINE": the stamps spent behind the walk
+    NAMES = ["offsets + ingest + decode + walk", "walk's result, time text", "span reads", "field sizes", "rules", "time", "stores"]
 for nbuf in cfgs:
     os.environ["FLBGPU_STAGE_NBUF"] = nbuf
     p = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
