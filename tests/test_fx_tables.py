@@ -427,7 +427,11 @@ def test_fx3_tables_give_the_single_steps_answers():
         b5 = (ctypes.c_int * 40)(); e5 = (ctypes.c_int * 40)(); inf5 = (ctypes.c_int * 2)(-2, 0)
         n5 = L.flbgpu_rx_simulate_fx3(h, s, len(s), b5, e5, inf5)
         if n5 != -4:
-            assert n4 != -4 and n5 == n4, (s, n4, n5)
+            # (-1: a cell with two writes at one position sends the three-port walk to the absorbing row with the FAIL slot -- the record
+            # takes the complete algorithm, whatever the four-port walk says of it, a later byte >= 0x80 included)
+            assert n4 != -4 and (n5 == n4 or n5 == -1), (s, n4, n5)
+            if n5 != n4:
+                stats["ports3_handed_on"] = stats.get("ports3_handed_on", 0) + 1
             if n5 >= 0:
                 assert list(b5[:n5 + 1]) == list(b4[:n5 + 1]) and list(e5[:n5 + 1]) == list(e4[:n5 + 1]), (s, list(b5[:n5 + 1]), list(b4[:n5 + 1]))
             stats["ports3"] = stats.get("ports3", 0) + 1
