@@ -1199,7 +1199,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     MiscWords *dm = f->d_misc.as<MiscWords>();
     // host mirror of the counters + the output size, page-locked so that the small copies are real
     // asynchronous DMA transfers
-    if (!f->hp_misc.ensure(sizeof(MiscWords) + 2 * sizeof(uint64_t))) return false;
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + 4 * sizeof(uint64_t))) return false;
     MiscWords &hm = *f->hp_misc.as<MiscWords>();
     *dm_out = dm; *hm_out = &hm;
     const uint64_t *row_off = in->row_off;
@@ -1663,7 +1663,7 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     MiscWords *dm = f->d_misc.as<MiscWords>();
     // host mirror of the counters + the output size, page-locked so that the small copies are real
     // asynchronous DMA transfers
-    if (!f->hp_misc.ensure(sizeof(MiscWords) + 2 * sizeof(uint64_t))) return false;
+    if (!f->hp_misc.ensure(sizeof(MiscWords) + 4 * sizeof(uint64_t))) return false;
     MiscWords &hm = *f->hp_misc.as<MiscWords>();
     uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     memset(&hm, 0, sizeof(hm));
@@ -1857,6 +1857,8 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
 static std::atomic<uint64_t> g_fused_failures{0};          // fused passes that failed on the device (flbgpu_diag_fused_failures)
 extern "C" uint64_t flbgpu_diag_fused_failures(void) { return g_fused_failures.load(); }
 
+namespace flbgpu { void launch_pg_emit_plain(const PgEmitArgs &a, int nfields, int cus, hipStream_t st); }   // (fused_kernels.inc: k_pg_emit<true>)
+
 static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, flbgpu_chain_stat *stats2) {
     hipStream_t st = fp->stream;
     uint64_t n = in->n;
@@ -1937,11 +1939,14 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
         PgEmitArgs ea;
         emit_args(ea);
         ea.out_cap = fg->d_out.cap - 16;
-        { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
+        // (the plain build when the parser's fields are plain strings and the descriptors exist; a record it does not take -- counts[15] --
+        // sends the call round again the usual way, where the general build follows)
+        const bool plain_emit = ea.ec.ok && pc.desc != nullptr && !getenv("FLBGPU_EMIT_GENERAL");
+        { ProfScope ps(fp, st, "k_pg_emit"); if (plain_emit) launch_pg_emit_plain(ea, d0.nfields, cus, st); else launch_pg_emit(ea, d0.nfields, cus, st); }
         uint8_t *sink = g_spec.last ? g_spec.sink : nullptr;
         launch_finish_to_host(ea.out, ea.out_cap, ea.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
-        if (defer_failed(hm.counts[13]) || !ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.counts[14] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
+        if (defer_failed(hm.counts[13]) || (plain_emit && hm.counts[15] > 0) || !ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.counts[14] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
             SpecOff usual;
             return run_pair_fused(fp, fg, in, out, stats2);
         }
@@ -1975,12 +1980,18 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     if (!fg->d_out.ensure(total + 16)) return -1;
     PgEmitArgs ea;
     emit_args(ea);
-    { ProfScope ps(fp, st, "k_pg_emit"); launch_pg_emit(ea, d0.nfields, cus, st); }
-    unsigned long long &c13 = *(unsigned long long *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords) + sizeof(uint64_t));
-    c13 = 0;
-    if (hipMemcpyAsync(&c13, &dm->counts[13], sizeof(c13), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    const bool plain_emit = ea.ec.ok && pc.desc != nullptr && !getenv("FLBGPU_EMIT_GENERAL");
+    { ProfScope ps(fp, st, "k_pg_emit"); if (plain_emit) launch_pg_emit_plain(ea, d0.nfields, cus, st); else launch_pg_emit(ea, d0.nfields, cus, st); }
+    unsigned long long *c13 = (unsigned long long *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords) + sizeof(uint64_t));     // counts[13 .. 15]
+    c13[0] = c13[1] = c13[2] = 0;
+    if (hipMemcpyAsync(c13, &dm->counts[13], 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
-    if (defer_failed(c13)) return run_pair_fused(fp, fg, in, out, stats2);
+    if (defer_failed(c13[0])) return run_pair_fused(fp, fg, in, out, stats2);
+    if (plain_emit && c13[2] > 0) {
+        // records the plain build left alone (no descriptor, another parser's, larger than its staging area): the general build over the chunk
+        { ProfScope ps(fp, st, "k_pg_emit_general"); launch_pg_emit(ea, d0.nfields, cus, st); }
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    }
     out->data = fg->d_out.p; out->row_off = fp->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     return 1;
 }

@@ -247,3 +247,56 @@ def test_time_lookup_left_to_the_emit_pass(g):
                 assert int(st[0]["out_records"]) == n1, (where, env, rep, int(st[0]["out_records"]), n1)
             fg.close(); fp.close(); p.close()
     os.environ.pop("FLBGPU_DEFER_TIME", None)
+
+
+def test_plain_emit_build_hands_on_what_it_does_not_take(g):
+    """round 5: k_pg_emit<PLAIN> (no general writer in it, three workgroups per CU) writes the kept records that carry a descriptor and fit its
+    staging area; anything else -- a kept record of 12 KB (larger than the staging area), kept rows the single pass left to k_parser_finish
+    (a time text of another length: no descriptor) -- is counted and the general build runs over the chunk.  Same bytes as the oracle, with
+    the plain build, and with the general one forced (FLBGPU_EMIT_GENERAL=1)."""
+    import re
+    rng = random.Random(41)
+    data, off, _ = synth.apache_records(2000)
+    blob = bytes(data)
+    lines = [blob[int(off[i]) + 21:int(off[i + 1])] for i in range(2000)]
+    recs = []
+    for i, ln in enumerate(lines):
+        r = rng.random()
+        if r < 0.01:
+            ln = ln[:-1] + b"x" * 12000 + b'"'                                   # a 12 KB agent
+            ln = re.sub(rb'" \d\d\d ', b'" 503 ', ln, count=1)
+        elif r < 0.05:
+            ln = re.sub(rb"\[[^\]]*\]", b"[5/Mar/2024:08:34:03 +0900]", ln, count=1)   # another length: the strptime interpreter, no descriptor
+            ln = re.sub(rb'" \d\d\d ', b'" 500 ', ln, count=1)
+        recs.append(_rec({"log": ln}, sec=1700000000 + i, nsec=i))
+    chunk = b"".join(recs)
+    pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    rules = [("regex", r"code ^5\d\d$")]
+    want1 = ob.FilterParser("log", [ob.Parser(**pargs)]).filter(chunk)
+    want2 = ob.Grep(rules).filter(want1[1])
+    assert want2[0] == ob.MODIFIED and len(want2[1]) > 200000
+    _set_mode("reg")
+    for env in (None, "1"):
+        os.environ.pop("FLBGPU_EMIT_GENERAL", None)
+        if env:
+            os.environ["FLBGPU_EMIT_GENERAL"] = env
+        p = g.Parser(**pargs)
+        fp, fg = g.FilterParser("log", [p]), g.FilterGrep(rules)
+        ch = g.FilterChain([fp, fg])
+        r3, o3 = ch.filter(chunk)
+        assert r3 == g.MODIFIED and o3 == want2[1], (env, len(o3), len(want2[1]))
+        # the device-level call (no look-ahead launches): the plain build, then the general one
+        import numpy as np
+        L = g.lib()
+        arr = np.frombuffer(chunk, dtype=np.uint8)
+        n, offs, _c = g.index_host(chunk)
+        d_data = L.flbgpu_dev_alloc(arr.nbytes + 512); d_off = L.flbgpu_dev_alloc(offs.nbytes)
+        L.flbgpu_memcpy_h2d(d_data, arr.ctypes.data, arr.nbytes); L.flbgpu_memcpy_h2d(d_off, offs.ctypes.data, offs.nbytes)
+        r4, o4 = ch.filter_dev(g.DevChunk(d_data, d_off, n, arr.nbytes))
+        got = np.empty(int(o4.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(got.ctypes.data, o4.data, int(o4.bytes))
+        koff = np.empty(n + 1, dtype=np.uint64)
+        L.flbgpu_memcpy_d2h(koff.ctypes.data, o4.row_off, koff.nbytes)
+        assert r4 == g.MODIFIED and int(koff[n]) == len(want2[1]) and got.tobytes()[:len(want2[1])] == want2[1], (env, int(o4.bytes), len(want2[1]))
+        fg.close(); fp.close(); p.close()
+    os.environ.pop("FLBGPU_EMIT_GENERAL", None)
