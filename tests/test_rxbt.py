@@ -333,3 +333,17 @@ def test_call_inherits_the_peek_of_its_definition():
         assert bt_search(L, h, b"ab/") == [(0, 3), (3, 3)] and rxdiff.RefRegex(ref, pat).search(b"ab/") is None
     finally:
         L.flbgpu_rxbt_free(h)
+
+
+@needs_ref
+def test_more_than_31_groups_go_to_the_host_matcher():
+    """round 5: the tables keep a group set in 32 bits; a pattern with more groups (the reference takes 32 767, onigmo.h:441) no longer aborts
+    start-up: flbgpu_rx_is_nonregular says 1 and the host's matcher answers it (here with a back-reference to group 40)"""
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(5)
+    for pat in [b"^" + b"".join(b"(%c)" % (97 + i % 26) for i in range(40)) + b"\\40", b"(\\d)" * 33 + b"-(x|y)+$", b"(?:" + b"(a)|" * 34 + b"(b))c"]:
+        assert L.flbgpu_rx_is_nonregular(pat, len(pat), 0) == 1, pat
+        base = bytes(97 + i % 26 for i in range(40))
+        n, m = compare(L, ref, pat, subjects(L, rng, pat, 40) + [base + b"n", base + b"m", b"1" * 33 + b"-xyx", b"1" * 32 + b"-x", b"aab" * 3 + b"c"])
+        assert n > 0 and m > 0, (pat, n, m)

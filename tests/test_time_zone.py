@@ -222,6 +222,28 @@ def test_product_refusals():
     fb.Parser(regex=rx, time_key="time", time_fmt=FMT, time_system_timezone=True).close()
 
 
+@pytest.mark.gpu
+def test_process_zone_that_is_not_utc_refuses_what_depends_on_it():
+    """%Z's last resort and Time_System_Timezone read the PROCESS's zone (src/flb_strptime.c:611-650, flb_parser.h:80-94); the
+    device restates a process without a zone.  In a process with TZ=Europe/Berlin both are refused at create, with the reason; a format
+    without %Z is not affected."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load(); fb.init()\n"
+            "rx = r'^(?<time>\\S+ \\S+ \\S+) (?<m>.*)$'\n"
+            "out = []\n"
+            "for kw in (dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%Z'), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S', time_system_timezone=True), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%z')):\n"
+            "    try:\n"
+            "        fb.Parser(regex=rx, time_key='time', **kw).close(); out.append('ok')\n"
+            "    except ValueError as e:\n"
+            "        out.append('refused: ' + str(e))\n"
+            "print('|'.join(out))\n") % os.path.dirname(HERE)
+    env = dict(os.environ, TZ="Europe/Berlin", TZDIR=TZDIR)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    a, b, c = r.stdout.strip().splitlines()[-1].split("|")
+    assert a.startswith("refused") and "%Z" in a and b.startswith("refused") and "Time_System_Timezone" in b and c == "ok", (a, b, c)
+
+
 # ------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 def test_filter_parser_with_a_zone_on_the_device():
