@@ -1136,12 +1136,22 @@ static inline bool spec_wanted(uint64_t n, uint64_t bytes) { return n <= SPEC_MA
 // fx5 (three write ports) hands a record with an empty field at an even position to the generic kernel: when the fast walk does not
 // settle more than 1 row in 64 of a chunk, this filter takes the four-port tables from the next call on (both are on the device)
 static void note_fx5(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
-    if (!f->fx5_off && n >= 1024 && hm.counts[9] * 64 > n && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok) f->fx5_off = true;
+    if (!f->fx5_off && n >= 64 && hm.counts[9] * 64 > n && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok) f->fx5_off = true;
+}
+// values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when that is the rule for
+// this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on.  NOT after a launch that walked the
+// three-port tables while the four-port ones stand by (round 5): what it handed on is those tables' doing -- every even-length line
+// without the pattern's optional tail ends in a cell with two writes at one position: 46 % of bench.py's mixed shapes --, note_fx5 answers
+// it with the other tables, and declining the single pass on top of that left such data to the phase kernels for good
+// (secondary.mixed_shapes 1.85 -> 4.15 ms when the three-port tables came in).
+static void note_unsettled(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
+    if (f->last_fx5 && f->parsers[0]->fx2b.ok) return;
+    if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
 }
 static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
     note_fx5(f, hm, n);
     if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
-    if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
+    note_unsettled(f, hm, n);
     return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
 }
 
@@ -1324,6 +1334,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
+    f->last_fx5 = use_tile && !tile_in_lds && ma.use_fx2 == 5;
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
@@ -1522,11 +1533,9 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             // when most of the data is of that kind the phase kernels (tiled, general) are the better choice from now on
             if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
         }
-        // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when
-        // that is the rule for this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on
         if (d_trace) trace_out();
         note_fx5(f, hm, n);
-        if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
+        note_unsettled(f, hm, n);
         if (hm.counts[8] > 0) {
             // rows whose time text needs the strptime interpreter, sizes that depend on the record's bytes, ...
             { ProfScope ps(f, st, "k_parser_finish"); launch_parser_finish(ma, cus, st); }

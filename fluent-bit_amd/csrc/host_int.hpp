@@ -143,6 +143,7 @@ struct flbgpu_filter {
     uint32_t caps_stride = 0;
     bool tile_declined = false;       // k_parser_tile sent too many values through its fallback: phase kernels from now on
     bool defer_time_off = false;      // pair mode: a kept record's time text was not settled by the fixed-layout plan in k_pg_emit: the lookup stays in the single pass
+    bool last_fx5 = false;            // the last launch of the register kernel walked the three-port tables
     bool fx5_off = false, fx5_off_uploaded = false;   // the three-port pair tables handed on too many rows: the four-port ones from now on (flbgpu.cpp note_fx5)
     bool has_decoders = false;        // a parser of the list has Decode_Field / Decode_Field_As rules (dec_dev.inc: k_parser_dec)
     // filter_grep (and the rule gate of filter_log_to_metrics)

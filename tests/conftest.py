@@ -19,3 +19,19 @@ def pytest_configure(config):
             os.path.join(ROOT, "oracle", "_ref", "libonig_ref.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True,
                        stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def rccl_ok():
+    """RCCL's communicator set-up was seen to HANG on one box of the pool (round 5: a full-suite run sat in the one-rank communicator of
+    tests/test_l2m_gpu.py::test_rccl_all_reduce_in_c_single_rank until the call's limit; the same test passed on every other box that day).
+    The tests that need a communicator first make one in a child process with a limit of its own: a child that does not come back skips
+    them (the pool's box, not the product); a child that FAILS fails them."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import flbamd_loader; g = flbamd_loader.load(); g.init(0); "
+            "c = g.RcclComm(1, 0); c.close(); print('rccl-ok')" % (ROOT, os.path.join(ROOT, "tests")))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=150)
+    except subprocess.TimeoutExpired:
+        pytest.skip("an RCCL communicator of one rank did not come up within 150 s on this box")
+    assert r.returncode == 0 and b"rccl-ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-800:])
+    return True

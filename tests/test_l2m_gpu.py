@@ -306,7 +306,7 @@ def test_numconv_on_device(g):
                 assert cons[i] == -1, (c, mode)
 
 
-def test_rccl_all_reduce_in_c_single_rank(g):
+def test_rccl_all_reduce_in_c_single_rank(g, rccl_ok):
     """flbgpu_l2m_all_reduce (librccl loaded by libflbgpu.so, ncclAllGather + ncclAllReduce MAX / SUM on device
     buffers): with one rank the merged state is the rank's own export, through the same code path N ranks take.
     (The merge algebra across ranks is tests/test_l2m_merge.py, gloo, world_size 2.)"""

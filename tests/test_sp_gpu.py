@@ -245,7 +245,7 @@ def test_shards_merge_like_one_task(g):
             t.close()
 
 
-def test_rccl_timer_single_rank(g):
+def test_rccl_timer_single_rank(g, rccl_ok):
     """flbgpu_sp_timer_all_reduce over a real RCCL communicator (one rank: the exchange is the identity)"""
     rng = random.Random(0xCC1)
     q = "SELECT host, COUNT(*), AVG(latency) FROM STREAM:x WINDOW TUMBLING (5 SECOND) GROUP BY host;"

@@ -230,7 +230,7 @@ def test_process_zone_that_is_not_utc_refuses_what_depends_on_it():
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load(); fb.init()\n"
             "rx = r'^(?<time>\\S+ \\S+ \\S+) (?<m>.*)$'\n"
-            "out = []\n"
+            "import time; out = [str(time.timezone)]\n"
             "for kw in (dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%Z'), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S', time_system_timezone=True), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%z')):\n"
             "    try:\n"
             "        fb.Parser(regex=rx, time_key='time', **kw).close(); out.append('ok')\n"
@@ -240,7 +240,9 @@ def test_process_zone_that_is_not_utc_refuses_what_depends_on_it():
     env = dict(os.environ, TZ="Europe/Berlin", TZDIR=TZDIR)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-800:]
-    a, b, c = r.stdout.strip().splitlines()[-1].split("|")
+    tzsec, a, b, c = r.stdout.strip().splitlines()[-1].split("|")
+    if tzsec == "0":
+        pytest.skip("TZ=Europe/Berlin has no effect in this image's C library (no zone files where it looks)")
     assert a.startswith("refused") and "%Z" in a and b.startswith("refused") and "Time_System_Timezone" in b and c == "ok", (a, b, c)
 
 
