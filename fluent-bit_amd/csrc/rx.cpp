@@ -453,6 +453,27 @@ using AstP = std::unique_ptr<Ast>;
 
 AstP mk(Ast::T t) { AstP a(new Ast); a->t = t; return a; }
 
+// (?i) over non-ASCII characters, host matcher only (round 5): the partners of a character and the multi-character folds as the
+// reference's engine applies them, probed from it (tools/gen_casefold.py)
+#include "casefold.inc"
+static const size_t CF_NSIMPLE = sizeof(CF_SIMPLE) / sizeof(CF_SIMPLE[0]), CF_NMULTI = sizeof(CF_MULTI) / sizeof(CF_MULTI[0]);
+// first row of character c in CF_SIMPLE (rows are sorted by character), CF_NSIMPLE when it has none
+static size_t cf_first(uint32_t c) {
+    size_t lo = 0, hi = CF_NSIMPLE;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (CF_SIMPLE[mid][0] < c) lo = mid + 1; else hi = mid; }
+    return lo < CF_NSIMPLE && CF_SIMPLE[lo][0] == c ? lo : CF_NSIMPLE;
+}
+// the folded form of c: what CF_MULTI's sequences are spelled in (ASCII letters: lower case)
+static uint32_t cf_key(uint32_t c) {
+    if (c < 0x80) return (c >= 'A' && c <= 'Z') ? c + 32 : c;
+    const size_t i = cf_first(c);
+    return i < CF_NSIMPLE ? CF_SIMPLE[i][2] : c;
+}
+static const uint32_t *cf_multi(uint32_t c) {
+    for (size_t i = 0; i < CF_NMULTI; i++) if (CF_MULTI[i][0] == c) return CF_MULTI[i];
+    return nullptr;
+}
+
 struct Syntax {
     const unsigned char *s, *e, *p;
     bool has_named = false;
@@ -675,7 +696,33 @@ struct Syntax {
 
     AstP literal(uint32_t c, unsigned opts) {
         AstP a = mk(Ast::SET);
-        if ((opts & OPT_IGNORECASE) && c >= 0x80) { fail("case-insensitive non-ASCII literals are not supported"); return a; }
+        if ((opts & OPT_IGNORECASE) && c >= 0x80) {
+            // the host's matcher takes it (round 5): the character and its partners as a class; a character that stands for a sequence
+            // (U+00DF: "ss") also matches the sequence, each of its characters folded in turn
+            nonregular = true;
+            if (!ext) { fail("case-insensitive non-ASCII literals are not supported on the GPU path"); return a; }
+            a->cc.kind = CC::CLASS;
+            a->cc.add_cp(c, c);
+            for (size_t i = cf_first(c); i < CF_NSIMPLE && CF_SIMPLE[i][0] == c; i++) {
+                const uint32_t m = CF_SIMPLE[i][1];
+                a->cc.add_cp(m, m);
+                if (m < 0x80) a->cc.asc.set((int) m);
+            }
+            a->cc.mb.norm(); a->cc.mbx.norm();
+            a->ilit = cf_key(c);
+            a->icase = true;
+            if (const uint32_t *mf = cf_multi(c)) {
+                if (++fold_budget > 4000) { fail("pattern too large (case folds)"); return a; }
+                AstP seq = mk(Ast::CAT);
+                for (uint32_t k = 0; k < mf[1]; k++) seq->kids.push_back(literal(mf[2 + k], opts));
+                AstP alt = mk(Ast::ALT);
+                a->ilit = 0;                            // (not part of a run of letters: it is an alternation now)
+                alt->kids.push_back(std::move(a));
+                alt->kids.push_back(std::move(seq));
+                return alt;
+            }
+            return a;
+        }
         if ((opts & OPT_IGNORECASE) && ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'))) {
             // a folded letter is a small class (both cases; k and s also reach U+212A / U+017F)
             a->cc.kind = CC::CLASS;
@@ -1056,6 +1103,32 @@ struct Syntax {
             alts.push_back(std::move(c));
         };
         add(clone_set(run[i].get()), 1);
+        if (ext) {
+            // every multi-character fold whose sequence starts here: the characters that stand for it, as one class per sequence
+            for (size_t m = 0; m < CF_NMULTI; m++) {
+                const uint32_t *mf = CF_MULTI[m];
+                bool same = true, first = true;
+                for (uint32_t k = 0; same && k < mf[1]; k++) same = at(i + k, mf[2 + k]);
+                if (!same) continue;
+                for (size_t m2 = 0; m2 < m; m2++)            // (one alternative per sequence, for all its characters)
+                    if (CF_MULTI[m2][1] == mf[1] && CF_MULTI[m2][2] == mf[2] && CF_MULTI[m2][3] == mf[3] && CF_MULTI[m2][4] == mf[4]) first = false;
+                if (!first) continue;
+                AstP cl = mk(Ast::SET);
+                cl->cc.kind = CC::CLASS;
+                for (size_t m2 = m; m2 < CF_NMULTI; m2++)
+                    if (CF_MULTI[m2][1] == mf[1] && CF_MULTI[m2][2] == mf[2] && CF_MULTI[m2][3] == mf[3] && CF_MULTI[m2][4] == mf[4]) {
+                        const uint32_t c0 = CF_MULTI[m2][0];
+                        cl->cc.add_cp(c0, c0);
+                        for (size_t q = cf_first(c0); q < CF_NSIMPLE && CF_SIMPLE[q][0] == c0; q++) cl->cc.add_cp(CF_SIMPLE[q][1], CF_SIMPLE[q][1]);
+                    }
+                cl->cc.mb.norm(); cl->cc.mbx.norm();
+                add(std::move(cl), mf[1]);
+            }
+            if (alts.size() == 1) return std::move(alts[0]);
+            AstP alt = mk(Ast::ALT);
+            for (auto &x : alts) alt->kids.push_back(std::move(x));
+            return alt;
+        }
         if (at(i, 's') && at(i + 1, 's')) add(cp_class({0xDF, 0x1E9E}), 2);
         if (at(i, 's') && at(i + 1, 't')) add(cp_class({0xFB05, 0xFB06}), 2);
         if (at(i, 'f') && at(i + 1, 'f')) {
@@ -1081,6 +1154,7 @@ struct Syntax {
             for (size_t q = i; q + 1 < j && !hit; q++) {
                 const uint32_t a = k[q]->ilit, b = k[q + 1]->ilit;
                 hit = (a == 's' && (b == 's' || b == 't')) || (a == 'f' && (b == 'f' || b == 'i' || b == 'l'));
+                if (ext && !hit) for (size_t m = 0; m < CF_NMULTI && !hit; m++) hit = CF_MULTI[m][2] == a && CF_MULTI[m][3] == b;
             }
             if (!hit) { for (size_t q = i; q < (j > i ? j : i + 1); q++) out.push_back(std::move(k[q])); i = j > i ? j : i + 1; continue; }
             std::vector<AstP> run;
