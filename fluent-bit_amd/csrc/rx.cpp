@@ -688,9 +688,33 @@ struct Syntax {
         }
         s.mb.norm();
         if (have_acc) { s.mbx.norm(); s = cc_and(acc, s); s.mb.norm(); s.mbx.norm(); }
-        if ((opts & OPT_IGNORECASE) && !fold_case(s)) return fail("case-insensitive classes with non-ASCII members are not supported");
+        if ((opts & OPT_IGNORECASE) && !fold_case_any(s)) return fail("case-insensitive classes with non-ASCII members are not supported on the GPU path");
+        if (neg) cc_multi.clear();                  // (a negated class takes no sequences)
         s.neg = neg;
         out = s;
+        return true;
+    }
+
+    // (?i) over a class with some non-ASCII members, host matcher only (round 5): the class's (positive) members are closed under the
+    // engine's fold pairs (regparse.c i_apply_case_fold with CASE_FOLD_IS_APPLIED_INSIDE_NEGATIVE_CCLASS; a pair that crosses the ASCII
+    // boundary from an ASCII letter only for members of the shadow class); the members that stand for a sequence are noted in cc_multi --
+    // the class then also matches those sequences, unless it is negated
+    std::vector<const uint32_t *> cc_multi;
+    bool fold_case_any(CC &cc) {
+        if (fold_case(cc)) return true;
+        if (!ext) { nonregular = true; return false; }
+        const CodeSet before = cc.mb;
+        const ByteSet bs0 = cc.bs;
+        auto has = [&](uint32_t c) { return c < 0x80 ? bs0.has((int) c) : before.has(c); };
+        for (size_t i = 0; i < CF_NSIMPLE; i++) {
+            const uint32_t c = CF_SIMPLE[i][0], m = CF_SIMPLE[i][1];
+            // (a partner below 0x100 goes into the BIT SET, which a well-formed two-byte character is never tested on -- only a stray byte
+            // of that value is: (?i)[\xe0-\xff] does not take U+00C0 in the reference, i_apply_case_fold's SINGLE_BYTE_SIZE branch)
+            if (has(c) && !has(m)) { if (m < 0x100) cc.bs.set((int) m); else { cc.mb.add(m, m); cc.mbx.add(m, m); } }
+            if (m < 0x80 && has(m) && cc.asc.has((int) m) && !has(c)) { cc.mb.add(c, c); cc.mbx.add(c, c); }
+        }
+        for (size_t i = 0; i < CF_NMULTI; i++) if (before.has(CF_MULTI[i][0])) cc_multi.push_back(CF_MULTI[i]);
+        cc.mb.norm(); cc.mbx.norm();
         return true;
     }
 
@@ -715,6 +739,7 @@ struct Syntax {
                 if (++fold_budget > 4000) { fail("pattern too large (case folds)"); return a; }
                 AstP seq = mk(Ast::CAT);
                 for (uint32_t k = 0; k < mf[1]; k++) seq->kids.push_back(literal(mf[2 + k], opts));
+                fold_strings(seq.get());
                 AstP alt = mk(Ast::ALT);
                 a->ilit = 0;                            // (not part of a run of letters: it is an alternation now)
                 alt->kids.push_back(std::move(a));
@@ -889,8 +914,25 @@ struct Syntax {
         if (c == '[') {
             p++;
             AstP a = mk(Ast::SET);
+            cc_multi.clear();
             if (!char_class(a->cc, opts)) return nullptr;
             a->icase = (opts & OPT_IGNORECASE) != 0;
+            if (!cc_multi.empty()) {
+                // (?:[class]|seq1|seq2 ..): the members that stand for a sequence also match it, folded (regparse.c i_apply_case_fold, to_len > 1)
+                std::vector<const uint32_t *> ms;
+                ms.swap(cc_multi);
+                AstP alt = mk(Ast::ALT);
+                alt->kids.push_back(std::move(a));
+                for (const uint32_t *mf : ms) {
+                    AstP seq = mk(Ast::CAT);
+                    for (uint32_t k = 0; k < mf[1]; k++) seq->kids.push_back(literal(mf[2 + k], opts));
+                    fold_strings(seq.get());                   // (the sequence is compared folded: it also takes the characters that stand for it)
+                    alt->kids.push_back(std::move(seq));
+                }
+                AstP g = mk(Ast::GROUP);
+                g->kids.push_back(std::move(alt));
+                return g;
+            }
             return a;
         }
         if (c == '.') {

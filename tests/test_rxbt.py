@@ -398,3 +398,29 @@ def test_case_insensitive_non_ascii_literals():
             n, m = compare(L, ref, pat, subj)
             total += n; matched += m
     assert total > 10000 and matched > 1200 and CORNERS[0] >= 0, (total, matched)
+
+
+ICASE_CLASSES = ["[а-яё]+", "[ßa]x", "[^é]x", "[à-ÿ]{2,}", "[ΐk]s", "x[ǆ-ǌ]", "[ſ]t", "[K]", "[k-m]+", "[α-ω]+ς?", "[^а-я ]+", "[éa-c]+\\d", "[ﬁﬂ]n", "[\\x{1F80}-\\x{1FAF}]",
+                 "[İı]", "[A-Zà-þ]+", "[ԱԲ]+", "[Ꭰ-Ꮿ]+", "[ꭰ-ꮿ]+", "[Ａ-Ｚ]+!", "[𐐀-𐐧]+", "[^ß]", "[ẞ]", "[ŉǰ]", "x[ẖ-ẚ]y"]
+
+
+@needs_ref
+def test_case_insensitive_classes_with_non_ascii_members():
+    """round 5: (?i)[..] with some non-ASCII members on the host's matcher: the positive members closed under the engine's fold pairs,
+    the members that stand for a sequence also match it (not in a negated class); against the real engine"""
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(78)
+    total = matched = 0
+    for cl in ICASE_CLASSES:
+        for pat in [("(?i)" + cl).encode(), ("(?i)^" + cl + "$").encode(), ("a(?i:" + cl + ")b").encode()]:
+            subj = []
+            for w2 in rng.sample(ICASE_WORDS, 8):
+                subj += icase_subjects(rng, w2)
+            letters = "".join(ch for ch in cl if ord(ch) >= 0x80) or "k"
+            for ch in letters:
+                for f in {ch, ch.lower(), ch.upper(), ch.casefold(), ch.title()}:
+                    subj += [f.encode(), ("x" + f + "y").encode(), (f + "s").encode(), (f + "t").encode(), (f + "n!").encode(), ("a" + f + "b").encode(), (f * 3 + "7").encode()]
+            n, m = compare(L, ref, pat, subj)
+            total += n; matched += m
+    assert total > 10000 and matched > 800, (total, matched)
