@@ -1028,6 +1028,30 @@ struct Syntax {
                 nonregular = true;
                 return a;
             }
+            if (c == 'X' && ext) {
+                // \X, an extended grapheme cluster: the reference builds it from property classes (regparse.c node_extended_grapheme_cluster,
+                // UAX #29 as of Unicode 11) -- CR LF | a control | Prepend* core postcore* | any character, atomic, case folding off --;
+                // spelled here as a pattern over the same properties (their members: unicode_props.inc, probed from the engine) and parsed
+                // by this front end
+                static const char XGC[] =
+                    "(?>\\x0D\\x0A|[\\p{Grapheme_Cluster_Break=Control}\\x0A\\x0D]|"
+                    "\\p{Grapheme_Cluster_Break=Prepend}*"
+                    "(?:\\p{Grapheme_Cluster_Break=L}*(?:\\p{Grapheme_Cluster_Break=V}+|\\p{Grapheme_Cluster_Break=LV}\\p{Grapheme_Cluster_Break=V}*|\\p{Grapheme_Cluster_Break=LVT})\\p{Grapheme_Cluster_Break=T}*"
+                    "|\\p{Grapheme_Cluster_Break=L}+|\\p{Grapheme_Cluster_Break=T}+|\\p{Regional_Indicator}{2}"
+                    "|\\p{Extended_Pictographic}(?:\\p{Grapheme_Cluster_Break=Extend}*\\x{200D}\\p{Extended_Pictographic})*"
+                    "|[\\P{Grapheme_Cluster_Break=Control}&&[^\\x0A\\x0D]])"      // (a POSITIVE class of the complement, as the reference adds it: a cut sequence is no member)
+                    "[\\p{Grapheme_Cluster_Break=Extend}\\p{Grapheme_Cluster_Break=SpacingMark}\\x{200D}]*"
+                    "|(?m:.))";
+                p++;
+                nonregular = true;
+                Syntax sub;
+                sub.ext = true;
+                sub.s = sub.p = (const unsigned char *) XGC;
+                sub.e = sub.s + sizeof(XGC) - 1;
+                AstP n = sub.alternation(opts & ~(unsigned) OPT_IGNORECASE, depth + 1);
+                if (sub.failed() || !sub.eof()) { fail("\\X: " + sub.err); return nullptr; }
+                return n;
+            }
             if (c == 'R' && ext) {
                 // \R: (?>\x0D\x0A|[\x0A-\x0D\x{85}\x{2028}\x{2029}])  (regparse.c node_linebreak)
                 p++;
@@ -1046,7 +1070,7 @@ struct Syntax {
                 return at;
             }
             if (c == 'R') nonregular = true;
-            if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k' || c == 'g') nonregular = true; fail("unsupported escape"); return nullptr; }
+            if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k' || c == 'g' || c == 'X') nonregular = true; fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') {
                 nonregular = true;
                 if (!ext) { fail("back-references are not supported on the GPU path"); return nullptr; }

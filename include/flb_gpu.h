@@ -218,7 +218,7 @@ void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t 
  * change the byte length): the product answered leftmost-first, the reference MAY have answered otherwise.  Not silent: the plugin
  * shims warn once when this is non-zero (filter_gpu_plugins.c). */
 uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f);
-/* Rules / parsers whose pattern is NOT a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K; round 5: the absent operator (?~X), subexpression calls \g<..>, more than 31 groups, (?i) over non-ASCII literals)
+/* Rules / parsers whose pattern is NOT a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K; round 5: the absent operator (?~X), subexpression calls \g<..>, more than 31 groups, (?i) over non-ASCII literals and classes, \X)
  * do not fail the create calls: the device does everything but the search of that pattern, which the product's backtracking matcher
  * (csrc/rxbt.inc) runs on the host over the values the device located -- filter_grep rules, filter_log_to_metrics rules (run as a
  * filter_grep in front of the metric kernels) and single-parser filter_parser lists; the fused pair and multiline rules still refuse them.  out4: [0] host rules / parsers of this filter, [1] values searched

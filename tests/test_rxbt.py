@@ -257,7 +257,7 @@ def test_regular_patterns_through_the_backtracker():
 def test_what_stays_refused():
     """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
     L = flbamd_loader.load().lib()
-    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Age=6.0}", rb"\X", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
+    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Age=6.0}", rb"(?i)\p{Greek}", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
         h, err = bt_compile(L, pat)
         assert h is None and err, pat
 
@@ -424,3 +424,31 @@ def test_case_insensitive_classes_with_non_ascii_members():
             n, m = compare(L, ref, pat, subj)
             total += n; matched += m
     assert total > 10000 and matched > 800, (total, matched)
+
+
+GRAPHEME_POOL = ["a", "b", " ", "\r", "\n", "\r\n", "\x01", "\u0301", "\u0308", "\u0300", "\u200d", "\u0903", "\u0600", "\U000110bd", "\u1100", "\u1161", "\u11a8", "\uac00", "\uac01",
+                 "\U0001f1ef", "\U0001f1f5", "\U0001f1fa", "\U0001f468", "\U0001f469", "\U0001f467", "\U0001f3fb", "\u2764", "\ufe0f", "\u0e33", "\u0d4e", "é", "日", "\u00ad", "\u200c", "\u2028"]
+
+
+@needs_ref
+def test_extended_grapheme_cluster():
+    """round 5: \\X on the host's matcher, spelled over the same property classes the reference builds it from (regparse.c
+    node_extended_grapheme_cluster); texts of combining marks, Hangul jamo, regional indicators, ZWJ sequences, CR LF, controls,
+    Prepend / SpacingMark characters -- well-formed and cut -- against the real engine"""
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(79)
+    total = matched = 0
+    for pat in [rb"\X", rb"^\X$", rb"^\X\X$", rb"a\X+b", rb"(?<g>\X)\k<g>", rb"\X{3}", rb"^(?:\X)*$", rb"(?i)\Xa", rb"\X(?=\u200d)".replace(b"\\u200d", "\u200d".encode()), rb"[^a]\X"]:
+        assert L.flbgpu_rx_is_nonregular(pat, len(pat), 0) == 1, pat
+        subj = []
+        for _ in range(300):
+            t = "".join(rng.choice(GRAPHEME_POOL) for _ in range(rng.randint(1, 7))).encode()
+            if rng.random() < 0.15:
+                t = t[:rng.randrange(len(t) + 1)]                            # cut anywhere: ill-formed tails
+            if rng.random() < 0.1:
+                k = rng.randrange(len(t) + 1); t = t[:k] + rng.choice([b"\xff", b"\x80", b"\xe2\x80"]) + t[k:]
+            subj.append(t)
+        n, m = compare(L, ref, pat, subj)
+        total += n; matched += m
+    assert total > 2500 and matched > 1000, (total, matched)
