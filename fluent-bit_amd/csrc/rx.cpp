@@ -585,7 +585,6 @@ struct Syntax {
         // (\p{Punct} is the Unicode category P -- without $ + < = > ^ ` | ~, which [[:punct:]] has: the property table's set, not the bracket's)
         if (nm != "punct" && add_posix(cc, nm, neg, false)) return true;
         if (add_uniprop(cc, nm, neg)) return true;
-        if (nm.compare(0, 4, "age=") == 0) return fail(("the character property \\p{" + nm + "} is not supported (Unicode ages are not in the property table)").c_str());
         return fail(("invalid character property name {" + nm + "}").c_str());
     }
 

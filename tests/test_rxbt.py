@@ -257,7 +257,7 @@ def test_regular_patterns_through_the_backtracker():
 def test_what_stays_refused():
     """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
     L = flbamd_loader.load().lib()
-    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{Age=6.0}", rb"(?i)\p{Greek}", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
+    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{NoSuchProperty}", rb"(?i)\p{Greek}", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
         h, err = bt_compile(L, pat)
         assert h is None and err, pat
 
