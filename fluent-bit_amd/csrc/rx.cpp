@@ -717,6 +717,26 @@ struct Syntax {
         return true;
     }
 
+    // (?:[class]|seq1|seq2 ..): the members of a folded class that stand for a sequence (cc_multi) also match it, folded (regparse.c
+    // i_apply_case_fold, to_len > 1)
+    AstP with_sequences(AstP a, unsigned opts) {
+        if (cc_multi.empty()) return a;
+        std::vector<const uint32_t *> ms;
+        ms.swap(cc_multi);
+        if (ms.size() > 120) { fail("pattern too large (case folds)"); return a; }
+        AstP alt = mk(Ast::ALT);
+        alt->kids.push_back(std::move(a));
+        for (const uint32_t *mf : ms) {
+            AstP seq = mk(Ast::CAT);
+            for (uint32_t k = 0; k < mf[1]; k++) seq->kids.push_back(literal(mf[2 + k], opts));
+            fold_strings(seq.get());                   // (the sequence is compared folded: it also takes the characters that stand for it)
+            alt->kids.push_back(std::move(seq));
+        }
+        AstP g = mk(Ast::GROUP);
+        g->kids.push_back(std::move(alt));
+        return g;
+    }
+
     AstP literal(uint32_t c, unsigned opts) {
         AstP a = mk(Ast::SET);
         if ((opts & OPT_IGNORECASE) && c >= 0x80) {
@@ -916,23 +936,7 @@ struct Syntax {
             cc_multi.clear();
             if (!char_class(a->cc, opts)) return nullptr;
             a->icase = (opts & OPT_IGNORECASE) != 0;
-            if (!cc_multi.empty()) {
-                // (?:[class]|seq1|seq2 ..): the members that stand for a sequence also match it, folded (regparse.c i_apply_case_fold, to_len > 1)
-                std::vector<const uint32_t *> ms;
-                ms.swap(cc_multi);
-                AstP alt = mk(Ast::ALT);
-                alt->kids.push_back(std::move(a));
-                for (const uint32_t *mf : ms) {
-                    AstP seq = mk(Ast::CAT);
-                    for (uint32_t k = 0; k < mf[1]; k++) seq->kids.push_back(literal(mf[2 + k], opts));
-                    fold_strings(seq.get());                   // (the sequence is compared folded: it also takes the characters that stand for it)
-                    alt->kids.push_back(std::move(seq));
-                }
-                AstP g = mk(Ast::GROUP);
-                g->kids.push_back(std::move(alt));
-                return g;
-            }
-            return a;
+            return with_sequences(std::move(a), opts);
         }
         if (c == '.') {
             p++;
@@ -968,9 +972,11 @@ struct Syntax {
                 if (!property(a->cc, &not_flag)) return nullptr;
                 a->cc.neg = not_flag;
                 a->cc.mb.norm(); a->cc.mbx.norm();
-                if ((opts & OPT_IGNORECASE) && !fold_case(a->cc)) { fail("case-insensitive classes with non-ASCII members are not supported"); return nullptr; }
+                cc_multi.clear();
+                if ((opts & OPT_IGNORECASE) && !fold_case_any(a->cc)) { fail("case-insensitive classes with non-ASCII members are not supported on the GPU path"); return nullptr; }
                 a->icase = (opts & OPT_IGNORECASE) != 0;
-                return a;
+                if (a->cc.neg) cc_multi.clear();
+                return with_sequences(std::move(a), opts);
             }
             if (c == 'Z') {
                 nonregular = true;

@@ -257,7 +257,7 @@ def test_regular_patterns_through_the_backtracker():
 def test_what_stays_refused():
     """constructs neither engine nor the backtracker takes are refused with their name, not run wrongly"""
     L = flbamd_loader.load().lib()
-    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{NoSuchProperty}", rb"(?i)\p{Greek}", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
+    for pat in [rb"(?(1)a|b|c)", rb"\g<1>", rb"\p{NoSuchProperty}", rb"\p{Age=99.0}", rb"(?<=a+)b", rb"(a)\2", rb"\k<nope>", rb"(?<a>x\g<a>)", rb"(?<a>\g<a>x)", rb"(?<a>x)(?<a>y)\g<a>", rb"\g<0>", rb"(?<a>x|\g<a>y)", rb"(?<a>x\g<b>)(?<b>y\g<a>)"]:
         h, err = bt_compile(L, pat)
         assert h is None and err, pat
 
@@ -401,7 +401,8 @@ def test_case_insensitive_non_ascii_literals():
 
 
 ICASE_CLASSES = ["[а-яё]+", "[ßa]x", "[^é]x", "[à-ÿ]{2,}", "[ΐk]s", "x[ǆ-ǌ]", "[ſ]t", "[K]", "[k-m]+", "[α-ω]+ς?", "[^а-я ]+", "[éa-c]+\\d", "[ﬁﬂ]n", "[\\x{1F80}-\\x{1FAF}]",
-                 "[İı]", "[A-Zà-þ]+", "[ԱԲ]+", "[Ꭰ-Ꮿ]+", "[ꭰ-ꮿ]+", "[Ａ-Ｚ]+!", "[𐐀-𐐧]+", "[^ß]", "[ẞ]", "[ŉǰ]", "x[ẖ-ẚ]y"]
+                 "[İı]", "[A-Zà-þ]+", "[ԱԲ]+", "[Ꭰ-Ꮿ]+", "[ꭰ-ꮿ]+", "[Ａ-Ｚ]+!", "[𐐀-𐐧]+", "[^ß]", "[ẞ]", "[ŉǰ]", "x[ẖ-ẚ]y",
+                 "\\p{Greek}+", "\\P{Cyrillic}x", "[\\p{Lu}]+", "\\p{Ll}{2}", "\\p{Lu}s", "[\\p{Armenian}x]+", "\\p{^Latin}+"]
 
 
 @needs_ref
