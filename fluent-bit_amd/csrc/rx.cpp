@@ -478,6 +478,7 @@ struct Syntax {
     const unsigned char *s, *e, *p;
     bool has_named = false;
     int ncap = 0;
+    int nopen = 0;                    // groups opened so far, the plain ones next to named ones included (regparse.c env->num_mem while parsing)
     std::string err;
     std::vector<std::string> names;
     std::vector<std::vector<int>> name_groups;
@@ -512,6 +513,51 @@ struct Syntax {
         if (c >= 'a' && c <= 'f') return c - 'a' + 10;
         if (c >= 'A' && c <= 'F') return c - 'A' + 10;
         return -1;
+    }
+
+    // \cX  \C-X  \M-X and their nestings (regparse.c:2429 fetch_escaped_value): a code point -- \M-a is U+00E1, two bytes of subject --,
+    // never a raw byte.  p stands behind the backslash.
+    bool escaped_value(uint32_t &out) {
+        if (eof()) return fail("end pattern at escape");
+        uint32_t c = take_cp();
+        if (c == 'M') {
+            if (eof()) return fail("end pattern at meta");
+            if (take_cp() != '-') return fail("invalid meta-code syntax");
+            if (eof()) return fail("end pattern at meta");
+            c = take_cp();
+            if (c == '\\' && !escaped_value(c)) return false;
+            c = (c & 0xff) | 0x80;
+        }
+        else if (c == 'C' || c == 'c') {
+            if (c == 'C') {
+                if (eof()) return fail("end pattern at control");
+                if (take_cp() != '-') return fail("invalid control-code syntax");
+            }
+            if (eof()) return fail("end pattern at control");
+            c = take_cp();
+            if (c == '?') c = 0177;
+            else {
+                if (c == '\\' && !escaped_value(c)) return false;
+                c &= 0x9f;
+            }
+        }
+        else {
+            switch (c) {                    // (regparse.c conv_backslash_value)
+            case 'n': c = 10; break; case 't': c = 9; break; case 'r': c = 13; break; case 'f': c = 12; break;
+            case 'a': c = 7; break; case 'b': c = 8; break; case 'e': c = 27; break; case 'v': c = 11; break;
+            }
+        }
+        out = c;
+        return !failed();
+    }
+
+    // \1 .. \777 inside brackets: always octal there (regparse.c fetch_token_in_cc)
+    bool class_octal(uint32_t &out) {
+        uint32_t v = 0; int n = 0;
+        while (!eof() && *p >= '0' && *p <= '7' && n < 3) { v = v * 8 + (uint32_t) (*p++ - '0'); n++; }
+        if (v >= 0x80) return fail("raw byte escapes >= 0x80 are not supported");
+        out = v;
+        return true;
     }
 
     // after the backslash: escapes denoting one code point
@@ -554,7 +600,7 @@ struct Syntax {
             out = v; return true;
         }
         case 'c': case 'C': case 'M':
-            fail("control/meta escapes are not supported"); return true;
+            escaped_value(out); return true;
         }
         if (in_class && c == 'b') { p++; out = 8; return true; }
         return false;
@@ -656,12 +702,7 @@ struct Syntax {
                     if (c == 'p' || c == 'P') { if (!property(s)) return false; continue; }
                     if (c == 'R' || c == 'X') return fail("\\R / \\X are not supported");
                     if (escape_cp(lo, true)) { if (failed()) return false; }
-                    else if (c >= '1' && c <= '7') {
-                        uint32_t v = 0; int n = 0;
-                        while (!eof() && *p >= '0' && *p <= '7' && n < 3) { v = v * 8 + (*p++ - '0'); n++; }
-                        if (v >= 0x80) return fail("raw byte escapes >= 0x80 are not supported");
-                        lo = v;
-                    }
+                    else if (c >= '1' && c <= '7') { if (!class_octal(lo)) return false; }
                     else lo = take_cp();
                 }
                 else lo = take_cp();
@@ -677,6 +718,7 @@ struct Syntax {
                     if (eof()) return fail("end pattern at escape");
                     if (strchr("dwshDWSHpP", *p)) p = save;
                     else if (escape_cp(hi, true)) { if (failed()) return false; }
+                    else if (*p >= '1' && *p <= '7') { if (!class_octal(hi)) return false; }
                     else hi = take_cp();
                 }
                 else hi = take_cp();
@@ -842,7 +884,7 @@ struct Syntax {
                         p++;
                     }
                     if (eof() || p == nm || (*nm >= '0' && *nm <= '9')) { fail("invalid group name"); return nullptr; }
-                    g->cap = ++ncap;
+                    g->cap = ++ncap; nopen++;
                     note_name(std::string((const char *) nm, p - nm), g->cap);
                     p++;
                     g->kids.push_back(alternation(opts, depth + 1));
@@ -923,6 +965,7 @@ struct Syntax {
             }
             else {
                 if (!has_named) g->cap = ++ncap;
+                nopen++;
                 g->kids.push_back(alternation(opts, depth + 1));
             }
             if (failed()) return nullptr;
@@ -1077,11 +1120,23 @@ struct Syntax {
             if (c == 'R') nonregular = true;
             if (strchr("GKRXkg", c)) { if (c == 'G' || c == 'K' || c == 'k' || c == 'g' || c == 'X') nonregular = true; fail("unsupported escape"); return nullptr; }
             if (c >= '1' && c <= '9') {
+                // a decimal number is a back-reference while it is at most 9 or at most the groups opened so far; otherwise \8 \9 are
+                // the digits themselves and the rest an octal escape of up to three digits (regparse.c fetch_token '1'..'9')
+                const unsigned char *prev = p;
+                int v = 0;
+                while (!eof() && *p >= '0' && *p <= '9') { if (v <= 1000) v = v * 10 + (*p - '0'); p++; }
+                if (!(v <= 1000 && (v <= nopen || v <= 9))) {
+                    p = prev;
+                    if (c == '8' || c == '9') { p++; return literal((uint32_t) c, opts); }
+                    uint32_t o = 0; int n = 0;
+                    while (!eof() && *p >= '0' && *p <= '7' && n < 3) { o = o * 8 + (uint32_t) (*p++ - '0'); n++; }
+                    if (o > 0xff) { fail("too big number"); return nullptr; }
+                    if (o >= 0x80) { fail("raw byte escapes >= 0x80 are not supported"); return nullptr; }
+                    return literal(o, opts);
+                }
                 nonregular = true;
                 if (!ext) { fail("back-references are not supported on the GPU path"); return nullptr; }
                 if (has_named) { fail("numbered backref/call is not allowed. (use name)"); return nullptr; }
-                int v = 0;
-                while (!eof() && *p >= '0' && *p <= '9' && v < 1000) { v = v * 10 + (*p - '0'); p++; }
                 AstP a = mk(Ast::BACKREF);
                 a->ref_icase = (opts & OPT_IGNORECASE) != 0;
                 a->refs.push_back(v);
