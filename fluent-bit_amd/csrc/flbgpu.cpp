@@ -472,6 +472,17 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
                                          int time_keep, int time_strict, const char *types) {
     if (!is_json && !regex) { set_err("parser '%s': missing regex", name ? name : ""); return nullptr; }
     if (is_json) regex = "";
+    if (time_fmt && strstr(time_fmt, "%Z")) {
+        // %Z's last resort for a zone text that is in neither of flb_strptime's tables is the PROCESS's zone -- tzname[] and -timezone
+        // (src/flb_strptime.c:611-650) --; the device restates that for a process without a zone (UTC).  In any other process the
+        // answer for such texts would differ: refused at create, like Time_System_Timezone.  (Before anything touches the
+        // device: the refusal is the same on a host without one.)
+        tzset();
+        if (timezone != 0 || daylight != 0) {
+            set_err("parser '%s': Time_Format with %%Z in a process whose zone is not UTC is not supported (the zone text's last resort is the process's tzname[])", name ? name : "");
+            return nullptr;
+        }
+    }
     auto *p = new flbgpu_parser();
     p->name = name ? name : "";
     DevParser &d = p->dev;
@@ -522,16 +533,6 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
         d.has_time = 1;
         d.time_with_tz = (tf.find("%z") != std::string::npos || tf.find("%Z") != std::string::npos ||
                           tf.find("%SZ") != std::string::npos || tf.find("%S.%LZ") != std::string::npos) ? 1 : 0;
-        if (tf.find("%Z") != std::string::npos) {
-            // %Z's last resort for a zone text that is in neither of flb_strptime's tables is the PROCESS's zone -- tzname[] and -timezone
-            // (src/flb_strptime.c:611-650) --; the device restates that for a process without a zone (UTC).  In any other process the
-            // answer for such texts would differ: refused at create, like Time_System_Timezone
-            tzset();
-            if (timezone != 0 || daylight != 0) {
-                set_err("parser '%s': Time_Format with %%Z in a process whose zone is not UTC is not supported (the zone text's last resort is the process's tzname[])", p->name.c_str());
-                delete p; return nullptr;
-            }
-        }
         std::string f1 = tf, f2;
         size_t lpos = tf.find("%L");
         if (lpos != std::string::npos) { f1 = tf.substr(0, lpos); f2 = tf.substr(lpos + 2); d.has_frac = 1; }

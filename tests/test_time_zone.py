@@ -222,6 +222,29 @@ def test_product_refusals():
     fb.Parser(regex=rx, time_key="time", time_fmt=FMT, time_system_timezone=True).close()
 
 
+def test_process_zone_that_is_not_utc_refuses_the_zone_name_directive_before_any_device_work():
+    """the %Z half of the test below without a GPU: the refusal comes before the parser touches the device, so a host without one
+    gives the same message (and, in a UTC process, gets as far as the device: 'no ROCm-capable device')"""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load()\n"
+            "import time; out = [str(time.timezone)]\n"
+            "for fmt_ in ('json', 'regex', 'logfmt'):\n"
+            "    try:\n"
+            "        fb.Parser(regex=r'^(?<time>.*)$' if fmt_ == 'regex' else None, format=fmt_, time_key='time', time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%Z').close(); out.append('ok')\n"
+            "    except (ValueError, RuntimeError) as e:\n"
+            "        out.append(str(e))\n"
+            "print('|'.join(out))\n") % os.path.dirname(HERE)
+    seen = {}
+    for tz in ("Europe/Berlin", "UTC"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TZ=tz, TZDIR=TZDIR), timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        seen[tz] = r.stdout.strip().splitlines()[-1].split("|")
+    if seen["Europe/Berlin"][0] == "0":
+        pytest.skip("TZ=Europe/Berlin has no effect in this image's C library (no zone files where it looks)")
+    assert all("%Z" in m and "not UTC" in m for m in seen["Europe/Berlin"][1:]), seen
+    assert seen["UTC"][0] == "0" and not any("not UTC" in m for m in seen["UTC"][1:]), seen
+
+
 @pytest.mark.gpu
 def test_process_zone_that_is_not_utc_refuses_what_depends_on_it():
     """%Z's last resort and Time_System_Timezone read the PROCESS's zone (src/flb_strptime.c:611-650, flb_parser.h:80-94); the
