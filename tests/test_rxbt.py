@@ -505,3 +505,36 @@ def test_control_meta_and_octal_escapes():
         assert h is None and err, pat
         if pat in ESCAPES_REFUSED_BY_BOTH:
             assert not rxdiff.RefRegex(ref, pat).ok, pat
+
+
+def test_searches_from_several_threads_at_once():
+    """flbgpu.cpp parallel_rows searches one compiled program from up to 16 threads, each on its thread's own search stack (rxbt.inc: the
+    stack switch is a few instructions of x86-64 since round 5, swapcontext elsewhere and under the sanitizers): 8 threads, shallow and
+    deep searches mixed, every answer equal to the single-threaded one"""
+    import threading
+    L = flbamd_loader.load().lib()
+    pats = [rb"(?<=user=)(\w+) id=\1", rb"^(?!.*(?:health|ping)).*\d$", rb"(?>a+)b", rb"(?i)(ab)\1", rb"(a)?(?(1)b|c)", rb"a\Rb", rb"(?=a)(?:ab)*!", rb"\Anope(?!x)", rb"^x(?=y)"]
+    hs = []
+    for p in pats:
+        h, err = bt_compile(L, p)
+        assert h, (p, err)
+        hs.append(h)
+    subj = [b"user=alice id=alice", b"GET /health 200", b"GET /x 200 5", b"aaab", b"ABab", b"ab", b"c", b"a\r\nb", b"x" * 200, b"host rest of line",
+            b"ab" * 6000 + b"!", b"ab" * 20000, b"q\nxy", "é".encode() * 50 + b"aab"]
+    base = {(i, j): bt_search(L, h, s) for i, h in enumerate(hs) for j, s in enumerate(subj)}
+    assert base[(6, 10)] == [(0, 12001)] and base[(8, 12)] == [(2, 3)]
+    bad = []
+
+    def work(seed):
+        rng = random.Random(seed)
+        for _ in range(500):
+            i = rng.randrange(len(hs)); j = rng.randrange(len(subj))
+            r = bt_search(L, hs[i], subj[j])
+            if r != base[(i, j)]:
+                bad.append((i, j, r))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for h in hs:
+        L.flbgpu_rxbt_free(h)
+    assert not bad, bad[:3]
