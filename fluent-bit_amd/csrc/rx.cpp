@@ -440,6 +440,9 @@ struct Ast {
     std::vector<int> refs;                 // BACKREF: the groups the reference names, in group order
     bool ref_icase = false;
     CodeSet btmb;                          // SET, rxbt: the well-formed multi-byte characters it accepts
+    uint64_t btasc[2] = {0, 0};            // SET, rxbt: the ASCII characters it accepts, a bit each
+    uint64_t btnext[4] = {0, 0, 0, 0};     // REPEAT inside a CAT, rxbt: the bytes what FOLLOWS it in the CAT can begin with (btnext_on:
+    bool btnext_on = false;                //   that rest takes at least one character, so an end of the repeat in front of another byte fails)
     CC cc;
     std::vector<std::unique_ptr<Ast>> kids;
     int cap = 0;

@@ -23,6 +23,14 @@ KNOWN = [
     rb"(?<q>['\"])(?<body>.*?)\k<q>", rb"^(?<host>\S+) (?!-)(?<user>\S+)", rb"(?<n>\d+)-\k<n>", rb"(?=(a+))a*b\1", rb"(?<!\\)\"", rb"(\d+)(?<=5)x", rb"a(?=b|c)(?<=a).",
 ]
 
+# (round 5: ends of a one-character repeat in front of a byte the rest cannot begin with are not tried, searches start only where a
+# match can -- patterns where that pruning sits next to capture bookkeeping, look-arounds, lazy repeats, multi-byte characters)
+PRUNING = [
+    rb"(a*)*b", rb"(?:(a*)b|\1c)+", rb"((a*)b\2)", rb"(x*|y)\1z", rb".*(?=b)b", rb"\w*(?<=a)b", rb"[^b]*?(?!c)b", rb"(a*)(?:b|\1)c", "é*b".encode(), "[aé]*é".encode(),
+    rb"a*(?:b|)c", rb"a*(b)?c", rb"a*\Kb", rb"(?i)x*Mozilla(?!/4)", rb"\d*(?>\d)x", rb"^a*b|^c", rb"(?:^|\A)a*b", rb"\Ga*b", rb"(^a*)b", rb"(?:^a)+b", rb"a*$\n?b", rb"(?=a)a*a", rb"a{2,5}?a(?<!aaaa)b",
+    rb"[^\n]*\n(?=x)", rb"(?<=\n)a*b", rb"^\s*(?<k>\w+)\s*=\s*(?<v>.*?)\s*$(?<!;)", rb"(a|ab)*c", rb".*?(\d+)(?!\d)", rb".*\b(\w+)\1",
+]
+
 LOOK_BODY = [rb"a", rb"b", rb"ab", rb"\d", rb"\w", rb"[a-c]", rb" ", rb"x|y", rb"ab|cd", rb"a|bc", rb"\s", rb"[^a]", rb".", "é".encode(), rb"\d\d", rb"^", rb"$", rb"\b"]
 
 
@@ -218,6 +226,20 @@ def test_known_nonregular_patterns():
         assert n > 0, pat                                                       # the real engine takes every one of them
         total += n; matched += m
     assert total > 4000 and matched > 300, (total, matched)
+
+
+@needs_ref
+def test_pruned_searches_give_the_same_answers():
+    L = flbamd_loader.load().lib()
+    ref = rxdiff.load_ref()
+    rng = random.Random(23)
+    total = matched = 0
+    for pat in PRUNING:
+        extra = [b"aab", b"aaaab", b"ab\nab", b"\naab", b"xaab\ncc", "ééb".encode(), "aéé".encode(), b"k = v ;", b" k=v", b"12 345", b"ab ab", b"aaaaab", b"aaac", b"xxMOZILLA/5", b"xmozilla/4"]
+        n, m = compare(L, ref, pat, subjects(L, rng, pat, 150) + extra)
+        assert n > 0, pat
+        total += n; matched += m
+    assert total > 4000 and matched > 1000, (total, matched)
 
 
 @needs_ref
