@@ -111,6 +111,8 @@ def lib():
     L.flbgpu_json_run_dev.argtypes = [c_void_p, POINTER(DevChunk), c_int, c_uint, c_uint, POINTER(DevChunk)]
     L.flbgpu_json_row_info.argtypes = [c_void_p, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
     L.flbgpu_json_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+    L.flbgpu_json_tile_stats.argtypes = [c_void_p, POINTER(c_uint64)]
+    L.flbgpu_json_tile_debug.argtypes = [c_void_p, c_int, c_int, POINTER(c_uint64)]
     L.flbgpu_split_lines_host.restype = c_int64
     L.flbgpu_split_lines_host.argtypes = [c_char_p, c_size_t, c_void_p, c_size_t]
     L.flbgpu_filter_l2m_create.restype = c_void_p
@@ -1028,6 +1030,17 @@ class JsonPacker:
         o = (c_uint64 * 3)()
         lib().flbgpu_json_stats(self.h, o)
         return dict(generic_rows=o[0], values=o[1], error_rows=o[2])
+
+    def tile_stats(self):
+        o = (c_uint64 * 4)()
+        lib().flbgpu_json_tile_stats(self.h, o)
+        return dict(tile_rows=o[0], left_rows=o[1], launches=o[2], tokens=o[3])
+
+    def tile_debug(self, prof=False, no_lookback=False):
+        """measurement only: phase stamps / no look-back for the next runs; returns the last run's phase cycles"""
+        o = (c_uint64 * 8)()
+        lib().flbgpu_json_tile_debug(self.h, int(prof), int(no_lookback), o)
+        return list(o)
 
     def run_host(self, rows, events=False, ts=(0, 0)):
         """rows: list of bytes -> (list of output rows, records, consumed, root_type, status)"""

@@ -673,7 +673,22 @@ struct JsonArgs {
     uint32_t *cnt;              // [8][n] element counts of each row's first containers (size pass -> emit pass)
     int events;                 // wrap single-object rows as V2 log events with the timestamp below
     uint32_t ts_sec, ts_nsec;
-    unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error
+    unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error; the tile pass (jtile_kernels.inc): [3] rows it left
+                                // to the row-per-lane kernels, [4] bytes it wrote, [5] tiles without room in `out`, [6] tokens, [7] its tile counter
+    int tile_mode;              // the tile pass ran first: the row-per-lane kernels take only the rows it marked JS_TDEFER
+};
+
+// the NDJSON tile pass (jtile_kernels.inc): one wave per tile of rows, text read once, output placed by a look-back over the tiles
+struct JtArgs {
+    JsonArgs j;                 // text, row_off, n, the row columns, out, events, ts, counts
+    uint64_t *off_out;          // [n + 1] row offsets of the output (written by the pass)
+    unsigned long long *tile_state;   // [ntiles] look-back words (zeroed by the host)
+    unsigned long long *ticket;       // tile counter (zeroed)
+    uint64_t ntiles;
+    uint32_t rows_per_tile;     // <= 64
+    uint64_t out_cap;           // room in j.out; a tile that would pass it writes nothing and raises counts[5]
+    unsigned long long *prof;   // [8] cycles per phase summed over the waves (nullptr: no stamps); tools/perf_json.py
+    int lb_off;                 // timing experiments only: no look-back, every workgroup writes at a place of its own
 };
 
 
@@ -839,6 +854,9 @@ void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
 void launch_json_size(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_generic(const JsonArgs &a, bool emit, hipStream_t st);
+void launch_json_tile(const JtArgs &a, int cus, hipStream_t st);
+int json_tile_text_bytes();
+uint64_t json_tile_units(uint64_t ntiles);
 size_t idx_tiles(uint64_t bytes);
 size_t idx_blocks(uint64_t nc);
 void launch_idx_count(const uint8_t *data, uint64_t bytes, uint64_t *masks, uint32_t *tile_cnt, hipStream_t st);

@@ -16,6 +16,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <unordered_map>
 #include <sys/mman.h>
 #include <ucontext.h>

@@ -273,6 +273,13 @@ int flbgpu_json_run_dev(flbgpu_json *j, const flbgpu_dev_chunk *text_rows, int e
 int flbgpu_json_row_info(flbgpu_json *j, uint64_t first, uint64_t count, uint32_t *records, uint32_t *consumed,
                          uint8_t *root_type, uint8_t *status);
 void flbgpu_json_stats(flbgpu_json *j, uint64_t *out3);   /* rows sent to the generic kernels, values, error rows */
+/* the last run's first leg (the tile pass: a wave per tile of rows, csrc/jtile_kernels.inc): rows it wrote, rows it left to the
+ * row-per-lane kernels, its launches (0: not used, 2: the output outgrew the first estimate), tokens it saw */
+void flbgpu_json_tile_stats(flbgpu_json *j, uint64_t *out4);
+/* measurement only (tools/perf_json.py): prof != 0 makes the tile pass stamp its phases (shader cycles summed over the waves, read back
+ * into phases8 by the next call of this function: staging, bytes, numbers, rows, tokens, look-back, headers, string bodies);
+ * no_lookback != 0 lets every workgroup write at a place of its own -- the output is then NOT the packed chunk, only the time is of use */
+void flbgpu_json_tile_debug(flbgpu_json *j, int prof, int no_lookback, uint64_t *phases8);
 /* ---- in_tail: a file buffer cut into lines, every line one log event ------------------------------------------------
  * plugins/in_tail/tail_file.c:689-1040 (process_content: leading NULs skipped, lines end at '\n', Skip_Empty_Lines, the CR of
  * a CR LF dropped, what follows the last newline stays in the buffer) + :552-604 (flb_tail_file_pack_line: Path_Key, Offset_Key

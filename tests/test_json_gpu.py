@@ -56,6 +56,107 @@ def test_fuzz_against_oracle(g):
     assert stats["generic_rows"] > 0          # deep nesting / hard decimals reached the generic kernels
 
 
+def _object_rows(seed, n):
+    """rows as log shippers write them (one JSON object a row) in every shape the tile pass has a branch for, with the rows it must
+    leave to the row-per-lane kernels mixed in"""
+    rng = random.Random(seed)
+    esc = ['\\"', "\\\\", "\\/", "\\b", "\\f", "\\n", "\\r", "\\t"]
+
+    def s(maxlen=40):
+        k = rng.randrange(10)
+        n_ = rng.choice([0, 1, 5, 31, 32, 33, 255, 256, 300]) if k == 0 else rng.randrange(maxlen)
+        parts = []
+        for _ in range(n_):
+            q = rng.randrange(40)
+            if q == 0: parts.append(rng.choice(esc))
+            elif q == 1: parts.append(rng.choice(["é", "中", "😀", "{", "}", "[", "]", ":", ",", " "]))
+            elif q == 2 and k == 1: parts.append(rng.choice(esc) * rng.randrange(1, 4))
+            else: parts.append(rng.choice("abcdefghijklmnopqrstuvwxyz0123456789 _-./=?"))
+        return '"' + "".join(parts) + '"'
+
+    def num():
+        k = rng.randrange(8)
+        if k < 3: return str(rng.randrange(-10 ** rng.randrange(1, 20), 10 ** rng.randrange(1, 21)))
+        if k < 5: return repr(round(rng.uniform(-1000, 1000), rng.randrange(6)))
+        if k == 5: return "%de%d" % (rng.randrange(1, 99), rng.randrange(-20, 20))
+        if k == 6: return rng.choice(["0", "-0", "0.0", "1E3", "1e+3", "18446744073709551615", "18446744073709551616", "-9223372036854775808", "-9223372036854775809"])
+        return repr(rng.uniform(-1, 1) * 10.0 ** rng.randrange(-300, 300))
+
+    ws = lambda: rng.choice(["", "", "", "", " ", "  ", "\t"])
+
+    def val(depth):
+        k = rng.randrange(8 + max(0, 5 - depth) if depth < 9 else 8)
+        if k < 4: return s()
+        if k < 7: return num()
+        if k == 7: return rng.choice(["true", "false", "null"])
+        if k < 10: return obj(depth + 1, rng.choice([0, 1, 2, 3, 15, 16, 17]) if rng.random() < 0.05 else rng.randrange(4))
+        m = rng.choice([0, 1, 15, 16, 17, 40]) if rng.random() < 0.05 else rng.randrange(5)
+        return "[" + ws() + ("," + ws()).join(val(depth + 1) for _ in range(m)) + ws() + "]"
+
+    def obj(depth, m):
+        return "{" + ws() + ("," + ws()).join(s(12) + ws() + ":" + ws() + val(depth) for _ in range(m)) + ws() + "}"
+
+    rows = []
+    for i in range(n):
+        k = rng.randrange(100)
+        r = obj(1, rng.randrange(1, 9) if k else rng.choice([0, 15, 16, 17, 70]))
+        if k == 1: r = ""                                     # blank
+        elif k == 2: r = "   "
+        elif k == 3: r = r[:-1]                                # not closed
+        elif k == 4: r = r + r                                 # two values
+        elif k == 5: r = r.replace('"', "", 1)                 # a quote missing: the string parity of the row is odd
+        elif k == 6: r = r + "\\"                                # ends on a backslash
+        elif k == 7: r = '{"u":"\\u00e9\\ud83d\\ude00"}'
+        elif k == 8: r = '{"c":"a\x01b"}'
+        elif k == 9: r = '{"d":' + "[" * 9 + "]" * 9 + "}"    # deeper than the pass's eight levels
+        elif k == 10: r = '{"big":"' + "x" * 5000 + '"}'       # longer than a tile
+        elif k == 11: r = '{"e":0.1234567890123456789012345678901234567890}'
+        elif k == 12: r = "[" + r + "]"
+        elif k == 13: r = '{"a":tru}'
+        elif k == 14: r = '{"a":1,}'
+        elif k == 15: r = '{"a" 1}'
+        elif k == 16: r = '{"a":-}'
+        elif k == 17: r = '{"a":01}'
+        elif k == 18: r = '{"a":"\\x"}'
+        elif k == 19: r = '\\"{"a":1}'
+        rows.append(r.encode("utf-8") + rng.choice([b"\n", b"\n", b"\n", b"\r\n", b"", b" \n"]))
+    return rows
+
+
+def test_tile_pass_object_rows(g):
+    """the first leg of flbgpu_json_run_dev (csrc/jtile_kernels.inc: a wave per tile of rows): the rows it writes and the rows it leaves,
+    both modes, against the oracle row by row"""
+    rows = _object_rows(7, 30000)
+    o = jf.oracle()
+    want = [o(r) for r in rows]
+    for events in (False, True):
+        p = g.JsonPacker()
+        outs, rec, cons, rt, st = p.run_host(rows, events=events, ts=(1700000001, 9))
+        ts = p.tile_stats()
+        p.close()
+        assert ts["launches"] >= 1 and ts["tile_rows"] > 0.6 * len(rows) and ts["left_rows"] > 0.05 * len(rows), ts
+        for i, r in enumerate(rows):
+            w = want[i]
+            if not events:
+                if w[0] != 0: assert st[i] == 1 and outs[i] == b"", (i, r[:80], st[i], outs[i][:40])
+                else: assert st[i] == 0 and (0, outs[i], int(rt[i]), int(rec[i]), int(cons[i])) == w, (i, r[:120], outs[i][:60], w[1][:60], rt[i], rec[i], cons[i], w[2:])
+            else:
+                one = w[0] == 0 and w[3] == 1 and w[2] == 1 and r[w[4]:].strip(b" \t\r\n") == b""
+                exp = v2_record(1700000001, 9, Raw(w[1])) if one else b""
+                assert outs[i] == exp, (i, r[:120], outs[i][:60], exp[:60])
+    # a chunk of nothing but plain lines is written by the pass alone, in one launch
+    plain = [r for i, r in enumerate(rows) if want[i][0] == 0 and want[i][3] == 1 and want[i][2] == 1 and len(r) < 1500 and b"\\u" not in r and b"\x01" not in r
+             and b"[[[[[[[[" not in r and b"0.12345678901234567890" not in r][:8000]
+    p = g.JsonPacker()
+    outs, rec, cons, rt, st = p.run_host(plain, events=True, ts=(5, 6))
+    ts = p.tile_stats()
+    p.close()
+    left = [plain[i] for i in range(len(plain)) if False]
+    assert ts["left_rows"] <= len(plain) // 50, (ts, left)
+    for i, r in enumerate(plain):
+        assert outs[i] == v2_record(5, 6, Raw(o(r)[1])), (i, r[:120])
+
+
 def test_scalar_entry_point_is_flb_pack_json(g):
     o = jf.oracle()
     for js in [b'{"a":1}', b'{"a":1}{"b":[1,2.5,"x"]}\n', b'  ', b'', b'x', b'[1,]', b'123 456', b'"\\ud83d\\ude00"',

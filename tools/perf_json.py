@@ -24,6 +24,8 @@ def main():
     L.flbgpu_memcpy_h2d(d_off, off.ctypes.data, off.nbytes)
     chunk = g.DevChunk(d_data, d_off, n, reps * blen)
     pk = g.JsonPacker()
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    pk.tile_debug(prof="prof" in mode, no_lookback="nolb" in mode)
     ev = pk.run_dev(chunk, events=True, ts=(1, 0))
     L.flbgpu_sync()
     t0 = time.perf_counter()
@@ -31,10 +33,15 @@ def main():
         ev = pk.run_dev(chunk, events=True, ts=(1, 0))
     L.flbgpu_sync()
     dt = (time.perf_counter() - t0) / 5
+    if mode:
+        ph = pk.tile_debug(prof="prof" in mode, no_lookback="nolb" in mode)
+        tot = sum(ph) or 1
+        print("mode %s; phase cycles (share): " % mode + ", ".join("%s %.1f%%" % (nm, 100.0 * c / tot) for nm, c in zip(
+            ["stage", "A bytes", "C0 numbers", "B rows", "C tokens", "look-back", "C' headers", "D bodies"], ph)) + "; cycles per line %.0f" % (tot / n))
     host = np.empty(min(int(ev.bytes), 256 << 20), dtype=np.uint8)
     L.flbgpu_memcpy_d2h(host.ctypes.data, ev.data, host.nbytes)
     print("lines %d text %d B events %d B: %.3f ms per call = %.3f ms per 10 M lines, %.1f M lines/s; sha %s stats %s" % (
-        n, reps * blen, ev.bytes, dt * 1e3, dt * 1e3 * 1e7 / n, n / dt / 1e6, hashlib.sha256(host).hexdigest()[:16], pk.stats() if hasattr(pk, "stats") else ""))
+        n, reps * blen, ev.bytes, dt * 1e3, dt * 1e3 * 1e7 / n, n / dt / 1e6, hashlib.sha256(host).hexdigest()[:16], (pk.stats(), pk.tile_stats())))
 
 if __name__ == "__main__":
     main()
