@@ -6,6 +6,7 @@
 //                                             V2 log events, ready for the filter chain
 // Kernels: json_kernels.inc (size pass, scan, emit pass; generic twins for deep / hard rows).
 #include "host_int.hpp"
+#include "jtile.hpp"
 
 using namespace flbgpu;
 
@@ -62,14 +63,14 @@ static bool json_run(flbgpu_json *j, const flbgpu_dev_chunk *in, int events, uin
     j->tile_stats[0] = j->tile_stats[1] = j->tile_stats[2] = j->tile_stats[3] = 0;
     if (tile) {
         const uint64_t avg = in->bytes / n + 1;
-        uint64_t R = (uint64_t) (json_tile_text_bytes() - 16) * 85 / 100 / avg;
+        uint64_t R = (uint64_t) (json_lane_text_bytes() - 16) * 92 / 100 / avg;
         if (R < 1) R = 1;
         if (R > 64) R = 64;
         JtArgs t;
         memset(&t, 0, sizeof(t));
         t.ntiles = (n + R - 1) / R;
         t.rows_per_tile = (uint32_t) R;
-        const uint64_t nunits = json_tile_units(t.ntiles);
+        const uint64_t nunits = json_lane_units(t.ntiles);
         if (!j->d_tiles.ensure(nunits * 8 + 8)) return false;
         if (j->dbg_prof) { if (!j->d_prof.ensure(64)) return false; HIPOK(hipMemsetAsync(j->d_prof.p, 0, 64, st)); t.prof = j->d_prof.as<unsigned long long>(); }
         t.lb_off = j->dbg_lb_off;
@@ -86,7 +87,7 @@ static bool json_run(flbgpu_json *j, const flbgpu_dev_chunk *in, int events, uin
             t.tile_state = j->d_tiles.as<unsigned long long>();
             t.ticket = &j->d_misc.as<JsonMisc>()->counts[7];
             t.out_cap = cap;
-            launch_json_tile(t, cus, st);
+            launch_json_lane(t, cus, st);
             HIPOK(hipMemcpyAsync(&hm, j->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
             j->tile_stats[2]++;

@@ -1,4 +1,4 @@
-// kernels_jtile.hip -- the NDJSON tile pass (a wave per tile of rows; shares kdev.inc / json_dev.inc with kernels_misc.hip)
+// kernels_jtile.hip -- the one-pass NDJSON kernel (a row per lane, rewritten in place in LDS; shares kdev.inc / json_dev.inc with kernels_misc.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -6,10 +6,11 @@
 #include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
+#include "jtile.hpp"
 
 namespace flbgpu {
 
 #include "kdev.inc"
-#include "jtile_kernels.inc"
+#include "jlane_kernels.inc"
 
 }  // namespace flbgpu

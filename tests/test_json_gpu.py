@@ -124,8 +124,8 @@ def _object_rows(seed, n):
 
 
 def test_tile_pass_object_rows(g):
-    """the first leg of flbgpu_json_run_dev (csrc/jtile_kernels.inc: a wave per tile of rows): the rows it writes and the rows it leaves,
-    both modes, against the oracle row by row"""
+    """the first leg of flbgpu_json_run_dev (csrc/jlane_kernels.inc: one pass, a row per lane rewritten in place in LDS, the output placed by
+    a look-back over the workgroups): the rows it writes and the rows it leaves to the two-launch kernels, both modes, against the oracle row by row"""
     rows = _object_rows(7, 30000)
     o = jf.oracle()
     want = [o(r) for r in rows]
@@ -134,7 +134,7 @@ def test_tile_pass_object_rows(g):
         outs, rec, cons, rt, st = p.run_host(rows, events=events, ts=(1700000001, 9))
         ts = p.tile_stats()
         p.close()
-        assert ts["launches"] >= 1 and ts["tile_rows"] > 0.6 * len(rows) and ts["left_rows"] > 0.05 * len(rows), ts
+        assert ts["launches"] >= 1 and ts["tile_rows"] > 0.5 * len(rows) and ts["left_rows"] > 0.05 * len(rows), ts
         for i, r in enumerate(rows):
             w = want[i]
             if not events:
@@ -144,15 +144,14 @@ def test_tile_pass_object_rows(g):
                 one = w[0] == 0 and w[3] == 1 and w[2] == 1 and r[w[4]:].strip(b" \t\r\n") == b""
                 exp = v2_record(1700000001, 9, Raw(w[1])) if one else b""
                 assert outs[i] == exp, (i, r[:120], outs[i][:60], exp[:60])
-    # a chunk of nothing but plain lines is written by the pass alone, in one launch
-    plain = [r for i, r in enumerate(rows) if want[i][0] == 0 and want[i][3] == 1 and want[i][2] == 1 and len(r) < 1500 and b"\\u" not in r and b"\x01" not in r
-             and b"[[[[[[[[" not in r and b"0.12345678901234567890" not in r][:8000]
+    # a chunk of nothing but a service's log lines is written by the pass alone, in one launch
+    import ndjson_synth as ns
+    plain = ns.lines(20000, seed=3)
     p = g.JsonPacker()
     outs, rec, cons, rt, st = p.run_host(plain, events=True, ts=(5, 6))
     ts = p.tile_stats()
     p.close()
-    left = [plain[i] for i in range(len(plain)) if False]
-    assert ts["left_rows"] <= len(plain) // 50, (ts, left)
+    assert ts == dict(tile_rows=len(plain), left_rows=0, launches=1, tokens=0), ts
     for i, r in enumerate(plain):
         assert outs[i] == v2_record(5, 6, Raw(o(r)[1])), (i, r[:120])
 
