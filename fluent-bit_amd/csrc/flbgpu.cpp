@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 #include "host_int.hpp"
+#include "grep_lane.hpp"
 
 using namespace flbgpu;
 
@@ -1787,10 +1788,76 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
         hm.first_bad = ~0ull;
         HIPOK(hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st));
     }
+    const bool ahead = g_spec.on;
+    // ---- ONE pass (glane_kernels.inc): a lane decides its record, the kept records are placed by a look-back over the workgroups and
+    // leave LDS at once -- no scan, no second read of the chunk.  Taken whenever every rule runs on the device with its tables in LDS
+    // (a call launched ahead of its sizes, SpecCall, keeps the three launches: its writer must not wait for anybody).
+    static const bool lane_off = getenv("FLBGPU_GREP_LANE") && atoi(getenv("FLBGPU_GREP_LANE")) == 0;
+    if (!lane_off && !ahead && !f->has_host_rules && ((uintptr_t) in->data & 15) == 0 && !f->rules.empty() && f->rules.size() <= (size_t) MAX_RULES) {
+        GrepLaneArgs la;
+        memset(&la, 0, sizeof(la));
+        la.g = ga;
+        bool fits = true;
+        {
+            // all the tables in LDS, every rule's top-level key in a slot
+            uint32_t used = 0;
+            const uint32_t room = grep_lane_table_room();
+            for (size_t i = 0; i < f->rules.size(); i++) {
+                const DevDfa &df = f->rules[i].dfa;
+                const uint32_t blob = (uint32_t) ((df.d_final + df.nD) - df.cls);
+                la.g.rule_lds_off[i] = used; la.g.rule_lds_bytes[i] = blob;
+                used += (blob + 15) & ~15u;
+                if (used > room) { fits = false; break; }
+            }
+            la.g.rules_lds_total = used;
+            la.g.nslots = 0;
+            for (size_t i = 0; fits && i < f->rules.size(); i++) {
+                const DevKey &k = f->rules[i].key;
+                int slot = -1;
+                for (int s = 0; s < la.g.nslots; s++) {
+                    const DevKey &o = f->rules[la.g.slot_rule[s]].key;
+                    if (o.key_len == k.key_len && memcmp(o.key, k.key, (size_t) k.key_len) == 0) { slot = s; break; }
+                }
+                if (slot < 0) {
+                    if (la.g.nslots >= GREP_SLOTS || k.key_len < 1 || k.key_len > 32) { fits = false; break; }
+                    slot = la.g.nslots++;
+                    la.g.slot_rule[slot] = (uint8_t) i;
+                    la.slot_klen[slot] = (uint8_t) k.key_len;
+                    memcpy(la.slot_kw[slot], k.key, (size_t) k.key_len);           // (little endian host, zero padded by the memset above)
+                }
+                la.g.rule_slot[i] = (uint8_t) slot;
+            }
+        }
+        if (fits) {
+            const uint64_t avg = in->bytes / n + 1;
+            uint64_t R = (uint64_t) (grep_lane_text_bytes() - 16) * 92 / 100 / avg;
+            if (R < 1) R = 1;
+            if (R > 64) R = 64;
+            la.ntiles = (n + R - 1) / R;
+            la.rows_per_tile = (uint32_t) R;
+            const uint64_t nunits = grep_lane_units(la.ntiles);
+            if (!f->d_units.ensure(nunits * 8 + 8) || !f->d_out.ensure(in->bytes + 32)) return false;
+            HIPOK(hipMemsetAsync(f->d_units.p, 0, nunits * 8, st));
+            la.off_out = f->d_off.as<uint64_t>(); la.out = f->d_out.as<uint8_t>(); la.out_cap = in->bytes;
+            la.unit_state = f->d_units.as<unsigned long long>();
+            la.ticket = &dm->counts[12]; la.words = &dm->counts[10];
+            { ProfScope ps(f, st, "k_grep_lane"); launch_grep_lane(la, g_cus > 0 ? g_cus : 256, st); }
+            HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+            HIPOK(hipStreamSynchronize(st));
+            if (hm.counts[11]) { set_err("filter_grep: the one-pass kernel %s", (hm.counts[11] >> 32) ? "gave up waiting for the workgroups in front" : "found no room for its output"); return false; }
+            f->last_in = hm.counts[0];
+            f->last_out = hm.counts[0];
+            if (hm.first_bad != ~0ull || trailing_garbage) return true;           // (as below: a decoder error anywhere and the filter answers NOTOUCH)
+            if (hm.counts[0] == hm.counts[1]) return true;
+            f->last_out = hm.counts[1];
+            out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = hm.counts[10];
+            *ret = FLBGPU_FILTER_MODIFIED;
+            return true;
+        }
+    }
     { ProfScope ps(f, st, "k_grep_match"); launch_grep_match(ga, g_cus > 0 ? g_cus : 256, st); }
     { ProfScope ps(f, st, "k_scan"); launch_scan(f->d_len.as<uint32_t>(), n, f->d_scan_tmp.as<uint64_t>(), f->d_off.as<uint64_t>(), st); }
     total = 0;
-    const bool ahead = g_spec.on;
     uint8_t *sink = ahead && g_spec.last ? g_spec.sink : nullptr;
     if (ahead) {
         // launched ahead (SpecCall): the kept records are never more than the chunk -- the gather needs no size; one wait

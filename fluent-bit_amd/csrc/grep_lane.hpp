@@ -1,0 +1,24 @@
+// grep_lane.hpp -- filter_grep in one pass (kernels_glane.hip: glane_kernels.inc): argument block and launcher
+#pragma once
+#include "dev.hpp"
+namespace flbgpu {
+struct GrepLaneArgs {
+    GrepArgs g;                         // chunk, rules, logical_op, keep_len / status columns, first_bad, counts, the rules' LDS offsets, key slots
+    uint64_t *off_out;                  // [n + 1] row offsets of the output (a dropped record is an empty row)
+    uint8_t *out;
+    uint64_t out_cap;
+    unsigned long long *unit_state;     // [units] look-back words, zeroed
+    unsigned long long *ticket;         // zeroed
+    unsigned long long *words;          // [0] bytes written, [1] workgroups without room / that gave up waiting (<< 32)
+    uint64_t ntiles;
+    uint32_t rows_per_tile;             // <= 64
+    // the slots' keys as the dwords a lane reads them (little endian, zero padded): a name of up to 32 bytes is compared with eight
+    // masked dword tests, no byte loop
+    uint32_t slot_kw[GREP_SLOTS][8];
+    uint8_t slot_klen[GREP_SLOTS];
+};
+void launch_grep_lane(const GrepLaneArgs &a, int cus, hipStream_t st);
+int grep_lane_text_bytes();
+uint64_t grep_lane_units(uint64_t ntiles);
+uint32_t grep_lane_table_room();
+}  // namespace flbgpu

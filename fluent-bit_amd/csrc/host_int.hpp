@@ -167,7 +167,7 @@ struct flbgpu_filter {
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec, d_fix;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec, d_fix, d_units;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     flbgpu::PinnedBuf hp_misc, hp_args, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -186,7 +186,7 @@ struct flbgpu_filter {
         delete l2m_gate;
         d_hspans.release(); d_hbits.release();
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix};
+                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix, &d_units};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
         hp_misc.release(); hp_args.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();

@@ -1,4 +1,4 @@
-// kernels_jtile.hip -- the one-pass NDJSON kernel (a row per lane, rewritten in place in LDS; shares kdev.inc / json_dev.inc with kernels_misc.hip)
+// kernels_glane.hip -- filter_grep in one pass (a record per lane, staged in LDS, kept records placed by a look-back; shares kdev.inc with kernels.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -6,12 +6,13 @@
 #include <type_traits>
 #include "dev.hpp"
 #include "numconv.hpp"
-#include "jtile.hpp"
+#include "dec.hpp"
+#include "grep_lane.hpp"
 
 namespace flbgpu {
 
 #include "kdev.inc"
 #include "lookback.inc"
-#include "jlane_kernels.inc"
+#include "glane_kernels.inc"
 
 }  // namespace flbgpu
