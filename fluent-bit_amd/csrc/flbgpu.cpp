@@ -1804,9 +1804,10 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
             const uint32_t room = grep_lane_table_room();
             for (size_t i = 0; i < f->rules.size(); i++) {
                 const DevDfa &df = f->rules[i].dfa;
-                const uint32_t blob = (uint32_t) ((df.d_final + df.nD) - df.cls);
+                const uint32_t blob = grep_lane_table_bytes((uint32_t) df.nD, (uint32_t) df.ncls);
+                if ((uint64_t) df.nD * (uint64_t) (df.ncls + 1) >= 0xFFFEull) { fits = false; break; }      // (a cell holds a row's offset in 16 bits)
                 la.g.rule_lds_off[i] = used; la.g.rule_lds_bytes[i] = blob;
-                used += (blob + 15) & ~15u;
+                used += blob;
                 if (used > room) { fits = false; break; }
             }
             la.g.rules_lds_total = used;
@@ -1829,8 +1830,14 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
             }
         }
         if (fits) {
+            // a wave's LDS: what 64 records of this chunk's mean length need and half as much again (rows an earlier filter emptied come in runs), at most the kernel's maximum; the
+            // records of a tile that do not fit are decided and copied from the chunk itself
             const uint64_t avg = in->bytes / n + 1;
-            uint64_t R = (uint64_t) (grep_lane_text_bytes() - 16) * 92 / 100 / avg;
+            uint64_t cap = (64 * avg * 3 / 2 + 512 + 15) & ~15ull;
+            if (cap > (uint64_t) grep_lane_text_max()) cap = (uint64_t) grep_lane_text_max();
+            if (cap < 2048) cap = 2048;
+            la.text_cap = (uint32_t) cap;
+            uint64_t R = (cap - 16) * 92 / 100 / avg;
             if (R < 1) R = 1;
             if (R > 64) R = 64;
             la.ntiles = (n + R - 1) / R;
@@ -1841,9 +1848,21 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
             la.off_out = f->d_off.as<uint64_t>(); la.out = f->d_out.as<uint8_t>(); la.out_cap = in->bytes;
             la.unit_state = f->d_units.as<unsigned long long>();
             la.ticket = &dm->counts[12]; la.words = &dm->counts[10];
+            static const bool lane_prof = getenv("FLBGPU_GREP_PROF") != nullptr;      // (measurement only: the kernel stamps its phases)
+            ScopedDevBuf d_prof;
+            if (lane_prof) { if (!d_prof.ensure(64)) return false; HIPOK(hipMemsetAsync(d_prof.p, 0, 64, st)); la.prof = d_prof.as<unsigned long long>(); }
             { ProfScope ps(f, st, "k_grep_lane"); launch_grep_lane(la, g_cus > 0 ? g_cus : 256, st); }
             HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
+            if (lane_prof) {
+                unsigned long long ph[8];
+                HIPOK(hipMemcpy(ph, d_prof.p, 64, hipMemcpyDeviceToHost));
+                unsigned long long tot = 0;
+                for (int i = 0; i < 8; i++) tot += ph[i];
+                fprintf(stderr, "k_grep_lane phases (%% of %.0f cycles a record): staging %.1f, walk %.1f, values %.1f, automata %.1f, verdict %.1f, look-back %.1f, copy %.1f; text_cap %u rows %u\n",
+                        (double) tot / (double) n, 100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * (ph[4] > ph[1] + ph[2] + ph[3] ? ph[4] - ph[1] - ph[2] - ph[3] : 0) / tot,
+                        100.0 * ph[5] / tot, 100.0 * ph[6] / tot, la.text_cap, la.rows_per_tile);
+            }
             if (hm.counts[11]) { set_err("filter_grep: the one-pass kernel %s", (hm.counts[11] >> 32) ? "gave up waiting for the workgroups in front" : "found no room for its output"); return false; }
             f->last_in = hm.counts[0];
             f->last_out = hm.counts[0];

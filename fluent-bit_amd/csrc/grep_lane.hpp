@@ -12,13 +12,16 @@ struct GrepLaneArgs {
     unsigned long long *words;          // [0] bytes written, [1] workgroups without room / that gave up waiting (<< 32)
     uint64_t ntiles;
     uint32_t rows_per_tile;             // <= 64
+    unsigned long long *prof;           // measurement only (FLBGPU_GREP_PROF): [8] shader cycles per phase, summed over the waves
+    uint32_t text_cap;                  // LDS bytes of a wave's records (a multiple of 16, <= grep_lane_text_max())
     // the slots' keys as the dwords a lane reads them (little endian, zero padded): a name of up to 32 bytes is compared with eight
     // masked dword tests, no byte loop
     uint32_t slot_kw[GREP_SLOTS][8];
     uint8_t slot_klen[GREP_SLOTS];
 };
 void launch_grep_lane(const GrepLaneArgs &a, int cus, hipStream_t st);
-int grep_lane_text_bytes();
+int grep_lane_text_max();
 uint64_t grep_lane_units(uint64_t ntiles);
+uint32_t grep_lane_table_bytes(uint32_t nD, uint32_t ncls);    // LDS bytes of a rule's automaton in the lanes' layout
 uint32_t grep_lane_table_room();
 }  // namespace flbgpu
