@@ -1830,14 +1830,25 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
             }
         }
         if (fits) {
-            // a wave's LDS: what 64 records of this chunk's mean length need and half as much again (rows an earlier filter emptied come in runs), at most the kernel's maximum; the
-            // records of a tile that do not fit are decided and copied from the chunk itself
+            // a wave's LDS: what its 64 records need.  A large chunk is asked (one small launch over the row offsets: the longest run of
+            // 64 rows), a small one gets the mean and half as much again (rows an earlier filter emptied come in runs); a record that
+            // does not fit all the same is decided and copied from the chunk itself
             const uint64_t avg = in->bytes / n + 1;
-            uint64_t cap = (64 * avg * 3 / 2 + 512 + 15) & ~15ull;
-            if (cap > (uint64_t) grep_lane_text_max()) cap = (uint64_t) grep_lane_text_max();
+            uint64_t R = 64, cap = (64 * avg * 3 / 2 + 512 + 15) & ~15ull;
+            if (n >= 65536) {
+                HIPOK(hipMemsetAsync(&dm->counts[13], 0, 8, st));
+                launch_tile_max(in->row_off, n, 64, &dm->counts[13], st);
+                unsigned long long mx = 0;
+                HIPOK(hipMemcpyAsync(&mx, &dm->counts[13], 8, hipMemcpyDeviceToHost, st));
+                HIPOK(hipStreamSynchronize(st));
+                cap = (mx + 32 + 15) & ~15ull;
+            }
+            if (cap > (uint64_t) grep_lane_text_max()) {
+                R = (uint64_t) (grep_lane_text_max() - 16) * 92 / 100 / avg;      // records longer than a quarter kilobyte: fewer of them to a wave
+                cap = (uint64_t) grep_lane_text_max();
+            }
             if (cap < 2048) cap = 2048;
             la.text_cap = (uint32_t) cap;
-            uint64_t R = (cap - 16) * 92 / 100 / avg;
             if (R < 1) R = 1;
             if (R > 64) R = 64;
             la.ntiles = (n + R - 1) / R;

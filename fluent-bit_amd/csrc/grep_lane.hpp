@@ -20,6 +20,7 @@ struct GrepLaneArgs {
     uint8_t slot_klen[GREP_SLOTS];
 };
 void launch_grep_lane(const GrepLaneArgs &a, int cus, hipStream_t st);
+void launch_tile_max(const uint64_t *row_off, uint64_t n, uint32_t R, unsigned long long *out, hipStream_t st);   // *out (zeroed) = bytes of the longest run of R rows + 15
 int grep_lane_text_max();
 uint64_t grep_lane_units(uint64_t ntiles);
 uint32_t grep_lane_table_bytes(uint32_t nD, uint32_t ncls);    // LDS bytes of a rule's automaton in the lanes' layout
