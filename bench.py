@@ -633,27 +633,29 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         d_md = L.flbgpu_dev_alloc(len(mdata) + 16); d_mo = L.flbgpu_dev_alloc(moff.nbytes)
         L.flbgpu_memcpy_h2d(d_md, mdata, len(mdata)); L.flbgpu_memcpy_h2d(d_mo, moff.ctypes.data, moff.nbytes)
         mch = g.DevChunk(d_md, d_mo, mn, len(mdata))
-        # (the four-port pair tables selected at create: 46 % of these lines -- even length, no referer / agent -- end in a cell with two
-        # writes at one position, which the three-port tables hand to the generic kernel; a filter switches to the four-port tables after
-        # its first call on such data (flbgpu.cpp note_fx5 / note_unsettled), and that steady state is what is timed here)
-        _fx_was = os.environ.get("FLBGPU_FX")
-        os.environ["FLBGPU_FX"] = "4"
-        try:
-            p3 = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
-        finally:
-            if _fx_was is None:
-                os.environ.pop("FLBGPU_FX", None)
-            else:
-                os.environ["FLBGPU_FX"] = _fx_was
+        # (round 6: nothing is selected at create.  46 % of these lines -- even length, no referer / agent -- end in a cell with two writes
+        # at one position, which the three-port pair tables hand to the generic kernel; the filter notices on its first call and walks the
+        # four-port tables from its second call on, trying the three-port ones again at growing distances (flbgpu_filter_paths).  Timed:
+        # the first call, the second, and the steady state the filter is in after them -- tries included, they are part of the policy.)
+        p3 = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
         f3 = g.FilterParser("log", [p3]); g3 = g.FilterGrep([GREP_RULE])
         ch3 = g.FilterChain([f3, g3])
-        r3_, o3_ = ch3.filter_dev(mch)
+        first_ms = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r3_, o3_ = ch3.filter_dev(mch)
+            torch.cuda.synchronize()
+            first_ms.append(round((time.perf_counter() - t0) * 1e3, 3))
+        paths_after = f3.paths()
+        msteps = max(steps, 40)                                  # (more than two of the policy's 16-call intervals)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(msteps):
             r3_, o3_ = ch3.filter_dev(mch)
         torch.cuda.synchronize()
-        dt_x = (time.perf_counter() - t0) / steps
+        dt_x = (time.perf_counter() - t0) / msteps
+        paths_end = f3.paths()
         # parity at the timed size (round 4): (a) the whole fused output against the unfused kernels (filter_parser's full output through
         # filter_grep), by hash; (b) four blocks of 1 000 input rows spread over the chunk through the oracle's two filters -- the output
         # keeps one row per input row, so a block of input rows is a block of output rows
@@ -682,7 +684,8 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
                                "records_per_s_per_gpu": round(mn / dt_x, 1), "ms_per_step": round(dt_x * 1e3, 3), "chunk_GBps": round(len(mdata) / dt_x / 1e9, 1),
                                "kept": int(ch3.last_stats()[1]["out_records"]), "fused_sha256": sha_f, "fused_equals_unfused": bool(sha_f == sha_u),
                                "oracle_sample_rows": rows_, "oracle_sample_matches": bool(ok_),
-                               "tables": "four-port pair cells, selected at create (FLBGPU_FX=4): the state a filter reaches on this data after its first call"}
+                               "adaptive": {"first_calls_ms": first_ms, "steady_calls": msteps, "paths_after_three_calls": paths_after, "paths_at_the_end": paths_end,
+                                            "what": "no table form selected at create: the filter's own per-call choice (flbgpu_filter_paths), tries of the set-aside build included"}}
         f3.close(); g3.close(); p3.close(); L.flbgpu_dev_free(d_md); L.flbgpu_dev_free(d_mo)
     except Exception as e:
         out["mixed_shapes"] = {"error": repr(e)[:300]}

@@ -98,6 +98,8 @@ def lib():
     L.flbgpu_host_phases.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     L.flbgpu_filter_host_rules.restype = ctypes.c_int
     L.flbgpu_filter_host_rules.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    L.flbgpu_filter_paths.restype = ctypes.c_int
+    L.flbgpu_filter_paths.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     L.flbgpu_filter_regex_corners.restype = ctypes.c_uint64
     L.flbgpu_filter_regex_corners.argtypes = [c_void_p]
     L.flbgpu_rx_simulate_fx3.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
@@ -248,6 +250,15 @@ class _Filter:
         o = (ctypes.c_uint64 * 4)()
         lib().flbgpu_filter_host_rules(self.h, o)
         return dict(rules=int(o[0]), values=int(o[1]), budget_over=int(o[2]), unhandled=int(o[3]))
+
+    def paths(self):
+        """which builds this filter_parser instance ran last and which are set aside right now (flbgpu_filter_paths)"""
+        o = (ctypes.c_uint64 * 8)()
+        lib().flbgpu_filter_paths(self.h, o)
+        lp = int(o[0])
+        return dict(single_pass=bool(lp & 1), three_port=bool(lp & 2), emit_time=bool(lp & 4), plain_emit=bool(lp & 8),
+                    aside=dict(single_pass=bool(o[1]), three_port=bool(o[2]), emit_time=bool(o[3]), plain_emit=bool(o[4])),
+                    tries=int(o[5]), returns=int(o[6]), calls=int(o[7]))
 
     def profile(self, enable=True):
         lib().flbgpu_filter_profile(self.h, int(enable))

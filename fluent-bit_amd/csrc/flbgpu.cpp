@@ -1044,6 +1044,19 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
 
 extern "C" void flbgpu_filter_destroy(flbgpu_filter *f) { delete f; }
 
+// which builds a filter_parser instance runs (host_int.hpp Probe: no choice is for good): out[0] what the last call ran (bit 0 the single
+// pass, 1 the three-port pair tables, 2 the time lookup in k_pg_emit, 3 the plain emit build), out[1..4] whether the single pass / the
+// three-port tables / the emit-side lookup / the plain build are set aside right now, out[5] tries of a build that was set aside,
+// out[6] tries that brought it back, out[7] device-level calls so far
+extern "C" int flbgpu_filter_paths(flbgpu_filter *f, uint64_t *out8) {
+    if (!f || !out8) return -1;
+    out8[0] = f->last_path; out8[1] = f->tile.off; out8[2] = f->fx5.off; out8[3] = f->defer.off; out8[4] = f->plain.off;
+    out8[5] = f->tile.probes + f->fx5.probes + f->defer.probes + f->plain.probes;
+    out8[6] = f->tile.returns + f->fx5.returns + f->defer.returns + f->plain.returns;
+    out8[7] = f->calls;
+    return 0;
+}
+
 // host rules of a filter (see "host rules" below): out[0] = how many of its rules / parsers run on the host's backtracking matcher,
 // out[1] = values it has searched so far, out[2] = of these, searches that ended on the backtrack budget (answered "no match", as the
 // reference answers its own limit), out[3] = records a host parser did not take (duplicate Key_Name entries, values >= 64 KB)
@@ -1136,23 +1149,24 @@ static const uint64_t SPEC_MAX_RECORDS = 262144, SPEC_MAX_BYTES = 8u << 20;
 static inline bool spec_wanted(uint64_t n, uint64_t bytes) { return n <= SPEC_MAX_RECORDS && bytes <= SPEC_MAX_BYTES && !getenv("FLBGPU_NO_SPEC"); }
 // what parser_size_pass reads from the counters between its launches, for a pass launched ahead: false = run it the usual way
 // fx5 (three write ports) hands a record with an empty field at an even position to the generic kernel: when the fast walk does not
-// settle more than 1 row in 64 of a chunk, this filter takes the four-port tables from the next call on (both are on the device)
+// settle more than 1 row in 64 of a chunk, this filter takes the four-port tables for the next calls (both are on the device) and tries
+// the three-port ones again later (host_int.hpp Probe)
 static void note_fx5(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
-    if (!f->fx5_off && n >= 64 && hm.counts[9] * 64 > n && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok) f->fx5_off = true;
+    if (!f->last_fx5 || n < 64 || !f->parsers[0]->fx2b.ok) return;
+    if (hm.counts[9] * 64 > n) f->fx5.bad(); else f->fx5.good();
 }
 // values the forward walk from boundary 0 does not settle take the reverse pass with tables in global memory: when that is the rule for
-// this pattern / this data, the phase kernels (tables in LDS) are the better choice from now on.  NOT after a launch that walked the
-// three-port tables while the four-port ones stand by (round 5): what it handed on is those tables' doing -- every even-length line
+// this pattern / this data, the phase kernels (tables in LDS) are the better choice for the next calls.  NOT after a launch that walked
+// the three-port tables while the four-port ones stand by (round 5): what it handed on is those tables' doing -- every even-length line
 // without the pattern's optional tail ends in a cell with two writes at one position: 46 % of bench.py's mixed shapes --, note_fx5 answers
-// it with the other tables, and declining the single pass on top of that left such data to the phase kernels for good
-// (secondary.mixed_shapes 1.85 -> 4.15 ms when the three-port tables came in).
+// it with the other tables.
 static void note_unsettled(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
-    if (f->last_fx5 && f->parsers[0]->fx2b.ok) return;
-    if (hm.counts[9] * 8 > n && n >= 64) f->tile_declined = true;
+    if (n < 64 || !(f->last_path & 1u)) return;
+    if (f->last_fx5 && f->parsers[0]->fx2b.ok && hm.counts[9] * 64 > n) return;
+    if (hm.counts[9] * 8 > n || hm.counts[10] * 4 > n) f->tile.bad(); else f->tile.good();
 }
 static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
     note_fx5(f, hm, n);
-    if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
     note_unsettled(f, hm, n);
     return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
 }
@@ -1266,14 +1280,17 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     // (fx2 = the tables without special entries, k_parser_reg<.., FX3>; FLBGPU_FX3=0: the tables with look-ahead / pair entries)
     const char *fx3env = getenv("FLBGPU_FX3");
     const bool use_fx2 = f->parsers[0]->dev.fx2.ok && !(tmode0 && !strcmp(tmode0, "tile")) && !(fx3env && fx3env[0] == '0');
-    const bool fx5_fallback = use_fx2 && f->fx5_off && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok;
-    if (fx5_fallback && !f->fx5_off_uploaded) {
-        // this filter's device copy of parser 0 gets the four-port tables in the place of the three-port ones
-        HIPOK(hipMemcpyAsync((uint8_t *) f->d_parsers.as<DevParser>() + offsetof(DevParser, fx2), &f->parsers[0]->fx2b, sizeof(DevFx), hipMemcpyHostToDevice, st));
-        f->fx5_off_uploaded = true;
+    const bool has_fx5 = use_fx2 && f->parsers[0]->dev.fx2.pair_bias == 2 && f->parsers[0]->fx2b.ok;
+    const bool fx5_fallback = has_fx5 && !f->fx5.use(f->calls);
+    if (has_fx5 && (fx5_fallback ? 1 : 0) != f->fx_on_device) {
+        // this filter's device copy of parser 0 gets the tables this call walks in the slot the kernels read
+        HIPOK(hipMemcpyAsync((uint8_t *) f->d_parsers.as<DevParser>() + offsetof(DevParser, fx2), fx5_fallback ? &f->parsers[0]->fx2b : &f->parsers[0]->dev.fx2, sizeof(DevFx),
+                             hipMemcpyHostToDevice, st));
+        f->fx_on_device = fx5_fallback ? 1 : 0;
     }
     const DevFx &fx = use_fx2 ? (fx5_fallback ? f->parsers[0]->fx2b : f->parsers[0]->dev.fx2) : f->parsers[0]->dev.fx;
-    bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !f->tile_declined && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
+    bool use_tile = fx.ok && !f->parsers[0]->dev.is_json && !getenv("FLBGPU_NO_TILE") && !f->has_decoders;
+    if (use_tile) use_tile = f->tile.use(f->calls);
     for (int q = 0; q < f->parsers[0]->dev.nfields; q++) if (f->parsers[0]->dev.field_name_len[q] > 250) use_tile = false;   // (TileCfg::name_cost is a byte)
     uint32_t tile_wave_bytes = 0, tile_pg_room = 0;
     // two builds of the single pass: value bytes in registers (k_parser_reg, 16 waves per CU: the default) or the
@@ -1337,6 +1354,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
     f->last_fx5 = use_tile && !tile_in_lds && ma.use_fx2 == 5;
+    f->last_path = (use_tile ? 1u : 0u) | (f->last_fx5 ? 2u : 0u);
     if (use_tile) { ma.lds_bytes = 0; ma.caps_lds_off = 0; ma.lds_total = fx.bytes; }
     if (pair) {
         // the rules' match-only DFA blocks behind the tables and the span columns in k_parser_rx's LDS, while they fit
@@ -1373,7 +1391,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             tc.pg_static_drop = pair->pg.static_drop; tc.pg_time_fields = pair->pg.time_fields;
             tc.pg_fast = pair->pg.nrules <= TILE_RULES ? 1 : 0;
             // the time lookup left to k_pg_emit (dev.hpp TileCfg::defer_time; FLBGPU_DEFER_TIME=0: in the single pass, as before round 5)
-            if (pair->desc && d0.time_field >= 0 && d0.plan.ok && !d0.time_keep && d0.plan.len <= 4 * TBUF_WORDS && !f->defer_time_off &&
+            if (pair->desc && d0.time_field >= 0 && d0.plan.ok && !d0.time_keep && d0.plan.len <= 4 * TBUF_WORDS && f->defer.use(f->calls) &&
                 !(getenv("FLBGPU_DEFER_TIME") && getenv("FLBGPU_DEFER_TIME")[0] == '0')) {
                 int nyear = 0;
                 for (int k = 0; k < d0.plan.nops; k++) if (d0.plan.ops[k].kind == TP_YEAR4) { nyear++; tc.year_off = d0.plan.ops[k].off; }
@@ -1382,6 +1400,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
                 uint32_t ctp[32];
                 compile_time_plan(d0.plan, ctp);                       // (k_pg_emit reads the text through the compiled form)
                 tc.defer_time = nyear == 1 && ntime == 1 && ctp[31] ? 1 : 0;
+                if (tc.defer_time) f->last_path |= 4u;
             }
             for (int i = 0; i < pair->pg.nrules; i++) {
                 tc.pg_named |= pair->pg.rule_fmask[i];
@@ -1532,8 +1551,6 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             if (d_trace) trace_out();
             HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
             HIPOK(hipStreamSynchronize(st));
-            // when most of the data is of that kind the phase kernels (tiled, general) are the better choice from now on
-            if (hm.counts[10] * 4 > n && n >= 64) f->tile_declined = true;
         }
         if (d_trace) trace_out();
         note_fx5(f, hm, n);
@@ -2045,10 +2062,20 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     // RF_TIMEPEND rows k_pg_emit could not settle (a time text the fixed-layout plan refuses, a time the encoder refuses): the call
     // is repeated with the lookup inside the single pass, where the strptime interpreter stands behind the plan -- and stays there
     auto defer_failed = [&](unsigned long long c13) -> bool {
-        if (c13 == 0 || fp->defer_time_off) return false;
-        fp->defer_time_off = true;
+        if (!(fp->last_path & 4u)) return false;                // (the lookup was inside the pass)
+        if (c13 == 0) { fp->defer.good(); return false; }
+        fp->defer.bad();
         return true;
     };
+    // the plain build of k_pg_emit: a kept record it leaves alone (counts[15]) is written by the general build behind it; when that is more
+    // than 1 kept record in 16 the general build alone runs the next calls
+    auto plain_wanted = [&](const PgEmitArgs &ea) -> bool {
+        const bool can = ea.ec.ok && pc.desc != nullptr && !getenv("FLBGPU_EMIT_GENERAL");
+        const bool use = can && fp->plain.use(fp->calls);
+        if (use) fp->last_path |= 8u;
+        return use;
+    };
+    auto plain_result = [&](unsigned long long left, unsigned long long kept) { if (left * 16 > kept && kept >= 64) fp->plain.bad(); else fp->plain.good(); };
     if (ahead) {
         // launched ahead (SpecCall): the writer with room for the usual output, counters + size + (host-level call) the output itself
         // written to page-locked memory by the device, ONE wait
@@ -2058,11 +2085,12 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
         ea.out_cap = fg->d_out.cap - 16;
         // (the plain build when the parser's fields are plain strings and the descriptors exist; a record it does not take -- counts[15] --
         // sends the call round again the usual way, where the general build follows)
-        const bool plain_emit = ea.ec.ok && pc.desc != nullptr && !getenv("FLBGPU_EMIT_GENERAL");
+        const bool plain_emit = plain_wanted(ea);
         { ProfScope ps(fp, st, "k_pg_emit"); if (plain_emit) launch_pg_emit_plain(ea, d0.nfields, cus, st); else launch_pg_emit(ea, d0.nfields, cus, st); }
         uint8_t *sink = g_spec.last ? g_spec.sink : nullptr;
         launch_finish_to_host(ea.out, ea.out_cap, ea.out_off + n, sink, g_spec.sink_cap, dm, &hm, (uint32_t) sizeof(hm), &total, st);
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (plain_emit) plain_result(hm.counts[15], hm.counts[5]);
         if (defer_failed(hm.counts[13]) || (plain_emit && hm.counts[15] > 0) || !ahead_counters_ok(fp, hm, n) || hm.counts[3] > 0 || hm.counts[14] > 0 || hm.ov_count > 0 || total > ea.out_cap) {
             SpecOff usual;
             return run_pair_fused(fp, fg, in, out, stats2);
@@ -2097,13 +2125,14 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     if (!fg->d_out.ensure(total + 16)) return -1;
     PgEmitArgs ea;
     emit_args(ea);
-    const bool plain_emit = ea.ec.ok && pc.desc != nullptr && !getenv("FLBGPU_EMIT_GENERAL");
+    const bool plain_emit = plain_wanted(ea);
     { ProfScope ps(fp, st, "k_pg_emit"); if (plain_emit) launch_pg_emit_plain(ea, d0.nfields, cus, st); else launch_pg_emit(ea, d0.nfields, cus, st); }
     unsigned long long *c13 = (unsigned long long *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords) + sizeof(uint64_t));     // counts[13 .. 15]
     c13[0] = c13[1] = c13[2] = 0;
     if (hipMemcpyAsync(c13, &dm->counts[13], 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
     if (hipStreamSynchronize(st) != hipSuccess) return -1;
     if (defer_failed(c13[0])) return run_pair_fused(fp, fg, in, out, stats2);
+    if (plain_emit) plain_result(c13[2], hm.counts[5]);
     if (plain_emit && c13[2] > 0) {
         // records the plain build left alone (no descriptor, another parser's, larger than its staging area): the general build over the chunk
         { ProfScope ps(fp, st, "k_pg_emit_general"); launch_pg_emit(ea, d0.nfields, cus, st); }
@@ -2117,6 +2146,7 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
 static int run_any_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, bool garbage) {
     int ret = FLBGPU_FILTER_NOTOUCH;
     bool ok;
+    f->calls++;
     if (f->kind == F_L2M) {
         ok = run_l2m_dev(f, in, st, &ret);
         if (ok && ret == FLBGPU_FILTER_MODIFIED && out) memset(out, 0, sizeof(*out));   // discard_logs: every record dropped
@@ -2255,6 +2285,7 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
             flbgpu_chain_stat s2[2];
             memset(s2, 0, sizeof(s2));
             g_spec.last = i + 2 == n;
+            filters[i]->calls++;
             const int fr = run_pair_fused(filters[i], filters[i + 1], &cur, &o, s2);
             if (fr == 1) {
                 if (stats) { stats[i] = s2[0]; stats[i + 1] = s2[1]; }

@@ -141,10 +141,40 @@ struct flbgpu_filter {
     std::vector<flbgpu_parser *> parsers;
     flbgpu::DevBuf d_parsers;
     uint32_t caps_stride = 0;
-    bool tile_declined = false;       // k_parser_tile sent too many values through its fallback: phase kernels from now on
-    bool defer_time_off = false;      // pair mode: a kept record's time text was not settled by the fixed-layout plan in k_pg_emit: the lookup stays in the single pass
+    // The choices between a fast build and the build that takes everything are made per call from what the last calls showed -- no
+    // choice is for good (round 5's latches: one odd chunk moved a filter to the slower build for the life of the process):
+    //   tile   the single pass (k_parser_reg / k_parser_tile) or the phase kernels: bad when the pass left more than 1 value in 8 to its
+    //          reverse-pass fallback or more than 1 row in 4 to the fix-up
+    //   fx5    the three-port pair tables or the four-port ones: bad when the three-port walk handed on more than 1 row in 64
+    //   defer  the kept records' time looked up by k_pg_emit or inside the single pass: bad when k_pg_emit met a text its plan does not settle
+    //   plain  k_pg_emit's plain build or the general one: bad when the plain build left more than 1 kept record in 16 alone
+    struct Probe {
+        bool off = false, trying = false;
+        uint32_t quiet = 0, interval = 16;
+        uint64_t asked = ~0ull;         // the call the answer below belongs to (a call asks more than once: repeated stages)
+        bool answer = true;
+        uint64_t probes = 0, returns = 0;
+        // may this call run the fast build?  While it is off the other build runs `interval` calls, then one call tries again.
+        bool use(uint64_t call) {
+            if (call == asked) return answer;
+            asked = call; trying = false;
+            if (!off) answer = true;
+            else if (++quiet >= interval) { trying = true; probes++; answer = true; }
+            else answer = false;
+            return answer;
+        }
+        void bad() {                    // the fast build did badly on this call's data
+            if (off && trying) interval = interval < 1024 ? interval * 2 : 1024;      // a try that failed: the next one later
+            else if (!off) interval = 16;
+            off = true; quiet = 0; trying = false; answer = false;
+        }
+        void good() { if (off && trying) { off = false; trying = false; returns++; } }
+    };
+    Probe tile, fx5, defer, plain;
+    uint64_t calls = 0;               // device-level calls so far (the Probes' clock)
     bool last_fx5 = false;            // the last launch of the register kernel walked the three-port tables
-    bool fx5_off = false, fx5_off_uploaded = false;   // the three-port pair tables handed on too many rows: the four-port ones from now on (flbgpu.cpp note_fx5)
+    int fx_on_device = 0;             // which pair tables this filter's device copy of parser 0 holds: 0 three-port (as created), 1 four-port
+    uint32_t last_path = 0;           // what the last call ran: bit 0 single pass, 1 three-port tables, 2 time lookup in k_pg_emit, 3 plain emit build
     bool has_decoders = false;        // a parser of the list has Decode_Field / Decode_Field_As rules (dec_dev.inc: k_parser_dec)
     // filter_grep (and the rule gate of filter_log_to_metrics)
     std::vector<flbgpu::GrepRule> rules;

@@ -218,6 +218,13 @@ void flbgpu_filter_last_counts(flbgpu_filter *f, uint64_t *in_records, uint64_t 
  * change the byte length): the product answered leftmost-first, the reference MAY have answered otherwise.  Not silent: the plugin
  * shims warn once when this is non-zero (filter_gpu_plugins.c). */
 uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f);
+/* Which builds a filter_parser instance runs.  The choices between a fast build and the build that takes everything (the single pass or
+ * the phase kernels, three or four capture-write ports in the pair tables, the kept records' time looked up at emit or inside the pass, the
+ * plain or the general emit build) are made per call from what the last calls showed; a build that did badly is set aside for 16 calls,
+ * then tried again (the interval doubles while the tries fail, up to 1024).  out8: [0] what the last call ran (bit 0 single pass, 1
+ * three-port tables, 2 emit-side time lookup, 3 plain emit build), [1..4] set aside right now: single pass / three-port tables / emit-side
+ * lookup / plain build, [5] tries of a build that was set aside, [6] tries that brought it back, [7] device-level calls so far. */
+int flbgpu_filter_paths(flbgpu_filter *f, uint64_t *out8);
 /* Rules / parsers whose pattern is NOT a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K; round 5: the absent operator (?~X), subexpression calls \g<..>, more than 31 groups, (?i) over non-ASCII literals and classes, \X)
  * do not fail the create calls: the device does everything but the search of that pattern, which the product's backtracking matcher
  * (csrc/rxbt.inc) runs on the host over the values the device located -- filter_grep rules, filter_log_to_metrics rules (run as a

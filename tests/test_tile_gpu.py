@@ -185,6 +185,77 @@ def test_empty_fields_and_the_two_pair_table_forms(g):
     os.environ.pop("FLBGPU_FX", None)
 
 
+def test_choices_between_builds_are_not_for_good(g):
+    """round 6: the choices a filter_parser instance makes between a fast build and the one that takes everything (single pass / phase
+    kernels, three / four write ports) are made per call from what the last calls showed (host_int.hpp Probe) -- round 5 latched them: one
+    odd chunk moved the filter to the slower build for the life of the process.  Plain chunks, then chunks that make each fast build do
+    badly, then plain chunks again: the filter sets the build aside, tries it again after 16 calls and comes back; the oracle's bytes on
+    every call."""
+    rng = random.Random(5)
+    data, off, _ = synth.apache_records(3000)
+    blob = bytes(data)
+    lines = [blob[int(off[i]) + 21:int(off[i + 1])] for i in range(3000)]
+    plain = b"".join(_rec({"log": ln}, sec=1700000000 + i, nsec=i) for i, ln in enumerate(lines))
+    # (a) empty referers: the three-port tables hand such lines on (two capture writes at one position)
+    odd = []
+    for i, ln in enumerate(lines):
+        q = ln.split(b'"')
+        if i % 3 == 0 and len(q) >= 6: q[3] = b""
+        odd.append(_rec({"log": b'"'.join(q)}, sec=1700000000 + i, nsec=i))
+    odd = b"".join(odd)
+    # (b) bodies of several keys: the single pass leaves them to its fix-up launch (more than one row in four: the phase kernels' data)
+    multi = b"".join(_rec({"a": "x", "log": ln, "z": 1} if i % 2 else {"log": ln}, sec=1700000000 + i, nsec=i) for i, ln in enumerate(lines))
+    pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    rules = [("regex", r"code ^[45]\d\d$")]
+    po = ob.Parser(**pargs)
+    want = {}
+    for name, chunk in (("plain", plain), ("odd", odd), ("multi", multi)):
+        w1 = ob.FilterParser("log", [po]).filter(chunk)
+        want[name] = (w1, ob.Grep(rules).filter(w1[1]))
+    _set_mode("reg")
+    os.environ.pop("FLBGPU_FX", None)
+    p = g.Parser(**pargs)
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep(rules); ch = g.FilterChain([fp, fg])
+    chunks = {"plain": plain, "odd": odd, "multi": multi}
+
+    def call(name):
+        r3, o3 = ch.filter(chunks[name])
+        assert r3 == ob.MODIFIED and o3 == want[name][1][1], name
+        return fp.paths()
+
+    st = call("plain")
+    assert st["single_pass"] and st["three_port"] and not any(st["aside"].values()), st
+    st = call("odd")                                            # walked with three ports, handed on a third of the rows
+    assert st["aside"]["three_port"] and not st["aside"]["single_pass"], st
+    st = call("odd")
+    assert st["single_pass"] and not st["three_port"], st      # the four-port tables, still the single pass
+    seen_back = None
+    for k in range(40):
+        st = call("plain")
+        if st["three_port"] and not st["aside"]["three_port"]:
+            seen_back = k
+            break
+    assert seen_back is not None and 10 <= seen_back <= 20, (seen_back, st)
+    st = call("multi")
+    assert st["aside"]["single_pass"], st
+    st = call("multi")
+    assert not st["single_pass"], st                           # the phase kernels
+    seen_back = None
+    for k in range(40):
+        st = call("plain")
+        if st["single_pass"] and not st["aside"]["single_pass"]:
+            seen_back = k
+            break
+    assert seen_back is not None and 10 <= seen_back <= 20, (seen_back, st)
+    assert st["returns"] >= 2 and st["tries"] >= 2, st
+    # data that stays odd: the tries come at growing distances
+    t0 = fp.paths()["tries"]
+    for k in range(60):
+        call("odd")
+    assert 2 <= fp.paths()["tries"] - t0 <= 3, fp.paths()
+    fg.close(); fp.close(); p.close()
+
+
 def test_time_lookup_left_to_the_emit_pass(g):
     """round 5 (dev.hpp TileCfg::defer_time): the pair's single pass leaves the time lookup of a fixed-layout Time_Format to k_pg_emit,
     which only sees the records grep keeps.  Everything a time text can change is compared with the oracle's two filters: the kept
