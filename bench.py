@@ -343,19 +343,28 @@ def measure_l2m_float(g, torch, L, evc, rank, world, args):
     ev, nbase, reps, base = evc
     nrec = int(ev.n)
     props = [("label_field", "level")]
-    f = g.FilterLogToMetrics("histogram", props, value_field="latency")
-    f.filter_dev(ev)
-    torch.cuda.synchronize()
-    snap = f.snapshot()
-    f.close()
-    f = g.FilterLogToMetrics("histogram", props, value_field="latency")
-    t0 = time.perf_counter()
-    for _ in range(3):
+    # both sum orders, each timed and each held against the real cmetrics: "reference" (the C ABI's default since round 6: cmetrics' own
+    # sequential f64 sum, k_l2m_seqsum) and "exact" (fixed-point digits rounded once)
+    snaps, ms = {}, {}
+    for so in ("reference", "exact"):
+        f = g.FilterLogToMetrics("histogram", props, value_field="latency")
+        f.set_sum_order(so == "reference")
         f.filter_dev(ev)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    f.close()
-    e = {"records_per_s_per_gpu": round(nrec / dt, 1), "ms_per_step": round(dt * 1e3, 3), "observations": int(sum(x["count"] for x in snap)),
+        torch.cuda.synchronize()
+        snaps[so] = f.snapshot()
+        f.close()
+        f = g.FilterLogToMetrics("histogram", props, value_field="latency")
+        f.set_sum_order(so == "reference")
+        t0 = time.perf_counter()
+        for _ in range(3):
+            f.filter_dev(ev)
+        torch.cuda.synchronize()
+        ms[so] = (time.perf_counter() - t0) / 3
+        f.close()
+    snap, dt = snaps["reference"], ms["reference"]
+    e = {"sum_order": "reference (the default: the histogram sum as cmetrics adds it up, one f64 addition per observation in record order)",
+         "records_per_s_per_gpu": round(nrec / dt, 1), "ms_per_step": round(dt * 1e3, 3), "ms_per_step_sum_order_exact": round(ms["exact"] * 1e3, 3),
+         "observations": int(sum(x["count"] for x in snap)),
          "series": len(snap), "value_field": "latency (msgpack float64 from the NDJSON text)", "label": "level"}
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libcmetrics_ref.so")
     if rank == 0 and world == 1 and not args.no_cpu and os.path.exists(ref_so):
@@ -388,7 +397,7 @@ def measure_l2m_float(g, torch, L, evc, rank, world, args):
         cdt = time.perf_counter() - t0
         nb = R.refcmt_nbuckets(h)
         bits = lambda x: _st.unpack("<q", _st.pack("<d", x))[0]
-        worst, structure = 0, rc == 0 and R.refcmt_nseries(h) == len(snap)
+        worst, worst_exact, structure = 0, 0, rc == 0 and R.refcmt_nseries(h) == len(snap)
         rel = 0.0
         for si in range(R.refcmt_nseries(h)):
             want_l = R.refcmt_label(h, si, 0)
@@ -399,11 +408,13 @@ def measure_l2m_float(g, torch, L, evc, rank, world, args):
             structure = structure and got["count"] == R.refcmt_count(h, si) and list(got["buckets"]) == [R.refcmt_bucket(h, si, b) for b in range(nb + 1)]
             ws = R.refcmt_sum(h, si)
             worst = max(worst, abs(bits(ws) - bits(got["sum"])))
-            rel = max(rel, abs(ws - got["sum"]) / abs(ws) if ws else 0.0)
+            worst_exact = max(worst_exact, abs(bits(ws) - bits(snaps["exact"][si]["sum"])))
+            rel = max(rel, abs(ws - snaps["exact"][si]["sum"]) / abs(ws) if ws else 0.0)
         R.refcmt_free(h)
         e["vs_cmetrics"] = {"kind": "reference (oracle/_ref/libcmetrics_ref.so: cmt_histogram_observe in record order)", "observations": int(len(vals)),
-                            "series_labels_buckets_counts_identical": bool(structure), "max_ulp_vs_cmetrics": int(worst), "max_rel_err": rel,
-                            "note": "device sum = exact sum rounded once; cmetrics = sequential f64 additions (its own rounding error grows with n)",
+                            "series_labels_buckets_counts_identical": bool(structure), "max_ulp_vs_cmetrics": int(worst),
+                            "sum_order_exact_max_ulp_vs_cmetrics": int(worst_exact), "sum_order_exact_max_rel_err": rel,
+                            "note": "sum_order reference = cmetrics' own bits (0 ULP); sum_order exact = the true sum rounded once -- cmetrics' sequential additions drift from it as n grows",
                             "cmetrics_observations_per_s": round(len(vals) / cdt, 1)}
     return e
 
@@ -445,6 +456,8 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         if shared_gpu:
             t0 = time.perf_counter()
             kr = g.l2m_all_reduce(f, dist, device="cpu")
+            if getattr(f, "sum_order", 0) == 2 and f.mode == 2:
+                g.l2m_chain(kr[0], dist, f, device="cpu")              # (the chain the C entry point runs over RCCL, here over gloo)
             return kr, time.perf_counter() - t0
         if "rccl" not in out:
             def exchange(raw):
@@ -456,14 +469,20 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         kr = g.l2m_all_reduce_rccl(f, out["rccl"])
         return kr, time.perf_counter() - t0
 
-    for name, mode, props, vf in (("l2m_counter", "counter", [("label_field", "method"), ("label_field", "code")], None),
-                                  ("l2m_histogram", "histogram", [("label_field", "code")], "size")):
+    # the histogram in both sum orders, each named: "exact" (digits that merge by addition: what N ranks all-reduce) and the reference's
+    # order -- 1 on one GPU (k_l2m_seqsum every call), 2 across ranks (the observations kept, folded rank after rank at the flush)
+    ref_order = 1 if dist is None else 2
+    for name, mode, props, vf, so in (("l2m_counter", "counter", [("label_field", "method"), ("label_field", "code")], None, None),
+                                      ("l2m_histogram", "histogram", [("label_field", "code")], "size", 0),
+                                      ("l2m_histogram_reference_order", "histogram", [("label_field", "code")], "size", ref_order)):
         f = g.FilterLogToMetrics(mode, props, value_field=vf)
+        if so is not None: f.set_sum_order(so)
         f.set_index_base(rank << 40)
         f.filter_dev(parsed_chunk)
         torch.cuda.synchronize()
         f.close()
         f = g.FilterLogToMetrics(mode, props, value_field=vf)      # (fresh state: the timed passes are the whole share)
+        if so is not None: f.set_sum_order(so)
         f.set_index_base(rank << 40)
         if dist is not None:
             dist.barrier()
@@ -474,6 +493,9 @@ def measure_secondary(g, torch, dist, rank, world, parsed_chunk, n, args, raw_ch
         dt = time.perf_counter() - t0
         e = {"records_per_s_per_gpu": round(n * passes / dt, 1), "ms_per_10M_records": round(dt / passes * 1e3 * (10_000_000 / n), 3),
              "records_per_gpu": n * passes, "passes_over_resident_chunk": passes}
+        if so is not None:
+            e["sum_order"] = {0: "exact (fixed-point digits, rounded once at read-out)", 1: "reference (cmetrics' sequential f64 sum, every call)",
+                              2: "reference across ranks (observations kept, the flush folds them rank after rank: in all_reduce_ms)"}[so]
         kr, ar_s = reduce_l2m(f)
         if kr is not None:
             e["all_reduce_ms"] = round(ar_s * 1e3, 3)

@@ -842,11 +842,60 @@ class FilterLogToMetrics(_Filter):
         b = (c_double * max(nb.value, 1))()
         lib().flbgpu_l2m_bounds(self.h, b)
         self.bounds = list(b[: nb.value])
+        self.sum_order = 1                  # the C ABI's default: the reference's order
 
     def set_sum_order(self, reference=True):
-        """sum_order reference: also keep the histogram sum as the reference adds it up (one f64 addition per observation in record order)"""
-        if lib().flbgpu_l2m_set_sum_order(self.h, int(bool(reference))) != 0:
+        """sum_order reference: also keep the histogram sum as the reference adds it up (one f64 addition per observation in record order);
+        reference=2: the same across ranks -- the interval's observations are kept and the flush folds them rank after rank (l2m_chain)"""
+        if lib().flbgpu_l2m_set_sum_order(self.h, 2 if reference == 2 else int(bool(reference))) != 0:
             raise RuntimeError(last_error())
+        self.sum_order = 2 if reference == 2 else int(bool(reference))
+
+    def _keys_args(self, keys):
+        import numpy as np
+        off = np.zeros(len(keys) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(k) for k in keys]) if keys else []
+        return off, b"".join(keys)
+
+    def chain_begin(self, keys):
+        """the sums the last flush ended on, for the union of the label tuples `keys` (0.0 for a new one)"""
+        off, blob = self._keys_args(keys)
+        sums = (c_double * max(len(keys), 1))()
+        L = lib()
+        L.flbgpu_l2m_chain_begin.argtypes = [c_void_p, c_uint64, c_void_p, c_char_p, POINTER(c_double)]
+        if L.flbgpu_l2m_chain_begin(self.h, len(keys), off.ctypes.data, blob, sums) != 0:
+            raise RuntimeError(last_error())
+        return [sums[i] for i in range(len(keys))]
+
+    def seq_replay(self, keys, sums):
+        """this rank's turn of the chain: its interval's observations are added, in record order, to `sums` (one per key)"""
+        off, blob = self._keys_args(keys)
+        buf = (c_double * max(len(keys), 1))(*sums)
+        L = lib()
+        L.flbgpu_l2m_seq_replay.argtypes = [c_void_p, c_uint64, c_void_p, c_char_p, POINTER(c_double)]
+        if L.flbgpu_l2m_seq_replay(self.h, len(keys), off.ctypes.data, blob, buf) != 0:
+            raise RuntimeError(last_error())
+        return [buf[i] for i in range(len(keys))]
+
+    def chain_end(self, keys, sums):
+        off, blob = self._keys_args(keys)
+        buf = (c_double * max(len(keys), 1))(*sums)
+        L = lib()
+        L.flbgpu_l2m_chain_end.argtypes = [c_void_p, c_uint64, c_void_p, c_char_p, POINTER(c_double)]
+        if L.flbgpu_l2m_chain_end(self.h, len(keys), off.ctypes.data, blob, buf) != 0:
+            raise RuntimeError(last_error())
+
+    def chain_sums(self):
+        """the sums of the last flush with sum_order 2 (flbgpu_l2m_all_reduce), in the order of its output"""
+        cap = 1 << 16
+        buf = (c_double * cap)()
+        L = lib()
+        L.flbgpu_l2m_chain_sums.restype = c_int64
+        L.flbgpu_l2m_chain_sums.argtypes = [c_void_p, c_uint64, POINTER(c_double)]
+        n = L.flbgpu_l2m_chain_sums(self.h, cap, buf)
+        if n < 0:
+            raise RuntimeError("no chain sums: %s" % last_error())
+        return [buf[i] for i in range(n)]
 
     def seq_sums(self):
         """the reference-order sums of the series, in snapshot() / export() order"""
@@ -885,11 +934,18 @@ class FilterLogToMetrics(_Filter):
             kcap = max(kcap, need.value)
 
     def snapshot(self, keys_rows=None):
-        """-> list of dict(labels=(bytes,..), value=, buckets=, count=, sum=) in first-appearance order"""
+        """-> list of dict(labels=(bytes,..), value=, buckets=, count=, sum=, sum_exact=) in first-appearance order.  A histogram's `sum`
+        is what its sum_order says: the reference's sequential sum (the default) for the filter's own state, the exact sum rounded
+        once otherwise (merged rows of several ranks carry only that one; sum_order 2: chain_sums()); `sum_exact` is always the latter"""
+        own = keys_rows is None
         keys, rows = keys_rows if keys_rows is not None else self.export()
+        seq = self.seq_sums() if (own and self.mode == 2 and self.sum_order == 1) else None
         out = []
-        for k, r in zip(keys, rows):
+        for j, (k, r) in enumerate(zip(keys, rows)):
             d = finalize_row(self.mode, self.nbuckets, r)
+            d["sum_exact"] = d["sum"]
+            if seq is not None and j < len(seq):
+                d["sum"] = seq[j]
             d["labels"] = tuple(k.split(b"\0")[:-1]) if self.label_count else ()
             out.append(d)
         return out
@@ -956,6 +1012,26 @@ def l2m_all_reduce(flt, dist, device=None):
     Returns (keys, rows) as FilterLogToMetrics.export() does, identical on every rank."""
     keys, rows = flt.export()
     return l2m_merge(keys, rows, flt.row_words, dist, device)
+
+
+def l2m_chain(keys, dist, rank_state, device=None):
+    """sum_order 2 over torch.distributed: the histogram sums as ONE reference process builds them that is fed the interval's records
+    of rank 0, then of rank 1, ... (lib/cmetrics/src/cmt_metric_histogram.c:124-137 adds in record order: no merge of per-rank sums
+    has those bits).  `keys`: the merged label tuples (l2m_merge's), the same list on every rank; `rank_state`: this rank's
+    FilterLogToMetrics -- or anything with chain_begin(keys) -> sums, seq_replay(keys, sums) -> sums, chain_end(keys, sums).  Rank
+    after rank takes its turn on the sums the rank in front ended on (one broadcast per rank).  -> the interval's sums, one per key."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    G = torch.tensor(rank_state.chain_begin(keys), dtype=torch.float64, device=dev)
+    for r in range(world):
+        if r == rank:
+            G = torch.tensor(rank_state.seq_replay(keys, G.cpu().tolist()), dtype=torch.float64, device=dev)
+        if world > 1 and len(keys):
+            dist.broadcast(G, src=r)
+    sums = G.cpu().tolist()
+    rank_state.chain_end(keys, sums)
+    return sums
 
 
 def l2m_merge(keys, rows, W, dist, device=None):

@@ -11,6 +11,7 @@
 #include <string>
 #include <strings.h>
 #include <vector>
+#include <unordered_map>
 
 #include "../../include/flb_gpu.h"
 #include "dev.hpp"
@@ -114,9 +115,16 @@ struct L2mState {
     uint64_t last_obs = 0, last_deferred = 0, last_stale = 0, grows = 0;
     // sum_order reference (flbgpu_l2m_set_sum_order): next to the exact sum, the histogram sum as cmetrics builds it -- one f64
     // addition per observation in record order (lib/cmetrics/src/cmt_metric_histogram.c:124-137) --, one binary64 per series id
-    int sum_order_ref = 0;
+    // 2 (round 6) = the same across ranks: every rank keeps its observations since the last flush (series id + value, in record order)
+    // and the flush folds them rank after rank, each rank continuing from the sums the rank in front ended on (l2m.cpp "the chain"):
+    // the bits of ONE process that was fed rank 0's records of the interval, then rank 1's ... -- for any number of ranks
+    int sum_order_ref = 1;                                   // (round 6: the reference's order is the default of the C ABI too, as it is the plugin shim's)
     flbgpu::DevBuf d_seq;
     uint32_t seq_cap = 0;
+    flbgpu::DevBuf d_log_sid, d_log_val, d_nobad;
+    uint64_t log_n = 0, log_cap = 0;
+    std::unordered_map<std::string, double> chain_sums;      // per label tuple: the sum the last flush ended on (the same on every rank)
+    std::vector<double> last_chain;                          // the last flush's sums in the order of its output
 };
 
 void l2m_state_destroy(L2mState *);

@@ -23,7 +23,7 @@ struct L2mMisc { unsigned long long first_bad; unsigned long long counts[3]; };
 void l2m_state_destroy(L2mState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->d_labels, &s->d_value_key, &s->d_bounds, &s->d_slot_hash, &s->d_slot_sid, &s->d_arena, &s->d_key_off,
-                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc, &s->d_seq};
+                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc, &s->d_seq, &s->d_log_sid, &s->d_log_val, &s->d_nobad};
     for (auto *b : all) b->release();
     delete s;
 }
@@ -324,7 +324,22 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
     g.rows = s->d_rows.as<unsigned long long>(); g.W = s->W; g.mode = s->mode; g.nb = s->nb;
     g.bounds = s->d_bounds.as<double>(); g.idx_base = s->idx_base; g.n_series = &s->d_ctr.as<L2mCtr>()->n_series;
     { ProfScope ps(f, st, "k_l2m_aggregate"); launch_l2m_aggregate(g, cus, st); }
-    if (s->sum_order_ref && s->mode == L2M_HISTOGRAM && hc.n_series) {
+    if (s->sum_order_ref == 2 && s->mode == L2M_HISTOGRAM) {
+        // the interval's observations, in record order, for the flush-time chain (what a decode error cuts off is not among them)
+        const uint64_t lim = hm.first_bad < n ? hm.first_bad : n;
+        if (s->log_n + lim > s->log_cap) {
+            uint64_t nc = s->log_cap ? s->log_cap : (1u << 20);
+            while (nc < s->log_n + lim) nc *= 2;
+            if (!grow_keep(s->d_log_sid, (size_t) nc * 4, (size_t) s->log_n * 4) || !grow_keep(s->d_log_val, (size_t) nc * 8, (size_t) s->log_n * 8)) return false;
+            s->log_cap = nc;
+        }
+        if (lim) {
+            HIPOK(hipMemcpyAsync(s->d_log_sid.as<uint32_t>() + s->log_n, g.sid_col, (size_t) lim * 4, hipMemcpyDeviceToDevice, st));
+            HIPOK(hipMemcpyAsync(s->d_log_val.as<uint64_t>() + s->log_n, g.val_col, (size_t) lim * 8, hipMemcpyDeviceToDevice, st));
+            s->log_n += lim;
+        }
+    }
+    else if (s->sum_order_ref && s->mode == L2M_HISTOGRAM && hc.n_series) {
         // the reference's own sum next to the exact one (host_int.hpp L2mState::sum_order_ref)
         if (hc.n_series > s->seq_cap) {
             uint32_t nc = s->seq_cap ? s->seq_cap : 64;
@@ -340,17 +355,107 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
     return true;
 }
 
-// sum_order: 0 = the exact sum rounded once (default), 1 = also the reference's sequential sum (flbgpu_l2m_seq_sums)
+// sum_order: 0 = the exact sum rounded once, 1 = also the reference's sequential sum (flbgpu_l2m_seq_sums), 2 = the sequential sum
+// across ranks (the chain below: flbgpu_l2m_all_reduce / flbgpu_l2m_chain_*)
 extern "C" int flbgpu_l2m_set_sum_order(flbgpu_filter *f, int reference) {
     if (!f || f->kind != F_L2M) return -1;
-    f->l2m->sum_order_ref = reference ? 1 : 0;
+    f->l2m->sum_order_ref = reference == 2 ? 2 : reference ? 1 : 0;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ the chain (sum_order 2)
+// cmetrics adds every observation to a binary64 in the order the records come (lib/cmetrics/src/cmt_metric_histogram.c:124-137): no
+// merge of per-rank sums gives those bits.  What gives them for ANY number of ranks is the fold itself, continued from rank to rank:
+// the order is "the interval's records of rank 0, then of rank 1, ..." (the record index ranges flbgpu_l2m_set_index_base hands out),
+// rank r starts its fold from the sums rank r - 1 ended on, the last rank's sums are the interval's.  A rank keeps its interval's
+// observations (d_log_*: 12 bytes each) for that; the flush replays them with k_l2m_seqsum.
+//   chain_begin  the sums the last flush ended on, for the union of the label tuples (0 for a new one)
+//   seq_replay   this rank's turn: its local series start from `sums`, the interval's observations are added in order, `sums` gets the
+//                result; the interval is closed
+//   chain_end    every rank keeps the final sums
+// flbgpu_l2m_all_reduce runs the three over RCCL (a broadcast per rank); the Python merge helper runs them over torch.distributed.
+static bool l2m_local_keys(L2mState *s, std::vector<std::string> &keys) {
+    L2mCtr c;
+    if (hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return false; }
+    const uint32_t ns = c.n_series;
+    std::vector<unsigned long long> hoff(ns);
+    std::vector<uint32_t> hlen(ns);
+    std::vector<uint8_t> arena(c.arena_used);
+    if (ns && (hipMemcpy(hoff.data(), s->d_key_off.p, (size_t) ns * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+               hipMemcpy(hlen.data(), s->d_key_len.p, (size_t) ns * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+               (!arena.empty() && hipMemcpy(arena.data(), s->d_arena.p, arena.size(), hipMemcpyDeviceToHost) != hipSuccess))) {
+        set_err("log_to_metrics: device read failed");
+        return false;
+    }
+    keys.resize(ns);
+    for (uint32_t i = 0; i < ns; i++) keys[i].assign((const char *) arena.data() + hoff[i], hlen[i]);
+    return true;
+}
+static std::vector<std::string> split_keys(uint64_t n, const uint64_t *key_off, const char *keys) {
+    std::vector<std::string> out(n);
+    for (uint64_t i = 0; i < n; i++) out[i].assign(keys + key_off[i], (size_t) (key_off[i + 1] - key_off[i]));
+    return out;
+}
+static bool l2m_seq_replay(flbgpu_filter *f, const std::vector<std::string> &ukeys, std::vector<double> &G, hipStream_t st) {
+    L2mState *s = f->l2m;
+    std::vector<std::string> lkeys;
+    if (!l2m_local_keys(s, lkeys)) return false;
+    const uint32_t ns = (uint32_t) lkeys.size();
+    if (ns == 0 || s->log_n == 0) { s->log_n = 0; return true; }
+    std::unordered_map<std::string, uint32_t> index;
+    for (size_t u = 0; u < ukeys.size(); u++) index.emplace(ukeys[u], (uint32_t) u);
+    std::vector<double> hseq(ns, 0.0);
+    std::vector<int64_t> uof(ns, -1);
+    for (uint32_t i = 0; i < ns; i++) { auto it = index.find(lkeys[i]); if (it != index.end()) { uof[i] = it->second; hseq[i] = G[it->second]; } }
+    if (ns > s->seq_cap) {
+        uint32_t nc = s->seq_cap ? s->seq_cap : 64;
+        while (nc < ns) nc *= 2;
+        if (!s->d_seq.ensure((size_t) nc * sizeof(double))) return false;
+        s->seq_cap = nc;
+    }
+    if (!s->d_nobad.p) { if (!s->d_nobad.ensure(8)) return false; HIPOK(hipMemsetAsync(s->d_nobad.p, 0xFF, 8, st)); }
+    HIPOK(hipMemcpyAsync(s->d_seq.p, hseq.data(), (size_t) ns * sizeof(double), hipMemcpyHostToDevice, st));
+    { ProfScope ps(f, st, "k_l2m_seqsum(chain)"); launch_l2m_seqsum(s->d_log_sid.as<uint32_t>(), s->d_log_val.as<uint64_t>(), s->log_n, s->d_nobad.as<unsigned long long>(), s->d_seq.as<double>(), ns, st); }
+    HIPOK(hipMemcpyAsync(hseq.data(), s->d_seq.p, (size_t) ns * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPOK(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < ns; i++) if (uof[i] >= 0) G[(size_t) uof[i]] = hseq[i];
+    s->log_n = 0;
+    return true;
+}
+extern "C" int flbgpu_l2m_chain_begin(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, double *sums) {
+    if (!f || f->kind != F_L2M || f->l2m->sum_order_ref != 2) { set_err("log_to_metrics: the chain needs sum_order 2"); return -1; }
+    const std::vector<std::string> uk = split_keys(n_keys, key_off, keys);
+    for (uint64_t u = 0; u < n_keys; u++) { auto it = f->l2m->chain_sums.find(uk[u]); sums[u] = it == f->l2m->chain_sums.end() ? 0.0 : it->second; }
+    return 0;
+}
+extern "C" int flbgpu_l2m_seq_replay(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, double *sums) {
+    if (!f || f->kind != F_L2M || f->l2m->sum_order_ref != 2 || f->l2m->mode != L2M_HISTOGRAM) { set_err("log_to_metrics: the chain needs a histogram with sum_order 2"); return -1; }
+    const std::vector<std::string> uk = split_keys(n_keys, key_off, keys);
+    std::vector<double> G(sums, sums + n_keys);
+    if (!l2m_seq_replay(f, uk, G, f->stream)) return -1;
+    for (uint64_t u = 0; u < n_keys; u++) sums[u] = G[u];
+    return 0;
+}
+extern "C" int flbgpu_l2m_chain_end(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, const double *sums) {
+    if (!f || f->kind != F_L2M || f->l2m->sum_order_ref != 2) { set_err("log_to_metrics: the chain needs sum_order 2"); return -1; }
+    const std::vector<std::string> uk = split_keys(n_keys, key_off, keys);
+    for (uint64_t u = 0; u < n_keys; u++) f->l2m->chain_sums[uk[u]] = sums[u];
+    f->l2m->last_chain.assign(sums, sums + n_keys);
+    return 0;
+}
+// the sums of the last flush (flbgpu_l2m_all_reduce with sum_order 2), in the order of its output
+extern "C" int64_t flbgpu_l2m_chain_sums(flbgpu_filter *f, uint64_t max_series, double *sums) {
+    if (!f || f->kind != F_L2M || f->l2m->sum_order_ref != 2) return -1;
+    const std::vector<double> &c = f->l2m->last_chain;
+    if (c.size() > max_series) return -(int64_t) c.size() - 2;
+    for (size_t i = 0; i < c.size(); i++) sums[i] = c[i];
+    return (int64_t) c.size();
 }
 
 // the sequential sums of the series flbgpu_l2m_export lists, in its order (first appearance); returns their number, -1 when the
 // filter does not keep them
 extern "C" int64_t flbgpu_l2m_seq_sums(flbgpu_filter *f, uint64_t max_series, double *sums) {
-    if (!f || f->kind != F_L2M || !f->l2m->sum_order_ref || f->l2m->mode != L2M_HISTOGRAM) return -1;
+    if (!f || f->kind != F_L2M || f->l2m->sum_order_ref != 1 || f->l2m->mode != L2M_HISTOGRAM) return -1;
     L2mState *s = f->l2m;
     L2mCtr c;
     if (hipMemcpy(&c, s->d_ctr.p, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) { set_err("log_to_metrics: device read failed"); return -1; }
@@ -547,6 +652,7 @@ extern "C" int flbgpu_nc_scan_double_dev(const char *strs, const uint32_t *off, 
 namespace {
 typedef int (*nccl_allreduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_bcast_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef int (*nccl_count_t)(void *, int *);
 typedef int (*nccl_getid_t)(void *);
 struct NcclId { char b[128]; };                      // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
@@ -557,6 +663,7 @@ struct Rccl {
     void *h = nullptr;
     nccl_allreduce_t all_reduce = nullptr;
     nccl_allgather_t all_gather = nullptr;
+    nccl_bcast_t bcast = nullptr;
     nccl_count_t comm_count = nullptr, comm_rank = nullptr;
     nccl_getid_t get_id = nullptr;
     nccl_initrank_t init_rank = nullptr;
@@ -564,7 +671,7 @@ struct Rccl {
     nccl_errstr_t errstr = nullptr;
 };
 Rccl g_rccl;
-constexpr int NCCL_UINT64 = 5, NCCL_UINT8 = 1, NCCL_SUM = 0, NCCL_MAX = 2;     // rccl.h: ncclDataType_t / ncclRedOp_t
+constexpr int NCCL_UINT64 = 5, NCCL_UINT8 = 1, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;     // rccl.h: ncclDataType_t / ncclRedOp_t
 
 bool rccl_load() {
     if (g_rccl.h) return true;
@@ -577,6 +684,7 @@ bool rccl_load() {
     Rccl r;
     r.h = h;
     r.all_reduce = (nccl_allreduce_t) dlsym(h, "ncclAllReduce"); r.all_gather = (nccl_allgather_t) dlsym(h, "ncclAllGather");
+    r.bcast = (nccl_bcast_t) dlsym(h, "ncclBroadcast");
     r.comm_count = (nccl_count_t) dlsym(h, "ncclCommCount"); r.comm_rank = (nccl_count_t) dlsym(h, "ncclCommUserRank");
     r.get_id = (nccl_getid_t) dlsym(h, "ncclGetUniqueId"); r.init_rank = (nccl_initrank_t) dlsym(h, "ncclCommInitRank");
     r.destroy = (nccl_destroy_t) dlsym(h, "ncclCommDestroy"); r.errstr = (nccl_errstr_t) dlsym(h, "ncclGetErrorString");
@@ -716,6 +824,25 @@ extern "C" int64_t flbgpu_l2m_all_reduce(flbgpu_filter *f, void *rccl_comm, void
     std::vector<uint32_t> order(n);
     for (size_t u = 0; u < n; u++) order[u] = (uint32_t) u;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ~mx[2 * (size_t) a] < ~mx[2 * (size_t) b]; });
+    if (s->sum_order_ref == 2 && s->mode == L2M_HISTOGRAM) {
+        // the chain: rank after rank folds its interval's observations into the sums the rank in front ended on
+        if (!g_rccl.bcast) { set_err("RCCL: ncclBroadcast missing in librccl"); return -1; }
+        std::vector<double> G(n, 0.0);
+        for (size_t u = 0; u < n; u++) { auto it = s->chain_sums.find(ukeys[u]); if (it != s->chain_sums.end()) G[u] = it->second; }
+        ScopedDevBuf d_g;
+        if (n && !d_g.ensure(n * sizeof(double))) return -1;
+        for (int r = 0; r < world; r++) {
+            if (r == rank && !l2m_seq_replay(f, ukeys, G, st)) return -1;
+            if (n && world > 1) {
+                if (hipMemcpyAsync(d_g.p, G.data(), n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+                NCCLOK(g_rccl.bcast(d_g.p, d_g.p, n, NCCL_FLOAT64, r, rccl_comm, st));
+                if (hipMemcpyAsync(G.data(), d_g.p, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+            }
+        }
+        for (size_t u = 0; u < n; u++) s->chain_sums[ukeys[u]] = G[u];
+        s->last_chain.resize(n);
+        for (size_t j = 0; j < n; j++) s->last_chain[j] = G[order[j]];
+    }
     size_t kneed = 0;
     for (auto &k : ukeys) kneed += k.size();
     if (keys_needed) *keys_needed = kneed;

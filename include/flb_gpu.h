@@ -149,13 +149,26 @@ int64_t flbgpu_l2m_export(flbgpu_filter *f, uint64_t max_series, uint64_t *rows,
  * arithmetic on integers only; the sum is the exact sum of the observations rounded once. */
 int flbgpu_l2m_finalize_row(int mode, int nbuckets, const uint64_t *row, double *value, uint64_t *buckets, uint64_t *count,
                             double *sum);
-/* sum_order reference: next to the exact sum (the default, rounded once: flbgpu_l2m_finalize_row), the histogram sum as the
- * reference builds it -- cmt_metric_hist_sum_add, lib/cmetrics/src/cmt_metric_histogram.c:124-137: one binary64 addition per
- * observation in record order --, bit for bit.  flbgpu_l2m_set_sum_order(f, 1) before the first record; flbgpu_l2m_seq_sums fills
- * one sum per series in flbgpu_l2m_export's order and returns their number (-1: the filter does not keep them).  Sharded runs add
- * the shards' sums in shard order (there is no single record order across shards to reproduce). */
+/* sum_order.  A histogram keeps its sum twice: exactly (fixed-point digits that merge by addition; flbgpu_l2m_finalize_row rounds them
+ * once) and -- sum_order reference, THE DEFAULT since round 6 -- as the reference builds it: cmt_metric_hist_sum_add,
+ * lib/cmetrics/src/cmt_metric_histogram.c:124-137, one binary64 addition per observation in record order, bit for bit (the price: one
+ * wave per series walks the call's observations in order).  flbgpu_l2m_set_sum_order(f, 0) before the first record leaves only the exact
+ * sum (the reference's own sequential sum is hundreds of ULP from it after 10 M observations); flbgpu_l2m_seq_sums fills
+ * one sum per series in flbgpu_l2m_export's order and returns their number (-1: the filter does not keep them).
+ * flbgpu_l2m_set_sum_order(f, 2): the same ACROSS RANKS.  The order the bits belong to is "the records of the interval (since the last
+ * flush) of rank 0, then of rank 1, ..." -- the index ranges flbgpu_l2m_set_index_base hands out --, i.e. one reference process fed the
+ * ranks' shards one after the other; every rank keeps its interval's observations (12 bytes each) and flbgpu_l2m_all_reduce folds them
+ * rank after rank, each continuing from the sums the rank in front ended on (one ncclBroadcast of the sums per rank): bit-identical
+ * to that process for ANY number of ranks.  flbgpu_l2m_chain_sums: the last flush's sums in the order of its output.  The three steps
+ * of the chain are entry points of their own for a merge that runs over another transport (the Python helper over torch.distributed):
+ * chain_begin fills `sums` with what the last flush ended on for the union of the label tuples (key_off / keys as flbgpu_l2m_export
+ * writes them), seq_replay is this rank's turn (in / out), chain_end keeps the final sums on every rank. */
 int flbgpu_l2m_set_sum_order(flbgpu_filter *f, int reference);
 int64_t flbgpu_l2m_seq_sums(flbgpu_filter *f, uint64_t max_series, double *sums);
+int flbgpu_l2m_chain_begin(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, double *sums);
+int flbgpu_l2m_seq_replay(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, double *sums);
+int flbgpu_l2m_chain_end(flbgpu_filter *f, uint64_t n_keys, const uint64_t *key_off, const char *keys, const double *sums);
+int64_t flbgpu_l2m_chain_sums(flbgpu_filter *f, uint64_t max_series, double *sums);
 /* ---- multi-GPU: the collective of the log_to_metrics aggregates (one process per GPU, records sharded) --------
  * Same configuration on every rank; each rank runs the filter on its own shard (flbgpu_l2m_set_index_base gives
  * the ranks disjoint record index ranges).  flbgpu_l2m_all_reduce makes the label dictionaries identical

@@ -50,3 +50,30 @@ def encode_rows(mode, bounds, observations):
                     r[W_LIMB + j + k] = (r[W_LIMB + j + k] + sign * d) & M64
     keys = sorted(rows, key=lambda k: ~rows[k][W_FIRST] & M64)
     return keys, np.array([rows[k] for k in keys], dtype=np.uint64).reshape(len(keys), W)
+
+
+class SeqRank:
+    """a rank's side of the chain of sum_order 2 (csrc/l2m.cpp "the chain") without a GPU: the interval's observations in record order
+    and the sums the last flush ended on -- the same three entry points as FilterLogToMetrics, for fluent_bit_amd.l2m_chain"""
+
+    def __init__(self):
+        self.log = []            # (key, value)
+        self.sums = {}
+
+    def observe(self, key, value):
+        self.log.append((key, float(value)))
+
+    def chain_begin(self, keys):
+        return [self.sums.get(k, 0.0) for k in keys]
+
+    def seq_replay(self, keys, sums):
+        at = {k: i for i, k in enumerate(keys)}
+        acc = list(sums)
+        for k, v in self.log:
+            acc[at[k]] = acc[at[k]] + v          # one binary64 addition per observation, in record order
+        self.log = []
+        return acc
+
+    def chain_end(self, keys, sums):
+        for k, x in zip(keys, sums):
+            self.sums[k] = x

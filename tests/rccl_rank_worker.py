@@ -58,6 +58,25 @@ def main():
         assert f.snapshot((keys, rows)) == one.snapshot()
         res["l2m_" + mode] = hashlib.sha256(repr((keys, rows.tolist())).encode()).hexdigest()
         f.close(); one.close()
+    # sum_order 2: the histogram sum as ONE reference process adds it up that is fed rank 0's records, then rank 1's, ... -- the chain
+    # inside flbgpu_l2m_all_reduce (a broadcast of the sums per rank), two intervals; against one filter with sum_order 1 over the chunks
+    # in that order, bit for bit
+    mode, props, vf = L2M[1]
+    f = g.FilterLogToMetrics(mode, props, value_field=vf); f.set_sum_order(2); f.set_index_base(rank << 40)
+    one = g.FilterLogToMetrics(mode, props, value_field=vf); one.set_sum_order(1)
+    for interval in range(2):
+        cut = [int(g.index_host(c)[1][g.index_host(c)[0] // 2]) for c in parsed]                      # (a record boundary near the middle)
+        part = [c[cut[q]:] if interval else c[: cut[q]] for q, c in enumerate(parsed)]
+        f.filter(part[rank])
+        keys, rows = g.l2m_all_reduce_rccl(f, comm)
+        for c in part:
+            one.filter(c)
+        got, want = f.chain_sums(), one.seq_sums()
+        k1, _ = one.export()
+        assert keys == k1 and [x.hex() for x in map(float, got)] == [x.hex() for x in map(float, want)], \
+            "log_to_metrics sum_order 2: the chain of %d ranks differs from one filter over the records in rank order (interval %d)" % (world, interval)
+    res["l2m_chain"] = hashlib.sha256(repr([float(x).hex() for x in got]).encode()).hexdigest()
+    f.close(); one.close()
     rng = random.Random(0x5AD)
     chunks = [sp_synth.chunk(rng, N_SP, clean=True) for _ in range(world)]
     t, one = g.StreamTask(SQL), g.StreamTask(SQL)

@@ -56,15 +56,19 @@ def check(g, mode, props, chunks, k8s=False, value_field=None, exact_sums=None, 
             continue
         assert a["buckets"] == b["buckets"], (a, b)
         assert a["count"] == b["count"]
+        # `sum`: the reference's order, the C ABI's default since round 6 -- the oracle's bits (= cmetrics'), no tolerance
+        if sum_mode != "none":
+            assert same_f64(a["sum"], b["sum"]), (a, b)
+        # `sum_exact`: the fixed-point digits rounded once
         if exact_sums is not None:
-            assert same_f64(a["sum"], exact_sums[a["labels"]]), (a["labels"], a["sum"], exact_sums[a["labels"]])
+            assert same_f64(a["sum_exact"], exact_sums[a["labels"]]), (a["labels"], a["sum_exact"], exact_sums[a["labels"]])
         if sum_mode == "exact":
-            assert same_f64(a["sum"], b["sum"]), (a, b)
+            assert same_f64(a["sum_exact"], b["sum"]), (a, b)
         elif math.isnan(b["sum"]) or math.isinf(b["sum"]):
-            assert same_f64(a["sum"], b["sum"]), (a, b)
+            assert same_f64(a["sum_exact"], b["sum"]), (a, b)
         elif sum_mode != "none":
-            tol = max(a["count"] - 1, 0) * 2.0 ** -52 * max(abs(a["sum"]), abs(b["sum"]), 1e-300) * 4
-            assert abs(a["sum"] - b["sum"]) <= tol, (a, b)
+            tol = max(a["count"] - 1, 0) * 2.0 ** -52 * max(abs(a["sum_exact"]), abs(b["sum"]), 1e-300) * 4
+            assert abs(a["sum_exact"] - b["sum"]) <= tol, (a, b)
     st = f.stats()
     f.close()
     return gsn, st
@@ -361,6 +365,62 @@ def test_histogram_sum_in_reference_order(g):
     for a, b, q in zip(gsn, osn, seq):
         assert a["buckets"] == b["buckets"] and a["count"] == b["count"]
         assert same_f64(q, b["sum"]), (a["labels"], q, b["sum"])             # the reference's own bits
-        differs += not same_f64(a["sum"], b["sum"])                             # (the exact sum is another number here)
+        assert same_f64(a["sum"], q)                                            # (snapshot() reports what the filter's sum_order says)
+        differs += not same_f64(a["sum_exact"], b["sum"])                       # (the exact sum is another number here)
     assert differs >= 1
     f.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sequential_sums_across_ranks_on_the_device(g, world):
+    """sum_order 2 (csrc/l2m.cpp "the chain"): every rank's filter keeps its interval's observations on the device, the flush replays them
+    rank after rank (k_l2m_seqsum) from the sums the rank in front ended on.  `world` filters of one process stand for the ranks (the
+    chain's three entry points are what flbgpu_l2m_all_reduce runs over RCCL and fluent_bit_amd.l2m_chain over torch.distributed);
+    the oracle's filter -- pinned on the real cmetrics -- is fed the same records in the chain's order: interval by interval, rank by
+    rank.  Bit for bit, for one, two and three ranks, over three intervals with chunks of several sizes and a decode error."""
+    import random
+    rng = random.Random(31 + world)
+    props = [("label_field", "color"), ("bucket", "0.5"), ("bucket", "10"), ("bucket", "1e6")]
+
+    def rec(i, color=None):
+        r = rng.random()
+        if r < 0.03: v = rng.choice(["1e16", "-1e16", "9007199254740993", "3e15"])
+        elif r < 0.05: v = rng.choice(["junk", "", "1e-9"])
+        else: v = repr(rng.uniform(-1000, 1000) * 10 ** rng.randint(-6, 6))
+        return v2_record(1700000000 + i, 0, {"duration": v, "color": color or rng.choice(["red", "green", "blue"])})
+
+    o = ob.L2M("histogram", props, value_field="duration")
+    ranks = []
+    for r in range(world):
+        f = g.FilterLogToMetrics("histogram", props, value_field="duration")
+        f.set_sum_order(2)
+        f.set_index_base(r << 40)
+        ranks.append(f)
+    i = 0
+    for interval in range(3):
+        for r, f in enumerate(ranks):
+            for chunk_n in (700, 1, 1300):
+                recs = [rec(i + j) for j in range(chunk_n)]
+                if r == world - 1 and chunk_n == 1: recs = [rec(i, "late%d" % interval)]        # a series first seen on the last rank
+                if interval == 2 and r == 0 and chunk_n == 1: recs = [rec(i, "late0")]           # ... and on rank 0 two intervals later
+                i += chunk_n
+                c = b"".join(recs)
+                assert o.filter(c) == f.filter(c)[0]
+        # the flush: union of the label tuples in first-appearance order, then the chain
+        allk, seen = [], set()
+        for f in ranks:
+            for k in f.export()[0]:
+                if k not in seen:
+                    seen.add(k); allk.append(k)
+        G = ranks[0].chain_begin(allk)
+        for f in ranks:
+            G = f.seq_replay(allk, G)
+        for f in ranks:
+            f.chain_end(allk, G)
+        want = {tuple(s["labels"]): s["sum"] for s in o.snapshot()[2]}
+        assert len(allk) == len(want) >= 4
+        for k, x in zip(allk, G):
+            lab = tuple(k.split(b"\0")[:-1])
+            assert same_f64(x, want[lab]), (world, interval, lab, x, want[lab])
+    for f in ranks:
+        f.close()

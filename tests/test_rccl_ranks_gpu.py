@@ -24,7 +24,7 @@ def run_ranks(n):
 
 def test_rank_program_world_of_one(rccl_ok):
     d = run_ranks(1)
-    assert d["rccl_ranks"] == 1 and d["ranks_agree"] and set(d["sha"]) == {"l2m_counter", "l2m_histogram", "l2m_gauge", "sp"}
+    assert d["rccl_ranks"] == 1 and d["ranks_agree"] and set(d["sha"]) == {"l2m_counter", "l2m_histogram", "l2m_gauge", "l2m_chain", "sp"}
 
 
 def test_two_ranks_on_two_gpus_equal_the_single_pass(rccl_ok):
