@@ -11,6 +11,7 @@ namespace flbgpu {
 
 #include "kdev.inc"
 
+#include "l2m_dev.inc"
 #include "l2m_kernels.inc"
 
 #include "sp_kernels.inc"

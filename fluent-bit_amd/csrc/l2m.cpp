@@ -11,6 +11,7 @@
 // and stay with the engine (out of scope).
 #include "host_int.hpp"
 #include "numconv.hpp"
+#include "l2m_lane.hpp"
 
 #include <algorithm>
 #include <string>
@@ -300,7 +301,42 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
         a.t = l2m_table_of(s);
         a.sid_col = s->d_sid.as<uint32_t>(); a.val_col = s->d_val.as<uint64_t>();
         a.first_bad = &s->d_misc.as<L2mMisc>()->first_bad; a.counts = s->d_misc.as<L2mMisc>()->counts;
-        { ProfScope ps(f, st, "k_l2m_extract"); launch_l2m_extract(a, cus, st); }
+        // the extraction with ONE lean walk per record on LDS pointers (l2mlane_kernels.inc) when the filter has no rules and its value
+        // field and labels are top-level names; k_l2m_extract (a generic walk per name) otherwise
+        static const bool lane_off = getenv("FLBGPU_L2M_LANE") && atoi(getenv("FLBGPU_L2M_LANE")) == 0;
+        L2mLaneArgs la;
+        bool lane_ok = !lane_off && a.nrules == 0 && ((uintptr_t) in->data & 15) == 0 && s->labels.size() <= 4;                 // (L2M_LV of l2m_dev.inc)
+        if (lane_ok) {
+            memset(&la, 0, sizeof(la));
+            auto plain = [](const DevKey &k) { return k.key_len >= 1 && k.key_len <= 32 && k.nsub == 0; };
+            for (size_t i = 0; lane_ok && i < s->labels.size(); i++) {
+                if (!plain(s->labels[i])) { lane_ok = false; break; }
+                la.slot_klen[i] = (uint8_t) s->labels[i].key_len;
+                memcpy(la.slot_kw[i], s->labels[i].key, (size_t) s->labels[i].key_len);
+            }
+            la.nslots = (int) s->labels.size();
+            la.value_slot = -1;
+            if (lane_ok && s->mode != L2M_COUNTER) {
+                if (!plain(s->value_key)) lane_ok = false;
+                else {
+                    la.value_slot = la.nslots++;
+                    la.slot_klen[la.value_slot] = (uint8_t) s->value_key.key_len;
+                    memcpy(la.slot_kw[la.value_slot], s->value_key.key, (size_t) s->value_key.key_len);
+                }
+            }
+        }
+        if (lane_ok) {
+            const uint64_t avg = in->bytes / n + 1;
+            uint64_t cap = (64 * avg * 5 / 4 + 512 + 15) & ~15ull, R = 64;
+            if (cap > (uint64_t) l2m_lane_text_max()) { R = (uint64_t) (l2m_lane_text_max() - 16) * 92 / 100 / avg; cap = (uint64_t) l2m_lane_text_max(); }
+            if (cap < 2048) cap = 2048;
+            if (R < 1) R = 1;
+            if (R > 64) R = 64;
+            la.a = a; la.text_cap = (uint32_t) cap; la.rows_per_tile = (uint32_t) R;
+            ProfScope ps(f, st, "k_l2m_lane");
+            launch_l2m_lane(la, cus, st);
+        }
+        else { ProfScope ps(f, st, "k_l2m_extract"); launch_l2m_extract(a, cus, st); }
         HIPOK(hipMemcpyAsync(&hm, s->d_misc.p, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipMemcpyAsync(&hc, s->d_ctr.p, sizeof(hc), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));

@@ -99,6 +99,24 @@ def test_grep_edge_cases(g):
             assert a == b, (rules, d[:40], a[0], b[0], first_diff(a[1], b[1]))
 
 
+def test_grep_names_of_every_length(g):
+    """round 6: the one-pass kernel (glane_kernels.inc) compares a record's names with the rules' as masked dwords -- names of 1 .. 33
+    bytes (33: the three launches take the filter), names that differ in their last byte only, the last of two entries of a name, a
+    nested name; against the oracle under every Logical_Op"""
+    names = ["k" * n for n in range(1, 34)] + ["direction", "directioN", "namespace_name", "namespace_nam3", "abcdefgh", "abcdefgX", "abcdefghi"]
+    recs = []
+    for i, nm in enumerate(names):
+        recs.append(_rec({nm: "hit%d" % (i % 3), "pad": "x" * (i % 7)}))
+        recs.append(_rec(synth.KV([(nm, "first"), ("z", 1), (nm, "hit1")])))
+        recs.append(_rec({"outer": {nm: "hit2"}, nm[:-1] + "?": "hit0"}))
+    data = b"".join(recs)
+    for nm in names:
+        for rules, op in (([("regex", "%s ^hit1$" % nm)], None), ([("exclude", "%s hit[02]" % nm), ("regex", "pad x")], None),
+                          ([("regex", "%s hit1" % nm), ("regex", "$outer['%s'] hit2" % nm)], "OR"), ([("exclude", "%s t1$" % nm), ("exclude", "pad ^$")], "AND")):
+            a, b = both_grep(g, data, rules, op)
+            assert a == b, (nm, rules, op, a[0], b[0], first_diff(a[1], b[1]))
+
+
 def test_filter_parser_semantics(g):
     ty = dict(regex=r"^(?<INT>[^ ]+) (?<FLOAT>[^ ]+) (?<BOOL>[^ ]+) (?<STRING>.+)$", types="INT:integer BOOL:bool STRING:string")
     src = _rec({"data": "100 0.5 true x", "extra": "y"}) + _rec({"data": "-7 1 nope zz zz", "n": {"a": [1, 2.5, None, True]}}) + _rec({"nodata": 1})
