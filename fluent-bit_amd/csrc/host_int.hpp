@@ -121,7 +121,7 @@ struct L2mState {
     int sum_order_ref = 1;                                   // (round 6: the reference's order is the default of the C ABI too, as it is the plugin shim's)
     flbgpu::DevBuf d_seq;
     uint32_t seq_cap = 0;
-    flbgpu::DevBuf d_log_sid, d_log_val, d_nobad;
+    flbgpu::DevBuf d_log_sid, d_log_val, d_nobad, d_seqwork;
     uint64_t log_n = 0, log_cap = 0;
     std::unordered_map<std::string, double> chain_sums;      // per label tuple: the sum the last flush ended on (the same on every rank)
     std::vector<double> last_chain;                          // the last flush's sums in the order of its output

@@ -12,6 +12,7 @@
 #include "host_int.hpp"
 #include "numconv.hpp"
 #include "l2m_lane.hpp"
+#include "seqsum.hpp"
 
 #include <algorithm>
 #include <string>
@@ -24,7 +25,7 @@ struct L2mMisc { unsigned long long first_bad; unsigned long long counts[3]; };
 void l2m_state_destroy(L2mState *s) {
     if (!s) return;
     DevBuf *all[] = {&s->d_labels, &s->d_value_key, &s->d_bounds, &s->d_slot_hash, &s->d_slot_sid, &s->d_arena, &s->d_key_off,
-                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc, &s->d_seq, &s->d_log_sid, &s->d_log_val, &s->d_nobad};
+                     &s->d_key_len, &s->d_series_hash, &s->d_rows, &s->d_ctr, &s->d_sid, &s->d_val, &s->d_tmp, &s->d_misc, &s->d_seq, &s->d_log_sid, &s->d_log_val, &s->d_nobad, &s->d_seqwork};
     for (auto *b : all) b->release();
     delete s;
 }
@@ -383,8 +384,13 @@ bool run_l2m_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, i
             if (!grow_keep(s->d_seq, (size_t) nc * sizeof(double), (size_t) s->seq_cap * sizeof(double))) return false;
             s->seq_cap = nc;
         }
+        // (round 6: the observations sorted by series, then a lane / a wave per series -- kernels_seqsum.hip; round 4's kernel read the
+        // whole call once per series: 345 ms per 10 M observations on ten series)
+        const uint64_t lim = hm.first_bad < n ? hm.first_bad : n;
+        const size_t wb = seqsum_work_bytes(lim, hc.n_series);
+        if (!s->d_seqwork.ensure(wb)) return false;
         ProfScope ps(f, st, "k_l2m_seqsum");
-        launch_l2m_seqsum(g.sid_col, g.val_col, n, g.first_bad, s->d_seq.as<double>(), hc.n_series, st);
+        if (!launch_seqsum_sorted(g.sid_col, g.val_col, lim, s->d_seq.as<double>(), hc.n_series, s->d_seqwork.p, s->d_seqwork.cap, st)) { set_err("log_to_metrics: the reference-order sum failed to launch"); return false; }
     }
     HIPOK(hipStreamSynchronize(st));
     s->idx_base += n;
@@ -449,9 +455,16 @@ static bool l2m_seq_replay(flbgpu_filter *f, const std::vector<std::string> &uke
         if (!s->d_seq.ensure((size_t) nc * sizeof(double))) return false;
         s->seq_cap = nc;
     }
-    if (!s->d_nobad.p) { if (!s->d_nobad.ensure(8)) return false; HIPOK(hipMemsetAsync(s->d_nobad.p, 0xFF, 8, st)); }
     HIPOK(hipMemcpyAsync(s->d_seq.p, hseq.data(), (size_t) ns * sizeof(double), hipMemcpyHostToDevice, st));
-    { ProfScope ps(f, st, "k_l2m_seqsum(chain)"); launch_l2m_seqsum(s->d_log_sid.as<uint32_t>(), s->d_log_val.as<uint64_t>(), s->log_n, s->d_nobad.as<unsigned long long>(), s->d_seq.as<double>(), ns, st); }
+    {
+        const size_t wb = seqsum_work_bytes(s->log_n, ns);
+        if (!s->d_seqwork.ensure(wb)) return false;
+        ProfScope ps(f, st, "k_l2m_seqsum(chain)");
+        if (!launch_seqsum_sorted(s->d_log_sid.as<uint32_t>(), s->d_log_val.as<uint64_t>(), s->log_n, s->d_seq.as<double>(), ns, s->d_seqwork.p, s->d_seqwork.cap, st)) {
+            set_err("log_to_metrics: the reference-order sum failed to launch");
+            return false;
+        }
+    }
     HIPOK(hipMemcpyAsync(hseq.data(), s->d_seq.p, (size_t) ns * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));
     for (uint32_t i = 0; i < ns; i++) if (uof[i] >= 0) G[(size_t) uof[i]] = hseq[i];
