@@ -971,6 +971,60 @@ def measure_cpu(data, off, n, args):
     return cpu
 
 
+def measure_engine_hosted(data, off, n):
+    """The drop-in inside the reference's own engine (oracle/_ref/engine: the reference built with its cmake, oracle/engine/engine_host.c):
+    in_lib -> filter_parser -> filter_grep -> out_lib with the built-in pair and with flb-filter_{parser,grep}_gpu.so loaded by the real
+    flb_plugin_load_router -- 2 MB appends (7 000 lines a push), records/s from the first push to the last chunk out_lib hands over (the
+    engine's 0.2 s flush timer is in both) -- and, without the engine's input side, one 2 MB chunk through flb_processor_run
+    (the plugin's cb_filter under the unit's lock), per call.  The only numbers a user of the drop-in sees; test infrastructure, never `value`."""
+    import json as _json, subprocess, tempfile
+    eng = os.path.join(ROOT, "oracle", "_ref", "engine")
+    host = os.path.join(eng, "engine_host")
+    so = {x: os.path.join(eng, "plugins", "flb-filter_%s_gpu.so" % x) for x in ("grep", "parser")}
+    if not (os.path.exists(host) and all(os.path.exists(v) for v in so.values())):
+        return {"skipped": "oracle/_ref/engine not built (bash oracle/build_engine.sh where /root/reference is)"}
+    pspec = "apache2|%s|%s|time|0" % (APACHE2, TIME_FMT)
+    m = min(n, 1_000_000)
+    out = {"lines": m, "lines_per_push": 7000}
+
+    def last_json(r):
+        ls = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return _json.loads(ls[-1]) if ls else {"error": (r.stdout[-300:] + r.stderr[-300:])}
+    with tempfile.TemporaryDirectory() as d:
+        blob = bytes(data[: int(off[m])])
+        jl, mp = os.path.join(d, "in.json"), os.path.join(d, "in.mp")
+        with open(jl, "w") as f:
+            for i in range(m):
+                f.write(_json.dumps([1700000000 + i, {"log": blob[int(off[i]) + 21:int(off[i + 1])].decode("latin1")}]) + "\n")
+        open(mp, "wb").write(blob[: int(off[7000])])
+        for name, extra, pf, gf in (("builtin", [], "parser", "grep"), ("gpu_plugins", ["-e", so["parser"], "-e", so["grep"]], "parser_gpu", "grep_gpu")):
+            e = {}
+            try:
+                r = subprocess.run([host, "lib"] + extra + ["--parser", pspec, "--batch", "7000", jl, os.path.join(d, "out.bin"),
+                                                            "--filter", pf, "key_name=log", "parser=apache2", "--filter", gf, "regex=code ^5\\d\\d$"],
+                                   capture_output=True, text=True, timeout=600)
+                j = last_json(r)
+                e["whole_engine"] = dict(j, records_per_s=round(j["pushed"] / j["seconds"], 1)) if "seconds" in j and j.get("seconds") else j
+                r = subprocess.run([host, "processor"] + extra + ["--parser", pspec, "--repeat", "50", mp, os.path.join(d, "out.mp"),
+                                                                  "--unit", pf, "key_name=log", "parser=apache2", "--unit", gf, "regex=code ^5\\d\\d$"],
+                                   capture_output=True, text=True, timeout=600)
+                j = last_json(r)
+                if "seconds" in j:
+                    e["processor_2MB_chunk"] = {"ms_per_call": round(j["seconds"] / j["repeat"] * 1e3, 3), "records_per_s": round(7000 * j["repeat"] / j["seconds"], 1),
+                                                "out_bytes": j["out_bytes"], "units": j.get("units")}
+                else:
+                    e["processor_2MB_chunk"] = j
+            except Exception as ex:
+                e["error"] = repr(ex)[:300]
+            out[name] = e
+    try:
+        out["same_kept_bytes"] = out["builtin"]["whole_engine"]["log_bytes"] == out["gpu_plugins"]["whole_engine"]["log_bytes"] and \
+            out["builtin"]["processor_2MB_chunk"]["out_bytes"] == out["gpu_plugins"]["processor_2MB_chunk"]["out_bytes"]
+    except Exception:
+        pass
+    return out
+
+
 def measure_host_level(g, data, off, n):
     """what one cb_filter / flb_filter_do call sees from host memory (PCIe inclusive; never `value`): the chain on
     an engine-sized chunk (~2 MB, what the engine appends at a time) and on a 28 MB chunk"""
@@ -1231,6 +1285,7 @@ def main():
                 secondary["parser_only"] = parser_only
             if rank == 0 and world == 1:
                 secondary["host_level"] = measure_host_level(g, data, off, n)
+                secondary["engine_hosted"] = measure_engine_hosted(data, off, n)
         except Exception as e:                      # the headline line must survive a failure here
             secondary = {"error": repr(e)[:300]}
 
