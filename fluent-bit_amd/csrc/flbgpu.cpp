@@ -1691,6 +1691,71 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     return true;
 }
 
+// a filter_grep's tables and names into the one-pass kernel's arguments (glane_kernels.inc): the tables behind `used` in LDS, every rule's
+// top-level name in one of the slots the kernel's single walk looks for (two filters that run as one pass share them)
+static bool lane_rules(const flbgpu_filter *f, GrepArgs &g, GrepLaneArgs &la, uint32_t &used) {
+    const uint32_t room = grep_lane_table_room(), start = used;
+    if (f->rules.empty() || f->rules.size() > (size_t) MAX_RULES) return false;
+    for (size_t i = 0; i < f->rules.size(); i++) {
+        const DevDfa &df = f->rules[i].dfa;
+        const uint32_t blob = grep_lane_table_bytes((uint32_t) df.nD, (uint32_t) df.ncls);
+        if ((uint64_t) df.nD * (uint64_t) (df.ncls + 1) >= 0xFFFEull) return false;      // (a cell holds a row's offset in 16 bits)
+        g.rule_lds_off[i] = used; g.rule_lds_bytes[i] = blob;
+        used += blob;
+        if (used > room) return false;
+    }
+    g.rules_lds_total = used - start;
+    for (size_t i = 0; i < f->rules.size(); i++) {
+        const DevKey &k = f->rules[i].key;
+        int slot = -1;
+        if (k.key_len < 1 || k.key_len > 32) return false;
+        uint32_t kw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        memcpy(kw, k.key, (size_t) k.key_len);                                            // (little endian host, zero padded)
+        for (int s = 0; s < la.nslots; s++)
+            if (la.slot_klen[s] == (uint8_t) k.key_len && memcmp(la.slot_kw[s], kw, sizeof(kw)) == 0) { slot = s; break; }
+        if (slot < 0) {
+            if (la.nslots >= GREP_SLOTS) return false;
+            slot = la.nslots++;
+            la.slot_klen[slot] = (uint8_t) k.key_len;
+            memcpy(la.slot_kw[slot], kw, sizeof(kw));
+        }
+        g.rule_slot[i] = (uint8_t) slot;
+    }
+    return true;
+}
+
+// the rows a wave of the one-pass kernel takes and the LDS they need.  A large chunk is asked (one small launch over the row offsets: the
+// longest run of 64 rows), a small one gets the mean and half as much again (rows an earlier filter emptied come in runs); a record that
+// does not fit all the same is decided and copied from the chunk itself
+static bool lane_geometry(const flbgpu_dev_chunk *in, MiscWords *dm, hipStream_t st, GrepLaneArgs &la) {
+    const uint64_t n = in->n, avg = in->bytes / n + 1;
+    uint64_t R = 64, cap = (64 * avg * 3 / 2 + 512 + 15) & ~15ull;
+    if (n >= 65536) {
+        HIPOK(hipMemsetAsync(&dm->counts[13], 0, 8, st));
+        launch_tile_max(in->row_off, n, 64, &dm->counts[13], st);
+        unsigned long long mx = 0;
+        HIPOK(hipMemcpyAsync(&mx, &dm->counts[13], 8, hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+        cap = (mx + 32 + 15) & ~15ull;
+    }
+    if (cap > (uint64_t) grep_lane_text_max()) {
+        R = (uint64_t) (grep_lane_text_max() - 16) * 92 / 100 / avg;      // records longer than a quarter kilobyte: fewer of them to a wave
+        cap = (uint64_t) grep_lane_text_max();
+    }
+    if (cap < 2048) cap = 2048;
+    la.text_cap = (uint32_t) cap;
+    if (R < 1) R = 1;
+    if (R > 64) R = 64;
+    la.ntiles = (n + R - 1) / R;
+    la.rows_per_tile = (uint32_t) R;
+    return true;
+}
+
+static bool grep_lane_off() {
+    static const bool off = getenv("FLBGPU_GREP_LANE") && atoi(getenv("FLBGPU_GREP_LANE")) == 0;
+    return off;
+}
+
 static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st, int *ret,
                          bool trailing_garbage) {
     uint64_t n = in->n;
@@ -1809,67 +1874,18 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     // ---- ONE pass (glane_kernels.inc): a lane decides its record, the kept records are placed by a look-back over the workgroups and
     // leave LDS at once -- no scan, no second read of the chunk.  Taken whenever every rule runs on the device with its tables in LDS
     // (a call launched ahead of its sizes, SpecCall, keeps the three launches: its writer must not wait for anybody).
-    static const bool lane_off = getenv("FLBGPU_GREP_LANE") && atoi(getenv("FLBGPU_GREP_LANE")) == 0;
-    if (!lane_off && !ahead && !f->has_host_rules && ((uintptr_t) in->data & 15) == 0 && !f->rules.empty() && f->rules.size() <= (size_t) MAX_RULES) {
+    if (!grep_lane_off() && !ahead && !f->has_host_rules && ((uintptr_t) in->data & 15) == 0 && !f->rules.empty() && f->rules.size() <= (size_t) MAX_RULES) {
         GrepLaneArgs la;
         memset(&la, 0, sizeof(la));
         la.g = ga;
-        bool fits = true;
-        {
-            // all the tables in LDS, every rule's top-level key in a slot
-            uint32_t used = 0;
-            const uint32_t room = grep_lane_table_room();
-            for (size_t i = 0; i < f->rules.size(); i++) {
-                const DevDfa &df = f->rules[i].dfa;
-                const uint32_t blob = grep_lane_table_bytes((uint32_t) df.nD, (uint32_t) df.ncls);
-                if ((uint64_t) df.nD * (uint64_t) (df.ncls + 1) >= 0xFFFEull) { fits = false; break; }      // (a cell holds a row's offset in 16 bits)
-                la.g.rule_lds_off[i] = used; la.g.rule_lds_bytes[i] = blob;
-                used += blob;
-                if (used > room) { fits = false; break; }
-            }
-            la.g.rules_lds_total = used;
-            la.g.nslots = 0;
-            for (size_t i = 0; fits && i < f->rules.size(); i++) {
-                const DevKey &k = f->rules[i].key;
-                int slot = -1;
-                for (int s = 0; s < la.g.nslots; s++) {
-                    const DevKey &o = f->rules[la.g.slot_rule[s]].key;
-                    if (o.key_len == k.key_len && memcmp(o.key, k.key, (size_t) k.key_len) == 0) { slot = s; break; }
-                }
-                if (slot < 0) {
-                    if (la.g.nslots >= GREP_SLOTS || k.key_len < 1 || k.key_len > 32) { fits = false; break; }
-                    slot = la.g.nslots++;
-                    la.g.slot_rule[slot] = (uint8_t) i;
-                    la.slot_klen[slot] = (uint8_t) k.key_len;
-                    memcpy(la.slot_kw[slot], k.key, (size_t) k.key_len);           // (little endian host, zero padded by the memset above)
-                }
-                la.g.rule_slot[i] = (uint8_t) slot;
-            }
-        }
+        uint32_t used = 0;
+        // all the tables in LDS, every rule's top-level key in a slot (the filter's own, in the order of its rules: what the functions
+        // of k_grep_match, which decide the odd records, go by as well)
+        const bool fits = lane_rules(f, la.g, la, used);
         if (fits) {
-            // a wave's LDS: what its 64 records need.  A large chunk is asked (one small launch over the row offsets: the longest run of
-            // 64 rows), a small one gets the mean and half as much again (rows an earlier filter emptied come in runs); a record that
-            // does not fit all the same is decided and copied from the chunk itself
-            const uint64_t avg = in->bytes / n + 1;
-            uint64_t R = 64, cap = (64 * avg * 3 / 2 + 512 + 15) & ~15ull;
-            if (n >= 65536) {
-                HIPOK(hipMemsetAsync(&dm->counts[13], 0, 8, st));
-                launch_tile_max(in->row_off, n, 64, &dm->counts[13], st);
-                unsigned long long mx = 0;
-                HIPOK(hipMemcpyAsync(&mx, &dm->counts[13], 8, hipMemcpyDeviceToHost, st));
-                HIPOK(hipStreamSynchronize(st));
-                cap = (mx + 32 + 15) & ~15ull;
-            }
-            if (cap > (uint64_t) grep_lane_text_max()) {
-                R = (uint64_t) (grep_lane_text_max() - 16) * 92 / 100 / avg;      // records longer than a quarter kilobyte: fewer of them to a wave
-                cap = (uint64_t) grep_lane_text_max();
-            }
-            if (cap < 2048) cap = 2048;
-            la.text_cap = (uint32_t) cap;
-            if (R < 1) R = 1;
-            if (R > 64) R = 64;
-            la.ntiles = (n + R - 1) / R;
-            la.rows_per_tile = (uint32_t) R;
+            la.g.nslots = la.nslots;
+            for (size_t i = 0; i < f->rules.size(); i++) la.g.slot_rule[la.g.rule_slot[i]] = (uint8_t) i;
+            if (!lane_geometry(in, dm, st, la)) return false;
             const uint64_t nunits = grep_lane_units(la.ntiles);
             if (!f->d_units.ensure(nunits * 8 + 8) || !f->d_out.ensure(in->bytes + 32)) return false;
             HIPOK(hipMemsetAsync(f->d_units.p, 0, nunits * 8, st));
@@ -1943,6 +1959,90 @@ static bool run_grep_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_de
     out->data = f->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = total;
     *ret = FLBGPU_FILTER_MODIFIED;
     return true;
+}
+
+// Two filter_grep instances that follow each other in a chain, as ONE pass of the one-pass kernel.  flb_filter_do hands the second
+// instance what the first one keeps (src/flb_filter.c:247-269) and grep rewrites no record, so a record leaves the pair iff both keep
+// it: one read of the chunk, one walk of a record for the names of both, one output.  What each instance would have reported on its
+// own (records in and out, bytes out, MODIFIED or NOTOUCH: plugins/filter_grep/grep.c:356-385) comes from the pass's counters.
+static bool grep_pair_fusable(const flbgpu_filter *a, const flbgpu_filter *b, const flbgpu_dev_chunk *in) {
+    static const bool off = getenv("FLBGPU_GREP_PAIR") && atoi(getenv("FLBGPU_GREP_PAIR")) == 0;
+    if (off || grep_lane_off() || g_spec.on) return false;
+    if (a->kind != F_GREP || b->kind != F_GREP || a->has_host_rules || b->has_host_rules) return false;
+    if (a->rules.empty() || b->rules.empty() || a == b) return false;
+    return in->n > 0 && in->row_off && ((uintptr_t) in->data & 15) == 0;
+}
+
+// 1: done (s2 and *out filled; *out = *in when neither instance answers MODIFIED), 0: not for this pair (the instances run one by one)
+static int run_grep_pair(flbgpu_filter *f, flbgpu_filter *f2, const flbgpu_dev_chunk *in, flbgpu_dev_chunk *out, hipStream_t st,
+                         bool trailing_garbage, flbgpu_chain_stat *s2) {
+    const uint64_t n = in->n;
+    GrepLaneArgs la;
+    memset(&la, 0, sizeof(la));
+    uint32_t used = 0;
+    if (!lane_rules(f, la.g, la, used)) return 0;
+    const int own = la.nslots;
+    if (!lane_rules(f2, la.g2, la, used)) return 0;
+    if (!f->d_misc.ensure(sizeof(MiscWords)) || !f->hp_misc.ensure(sizeof(MiscWords) + 4 * sizeof(uint64_t))) return 0;
+    MiscWords *dm = f->d_misc.as<MiscWords>();
+    MiscWords &hm = *f->hp_misc.as<MiscWords>();
+    memset(&hm, 0, sizeof(hm));
+    hm.first_bad = ~0ull;
+    if (hipMemcpyAsync(dm, &hm, sizeof(hm), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    if (!f->d_len.ensure(n * sizeof(uint32_t)) || !f->d_status.ensure(n * sizeof(uint32_t)) || !f->d_off.ensure((n + 1) * sizeof(uint64_t))) return 0;
+    GrepArgs &ga = la.g;
+    ga.data = (const uint8_t *) in->data; ga.row_off = in->row_off; ga.n = n; ga.bytes = in->bytes; ga.rules = f->d_rules.as<GrepRule>();
+    ga.nrules = (int) f->rules.size(); ga.logical_op = f->logical_op; ga.keep_len = f->d_len.as<uint32_t>();
+    ga.status = f->d_status.as<uint32_t>(); ga.first_bad = &dm->first_bad; ga.counts = dm->counts;
+    // (the odd records go through the functions of k_grep_match: the first instance's names are the first slots, its own walk finds
+    // them; the second instance's rules look their values up one by one there)
+    ga.nslots = own;
+    for (size_t i = 0; i < f->rules.size(); i++) ga.slot_rule[ga.rule_slot[i]] = (uint8_t) i;
+    GrepArgs &gb = la.g2;
+    gb.data = ga.data; gb.row_off = ga.row_off; gb.n = n; gb.bytes = ga.bytes; gb.rules = f2->d_rules.as<GrepRule>();
+    gb.nrules = (int) f2->rules.size(); gb.logical_op = f2->logical_op; gb.keep_len = ga.keep_len; gb.status = ga.status;
+    gb.first_bad = ga.first_bad; gb.counts = ga.counts; gb.nslots = 0;
+    la.two = 1;
+    if (!lane_geometry(in, dm, st, la)) return 0;
+    const uint64_t nunits = grep_lane_units(la.ntiles);
+    if (!f->d_units.ensure(nunits * 8 + 8) || !f2->d_out.ensure(in->bytes + 32)) return 0;
+    if (hipMemsetAsync(f->d_units.p, 0, nunits * 8, st) != hipSuccess) return 0;
+    la.off_out = f->d_off.as<uint64_t>(); la.out = f2->d_out.as<uint8_t>(); la.out_cap = in->bytes;
+    la.unit_state = f->d_units.as<unsigned long long>();
+    la.ticket = &dm->counts[12]; la.words = &dm->counts[10];
+    { ProfScope ps(f, st, "k_grep_lane(two instances)"); launch_grep_lane(la, g_cus > 0 ? g_cus : 256, st); }
+    if (hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+    if (hm.counts[11]) return 0;
+    f->calls++; f2->calls++;
+    const uint64_t dec = hm.counts[0], kept1 = hm.counts[1], kept2 = hm.counts[2], bytes1 = hm.counts[3], bytes2 = hm.counts[10];
+    memset(s2, 0, 2 * sizeof(*s2));
+    *out = *in;
+    f->last_in = f->last_out = dec; f2->last_in = f2->last_out = dec;
+    s2[0].ret = s2[1].ret = FLBGPU_FILTER_NOTOUCH;
+    s2[0].in_records = s2[0].out_records = s2[1].in_records = s2[1].out_records = dec;
+    s2[0].out_bytes = s2[1].out_bytes = in->bytes;
+    if (hm.first_bad != ~0ull || trailing_garbage) return 1;             // a decoder error: both instances meet it, both answer NOTOUCH
+    const bool mod1 = kept1 != dec;
+    if (mod1) {
+        f->last_out = kept1;
+        s2[0].ret = FLBGPU_FILTER_MODIFIED; s2[0].out_records = kept1; s2[0].out_bytes = bytes1;
+        if (bytes1 == 0) {                                               // nothing left: flb_filter_do stops in front of the second instance
+            memset(&s2[1], 0, sizeof(s2[1]));
+            f2->last_in = f2->last_out = 0;
+            memset(out, 0, sizeof(*out));
+            out->data = f2->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = 0;
+            return 1;
+        }
+        f2->last_in = f2->last_out = kept1;
+        s2[1].in_records = s2[1].out_records = kept1; s2[1].out_bytes = bytes1;
+    }
+    const bool mod2 = kept2 != (mod1 ? kept1 : dec);
+    if (mod2) {
+        f2->last_out = kept2;
+        s2[1].ret = FLBGPU_FILTER_MODIFIED; s2[1].out_records = kept2; s2[1].out_bytes = bytes2;
+    }
+    if (mod1 || mod2) { out->data = f2->d_out.p; out->row_off = f->d_off.as<uint64_t>(); out->n = n; out->bytes = bytes2; }
+    return 1;
 }
 
 // the rule gate of a filter_log_to_metrics whose rules run on the host (host_int.hpp flbgpu_filter::l2m_gate)
@@ -2304,6 +2404,22 @@ static int chain_dev(flbgpu_filter *const *filters, int n, const flbgpu_dev_chun
                 g_fused_failures.fetch_add(1, std::memory_order_relaxed);
                 *out = *in;
                 return FLBGPU_FILTER_NOTOUCH;
+            }
+        }
+        if (i + 1 < n && grep_pair_fusable(filters[i], filters[i + 1], &cur)) {
+            flbgpu_chain_stat s2[2];
+            if (run_grep_pair(filters[i], filters[i + 1], &cur, &o, filters[i]->stream, garbage && !modified, s2) == 1) {
+                if (stats) { stats[i] = s2[0]; stats[i + 1] = s2[1]; }
+                const bool mod = s2[0].ret == FLBGPU_FILTER_MODIFIED || s2[1].ret == FLBGPU_FILTER_MODIFIED;
+                i++;
+                if (!mod) continue;
+                modified = true;
+                cur = o;
+                if (o.bytes == 0) {
+                    if (stats) for (int j = i + 1; j < n; j++) { memset(&stats[j], 0, sizeof(stats[j])); }
+                    break;
+                }
+                continue;
             }
         }
         g_spec.last = i + 1 == n;

@@ -14,6 +14,12 @@ struct GrepLaneArgs {
     uint32_t rows_per_tile;             // <= 64
     unsigned long long *prof;           // measurement only (FLBGPU_GREP_PROF): [8] shader cycles per phase, summed over the waves
     uint32_t text_cap;                  // LDS bytes of a wave's records (a multiple of 16, <= grep_lane_text_max())
+    // two filter_grep instances that follow each other in a chain run as ONE pass (flb_filter_do hands the second what the first keeps, and
+    // grep changes no record): g2 = the second filter's rules (its table offsets count on behind the first's; counts[2] = what it keeps,
+    // counts[3] = the bytes the first keeps); the slots below are the names of both
+    int two;
+    GrepArgs g2;
+    int nslots;                         // names in slot_kw / slot_klen (GrepArgs::rule_slot of both filters index them)
     // the slots' keys as the dwords a lane reads them (little endian, zero padded): a name of up to 32 bytes is compared with eight
     // masked dword tests, no byte loop
     uint32_t slot_kw[GREP_SLOTS][8];
