@@ -191,7 +191,11 @@ struct DevParser {
     const int64_t *tz_trans;             // device memory, owned by the flbgpu_parser
     const int32_t *tz_gmtoff;
     const uint8_t *tz_ttype;
+    // a HOST parser (the Regex is not a regular expression: the host's backtracking matcher answers, rxbt.inc): no tables above; in a
+    // list of parsers its answers for the chunk's values stand in ParserMatchArgs::host_res[host_slot] (k_parser_generic reads them)
+    int host_only, host_slot;
 };
+constexpr int MAX_HOST_PARSERS = 4;      // host parsers in one list of parsers
 
 // ---- record accessor / key
 struct DevKey {
@@ -355,6 +359,9 @@ struct ParserMatchArgs {
     const uint8_t *tail_buf;         // the chunk's bytes from tail_start on, followed by 512 zero bytes (wide loads of the last records)
     uint64_t tail_start;
     TileCfg tc;
+    // a list of parsers with host parsers in it: per host parser [1 + 2 * nfields][n] -- column 0 = 1 + the offset in the record of the
+    // value the matcher took (0: it did not match / the row is no candidate), then the capture spans as k_parser_rx writes them
+    const uint32_t *host_res[MAX_HOST_PARSERS];
     const ParserMatchArgs *self;     // this structure in device memory: what the out-of-line slow paths read (taking the address of a
                                      // kernel argument makes the compiler keep the whole argument block in scratch memory)
 };
@@ -673,12 +680,12 @@ struct JsonArgs {
     uint32_t *cnt;              // [8][n] element counts of each row's first containers (size pass -> emit pass)
     int events;                 // wrap single-object rows as V2 log events with the timestamp below
     uint32_t ts_sec, ts_nsec;
-    unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error; the tile pass (jtile_kernels.inc): [3] rows it left
-                                // to the row-per-lane kernels, [4] bytes it wrote, [5] tiles without room in `out`, [6] tokens, [7] its tile counter
-    int tile_mode;              // the tile pass ran first: the row-per-lane kernels take only the rows it marked JS_TDEFER
+    unsigned long long *counts; // [0] rows deferred, [1] values parsed, [2] rows in error; the one-pass kernel (jlane_kernels.inc): [3] rows it left
+                                // to the row-per-lane kernels, [4] bytes it wrote, [5] workgroups without room in `out`, [6] tokens, [7] its ticket counter
+    int tile_mode;              // the one-pass kernel ran first: the row-per-lane kernels take only the rows it marked JS_TDEFER
 };
 
-// the NDJSON tile pass (jtile_kernels.inc): one wave per tile of rows, text read once, output placed by a look-back over the tiles
+// the NDJSON one-pass kernel (jlane_kernels.inc): a row per lane in LDS, text read once, output placed by a look-back over the workgroups
 struct JtArgs {
     JsonArgs j;                 // text, row_off, n, the row columns, out, events, ts, counts
     uint64_t *off_out;          // [n + 1] row offsets of the output (written by the pass)
@@ -854,9 +861,6 @@ void launch_l2m_rehash(const L2mTable &t, uint32_t nseries, hipStream_t st);
 void launch_json_size(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_emit(const JsonArgs &a, int cus, hipStream_t st);
 void launch_json_generic(const JsonArgs &a, bool emit, hipStream_t st);
-void launch_json_tile(const JtArgs &a, int cus, hipStream_t st);
-int json_tile_text_bytes();
-uint64_t json_tile_units(uint64_t ntiles);
 size_t idx_tiles(uint64_t bytes);
 size_t idx_blocks(uint64_t nc);
 void launch_idx_count(const uint8_t *data, uint64_t bytes, uint64_t *masks, uint32_t *tile_cnt, hipStream_t st);

@@ -862,16 +862,21 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
         f->pcfg.key.key_len = (int) n;
     }
     std::vector<DevParser> dp;
-    // a HOST parser (a Regex that is not a regular expression, csrc/rxbt.inc) runs in the place of k_parser_rx for parser 0 of a
-    // one-entry list: it has no device tables for the generic kernel's "try every parser" loop (a list with such a
-    // parser at any index left records unparsed or walked null tables).  Refused here, with its reason, instead.
-    for (int i = 0; i < nparsers; i++)
-        if (parsers[i] && parsers[i]->bt && nparsers > 1) {
-            set_err("filter_parser: parser %d of %d has a Regex that is not a regular expression (look-around, back-reference, atomic group ...): "
-                    "such a parser is supported as the only Parser entry of a filter", i + 1, nparsers);
+    // a HOST parser (a Regex that is not a regular expression, csrc/rxbt.inc): as the only entry of a list it runs in the place of
+    // k_parser_rx (host_parser_rx); in a list of several parsers its answers for the chunk's values are computed before the list's
+    // kernel runs, which reads them where it would walk a device parser's tables (host_list_rx, k_parser_generic)
+    {
+        int nhost = 0;
+        for (int i = 0; i < nparsers; i++) if (parsers[i] && parsers[i]->bt) nhost++;
+        if (nparsers > 1 && nhost > MAX_HOST_PARSERS) {
+            set_err("filter_parser: %d of the %d parsers have a Regex that is not a regular expression (look-around, back-reference, atomic group ...): "
+                    "a list takes up to %d of them", nhost, nparsers, MAX_HOST_PARSERS);
             delete f;
             return nullptr;
         }
+        f->host_list = nparsers > 1 && nhost > 0;
+    }
+    int host_slot = 0;
     for (int i = 0; i < nparsers; i++) {
         f->parsers.push_back(parsers[i]);
         parsers[i]->dev.tz_trans = nullptr; parsers[i]->dev.tz_gmtoff = nullptr; parsers[i]->dev.tz_ttype = nullptr;
@@ -904,6 +909,8 @@ extern "C" flbgpu_filter *flbgpu_filter_parser_create(const char *key_name, int 
             f->has_decoders = true;
         }
         dp.push_back(parsers[i]->dev);
+        dp.back().host_only = parsers[i]->bt ? 1 : 0;
+        dp.back().host_slot = parsers[i]->bt ? (host_slot++ & (MAX_HOST_PARSERS - 1)) : 0;
         if ((uint32_t) parsers[i]->dev.nfields * 2 > f->caps_stride) f->caps_stride = (uint32_t) parsers[i]->dev.nfields * 2;
     }
     if (f->caps_stride == 0) f->caps_stride = 2;
@@ -1228,6 +1235,60 @@ static bool host_parser_rx(flbgpu_filter *f, const flbgpu_dev_chunk *in, const P
     return true;
 }
 
+// Host parsers inside a list of several parsers (plugins/filter_parser/filter_parser.c:286-323 tries the list in order on every value):
+// each one's capture search on the values k_parser_locate found, by the backtracking matcher, BEFORE the list's kernel runs -- per host
+// parser [1 + 2 * nfields][n] words (dev.hpp ParserMatchArgs::host_res).  Every candidate row goes to that kernel (RF_GENERIC).
+static bool host_list_rx(flbgpu_filter *f, const flbgpu_dev_chunk *in, ParserMatchArgs &ma, hipStream_t st) {
+    const uint64_t n = ma.n;
+    std::vector<uint32_t> info(3 * (size_t) n);
+    HIPOK(hipMemcpyAsync(info.data(), ma.info, info.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    std::vector<uint8_t> copy;
+    std::vector<uint64_t> off;
+    const uint8_t *hd = nullptr;
+    if (!host_chunk(in, st, copy, &hd, off)) { set_err("filter_parser: copying the chunk back for the host parsers failed"); return false; }
+    const uint64_t total_bytes = in->bytes;
+    int slot = 0;
+    std::atomic<uint64_t> over{0}, vals{0}, unhandled{0};
+    for (size_t q = 0; q < f->parsers.size(); q++) {
+        const flbgpu_parser *hp = f->parsers[q];
+        if (!hp->bt) continue;
+        const DevParser &d = hp->dev;
+        const int ncap = 2 * d.nfields, ng = rx::bt_ngroups(hp->bt);
+        std::vector<uint32_t> res((size_t) (1 + ncap) * n, 0u);
+        const bool first = slot == 0;
+        parallel_rows(n, [&](uint64_t a, uint64_t b) {
+            std::vector<int> beg((size_t) ng + 1), end((size_t) ng + 1);
+            uint64_t ov = 0, nv = 0, un = 0;
+            for (uint64_t r = a; r < b; r++) {
+                const uint32_t fl = info[r];
+                if (fl & RF_GENERIC) { if (first) un++; continue; }      // (duplicate Key_Name entries: the value was not located as one -- the matcher's answer is "no")
+                if (!(fl & RF_CAND)) continue;
+                const uint32_t vo = info[(size_t) n + r], vlen = info[2 * (size_t) n + r];
+                if (off[r] + vo + (uint64_t) vlen > total_bytes || vlen > 0x7FFFFFF0u) continue;
+                const int rr = rx::bt_search(hp->bt, hd + off[r] + vo, (int) vlen, beg.data(), end.data());
+                nv++;
+                if (rr == -4) ov++;
+                if (rr <= 0) continue;
+                res[r] = vo + 1;
+                for (int k = 0; k < d.nfields; k++) {
+                    const int g = d.field_group[k];
+                    res[(size_t) (1 + 2 * k) * n + r] = beg[(size_t) g] >= 0 ? (uint32_t) beg[(size_t) g] : CAP_UNSET;
+                    res[(size_t) (2 + 2 * k) * n + r] = end[(size_t) g] >= 0 ? (uint32_t) end[(size_t) g] : CAP_UNSET;
+                }
+            }
+            over += ov; vals += nv; unhandled += un;
+        });
+        if (!f->d_hres[slot].ensure(res.size() * sizeof(uint32_t))) return false;
+        HIPOK(hipMemcpy(f->d_hres[slot].p, res.data(), res.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ma.host_res[slot] = f->d_hres[slot].as<uint32_t>();
+        slot++;
+    }
+    f->host_budget_over += over.load(); f->host_values += vals.load(); f->host_unhandled += unhandled.load();
+    for (uint64_t r = 0; r < n; r++) if (info[r] & RF_CAND) info[r] |= RF_GENERIC;
+    HIPOK(hipMemcpy(ma.info, info.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return true;
+}
+
 static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipStream_t st, MiscWords **dm_out, MiscWords **hm_out, uint64_t *n_valid,
                              PairCtx *pair = nullptr, bool *ahead = nullptr) {
     uint64_t n = in->n;
@@ -1440,7 +1501,18 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         return true;
     };
     if ((f->parsers[0]->dev.is_json || !use_tile || tile_in_lds) && !prep_now()) return false;
-    if (f->parsers[0]->bt) {
+    if (f->host_list) {
+        // host parsers in a list of several: locate on the device, every host parser's capture search on the host, then the list's own
+        // kernel over every candidate -- it reads the answers where it would walk a device parser's tables
+        ParserMatchArgs ml = ma;
+        ml.caps_in_lds = 1; ml.chk_len = 0x7FFFFFFFu;
+        { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ml, cus, st); }
+        if (!host_list_rx(f, in, ma, st)) return false;
+        if (!run_generic()) return false;
+        HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
+        HIPOK(hipStreamSynchronize(st));
+    }
+    else if (f->parsers[0]->bt) {
         // a HOST parser (the Regex is not a regular expression): locate on the device, the capture search on the host, finish on the
         // device.  Every single candidate is located as one (no length limit of a device walker applies).
         ParserMatchArgs ml = ma;
@@ -2083,7 +2155,7 @@ static bool pair_fusable(const flbgpu_filter *fp, const flbgpu_filter *fg) {
     // call, inside the hot single-pass kernel): the unfused kernels take the pair
     if (d.utf8.nfa_on || d.ascii.stub) return false;
     for (const GrepRule &r : fg->rules) if (r.utf8.nfa_on) return false;
-    if (fp->parsers[0]->bt || fg->has_host_rules) return false;                 // (host rules: the unfused kernels)
+    if (fp->parsers[0]->bt || fp->host_list || fg->has_host_rules) return false;  // (host rules: the unfused kernels)
     return true;
 }
 

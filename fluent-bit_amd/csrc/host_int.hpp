@@ -201,6 +201,8 @@ struct flbgpu_filter {
     // filter_log_to_metrics whose regex / exclude rules hold a pattern that is not a regular expression: the rules live in this hidden
     // filter_grep (host rules, flbgpu.cpp) and run in FRONT of the metric kernels, which then see the kept records and no rules
     flbgpu_filter *l2m_gate = nullptr;
+    bool host_list = false;                     // filter_parser: a list of several parsers with host parsers in it (flbgpu.cpp host_list_rx)
+    flbgpu::DevBuf d_hres[flbgpu::MAX_HOST_PARSERS];   // their answers for the chunk at hand
     // msgpack -> JSON output formatter (packfmt.cpp)
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
@@ -223,6 +225,7 @@ struct flbgpu_filter {
         for (auto *b : host_rx) if (b) rx::bt_free(b);
         delete l2m_gate;
         d_hspans.release(); d_hbits.release();
+        for (auto &b : d_hres) b.release();
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
                                  &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix, &d_units};
         for (auto *b : all) b->release();

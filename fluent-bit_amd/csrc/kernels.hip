@@ -425,6 +425,8 @@ __global__ void __launch_bounds__(256) k_parser_generic(ParserMatchArgs a) {
                     last_ok = t.ok;
                     ps = t.sec; pn = t.nsec; nk = t.npairs; dm = t.skip;
                 }
+                else if (a.parsers[q].host_only)
+                    last_ok = host_parser_answer(a.parsers[q], a.host_res[a.parsers[q].host_slot & (MAX_HOST_PARSERS - 1)], a.n, r, vptr, (uint32_t) (vptr - rec), capg, &ps, &pn, &nk, &dm);
                 else
                 last_ok = try_parser(a.parsers[q], hot_global(a.parsers[q].ascii), vptr, vlen, chk, a.chk_len, a.chk_nfa_off, capg, &ps, &pn, &nk, &dm, 0u);
                 if (last_ok) {

@@ -1,7 +1,8 @@
 #!/bin/bash
 # build.sh -- builds the loadable plugins against the headers of a fluent-bit source tree (no cmake: the
 # generated headers are the stubs of mkstubs.sh -- with the layout switches of a STOCK engine build --, or, with FLB_INFO_DIR=<dir>, the
-# ones a configured engine tree generated) plus the test host that loads them:
+# ones a configured engine tree generated) plus the test host that loads them (tests/plugin_host.c: test infrastructure, not part of the
+# package; NO_HOST=1 leaves it out):
 #   _build/flb-filter_grep_gpu.so  _build/flb-filter_parser_gpu.so  _build/flb-filter_log_to_metrics_gpu.so
 #   _build/plugin_host
 # The file names and the exported data symbols filter_<x>_gpu_plugin are what `fluent-bit -e <file>` /
@@ -37,8 +38,8 @@ CMT=$HERE/../../oracle/_ref
 if [ -n "$NO_HOST" ]; then
   :
 elif [ -f $CMT/libcmetrics_ref.so ]; then
-  gcc -O2 -Wall -rdynamic -DHOST_WITH_CMT $INC -I$CMT/stub3 -o $B/plugin_host $HERE/plugin_host.c -L$CMT -lcmetrics_ref -lm -Wl,-rpath,'$ORIGIN/../../../oracle/_ref' -ldl
+  gcc -O2 -Wall -rdynamic -DHOST_WITH_CMT $INC -I$CMT/stub3 -o $B/plugin_host $HERE/../../tests/plugin_host.c -L$CMT -lcmetrics_ref -lm -Wl,-rpath,'$ORIGIN/../../../oracle/_ref' -ldl
 else
-  gcc -O2 -Wall -rdynamic $INC -o $B/plugin_host $HERE/plugin_host.c -ldl
+  gcc -O2 -Wall -rdynamic $INC -o $B/plugin_host $HERE/../../tests/plugin_host.c -ldl
 fi
 echo "built: $(ls $B | grep -v stub | tr '\n' ' ')"

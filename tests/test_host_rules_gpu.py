@@ -172,14 +172,54 @@ def test_host_parser_that_rejects_lines(g):
     assert r == ro and out == oo
 
 
-def test_host_parser_in_a_list_is_refused_with_its_reason(g):
-    """a host parser at any index of a several-parser list has no device tables for the list's loop; the filter says so at
-    create (a one-entry list runs, the tests above)"""
-    hp, dp = g.Parser(r"^(?!#)(?<key>[^=]+)=(?<val>.*)$"), g.Parser(r"^(?<all>.*)$")
-    for lst in ([hp, dp], [dp, hp]):
-        with pytest.raises(ValueError, match="not a regular expression"):
-            g.FilterParser("log", lst)
-    assert g.FilterParser("log", [hp]).host_rules()["rules"] == 1
+# (host form, the same language as a regular expression): pairs for lists of parsers
+HOST_KV = (r"^(?!#)(?<key>[^=]+)=(?<val>.*)$", r"^(?<key>[^#=][^=]*)=(?<val>.*)$")
+HOST_REQ = (r"^(?=[A-Z]+ /)(?<method>[A-Z]++) (?<path>\S+) (?<code>\d+)", r"^(?<method>[A-Z]+) (?<path>/\S*) (?<code>\d+)")
+HOST_NUM = (r"(?<word>[a-z]+(?>:)) (?<rest>.*)$", r"(?<word>[a-z]+:) (?<rest>.*)$")
+DEV_ALL = r"^(?<all>.+)$"
+DEV_PRICE = r"^price (?<amount>\d+) ?(?<cur>[A-Z]+)"
+
+
+@pytest.mark.parametrize("order", [
+    ["KV", "ALL"], ["ALL", "KV"],                        # a host parser first / last of two
+    ["PRICE", "KV", "ALL"],                              # ... between two device parsers
+    ["REQ", "KV", "NUM", "PRICE"],                       # three host parsers, a device parser behind them: rows nobody takes stay as they are
+    ["PRICE", "REQ", "ALL", "KV"],                       # a host parser behind a device parser that takes everything: never asked
+])
+@pytest.mark.parametrize("reserve", [False, True])
+def test_host_parsers_in_a_list(g, order, reserve):
+    """plugins/filter_parser/filter_parser.c:286-323: the list is tried in order on every value, the first parser that takes it wins.  A
+    host parser's answers are computed before the list's kernel runs, which reads them in the parser's turn -- against the oracle's
+    filter_parser over the same list with the equivalent regular expressions"""
+    recs, vals = records(6000, 31)
+    blob = b"".join(recs)
+    host = {"KV": HOST_KV, "REQ": HOST_REQ, "NUM": HOST_NUM}
+    dev = {"ALL": DEV_ALL, "PRICE": DEV_PRICE}
+    gp = [g.Parser(host[k][0]) if k in host else g.Parser(dev[k]) for k in order]
+    op = [ob.Parser(regex=host[k][1]) if k in host else ob.Parser(regex=dev[k]) for k in order]
+    f = g.FilterParser("log", gp, reserve, False)
+    assert f.host_rules()["rules"] == sum(1 for k in order if k in host)
+    r, out = f.filter(blob)
+    ro, oo = ob.FilterParser("log", op, reserve, False).filter(blob)
+    assert r == ro and out == oo
+    assert f.host_rules()["unhandled"] == 0
+    # ... the same list on a device-resident chunk in front of a device grep
+    ch = g.FilterChain([f, g.FilterGrep([("exclude", "key ^user$")])])
+    r2, o2 = ch.filter(blob)
+    r3, o3 = ob.Grep([("exclude", "key ^user$")]).filter(oo if ro == ob.MODIFIED else blob)
+    if r3 == ob.MODIFIED:
+        assert r2 == ob.MODIFIED and o2 == o3
+    else:
+        assert (r2, o2) == (ro, oo if ro == ob.MODIFIED else None)
+    f.close()
+
+
+def test_a_list_takes_four_host_parsers(g):
+    hp = [g.Parser(r"^(?!%s)(?<key>[^=]+)=(?<val>.*)$" % c) for c in "#;!%~"]
+    with pytest.raises(ValueError, match="a list takes up to 4"):
+        g.FilterParser("log", hp)
+    assert g.FilterParser("log", hp[:4]).host_rules()["rules"] == 4
+    assert g.FilterParser("log", hp[:1]).host_rules()["rules"] == 1
 
 
 def test_refused_when_asked_to(g):

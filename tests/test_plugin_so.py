@@ -1,6 +1,7 @@
 """The drop-in boundary as the engine sees it: flb-filter_<x>_gpu.so files (fluent-bit_amd/plugin/build.sh, compiled
 against the reference's headers) are dlopen'd by a minimal host that restates src/flb_plugin.c:194-320's loading and
-src/flb_filter.c's cb_init / cb_filter / cb_exit sequence (plugin/plugin_host.c), and their output is the oracle's."""
+src/flb_filter.c's cb_init / cb_filter / cb_exit sequence (tests/plugin_host.c), and their output is the oracle's.  The same objects inside the
+reference's own engine: tests/test_engine.py (oracle/engine/engine_host.c)."""
 import os, re, subprocess, tempfile
 import pytest
 
