@@ -1504,6 +1504,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     if (f->host_list) {
         // host parsers in a list of several: locate on the device, every host parser's capture search on the host, then the list's own
         // kernel over every candidate -- it reads the answers where it would walk a device parser's tables
+        if (!prep_now()) return false;
         ParserMatchArgs ml = ma;
         ml.caps_in_lds = 1; ml.chk_len = 0x7FFFFFFFu;
         { ProfScope ps(f, st, "k_parser_locate"); launch_parser_locate(ml, cus, st); }

@@ -201,7 +201,7 @@ def test_host_parsers_in_a_list(g, order, reserve):
     assert f.host_rules()["rules"] == sum(1 for k in order if k in host)
     r, out = f.filter(blob)
     ro, oo = ob.FilterParser("log", op, reserve, False).filter(blob)
-    assert r == ro and out == oo
+    assert r == ro and out == oo, g.last_error()
     assert f.host_rules()["unhandled"] == 0
     # ... the same list on a device-resident chunk in front of a device grep
     ch = g.FilterChain([f, g.FilterGrep([("exclude", "key ^user$")])])

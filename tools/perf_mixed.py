@@ -1,39 +1,45 @@
 #!/usr/bin/env python3
-"""secondary.mixed_shapes by kernel: the headline pair on line lengths 80-600 B, 10 % multi-key bodies, 1 % legacy events, and on
-sub-mixes (only the lengths / only the layouts) to see which property costs what"""
-import os, sys
-import numpy as np
+"""bench.py's mixed_shapes chunk (line lengths 80-600 B, 10 % multi-key bodies, 1 % legacy events) through the pair, per kernel.
+usage: perf_mixed.py [steps]"""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import flbamd_loader, synth, bench
-from bench import APACHE2, TIME_FMT, GREP_RULE
-g = flbamd_loader.load(); g.init(0); L = g.lib()
-recs = bench.mixed_shape_records()
-def is_plain(r): return r[:4] == b"\x92\x92\xd7\x00" and r[12:14] == b"\x80\x81"
-variants = {"all": recs,
-            "plain layout only (all lengths)": [r for r in recs if is_plain(r)],
-            "<= 277 B plain": [r for r in recs if is_plain(r) and len(r) <= 300],
-            "400 + 600 B plain": [r for r in recs if is_plain(r) and len(r) > 380],
-            "multi-key + legacy only": [r for r in recs if not is_plain(r)]}
-for name, rs in variants.items():
-    if not rs: continue
-    tiles = max(1, 3_000_000 // len(rs))
-    pool = b"".join(rs); mdata = pool * tiles
-    sizes = np.array([len(x) for x in rs], dtype=np.uint64)
-    moff = np.zeros(len(rs) * tiles + 1, dtype=np.uint64); np.cumsum(np.tile(sizes, tiles), out=moff[1:])
-    mn = len(rs) * tiles
+import numpy as np
+import flbamd_loader
+import bench as b
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    g = flbamd_loader.load(); g.init(0); L = g.lib()
+    recs = b.mixed_shape_records()
+    tiles = 3_000_000 // len(recs)
+    mdata = b"".join(recs) * tiles
+    sizes = np.array([len(x) for x in recs], dtype=np.uint64)
+    moff = np.zeros(len(recs) * tiles + 1, dtype=np.uint64)
+    np.cumsum(np.tile(sizes, tiles), out=moff[1:])
+    mn = len(recs) * tiles
     d_md = L.flbgpu_dev_alloc(len(mdata) + 16); d_mo = L.flbgpu_dev_alloc(moff.nbytes)
     L.flbgpu_memcpy_h2d(d_md, mdata, len(mdata)); L.flbgpu_memcpy_h2d(d_mo, moff.ctypes.data, moff.nbytes)
     mch = g.DevChunk(d_md, d_mo, mn, len(mdata))
-    p = g.Parser(APACHE2, time_fmt=TIME_FMT, time_key="time")
-    fp = g.FilterParser("log", [p]); fg = g.FilterGrep([GREP_RULE]); ch = g.FilterChain([fp, fg])
-    for _ in range(2): ch.filter_dev(mch)
-    fp.profile(True)
-    import time
-    L.flbgpu_sync(); t0 = time.perf_counter()
-    for _ in range(5): ch.filter_dev(mch)
-    L.flbgpu_sync(); dt = (time.perf_counter() - t0) / 5
-    prof = dict(fp.profile_read()); fp.profile(False)
-    print("%-34s %8d recs %6.1f MB  %.3f ms  %6.1f GB/s  %5.2f Grec/s | " % (name, mn, len(mdata) / 1e6, dt * 1e3, len(mdata) / dt / 1e9, mn / dt / 1e9) +
-          "  ".join("%s %.3f" % (k, v[0] / max(v[1], 1)) for k, v in prof.items()), flush=True)
-    fp.close(); fg.close(); p.close(); L.flbgpu_dev_free(d_md); L.flbgpu_dev_free(d_mo)
+    p = g.Parser(b.APACHE2, time_fmt=b.TIME_FMT, time_key="time")
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep([b.GREP_RULE])
+    ch = g.FilterChain([fp, fg])
+    for _ in range(3):
+        ch.filter_dev(mch)
+    L.flbgpu_sync()
+    for rnd in range(2):
+        fp.profile(True); fg.profile(True)
+        ts = []
+        for _ in range(steps):
+            L.flbgpu_sync(); t0 = time.perf_counter()
+            ch.filter_dev(mch)
+            L.flbgpu_sync(); ts.append((time.perf_counter() - t0) * 1e3)
+        pr = dict(fp.profile_read()); pr.update(fg.profile_read())
+        fp.profile(False); fg.profile(False)
+        print("calls ms:", " ".join("%.2f" % t for t in ts))
+        print("median %.3f ms  mean %.3f ms   %.0f GB/s at the median" % (sorted(ts)[len(ts) // 2], sum(ts) / len(ts), len(mdata) / sorted(ts)[len(ts) // 2] / 1e6))
+        print("   " + "  ".join("%s %.3f x%d" % (k, v[0] / max(v[1], 1), v[1]) for k, v in pr.items()))
+        print("   paths", fp.paths())
+
+if __name__ == "__main__":
+    main()
