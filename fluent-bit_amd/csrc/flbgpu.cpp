@@ -1413,6 +1413,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.lds_total = tab_bytes + caps_bytes; ma.debug_skip = getenv("FLBGPU_DEBUG_SKIP") ? (uint32_t) atoi(getenv("FLBGPU_DEBUG_SKIP")) : 0; ma.first_bad = &dm->first_bad; ma.counts = dm->counts;
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
+    for (auto &hr : ma.host_res) hr = nullptr;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
     f->last_fx5 = use_tile && !tile_in_lds && ma.use_fx2 == 5;
     f->last_path = (use_tile ? 1u : 0u) | (f->last_fx5 ? 2u : 0u);
@@ -1613,6 +1614,15 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
         if (d_trace && !(ma.trace_iters >> 31)) trace_out();
         HIPOK(hipMemcpyAsync(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost, st));
         HIPOK(hipStreamSynchronize(st));
+        if (f->last_fx5 && n >= 64 && f->parsers[0]->fx2b.ok && hm.counts[9] * 64 > n && !d_trace) {
+            // The three-port tables hand more than one row in 64 of THIS chunk on (a try of the set-aside tables on data that has not
+            // changed, or the first chunk of such data): the kernels behind the walk would now pay for every such row (6.1 ms of
+            // k_parser_generic on bench.py's mixed shapes, where the pass itself takes 0.9) -- the call again from the top instead, with the
+            // four-port tables (note_fx5's verdict, taken here; the caller sees `again`)
+            f->fx5.bad();
+            f->again = true;
+            return false;
+        }
         if (!tile_in_lds && hm.counts[10] > 0) {
             // rows the call-free kernel only flagged (another layout, the last records of the chunk): the same pass with the
             // general locate, guarded loads and the reverse-pass fallback, for those rows
@@ -1670,7 +1680,10 @@ static bool run_parser_dev(flbgpu_filter *f, const flbgpu_dev_chunk *in, flbgpu_
     if (n == 0) return true;
     MiscWords *dm = nullptr, *hmp = nullptr;
     bool ahead = false;
-    if (!parser_size_pass(f, in, st, &dm, &hmp, &n, nullptr, &ahead)) return false;
+    if (!parser_size_pass(f, in, st, &dm, &hmp, &n, nullptr, &ahead)) {
+        if (f->again) { f->again = false; return run_parser_dev(f, in, out, st, ret); }
+        return false;
+    }
     MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (f->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     const uint64_t *row_off = in->row_off;
@@ -2202,7 +2215,10 @@ static int run_pair_fused(flbgpu_filter *fp, flbgpu_filter *fg, const flbgpu_dev
     // whose rules could be settled on the spans
     if (!g_spec.on && hipMemsetAsync(pc.keep_len, 0xFF, n * sizeof(uint32_t), st) != hipSuccess) return -1;      // (ahead: parser_size_pass, with the counters)
     bool ahead = false;
-    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc, &ahead)) return -1;
+    if (!parser_size_pass(fp, in, st, &dm, &hmp, &n, &pc, &ahead)) {
+        if (fp->again) { fp->again = false; return run_pair_fused(fp, fg, in, out, stats2); }
+        return -1;
+    }
     MiscWords &hm = *hmp;
     uint64_t &total = *(uint64_t *) (fp->hp_misc.as<uint8_t>() + sizeof(MiscWords));
     // (counts[14]: a parsed time filter_grep's decoder would read as a group marker -- the unfused kernels restate that, the pair does not)

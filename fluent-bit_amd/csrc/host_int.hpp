@@ -180,6 +180,7 @@ struct flbgpu_filter {
     };
     Probe tile, fx5, defer, plain;
     uint64_t calls = 0;               // device-level calls so far (the Probes' clock)
+    bool again = false;               // parser_size_pass: "this call again from the top" (it has set a Probe aside: the next choice differs)
     bool last_fx5 = false;            // the last launch of the register kernel walked the three-port tables
     int fx_on_device = 0;             // which pair tables this filter's device copy of parser 0 holds: 0 three-port (as created), 1 four-port
     uint32_t last_path = 0;           // what the last call ran: bit 0 single pass, 1 three-port tables, 2 time lookup in k_pg_emit, 3 plain emit build
