@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 from ndjson_synth import GREP32_REGEX, GREP32_EXCLUDE          # noqa: E402  (tests/ is on sys.path)
 
 
-PMC_FILE = os.path.join("profiles", "r5_pmc_hbm_bench_10M.json")
+PMC_FILE = os.path.join("profiles", "r6_pmc_hbm_bench_10M.json")
 
 
 def _sha16(path):
