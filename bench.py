@@ -1049,7 +1049,7 @@ def measure_engine_hosted(data, off, n):
                 j = last_json(r)
                 if "seconds" in j:
                     e["processor_2MB_chunk"] = {"ms_per_call": round(j["seconds"] / j["repeat"] * 1e3, 3), "records_per_s": round(7000 * j["repeat"] / j["seconds"], 1),
-                                                "out_bytes": j["out_bytes"], "units": j.get("units")}
+                                                "out_bytes": j["out_bytes"], "first_call_ms": round(j.get("first_call_seconds", 0.0) * 1e3, 3), "calls_timed": j["repeat"], "units": j.get("units")}
                 else:
                     e["processor_2MB_chunk"] = j
             except Exception as ex:
