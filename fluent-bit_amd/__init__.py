@@ -256,7 +256,7 @@ class _Filter:
         o = (ctypes.c_uint64 * 8)()
         lib().flbgpu_filter_paths(self.h, o)
         lp = int(o[0])
-        return dict(single_pass=bool(lp & 1), three_port=bool(lp & 2), emit_time=bool(lp & 4), plain_emit=bool(lp & 8),
+        return dict(single_pass=bool(lp & 1), three_port=bool(lp & 2), emit_time=bool(lp & 4), plain_emit=bool(lp & 8), rows_by_length=bool(lp & 16),
                     aside=dict(single_pass=bool(o[1]), three_port=bool(o[2]), emit_time=bool(o[3]), plain_emit=bool(o[4])),
                     tries=int(o[5]), returns=int(o[6]), calls=int(o[7]))
 

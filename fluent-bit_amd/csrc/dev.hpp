@@ -362,6 +362,12 @@ struct ParserMatchArgs {
     // a list of parsers with host parsers in it: per host parser [1 + 2 * nfields][n] -- column 0 = 1 + the offset in the record of the
     // value the matcher took (0: it did not match / the row is no candidate), then the capture spans as k_parser_rx writes them
     const uint32_t *host_res[MAX_HOST_PARSERS];
+    // k_parser_reg<false>: the row a wave's lane takes is perm[its place] instead of its place -- the rows ordered by length class
+    // (kernels_perm.hip), so that the position-synchronous walk of a wave is as long as ITS rows and not as the chunk's longest line;
+    // nullptr: chunk order.  len_stat (chunk order only): += longest row x rows of a wave-iteration, [1] += the rows' bytes, from one
+    // wave in eight -- what the host decides the next call's order by
+    const uint32_t *perm;
+    unsigned long long *len_stat;
     const ParserMatchArgs *self;     // this structure in device memory: what the out-of-line slow paths read (taking the address of a
                                      // kernel argument makes the compiler keep the whole argument block in scratch memory)
 };
@@ -524,7 +530,6 @@ struct PgEmitArgs {
     uint64_t bytes;                  // chunk size (bounds the wide tail loads)
     uint64_t out_cap;                // as in ParserEmitArgs
     EmitCfg ec;
-    uint32_t ctp[32];                // the parser's compiled time plan (flbgpu.cpp compile_time_plan; [31] = 0: none, RF_TIMEPEND rows cannot occur)
     unsigned long long *counts;      // [13]: RF_TIMEPEND rows whose time text the fixed-layout plan does not settle (the host repeats the
                                      // call with the lookup inside the single pass, and keeps it there for this filter)
 };

@@ -15,6 +15,7 @@
 #include <thread>
 #include "host_int.hpp"
 #include "grep_lane.hpp"
+#include "perm.hpp"
 
 using namespace flbgpu;
 
@@ -473,7 +474,9 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
                                          int time_keep, int time_strict, const char *types) {
     if (!is_json && !regex) { set_err("parser '%s': missing regex", name ? name : ""); return nullptr; }
     if (is_json) regex = "";
-    if (time_fmt && strstr(time_fmt, "%Z")) {
+    // (a %Z DIRECTIVE: "%%Z" is a literal percent sign and a Z -- ADVICE r5)
+    auto has_zone_directive = [](const char *f) { for (; *f; f++) if (*f == '%') { f++; if (*f == 'Z') return true; if (!*f) break; } return false; };
+    if (time_fmt && has_zone_directive(time_fmt)) {
         // %Z's last resort for a zone text that is in neither of flb_strptime's tables is the PROCESS's zone -- tzname[] and -timezone
         // (src/flb_strptime.c:611-650) --; the device restates that for a process without a zone (UTC).  In any other process the
         // answer for such texts would differ: refused at create, like Time_System_Timezone.  (Before anything touches the
@@ -1052,7 +1055,7 @@ extern "C" flbgpu_filter *flbgpu_filter_grep_create(int nrules, const char *cons
 extern "C" void flbgpu_filter_destroy(flbgpu_filter *f) { delete f; }
 
 // which builds a filter_parser instance runs (host_int.hpp Probe: no choice is for good): out[0] what the last call ran (bit 0 the single
-// pass, 1 the three-port pair tables, 2 the time lookup in k_pg_emit, 3 the plain emit build), out[1..4] whether the single pass / the
+// pass, 1 the three-port pair tables, 2 the time lookup in k_pg_emit, 3 the plain emit build, 4 the rows walked in the order of their lengths), out[1..4] whether the single pass / the
 // three-port tables / the emit-side lookup / the plain build are set aside right now, out[5] tries of a build that was set aside,
 // out[6] tries that brought it back, out[7] device-level calls so far
 extern "C" int flbgpu_filter_paths(flbgpu_filter *f, uint64_t *out8) {
@@ -1084,7 +1087,7 @@ extern "C" void flbgpu_parser_destroy(flbgpu_parser *p) {
 }
 
 // ------------------------------------------------------------------------------------------ run (device level)
-struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[16]; unsigned int ov_count; unsigned int kept_count; };
+struct MiscWords { unsigned long long first_bad; unsigned long long max_row; unsigned long long counts[18]; unsigned int ov_count; unsigned int kept_count; };      // counts[16], [17]: ParserMatchArgs::len_stat
 static const unsigned int OV_CAP = 1u << 16;      // (record, index) pairs of FParserCfg's side list
 
 // Pass 1 of filter_parser on a device chunk: every record decoded, located, matched and sized (locate / rx /
@@ -1172,7 +1175,17 @@ static void note_unsettled(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
     if (f->last_fx5 && f->parsers[0]->fx2b.ok && hm.counts[9] * 64 > n) return;
     if (hm.counts[9] * 8 > n || hm.counts[10] * 4 > n) f->tile.bad(); else f->tile.good();
 }
+// The register kernel's walk is position-synchronous: a wave steps as far as its longest record.  counts[16] / counts[17] = what the walk
+// steps through in chunk order / what the rows hold (dev.hpp ParserMatchArgs::len_stat, perm.hpp): when the lines of this data differ
+// that much in length, the next calls walk the rows in the order of their lengths (kernels_perm.hip); back when they no longer do.
+static void note_lengths(flbgpu_filter *f, const MiscWords &hm) {
+    if (hm.counts[17] == 0) return;
+    const double ratio = (double) hm.counts[16] / (double) hm.counts[17];
+    if (ratio > 1.35) f->sort_rows = true;
+    else if (ratio < 1.15) f->sort_rows = false;
+}
 static bool ahead_counters_ok(flbgpu_filter *f, const MiscWords &hm, uint64_t n) {
+    note_lengths(f, hm);
     note_fx5(f, hm, n);
     note_unsettled(f, hm, n);
     return hm.counts[8] == 0 && hm.counts[2] == 0 && hm.first_bad >= n;
@@ -1414,6 +1427,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
     ma.bytes = in->bytes;
     ma.pg = nullptr; ma.pg_lds_off = 0; ma.pg_keep_len = nullptr; ma.self = nullptr; ma.desc = nullptr; ma.dstride = 0; ma.fix_first = 0; ma.fix_list = nullptr; ma.fix_count = &dm->counts[12]; ma.tail_buf = nullptr; ma.tail_start = 0; ma.stage_lds_off = 0; ma.stage_bytes = 0; ma.stage_nbuf = 0; ma.trace = nullptr; ma.trace_iters = 0;
     for (auto &hr : ma.host_res) hr = nullptr;
+    ma.perm = nullptr; ma.len_stat = nullptr;
     ma.tile_lds_off = 0; ma.tile_wave_bytes = tile_wave_bytes; ma.use_fx2 = use_fx2 ? (fx.pair_bias == 2 ? 5 : fx.pair_bias ? 4 : 3) : 0;
     f->last_fx5 = use_tile && !tile_in_lds && ma.use_fx2 == 5;
     f->last_path = (use_tile ? 1u : 0u) | (f->last_fx5 ? 2u : 0u);
@@ -1574,6 +1588,22 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             ma.fix_list = f->d_fix.as<uint32_t>();
             ma.fix_count = (unsigned long long *) (f->d_fix.as<uint32_t>() + nw * stride);
         }
+        // the rows in the order of their lengths (dev.hpp ParserMatchArgs::perm; note_lengths above decides from the last call's counters;
+        // FLBGPU_SORT_ROWS=0 / 1: never / always, for measurements); a call launched ahead of its sizes keeps the chunk's order
+        if (!tile_in_lds && ma.fix_list && n >= 4096) {
+            static const int sort_env = getenv("FLBGPU_SORT_ROWS") ? atoi(getenv("FLBGPU_SORT_ROWS")) : -1;
+            ma.len_stat = &dm->counts[16];
+            if ((sort_env >= 0 ? sort_env != 0 : f->sort_rows) && !g_spec.on) {
+                const size_t wb = row_perm_work_bytes(n);
+                if (f->d_perm.ensure(n * sizeof(uint32_t)) && f->d_permwork.ensure(wb)) {
+                    ProfScope ps(f, st, "k_row_perm");
+                    if (!launch_row_perm(row_off, n, f->d_perm.as<uint32_t>(), f->d_permwork.p, wb, &dm->counts[16], st)) { set_err("filter_parser: ordering the rows by length failed"); return false; }
+                    ma.perm = f->d_perm.as<uint32_t>();
+                    ma.stage_nbuf = 0;
+                    f->last_path |= 16u;
+                }
+            }
+        }
         ma.self = f->d_args.as<ParserMatchArgs>();
         memcpy(f->hp_args.p, &ma, sizeof(ma));                   // (page-locked: the copy below is a real asynchronous transfer)
         HIPOK(hipMemcpyAsync(f->d_args.p, f->hp_args.p, sizeof(ma), hipMemcpyHostToDevice, st));
@@ -1636,6 +1666,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             HIPOK(hipStreamSynchronize(st));
         }
         if (d_trace) trace_out();
+        note_lengths(f, hm);
         note_fx5(f, hm, n);
         note_unsettled(f, hm, n);
         if (hm.counts[8] > 0) {

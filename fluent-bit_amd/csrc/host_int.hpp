@@ -180,6 +180,7 @@ struct flbgpu_filter {
     };
     Probe tile, fx5, defer, plain;
     uint64_t calls = 0;               // device-level calls so far (the Probes' clock)
+    bool sort_rows = false;           // the register kernel walks the rows in the order of their lengths (flbgpu.cpp note_lengths)
     bool again = false;               // parser_size_pass: "this call again from the top" (it has set a Probe aside: the next choice differs)
     bool last_fx5 = false;            // the last launch of the register kernel walked the three-port tables
     int fx_on_device = 0;             // which pair tables this filter's device copy of parser 0 holds: 0 three-port (as created), 1 four-port
@@ -208,7 +209,7 @@ struct flbgpu_filter {
     flbgpu::JsonFmtCfg jcfg = {};
     flbgpu::DevBuf d_datekey, d_grow;
     // working buffers
-    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec, d_fix, d_units;
+    flbgpu::DevBuf d_info, d_caps, d_null, d_len, d_off, d_scan_tmp, d_out, d_rid, d_rid2, d_misc, d_status, d_out_off, d_ov, d_kept, d_keep, d_pg, d_args, d_desc, d_tail, d_dec, d_fix, d_units, d_perm, d_permwork;
     flbgpu::DevBuf h_in_data, h_in_off;        // device copies of host input (flbgpu_filter_run)
     flbgpu::PinnedBuf hp_misc, hp_args, hp_off, hp_stage[2];    // pinned record offsets / two staging slabs
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -228,7 +229,7 @@ struct flbgpu_filter {
         d_hspans.release(); d_hbits.release();
         for (auto &b : d_hres) b.release();
         flbgpu::DevBuf *all[] = {&d_parsers, &d_rules, &d_info, &d_caps, &d_null, &d_len, &d_off, &d_scan_tmp, &d_out, &d_rid, &d_rid2,
-                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix, &d_units};
+                                 &d_misc, &d_status, &d_out_off, &d_ov, &d_kept, &d_keep, &d_pg, &h_in_data, &h_in_off, &d_datekey, &d_grow, &d_args, &d_desc, &d_tail, &d_dec, &d_fix, &d_units, &d_perm, &d_permwork};
         for (auto *b : all) b->release();
         if (indexer) flbgpu_indexer_destroy(indexer);
         hp_misc.release(); hp_args.release(); hp_off.release(); hp_stage[0].release(); hp_stage[1].release();

@@ -235,7 +235,8 @@ uint64_t flbgpu_filter_regex_corners(flbgpu_filter *f);
  * the phase kernels, three or four capture-write ports in the pair tables, the kept records' time looked up at emit or inside the pass, the
  * plain or the general emit build) are made per call from what the last calls showed; a build that did badly is set aside for 16 calls,
  * then tried again (the interval doubles while the tries fail, up to 1024).  out8: [0] what the last call ran (bit 0 single pass, 1
- * three-port tables, 2 emit-side time lookup, 3 plain emit build), [1..4] set aside right now: single pass / three-port tables / emit-side
+ * three-port tables, 2 emit-side time lookup, 3 plain emit build, 4 the rows walked in the order of their lengths: chunks whose lines
+ * differ a lot in length), [1..4] set aside right now: single pass / three-port tables / emit-side
  * lookup / plain build, [5] tries of a build that was set aside, [6] tries that brought it back, [7] device-level calls so far. */
 int flbgpu_filter_paths(flbgpu_filter *f, uint64_t *out8);
 /* Rules / parsers whose pattern is NOT a regular expression (look-around, atomic groups, possessive repeats, back-references, \Z \G \K; round 5: the absent operator (?~X), subexpression calls \g<..>, more than 31 groups, (?i) over non-ASCII literals and classes, \X)

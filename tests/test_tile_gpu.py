@@ -371,3 +371,76 @@ def test_plain_emit_build_hands_on_what_it_does_not_take(g):
         assert r4 == g.MODIFIED and int(koff[n]) == len(want2[1]) and got.tobytes()[:len(want2[1])] == want2[1], (env, int(o4.bytes), len(want2[1]))
         fg.close(); fp.close(); p.close()
     os.environ.pop("FLBGPU_EMIT_GENERAL", None)
+
+
+def test_rows_walked_in_the_order_of_their_lengths(g):
+    """round 6 (dev.hpp ParserMatchArgs::perm, kernels_perm.hip): the register kernel's walk is position-synchronous, a wave steps as far
+    as its longest record; on a chunk whose lines differ a lot in length the next calls take the rows in the order of their lengths.
+    Nothing observable changes: the chain's output and every instance's counts are the chunk-order call's, the oracle's on blocks of rows,
+    and a chunk of even lines brings the chunk order back."""
+    import numpy as np
+    import bench
+    L = g.lib()
+    recs = bench.mixed_shape_records()[:40000]                  # lines of 80 .. 600 bytes, 10 % four-key bodies, 1 % legacy events
+    assert sum(len(r) for r in recs) > (9 << 20)                # (more than a call launched ahead of its sizes takes)
+    data, off, ep = synth.apache_records(40000)                 # ... and even lines: 256 bytes each
+
+    def upload(blob, sizes):
+        o = np.zeros(len(sizes) + 1, dtype=np.uint64)
+        np.cumsum(np.asarray(sizes, dtype=np.uint64), out=o[1:])
+        d, do = L.flbgpu_dev_alloc(len(blob) + 16), L.flbgpu_dev_alloc(o.nbytes)
+        L.flbgpu_memcpy_h2d(d, blob, len(blob)); L.flbgpu_memcpy_h2d(do, o.ctypes.data, o.nbytes)
+        return g.DevChunk(d, do, len(sizes), len(blob)), o
+
+    mixed_blob = b"".join(recs)
+    mixed, moff = upload(mixed_blob, [len(r) for r in recs])
+    even_blob = bytes(data)
+    even, eoff = upload(even_blob, np.diff(off))
+    _set_mode("reg")
+    os.environ.pop("FLBGPU_FX", None); os.environ.pop("FLBGPU_SORT_ROWS", None)
+    pargs = dict(regex=APACHE2, time_fmt=TF, time_key="time")
+    rules = [("regex", r"code ^[45]\d\d$")]
+    p = g.Parser(**pargs)
+    fp = g.FilterParser("log", [p]); fg = g.FilterGrep(rules); ch = g.FilterChain([fp, fg])
+
+    def call(chunk):
+        r, o = ch.filter_dev(chunk)
+        assert r == g.MODIFIED
+        out = np.empty(int(o.bytes), dtype=np.uint8)
+        L.flbgpu_memcpy_d2h(out.ctypes.data, o.data, int(o.bytes))
+        oo = np.empty(int(o.n) + 1, dtype=np.uint64)
+        L.flbgpu_memcpy_d2h(oo.ctypes.data, o.row_off, oo.nbytes)
+        return bytes(out), oo, ch.last_stats(), fp.paths()
+
+    outs = [call(mixed) for _ in range(4)]
+    assert not outs[0][3]["rows_by_length"]                     # the first chunk of such data: chunk order, and the counters say so
+    assert all(o[3]["rows_by_length"] for o in outs[1:]), [o[3] for o in outs]
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and (o[1] == outs[0][1]).all() and o[2] == outs[0][2]
+    # the oracle's two filters on blocks of input rows (the output keeps one row per input row)
+    po = ob.Parser(**pargs)
+    fo, go = ob.FilterParser("log", [po]), ob.Grep(rules)
+    got, goff = outs[2][0], outs[2][1]
+    for start in (0, 13000, 39000):
+        blob = mixed_blob[int(moff[start]): int(moff[start + 1000])]
+        r1, w1 = fo.filter(blob)
+        r2, w2 = go.filter(w1 if r1 == ob.MODIFIED else blob)
+        want = w2 if r2 == ob.MODIFIED else (w1 if r1 == ob.MODIFIED else blob)
+        assert got[int(goff[start]): int(goff[start + 1000])] == want, start
+    # filter_parser alone takes the same kernel
+    fp2 = g.FilterParser("log", [p])
+    a = [fp2.filter_dev(mixed) for _ in range(2)]
+    assert fp2.paths()["rows_by_length"]
+    r1, w1 = fo.filter(mixed_blob[: int(moff[2000])])
+    pb = np.empty(int(a[1][1].bytes), dtype=np.uint8)
+    L.flbgpu_memcpy_d2h(pb.ctypes.data, a[1][1].data, pb.nbytes)
+    poff = np.empty(2001, dtype=np.uint64)
+    L.flbgpu_memcpy_d2h(poff.ctypes.data, a[1][1].row_off, poff.nbytes)
+    assert bytes(pb[: int(poff[2000])]) == w1
+    # even lines: the order by length is still on for the first such chunk (its counters come from the ordering pass), then off
+    st = [call(even)[3]["rows_by_length"] for _ in range(3)]
+    assert st == [True, False, False], st
+    assert call(mixed)[3]["rows_by_length"] is False and call(mixed)[3]["rows_by_length"] is True
+    fp2.close(); fg.close(); fp.close(); p.close()
+    for c in (mixed, even):
+        L.flbgpu_dev_free(c.data); L.flbgpu_dev_free(c.row_off)
