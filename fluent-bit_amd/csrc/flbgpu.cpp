@@ -1584,7 +1584,7 @@ static bool parser_size_pass(flbgpu_filter *f, const flbgpu_dev_chunk *in, hipSt
             // (a region per wave of the launch: what a wave sees at most, rounded up to whole iterations; behind them one count per wave)
             const uint64_t nw = (uint64_t) grid * (uint64_t) (rx_threads / 64);
             const uint64_t stride = ((n + nw * 64 - 1) / (nw * 64)) * 64;
-            if (!f->d_fix.ensure((nw * stride + nw) * sizeof(uint32_t))) return false;
+            if (!f->d_fix.ensure((nw * stride + nw + nw + 1) * sizeof(uint32_t))) return false;     // (lists, counts, the batches in front of every wave)
             ma.fix_list = f->d_fix.as<uint32_t>();
             ma.fix_count = (unsigned long long *) (f->d_fix.as<uint32_t>() + nw * stride);
         }
