@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-FLBGPU_DEBUG_LDS=1 timeout 600 python tools/perf_mixed.py 2 2>&1 | grep "k_parser_reg" | sort | uniq -c | head
-echo "== 768 build of the fix-up"
-FLBGPU_FIXUP_512=0 timeout 600 python tools/perf_mixed.py 30 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 1500 python -m pytest tests/test_tile_gpu.py tests/test_small_call_gpu.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4
+timeout 600 python tools/perf_host_level.py 2>&1 | grep -v amdgpu.ids | tail -8
+timeout 600 python tools/perf_mixed.py 20 2>&1 | grep -v amdgpu.ids | tail -3
