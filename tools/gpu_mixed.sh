@@ -1,7 +1,8 @@
 #!/bin/bash
+# mixed record shapes through the pair on the GPU box: the suites that go through the register kernel, then tools/perf_mixed.py with the rows
+# in the order of their lengths (the filter's own choice) and in chunk order
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-for v in "0 0" "60000 0" "90000 0" "0 40000"; do
-  set -- $v
-  echo "== size pad $1  emit pad $2"
-  FLBGPU_FMT_SIZE_LDS=$1 FLBGPU_FMT_EMIT_LDS=$2 timeout 600 python tools/perf_fmt.py 10000000 2>&1 | grep -v amdgpu.ids | tail -1
-done
+timeout 1500 python -m pytest tests/test_tile_gpu.py tests/test_small_call_gpu.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4
+timeout 600 python tools/perf_mixed.py 30 2>&1 | grep -v amdgpu.ids | tail -3
+echo "== chunk order only"
+FLBGPU_SORT_ROWS=0 timeout 600 python tools/perf_mixed.py 20 2>&1 | grep -v amdgpu.ids | tail -3
