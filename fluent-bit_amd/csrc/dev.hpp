@@ -194,6 +194,12 @@ struct DevParser {
     // a HOST parser (the Regex is not a regular expression: the host's backtracking matcher answers, rxbt.inc): no tables above; in a
     // list of parsers its answers for the chunk's values stand in ParserMatchArgs::host_res[host_slot] (k_parser_generic reads them)
     int host_only, host_slot;
+    // %Z's last resort (src/flb_strptime.c:611-650): a zone text that is in neither of flb_strptime's tables is compared, without case and
+    // as a prefix, with the two names of the PROCESS's zone -- tzname[0], tzname[1] -- and either one means -timezone; read at create
+    // (tzset).  tz_names == 0: a process without a zone (both names "UTC")
+    int tz_names, tzn_gmtoff;
+    int tzn_len[2];
+    char tzn[2][16];
 };
 constexpr int MAX_HOST_PARSERS = 4;      // host parsers in one list of parsers
 

@@ -476,21 +476,27 @@ static flbgpu_parser *parser_create_impl(bool is_json, const char *name, const c
     if (is_json) regex = "";
     // (a %Z DIRECTIVE: "%%Z" is a literal percent sign and a Z -- ADVICE r5)
     auto has_zone_directive = [](const char *f) { for (; *f; f++) if (*f == '%') { f++; if (*f == 'Z') return true; if (!*f) break; } return false; };
+    // %Z's last resort for a zone text that is in neither of flb_strptime's tables is the PROCESS's zone -- tzname[] and -timezone
+    // (src/flb_strptime.c:611-650).  Rounds 4 and 5 restated that for a process without a zone and refused %Z in any other; round 6
+    // reads the two names and the offset here, once, like the reference's tzset() does, and the device compares with THEM.
+    char zn[2][16] = {{0}, {0}};
+    int zn_len[2] = {0, 0}, zn_off = 0, zn_set = 0;
     if (time_fmt && has_zone_directive(time_fmt)) {
-        // %Z's last resort for a zone text that is in neither of flb_strptime's tables is the PROCESS's zone -- tzname[] and -timezone
-        // (src/flb_strptime.c:611-650) --; the device restates that for a process without a zone (UTC).  In any other process the
-        // answer for such texts would differ: refused at create, like Time_System_Timezone.  (Before anything touches the
-        // device: the refusal is the same on a host without one.)
         tzset();
-        if (timezone != 0 || daylight != 0) {
-            set_err("parser '%s': Time_Format with %%Z in a process whose zone is not UTC is not supported (the zone text's last resort is the process's tzname[])", name ? name : "");
-            return nullptr;
+        for (int i = 0; i < 2; i++) {
+            const char *nm = tzname[i] ? tzname[i] : "";
+            const size_t L = strlen(nm);
+            if (L > 15) { set_err("parser '%s': Time_Format with %%Z in a process whose zone name '%s' is longer than 15 bytes is not supported", name ? name : "", nm); return nullptr; }
+            memcpy(zn[i], nm, L); zn_len[i] = (int) L;
         }
+        zn_off = (int) -timezone; zn_set = 1;
     }
     auto *p = new flbgpu_parser();
     p->name = name ? name : "";
     DevParser &d = p->dev;
     memset(&d, 0, sizeof(d));
+    d.tz_names = zn_set; d.tzn_gmtoff = zn_off; d.tzn_len[0] = zn_len[0]; d.tzn_len[1] = zn_len[1];
+    memcpy(d.tzn, zn, sizeof(zn));
     if (!is_json) {
         const char *s, *e;
         unsigned opts;

@@ -222,9 +222,10 @@ def test_product_refusals():
     fb.Parser(regex=rx, time_key="time", time_fmt=FMT, time_system_timezone=True).close()
 
 
-def test_process_zone_that_is_not_utc_refuses_the_zone_name_directive_before_any_device_work():
-    """the %Z half of the test below without a GPU: the refusal comes before the parser touches the device, so a host without one
-    gives the same message (and, in a UTC process, gets as far as the device: 'no ROCm-capable device')"""
+def test_the_zone_name_directive_is_taken_in_any_process_zone():
+    """round 6: %Z in a process whose zone is not UTC is no longer refused at create (rounds 4 and 5 refused it: the zone text's last
+    resort is the process's tzname[], src/flb_strptime.c:611-650, which the device now gets from the creating process).  Without a GPU
+    the create call gets as far as the device in either zone: the only error left is the missing device."""
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load()\n"
             "import time; out = [str(time.timezone)]\n"
@@ -239,34 +240,51 @@ def test_process_zone_that_is_not_utc_refuses_the_zone_name_directive_before_any
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TZ=tz, TZDIR=TZDIR), timeout=300)
         assert r.returncode == 0, r.stderr[-800:]
         seen[tz] = r.stdout.strip().splitlines()[-1].split("|")
-    if seen["Europe/Berlin"][0] == "0":
-        pytest.skip("TZ=Europe/Berlin has no effect in this image's C library (no zone files where it looks)")
-    assert all("%Z" in m and "not UTC" in m for m in seen["Europe/Berlin"][1:]), seen
-    assert seen["UTC"][0] == "0" and not any("not UTC" in m for m in seen["UTC"][1:]), seen
+    for tz in seen:
+        assert not any("not UTC" in m or "%Z" in m for m in seen[tz][1:]), seen
 
 
 @pytest.mark.gpu
-def test_process_zone_that_is_not_utc_refuses_what_depends_on_it():
-    """%Z's last resort and Time_System_Timezone read the PROCESS's zone (src/flb_strptime.c:611-650, flb_parser.h:80-94); the
-    device restates a process without a zone.  In a process with TZ=Europe/Berlin both are refused at create, with the reason; a format
-    without %Z is not affected."""
+def test_process_zone_that_is_not_utc():
+    """%Z's last resort and Time_System_Timezone read the PROCESS's zone (src/flb_strptime.c:611-650, flb_parser.h:80-94).  In a process
+    with TZ=Europe/Berlin: Time_System_Timezone is refused at create, with the reason (mktime's answer inside a zone's overlaps depends on
+    the thread's previous call); %Z is taken -- the zone texts of the reference's table, GMT / UTC, the process's own two names
+    in any case (CET and CEST: BOTH mean -timezone there), names of other zones and non-names (the parser fails: the record keeps its
+    time) -- and the records are the REFERENCE's own filter_parser's, run in the same zone (oracle/_ref/ref_filters)."""
     import subprocess, sys
-    code = ("import sys; sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load(); fb.init()\n"
-            "rx = r'^(?<time>\\S+ \\S+ \\S+) (?<m>.*)$'\n"
-            "import time; out = [str(time.timezone)]\n"
-            "for kw in (dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%Z'), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S', time_system_timezone=True), dict(time_fmt='%%Y-%%m-%%d %%H:%%M:%%S %%z')):\n"
-            "    try:\n"
-            "        fb.Parser(regex=rx, time_key='time', **kw).close(); out.append('ok')\n"
-            "    except ValueError as e:\n"
-            "        out.append('refused: ' + str(e))\n"
-            "print('|'.join(out))\n") % os.path.dirname(HERE)
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); import flbamd_loader; fb = flbamd_loader.load(); fb.init()\n"
+            "import ref_filters as rf, synth, time\n"
+            "rx = r'^(?<time>[^|]*)\\|(?<m>.*)$'\n"
+            "out = [str(time.timezone), '/'.join(time.tzname)]\n"
+            "try:\n"
+            "    fb.Parser(regex=rx, time_key='time', time_fmt='%%Y-%%m-%%d %%H:%%M:%%S', time_system_timezone=True).close(); out.append('ok')\n"
+            "except ValueError as e:\n"
+            "    out.append('refused: ' + str(e))\n"
+            "zones = ['CET', 'CEST', 'cet', 'Cest', 'CETX', 'CEST1', 'UTC', 'GMT', 'utc', 'EST', 'PDT', 'pst', 'WET', 'EET', 'MSK', 'XYZ', 'CE', '', 'Z', '+0100', 'JST', 'IST', 'AEDT']\n"
+            "texts = ['2024-0%%d-1%%d 0%%d:1%%d:2%%d %%s' %% (1 + i %% 9, i %% 9, i %% 9, i %% 6, i %% 6, z) for i, z in enumerate(zones * 3)]\n"
+            "data = b''.join(synth.v2_record(1700000000 + i, 5, {'log': t + '|x'}) for i, t in enumerate(texts))\n"
+            "for fmt in ('%%Y-%%m-%%d %%H:%%M:%%S %%Z', '%%Y-%%m-%%d %%H:%%M:%%S %%Z|', '%%Y-%%m-%%d %%H:%%M:%%S%%n%%Z'):\n"
+            "    for keep in (False, True):\n"
+            "        pa = dict(regex=rx, time_fmt=fmt, time_key='time', time_keep=keep)\n"
+            "        gp = fb.Parser(**pa); gf = fb.FilterParser('log', [gp])\n"
+            "        ret, got = gf.filter(data)\n"
+            "        res = rf.run([rf.parser_case('log', [pa], data)])\n"
+            "        want = res[0][1] if res[0][0] == rf.MODIFIED else None\n"
+            "        out.append('same' if (ret == rf.MODIFIED and got == want) or (ret != rf.MODIFIED and want is None) else 'DIFFERENT %%s %%s' %% (fmt, keep))\n"
+            "        gf.close(); gp.close()\n"
+            "print('|'.join(out))\n") % (os.path.dirname(HERE), HERE)
+    import ref_filters as rf
+    if not rf.available():
+        pytest.skip("oracle/_ref/ref_filters not built")
     env = dict(os.environ, TZ="Europe/Berlin", TZDIR=TZDIR)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0, r.stderr[-800:]
-    tzsec, a, b, c = r.stdout.strip().splitlines()[-1].split("|")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    parts = r.stdout.strip().splitlines()[-1].split("|")
+    tzsec, names, b = parts[0], parts[1], parts[2]
     if tzsec == "0":
         pytest.skip("TZ=Europe/Berlin has no effect in this image's C library (no zone files where it looks)")
-    assert a.startswith("refused") and "%Z" in a and b.startswith("refused") and "Time_System_Timezone" in b and c == "ok", (a, b, c)
+    assert b.startswith("refused") and "Time_System_Timezone" in b, b
+    assert names == "CET/CEST" and parts[3:] == ["same"] * 6, parts
 
 
 # ------------------------------------------------------------------------------------------------------------- GPU
