@@ -35,6 +35,6 @@ for k, v in out.items():
 PY
 # the default bench line LAST: it reads the PMC summary of the same kernel sources for roofline.traffic
 cp $O/pmc_summary.json $R/$(python -c "import sys; sys.path.insert(0,'$R'); import bench; print(bench.PMC_FILE)")
-python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+python $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err      # (the driver's own command line)
 head -12 $O/kernel_stats.csv | cut -c1-160
 cat $O/bench_default.json | cut -c1-2600
