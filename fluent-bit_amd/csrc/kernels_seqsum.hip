@@ -109,6 +109,7 @@ __device__ __forceinline__ long long ss_wave_sum(long long v) {
 __global__ void __launch_bounds__(64) k_ss_fold_heavy(const uint64_t *vals, const unsigned long long *start, const unsigned long long *end, const uint32_t *heavy,
                                                       const unsigned int *nheavy, double *seq) {
     const uint32_t lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double blk[512];
     for (uint32_t h = blockIdx.x; h < *nheavy; h += gridDim.x) {
         const uint32_t s = heavy[h];
         const unsigned long long b = start[s], e = end[s];
@@ -145,26 +146,33 @@ __global__ void __launch_bounds__(64) k_ss_fold_heavy(const uint64_t *vals, cons
                     continue;
                 }
             }
+            // The chain itself.  Round 6: ONE lane adds, reading the 512 values back from LDS two at a time -- an observation is one
+            // v_add_f64 (the chain's latency) and half a ds_read; handing every value to the chain by two v_readlane cost three vector
+            // operations an observation, 21 cycles against the addition's own 8 (53 -> ~20 ms for 10 M decimals on five series)
             #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const unsigned long long bits = (unsigned long long) __double_as_longlong(v[u]);
-                #pragma unroll
-                for (int k = 0; k < 64; k++) {
-                    const unsigned long long x = ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (bits >> 32), k) << 32) |
-                                                 (uint32_t) __builtin_amdgcn_readlane((int) bits, k);
-                    acc += __longlong_as_double((long long) x);
+            for (int u = 0; u < 8; u++) blk[64 * u + lane] = v[u];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                #pragma unroll 8
+                for (int k = 0; k < 512; k += 2) {
+                    const double2 d2 = *(const double2 *) &blk[k];
+                    acc += d2.x;
+                    acc += d2.y;
                 }
             }
+            acc = __shfl(acc, 0, 64);
+            __builtin_amdgcn_wave_barrier();
         }
         // the tail: 64 at a time
         for (; i < e; i += 64) {
             const unsigned long long left = e - i < 64 ? e - i : 64;
-            const unsigned long long bits = lane < left ? vals[i + lane] : 0;
-            for (uint32_t k = 0; k < left; k++) {
-                const unsigned long long x = ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (bits >> 32), k) << 32) |
-                                             (uint32_t) __builtin_amdgcn_readlane((int) bits, k);
-                acc += __longlong_as_double((long long) x);
-            }
+            blk[lane] = lane < left ? __longlong_as_double((long long) vals[i + lane]) : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) for (uint32_t k = 0; k < left; k++) acc += blk[k];
+            acc = __shfl(acc, 0, 64);
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) seq[s] = acc;
     }
