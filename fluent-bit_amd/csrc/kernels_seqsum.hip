@@ -154,11 +154,21 @@ __global__ void __launch_bounds__(64) k_ss_fold_heavy(const uint64_t *vals, cons
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
-                #pragma unroll 8
-                for (int k = 0; k < 512; k += 2) {
-                    const double2 d2 = *(const double2 *) &blk[k];
-                    acc += d2.x;
-                    acc += d2.y;
+                // (sixteen values in registers while the sixteen behind them are on their way from LDS: the reads' latency off the chain)
+                double2 qa[8], qb[8];
+                #pragma unroll
+                for (int j = 0; j < 8; j++) qa[j] = *(const double2 *) &blk[2 * j];
+                for (int k = 0; k < 512; k += 32) {
+                    #pragma unroll
+                    for (int j = 0; j < 8; j++) qb[j] = *(const double2 *) &blk[k + 16 + 2 * j];
+                    #pragma unroll
+                    for (int j = 0; j < 8; j++) { acc += qa[j].x; acc += qa[j].y; }
+                    if (k + 32 < 512) {
+                        #pragma unroll
+                        for (int j = 0; j < 8; j++) qa[j] = *(const double2 *) &blk[k + 32 + 2 * j];
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < 8; j++) { acc += qb[j].x; acc += qb[j].y; }
                 }
             }
             acc = __shfl(acc, 0, 64);
