@@ -216,14 +216,23 @@ chunks = []
 for c in range(3):
     chunks.append(b"".join(v2_record(1, 0, {"a": "k%%d" %% rng.randrange(6000), "b": rng.randrange(3), "v": rng.randrange(100)}) for _ in range(20000)))
 props = [("label_field", "a"), ("label_field", "b")]
-o = ob.L2M("histogram", props, value_field="v"); f = g.FilterLogToMetrics("histogram", props, value_field="v")
+o = ob.L2M("histogram", props, value_field="v")
 for c in chunks:
-    o.filter(c); f.filter(c)
-a = f.snapshot(); b = o.snapshot()[2]
-assert f.stats()["grows"] >= 5, f.stats()
-assert [x["labels"] for x in a] == [x["labels"] for x in b]
-assert all(x["buckets"] == y["buckets"] and x["sum"] == y["sum"] and x["count"] == y["count"] for x, y in zip(a, b))
-print("OK", len(a), f.stats())
+    o.filter(c)
+b = o.snapshot()[2]
+# (eight filters over the same chunks: a new entry's number and key bytes used to be taken with add / test / take back, and a lane that took
+# its number back after a neighbour had been handed the next one left two keys with one row -- about one run in fifty, round 6)
+for it in range(8):
+    f = g.FilterLogToMetrics("histogram", props, value_field="v")
+    for c in chunks:
+        f.filter(c)
+    a = f.snapshot()
+    assert f.stats()["grows"] >= 5, f.stats()
+    assert [x["labels"] for x in a] == [x["labels"] for x in b], it
+    assert all(x["buckets"] == y["buckets"] and x["sum"] == y["sum"] and x["count"] == y["count"] for x, y in zip(a, b)), it
+    st = f.stats()
+    f.close()
+print("OK", len(a), st)
 ''' % (ROOT, HERE)
     env = dict(os.environ, FLBGPU_L2M_INIT_CAP="16", FLBGPU_L2M_INIT_ARENA="64")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
